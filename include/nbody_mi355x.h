@@ -1,0 +1,189 @@
+/*
+ * nbody_mi355x.h -- C ABI of libnbody_mi355x.so, the MI355X (gfx950) engine that replaces the
+ * N-body hot path of blitzcode/rust-exp (rs-src/nbody.rs) behind that crate's own extern "C"
+ * surface.  Plain C: fixed-width ints, floats, raw pointers and sizes; no C++/torch types.
+ *
+ * Two levels:
+ *   Level 1 (nb_*)   the SIX symbols the reference exports and hs-src/RustNBodyExperiment.hs
+ *                    imports (RustNBodyExperiment.hs:101-106).  Same names, argument meaning and
+ *                    (absent) error reporting: they return void / a count; a fatal device error
+ *                    prints a diagnostic and abort()s, the analogue of the reference's panic!.
+ *   Level 2 (nbx_*)  additive, handle based, returns status codes.  This is what a Rust
+ *                    `nbody.rs` shim or any other host binds: state
+ *                    injection/extraction (the reference has none: its state is a private global,
+ *                    nbody.rs:28-32, and its RNG is OS-seeded, nbody.rs:46,:90), force-only
+ *                    evaluation, sharding across GPUs, profiling.
+ *
+ * There is NO CPU fallback: every step entry point needs a gfx950 device and fails loudly
+ * (NBX_ERR_NO_DEVICE / abort) without one.  Host-side entry points (presets, set/get, draw, tree
+ * build) work without a device.
+ *
+ * Citations `nbody.rs:A-B` are relative to /root/reference/rs-src/.
+ */
+#ifndef NBODY_MI355X_H
+#define NBODY_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------- */
+/* Level 1: drop-in replacements (process-global engine, internally serialised by a mutex like  */
+/* the reference's `PARTICLES: Mutex<Vec<Particle>>`, nbody.rs:28-32).                          */
+/* Environment knobs read once at first use: NB_DEVICE (ordinal, default 0), NB_SEED (u64,      */
+/* default: OS entropy, as the reference's thread_rng), NB_FORCE_MODE=fast|strict.              */
+
+/* replaces nbody.rs:34-37   pub extern fn nb_num_particles() -> i32 */
+int32_t nb_num_particles(void);
+
+/* replaces nbody.rs:39-64   pub extern fn nb_random_disk(num_particles: i32) */
+void nb_random_disk(int32_t num_particles);
+
+/* replaces nbody.rs:73-104  pub extern fn nb_stable_orbits(num_particles: i32, rmin: f32, rmax: f32) */
+void nb_stable_orbits(int32_t num_particles, float rmin, float rmax);
+
+/* replaces nbody.rs:106-162 pub extern fn nb_step_brute_force(dt: f32)
+ * O(N^2) pairwise force + kick-drift on the GPU; returns after the step completed (the Haskell
+ * caller wall-clocks this call, RustNBodyExperiment.hs:55-57). */
+void nb_step_brute_force(float dt);
+
+/* replaces nbody.rs:186-480 pub extern fn nb_step_barnes_hut(theta: f32, dt: f32, nthreads: i32)
+ * theta == 0.0 delegates to brute force (nbody.rs:197-200).  Otherwise: quadtree built on the
+ * host exactly as the reference builds it, force evaluation + integration + velocity-kill on
+ * the GPU.  `nthreads` (CPU worker count in the reference, nbody.rs:424-428) is accepted and
+ * ignored by the GPU evaluation; nthreads <= 0 (a division by zero panic in the reference) is a
+ * no-op here. */
+void nb_step_barnes_hut(float theta, float dt, int32_t nthreads);
+
+/* replaces nbody.rs:482-583 pub extern fn nb_draw(w: i32, h: i32, fb: *mut u32)
+ * fb: caller-owned w*h little-endian ABGR words, cleared and filled here, not retained. */
+void nb_draw(int32_t w, int32_t h, uint32_t *fb);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Level 2: handle API                                                                          */
+
+typedef struct nbx_engine nbx_engine;
+
+enum nbx_status {
+    NBX_OK = 0,
+    NBX_ERR_INVALID = -1,    /* bad argument */
+    NBX_ERR_NO_DEVICE = -2,  /* no usable gfx950 device: step entry points refuse (no CPU fallback) */
+    NBX_ERR_HIP = -3,        /* HIP runtime error; text in nbx_last_error() */
+    NBX_ERR_TREE_DEPTH = -4, /* quadtree depth > 50: the reference panics (nbody.rs:230-232) */
+    NBX_ERR_TREE = -5,       /* other reference tree assert (nbody.rs:267,:293,:304) */
+    NBX_ERR_ALLOC = -6,
+    NBX_ERR_STATE = -7       /* call not valid in the engine's current configuration */
+};
+
+enum nbx_option {
+    /* 0 = fast (default): a_i = sum_j m_j d/(|d|^2+eps) with v_rcp_f32 + FMA, tile order,
+     *     parity within the stated fp32 tolerance.
+     * 1 = strict: reference expression order, IEEE divide, ascending-j sequential sum, no FMA
+     *     contraction: BIT-EXACT with the reference arithmetic (2-D only, no j-split). */
+    NBX_OPT_FORCE_MODE = 0,
+    NBX_OPT_JSPLIT = 1,            /* source-range split factor S; 0 = auto */
+    NBX_OPT_BODIES_PER_THREAD = 2, /* register blocking B in {1,2,4}; 0 = auto */
+    NBX_OPT_DIM = 3,               /* 2 or 3; 0 = auto (2 when every z and vz is zero) */
+    NBX_OPT_PROFILE = 4,           /* 1 = record a HIP event pair around every kernel launch */
+    NBX_OPT_KERNEL_VARIANT = 5,    /* fast force kernel variant; 0 = default */
+    NBX_OPT_BH_LEAF_CAP = 6        /* reserved */
+};
+
+enum nbx_kernel_id {
+    NBX_K_FORCE = 0,     /* all-pairs force tile kernel (fast or strict) */
+    NBX_K_INTEGRATE = 1, /* partial-sum reduce + kick-drift */
+    NBX_K_BH_EVAL = 2,   /* Barnes-Hut traversal + kick-drift + velocity-kill */
+    NBX_K_COUNT = 3
+};
+
+typedef struct nbx_device_info {
+    char name[128];
+    char arch[64];
+    int32_t compute_units;
+    int32_t clock_khz;         /* max engine clock */
+    int32_t wavefront_size;
+    int32_t lds_bytes_per_cu;
+    double peak_fp32_flops;    /* CUs * clock * 256 flop/clk/CU (vector FMA roofline) */
+    uint64_t hbm_bytes;
+} nbx_device_info;
+
+const char *nbx_last_error(void); /* thread-local text of the most recent failure */
+const char *nbx_version(void);
+int32_t nbx_device_count(void);   /* 0 when no device / no driver */
+int32_t nbx_device_info_get(int32_t device, nbx_device_info *out);
+
+/* Lifetime. Device resources are created lazily at the first device operation, so an engine can
+ * be created and used for host-side work (presets, set/get, draw, tree build) without a GPU. */
+int32_t nbx_create(nbx_engine **out, int32_t device);
+void nbx_destroy(nbx_engine *e);
+
+int32_t nbx_set_option(nbx_engine *e, int32_t option, int64_t value);
+int64_t nbx_get_option(const nbx_engine *e, int32_t option);
+
+/* Presets: same sampling as nbody.rs:39-104, but from a seedable generator (splitmix64 -> top 24
+ * bits -> [0,1) f32, the rand 0.3 `next_f32` construction). */
+int32_t nbx_seed(nbx_engine *e, uint64_t seed);
+int32_t nbx_random_disk(nbx_engine *e, int32_t n);
+int32_t nbx_stable_orbits(nbx_engine *e, int32_t n, float rmin, float rmax);
+
+/* State in/out (host SoA buffers of n floats each). The 2-D forms set z = vz = 0.
+ * get: `cap` = capacity of each output array; returns the particle count or a negative status.
+ * Any output pointer may be NULL. */
+int32_t nbx_num_particles(const nbx_engine *e);
+int32_t nbx_set_particles(nbx_engine *e, int32_t n, const float *px, const float *py, const float *vx,
+                          const float *vy, const float *m);
+int32_t nbx_set_particles3(nbx_engine *e, int32_t n, const float *px, const float *py, const float *pz,
+                           const float *vx, const float *vy, const float *vz, const float *m);
+int32_t nbx_get_particles(nbx_engine *e, int32_t cap, float *px, float *py, float *vx, float *vy, float *m);
+int32_t nbx_get_particles3(nbx_engine *e, int32_t cap, float *px, float *py, float *pz, float *vx, float *vy,
+                           float *vz, float *m);
+
+/* Steps. Asynchronous on the engine's stream; nbx_synchronize / get / draw wait. */
+int32_t nbx_step_brute_force(nbx_engine *e, float dt);
+int32_t nbx_step_barnes_hut(nbx_engine *e, float theta, float dt, int32_t nthreads);
+int32_t nbx_synchronize(nbx_engine *e);
+
+/* Force evaluation without state update, for parity tests on accelerations.
+ * Writes F_i = m_i * a_i (the quantity nbody.rs:140-142 accumulates) for this engine's slab
+ * targets; fz may be NULL. theta == 0 -> all-pairs, else Barnes-Hut traversal. cap >= slab size. */
+int32_t nbx_forces(nbx_engine *e, float theta, int32_t cap, float *fx, float *fy, float *fz);
+
+int32_t nbx_draw(nbx_engine *e, int32_t w, int32_t h, uint32_t *fb);
+
+/* Host quadtree exactly as nbody.rs:388-415 builds it, dumped in pre-order (children UL,UR,LL,LR)
+ * as rows of 8 floats: x1,y1,x2,y2,px,py,m,has_children. Returns node count (may exceed cap; only
+ * cap rows are written) or a negative status. Runs without a device. */
+int32_t nbx_bh_tree_dump(nbx_engine *e, float *rows, int32_t cap);
+
+/* ---- multi-GPU: bodies shard as contiguous slabs of targets, the reference's own thread split  */
+/* (range = N/world, last rank takes the remainder; nbody.rs:426-428).  One process per GPU; every */
+/* rank holds the full (x,y,z,m) source array and its own slab's velocities.  Per step:            */
+/*   nbx_step_local()  ->  caller all-gathers the positions buffer (one RCCL all-gather, in place) */
+int32_t nbx_set_shard(nbx_engine *e, int32_t rank, int32_t world); /* call before set_particles */
+int32_t nbx_get_slab(const nbx_engine *e, int32_t *lo, int32_t *hi);
+/* Use a caller-owned DEVICE buffer (e.g. a torch tensor handed to torch.distributed) as the
+ * (x,y,z,m) float4 array instead of an engine-owned one. bytes >= nbx_positions_bytes(). Call
+ * after set_particles; the engine copies its current positions into it. */
+int32_t nbx_bind_positions(nbx_engine *e, void *device_ptr, size_t bytes);
+void *nbx_positions_device(nbx_engine *e); /* device pointer of the float4 (x,y,z,m) array */
+size_t nbx_positions_bytes(const nbx_engine *e); /* n_padded * 16 */
+int32_t nbx_set_stream(nbx_engine *e, void *hip_stream); /* run on a caller-owned hipStream_t */
+/* force + integrate for this rank's slab only, writing the new positions into the slab's slot of
+ * the positions buffer. The caller then performs the all-gather on the same stream. */
+int32_t nbx_step_local(nbx_engine *e, float dt);
+
+/* ---- profiling: HIP event pairs on the engine's stream around each kernel launch -------------- */
+int32_t nbx_profile_reset(nbx_engine *e);
+/* total milliseconds and launch count recorded for `kernel_id` since the last reset (synchronises) */
+int32_t nbx_profile_read(nbx_engine *e, int32_t kernel_id, double *total_ms, int32_t *launches);
+/* launch geometry the last force launch used (for DESIGN/bench reporting); any pointer may be NULL */
+int32_t nbx_last_launch(const nbx_engine *e, int32_t *grid, int32_t *block, int32_t *jsplit,
+                        int32_t *bodies_per_thread, int32_t *dim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_MI355X_H */

@@ -1,0 +1,170 @@
+// bh_eval.hip -- K3: Barnes-Hut force evaluation on gfx950.  COMPILED WITH -ffp-contract=off.
+//
+// Replaces Node::compute_force (nbody.rs:333-377), evaluated per body by the reference's worker
+// threads (nbody.rs:443-447).  The quadtree itself is built on the host exactly as the reference
+// builds it (bh_tree.cpp; nbody.rs:388-415) and flattened in PRE-ORDER (children UL,UR,LL,LR,
+// empty exterior nodes dropped) with a skip pointer per node, so the recursive descent becomes a
+// stackless walk:  open a node -> next index;  accept / leaf -> skip[index].
+//
+//   interior:  s = x2-x1 ; d = sqrt(dx^2+dy^2) ; if s/d < theta -> force(body, COM) else open   (:341-360)
+//   exterior:  skip if position bit-equal to the body (:365), else force(body, particle)        (:371)
+//
+// mode 0 (fast):   test as s < theta*d (same truth table incl. d = 0, s = 0), v_rcp_f32 pair law,
+//                  contributions accumulated in walk order.  Output = acceleration.
+// mode 1 (strict): IEEE sqrt and divide, force() in the reference's expression order, and the
+//                  reference's HIERARCHICAL summation (every opened node returns the left-to-right
+//                  sum of its four children, :354-360) reproduced with an explicit frame stack
+//                  (depth <= 52, the reference panics beyond depth 50).  Output = force, bit-exact.
+//
+// One thread per body; bodies arrive in particle-index order (a Morton reorder would improve wave
+// coherence but would change nothing numerically; see DESIGN.md "next").  Tree nodes are read-only
+// 32-B records (two 16-B loads) served by L1/L2.
+#include "kernels.h"
+
+namespace nbx {
+
+constexpr int kMaxFrames = 56;
+
+__global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict__ posm, const int lo,
+                                                        const int n_targets, const BhNode* __restrict__ nodes,
+                                                        const int n_nodes, const float theta,
+                                                        float2* __restrict__ out)
+{
+    const int it = blockIdx.x * kTile + threadIdx.x;
+    if (it >= n_targets) return;
+    const float4 pi = posm[lo + it];
+    float ax = 0.0f, ay = 0.0f;
+    int i = 0;
+    while (i < n_nodes) {
+        const float4 a = *reinterpret_cast<const float4*>(&nodes[i]);         // px,py,m,s
+        const int2 b = *reinterpret_cast<const int2*>(&nodes[i].skip);        // skip, interior
+        const float dx = a.x - pi.x;
+        const float dy = a.y - pi.y;
+        const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+        bool take;
+        if (b.y) {
+            take = a.w < theta * __builtin_sqrtf(d2);      // s/d < theta  (d=0 -> open)
+        } else {
+            take = !(a.x == pi.x && a.y == pi.y);          // nbody.rs:365
+        }
+        if (take) {
+            const float s = a.z * __builtin_amdgcn_rcpf(d2 + kEps);
+            ax = __builtin_fmaf(s, dx, ax);
+            ay = __builtin_fmaf(s, dy, ay);
+        }
+        i = (b.y && !take) ? i + 1 : b.x;
+    }
+    out[it] = make_float2(ax, ay);
+}
+
+__global__ __launch_bounds__(kTile) void k_bh_eval_strict(const float4* __restrict__ posm, const int lo,
+                                                          const int n_targets, const BhNode* __restrict__ nodes,
+                                                          const int n_nodes, const float theta,
+                                                          float2* __restrict__ out)
+{
+    const int it = blockIdx.x * kTile + threadIdx.x;
+    if (it >= n_targets) return;
+    const float4 pi = posm[lo + it];
+    // frame stack: partial sums of the enclosing opened nodes and where each subtree ends
+    float sfx[kMaxFrames], sfy[kMaxFrames];
+    int send[kMaxFrames];
+    int sp = 0;
+    float fx = 0.0f, fy = 0.0f;   // running sum of the innermost open frame (nbody.rs:336-337)
+    int i = 0;
+    for (;;) {
+        while (sp > 0 && i == send[sp - 1]) {   // subtree finished: return (fx,fy) to the parent's sum
+            sp--;
+            fx = __fadd_rn(sfx[sp], fx);        // nbody.rs:358  fx += fx_add
+            fy = __fadd_rn(sfy[sp], fy);
+        }
+        if (i >= n_nodes) break;
+        const float4 a = *reinterpret_cast<const float4*>(&nodes[i]);
+        const int2 b = *reinterpret_cast<const int2*>(&nodes[i].skip);
+        if (b.y) {
+            const float dx = __fsub_rn(a.x, pi.x);                               // :342
+            const float dy = __fsub_rn(a.y, pi.y);                               // :343
+            const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));  // :344
+            if (a.w / d < theta) {                                               // :345
+                // force(px,py,m, self.px,self.py,self.m)  :348
+                const float ddx = __fsub_rn(a.x, pi.x), ddy = __fsub_rn(a.y, pi.y);
+                const float dist_sq = __fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy));
+                const float f = __fmul_rn(pi.w, a.z) / __fadd_rn(dist_sq, kEps);
+                fx = __fadd_rn(fx, __fmul_rn(f, ddx));
+                fy = __fadd_rn(fy, __fmul_rn(f, ddy));
+                i = b.x;
+            } else if (sp < kMaxFrames) {
+                sfx[sp] = fx; sfy[sp] = fy; send[sp] = b.x; sp++;               // open: children sum from 0
+                fx = 0.0f; fy = 0.0f;
+                i = i + 1;
+            } else {
+                i = b.x;  // unreachable: the host build rejects depth > 50
+            }
+        } else {
+            if (!(a.x == pi.x && a.y == pi.y)) {                                 // :365
+                const float ddx = __fsub_rn(a.x, pi.x), ddy = __fsub_rn(a.y, pi.y);
+                const float dist_sq = __fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy));
+                const float f = __fmul_rn(pi.w, a.z) / __fadd_rn(dist_sq, kEps);
+                fx = __fadd_rn(fx, __fmul_rn(f, ddx));                           // :371-373 + :358
+                fy = __fadd_rn(fy, __fmul_rn(f, ddy));
+            }
+            i = b.x;
+        }
+    }
+    out[it] = make_float2(fx, fy);
+}
+
+// Kick-drift from a per-body force (divide by m, nbody.rs:453-454) or acceleration (is_accel),
+// optional velocity kill (nbody.rs:466-471).
+__global__ __launch_bounds__(kTile) void k_integrate_f2(float4* __restrict__ posm, const int lo, const int n_targets,
+                                                        float4* __restrict__ vel, const float2* __restrict__ force,
+                                                        const float dt, const int is_accel, const int killbox)
+{
+    const int i = blockIdx.x * kTile + threadIdx.x;
+    if (i >= n_targets) return;
+    const float2 f = force[i];
+    float4 v = vel[i];
+    float4 p = posm[lo + i];
+    if (is_accel) {
+        v.x = __fadd_rn(v.x, __fmul_rn(dt, f.x));
+        v.y = __fadd_rn(v.y, __fmul_rn(dt, f.y));
+    } else {
+        v.x = __fadd_rn(v.x, __fmul_rn(dt, f.x) / p.w);
+        v.y = __fadd_rn(v.y, __fmul_rn(dt, f.y) / p.w);
+    }
+    p.x = __fadd_rn(p.x, __fmul_rn(dt, v.x));
+    p.y = __fadd_rn(p.y, __fmul_rn(dt, v.y));
+    if (killbox) {
+        const float lim = __fmul_rn(100.0f, 0.55f);
+        if (fabsf(__fsub_rn(0.0f, p.x)) > lim || fabsf(__fsub_rn(0.0f, p.y)) > lim) {
+            v.x = 0.0f;
+            v.y = 0.0f;
+        }
+    }
+    vel[i] = v;
+    posm[lo + i] = p;
+}
+
+hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
+                          int mode, float2* force_out, hipStream_t stream)
+{
+    if (n_targets <= 0) return hipSuccess;
+    const dim3 grid((n_targets + kTile - 1) / kTile);
+    if (mode == 1)
+        hipLaunchKernelGGL(k_bh_eval_strict, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
+                           force_out);
+    else
+        hipLaunchKernelGGL(k_bh_eval_fast, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
+                           force_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel, const float2* force, float dt,
+                               int is_accel, int killbox, hipStream_t stream)
+{
+    if (n_targets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_integrate_f2, dim3((n_targets + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, lo,
+                       n_targets, vel, force, dt, is_accel, killbox);
+    return hipGetLastError();
+}
+
+}  // namespace nbx

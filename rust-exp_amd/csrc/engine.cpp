@@ -1,0 +1,848 @@
+// engine.cpp -- state owner and C ABI of libnbody_mi355x.so (see include/nbody_mi355x.h).
+//
+// Plays the role the north_star gives to "Rust host code": it owns the particle arrays (a host
+// SoA mirror + the device-resident float4 arrays), implements the reference's six extern "C"
+// entry points (rs-src/nbody.rs:34-35,:39-40,:73-74,:106-107,:186-187,:482-483) on top of a
+// handle API, and drives the gfx950 kernels.  No CPU fallback: steps need a device.
+//
+// HBM layout (all 16-B records, coalesced 16 B/lane):
+//   posm  float4[n_pad]        (x, y, z, m) for ALL bodies; n_pad = n rounded up to 256, padding
+//                              entries are (0,0,0,0): zero mass => exact zero contribution.
+//   vel   float4[slab]         (vx, vy, vz, 0) for this engine's slab of targets only.
+//   acc   float4[S][stride]    per-source-split partial accelerations of the fast kernel.
+//   f2    float2[slab]         forces (strict / Barnes-Hut paths).
+//   nodes BhNode[n_nodes]      flattened quadtree, rebuilt on the host every Barnes-Hut step.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/nbody_mi355x.h"
+#include "host_ops.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(NBX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct ProfRec {
+    int kernel;
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct nbx_engine {
+    int device = 0;
+    bool dev_ready = false;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int cu_count = 256;
+
+    nbx::HostState host;
+    bool host_pos_valid = true, host_vel_valid = true;  // host mirror current?
+    bool dev_valid = false;                             // device arrays current?
+    int n = 0, n_pad = 0;
+    int rank = 0, world = 1, lo = 0, hi = 0;
+
+    float4* d_posm = nullptr;
+    bool posm_external = false;
+    size_t posm_cap = 0;  // records
+    float4* d_vel = nullptr;
+    size_t vel_cap = 0;
+    float4* d_acc = nullptr;
+    size_t acc_cap = 0;
+    float2* d_f2 = nullptr;
+    size_t f2_cap = 0;
+    float4* d_out4 = nullptr;
+    size_t out4_cap = 0;
+    nbx::BhNode* d_nodes = nullptr;
+    size_t nodes_cap = 0;
+
+    // options
+    int force_mode = 0, jsplit = 0, bpt = 0, dim_opt = 0, profile = 0, variant = 0;
+    bool any_z = false;
+
+    nbx::Rng rng{0};
+    bool seeded = false;
+
+    nbx::QuadTree tree;
+    std::vector<nbx::BhNode> flat;
+
+    std::vector<ProfRec> prof;
+    nbx::ForceLaunch last{0, 0, 0, 0, 0, 0};
+
+    int slab() const { return hi - lo; }
+};
+
+namespace {
+
+using nbx::kTile;
+
+void compute_slab(nbx_engine* e)
+{
+    // the reference's static split: range = N / T, the last worker takes the remainder (nbody.rs:426-428)
+    const int range = e->n / e->world;
+    e->lo = range * e->rank;
+    e->hi = (e->rank == e->world - 1) ? e->n : range * (e->rank + 1);
+}
+
+int ensure_device(nbx_engine* e)
+{
+    if (e->dev_ready) {
+        HIP_TRY(hipSetDevice(e->device));
+        return NBX_OK;
+    }
+    int count = 0;
+    hipError_t err = hipGetDeviceCount(&count);
+    if (err != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(NBX_ERR_NO_DEVICE,
+                    "no HIP device available (%s); the MI355X engine has no CPU fallback by design",
+                    err == hipSuccess ? "device count 0" : hipGetErrorString(err));
+    }
+    if (e->device < 0 || e->device >= count) return fail(NBX_ERR_NO_DEVICE, "device %d out of range (%d present)", e->device, count);
+    HIP_TRY(hipSetDevice(e->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+    e->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (!e->stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+    e->dev_ready = true;
+    return NBX_OK;
+}
+
+template <typename T>
+int grow(T** ptr, size_t* cap, size_t need)
+{
+    if (need <= *cap && *ptr) return NBX_OK;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    const size_t want = std::max<size_t>(need, 256);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(ptr), want * sizeof(T)));
+    *cap = want;
+    return NBX_OK;
+}
+
+int upload(nbx_engine* e)
+{
+    int rc = ensure_device(e);
+    if (rc != NBX_OK) return rc;
+    if (e->dev_valid) return NBX_OK;
+    if (!(e->host_pos_valid && e->host_vel_valid)) return fail(NBX_ERR_STATE, "no valid state to upload");
+    const int n = e->n;
+    e->n_pad = ((n + kTile - 1) / kTile) * kTile;
+    if (e->n_pad == 0) e->n_pad = kTile;
+    if (e->posm_external) {
+        if ((size_t)e->n_pad > e->posm_cap) return fail(NBX_ERR_STATE, "bound positions buffer too small");
+    } else {
+        rc = grow(&e->d_posm, &e->posm_cap, (size_t)e->n_pad);
+        if (rc != NBX_OK) return rc;
+    }
+    const int slab = e->slab();
+    rc = grow(&e->d_vel, &e->vel_cap, (size_t)std::max(slab, 1));
+    if (rc != NBX_OK) return rc;
+    std::vector<float4> tmp((size_t)e->n_pad, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int i = 0; i < n; i++) tmp[i] = make_float4(e->host.px[i], e->host.py[i], e->host.pz[i], e->host.m[i]);
+    HIP_TRY(hipMemcpyAsync(e->d_posm, tmp.data(), sizeof(float4) * (size_t)e->n_pad, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (slab > 0) {
+        std::vector<float4> tv((size_t)slab);
+        for (int i = 0; i < slab; i++)
+            tv[i] = make_float4(e->host.vx[e->lo + i], e->host.vy[e->lo + i], e->host.vz[e->lo + i], 0.f);
+        HIP_TRY(hipMemcpyAsync(e->d_vel, tv.data(), sizeof(float4) * (size_t)slab, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    e->dev_valid = true;
+    return NBX_OK;
+}
+
+int download_positions(nbx_engine* e)
+{
+    if (e->host_pos_valid) return NBX_OK;
+    int rc = ensure_device(e);
+    if (rc != NBX_OK) return rc;
+    std::vector<float4> tmp((size_t)std::max(e->n, 1));
+    HIP_TRY(hipMemcpyAsync(tmp.data(), e->d_posm, sizeof(float4) * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < e->n; i++) {
+        e->host.px[i] = tmp[i].x; e->host.py[i] = tmp[i].y; e->host.pz[i] = tmp[i].z;
+    }
+    e->host_pos_valid = true;
+    return NBX_OK;
+}
+
+int download_velocities(nbx_engine* e)
+{
+    if (e->host_vel_valid) return NBX_OK;
+    int rc = ensure_device(e);
+    if (rc != NBX_OK) return rc;
+    const int slab = e->slab();
+    if (slab > 0) {
+        std::vector<float4> tmp((size_t)slab);
+        HIP_TRY(hipMemcpyAsync(tmp.data(), e->d_vel, sizeof(float4) * (size_t)slab, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int i = 0; i < slab; i++) {
+            e->host.vx[e->lo + i] = tmp[i].x; e->host.vy[e->lo + i] = tmp[i].y; e->host.vz[e->lo + i] = tmp[i].z;
+        }
+    }
+    e->host_vel_valid = true;
+    return NBX_OK;
+}
+
+struct ProfScope {
+    nbx_engine* e;
+    int idx = -1;
+    ProfScope(nbx_engine* eng, int kernel) : e(eng)
+    {
+        if (!e->profile) return;
+        ProfRec r{kernel, nullptr, nullptr};
+        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+        (void)hipEventRecord(r.start, e->stream);
+        e->prof.push_back(r);
+        idx = (int)e->prof.size() - 1;
+    }
+    ~ProfScope()
+    {
+        if (idx >= 0) (void)hipEventRecord(e->prof[idx].stop, e->stream);
+    }
+};
+
+void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* bpt, int* jsplit, int* dim)
+{
+    *dim = e->dim_opt ? e->dim_opt : (e->any_z ? 3 : 2);
+    int b = e->bpt ? e->bpt : 2;
+    if (b != 1 && b != 2 && b != 4) b = 2;
+    *bpt = b;
+    int s = e->jsplit;
+    if (s <= 0) {
+        // fill the chip: >= 8 workgroups (32 waves) per CU when the problem allows it
+        const int iblocks = (n_targets + kTile * b - 1) / (kTile * b);
+        const int want = e->cu_count * 8;
+        s = 1;
+        while (iblocks * s < want && s < 64) s *= 2;
+    }
+    s = std::max(1, std::min(s, tiles_total));
+    *jsplit = s;
+}
+
+int launch_forces_fast(nbx_engine* e)
+{
+    const int slab = e->slab();
+    const int tiles_total = e->n_pad / kTile;
+    int bpt, jsplit, dim;
+    choose_launch(e, slab, tiles_total, &bpt, &jsplit, &dim);
+    const int stride = ((slab + kTile - 1) / kTile) * kTile;
+    int rc = grow(&e->d_acc, &e->acc_cap, (size_t)jsplit * (size_t)std::max(stride, kTile));
+    if (rc != NBX_OK) return rc;
+    {
+        ProfScope ps(e, NBX_K_FORCE);
+        HIP_TRY(nbx::launch_force_tile(e->d_posm, e->lo, slab, tiles_total, jsplit, bpt, dim, e->variant, e->d_acc,
+                                       stride, e->stream, &e->last));
+    }
+    return NBX_OK;
+}
+
+int step_brute(nbx_engine* e, float dt)
+{
+    int rc = upload(e);
+    if (rc != NBX_OK) return rc;
+    const int slab = e->slab();
+    if (e->n == 0 || slab == 0) return NBX_OK;
+    if (e->force_mode == 1) {
+        rc = grow(&e->d_f2, &e->f2_cap, (size_t)slab);
+        if (rc != NBX_OK) return rc;
+        {
+            ProfScope ps(e, NBX_K_FORCE);
+            HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream));
+            e->last = nbx::ForceLaunch{(slab + kTile - 1) / kTile, kTile, 1, 1, 2, -1};
+        }
+        ProfScope ps(e, NBX_K_INTEGRATE);
+        HIP_TRY(nbx::launch_integrate_f2(e->d_posm, e->lo, slab, e->d_vel, e->d_f2, dt, 0, 0, e->stream));
+    } else {
+        rc = launch_forces_fast(e);
+        if (rc != NBX_OK) return rc;
+        const int stride = ((slab + kTile - 1) / kTile) * kTile;
+        ProfScope ps(e, NBX_K_INTEGRATE);
+        HIP_TRY(nbx::launch_integrate(e->d_posm, e->lo, slab, e->d_vel, e->d_acc, e->last.jsplit, stride, dt,
+                                      e->stream));
+    }
+    e->host_pos_valid = false;
+    e->host_vel_valid = false;
+    return NBX_OK;
+}
+
+// host tree (reference-faithful) -> flatten -> device
+int build_and_upload_tree(nbx_engine* e)
+{
+    int rc = download_positions(e);
+    if (rc != NBX_OK) return rc;
+    rc = e->tree.build(e->host.px.data(), e->host.py.data(), e->host.m.data(), e->n);
+    if (rc == NBX_ERR_TREE_DEPTH) return fail(rc, "quadtree depth > 50 (the reference panics here, nbody.rs:230-232)");
+    if (rc != NBX_OK) return fail(rc, "quadtree build hit a reference assert (nbody.rs:267/:293/:304)");
+    e->tree.flatten(e->flat);
+    rc = grow(&e->d_nodes, &e->nodes_cap, std::max<size_t>(e->flat.size(), 1));
+    if (rc != NBX_OK) return rc;
+    if (!e->flat.empty()) {
+        HIP_TRY(hipMemcpyAsync(e->d_nodes, e->flat.data(), sizeof(nbx::BhNode) * e->flat.size(), hipMemcpyHostToDevice,
+                               e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));  // flat is reused next step
+    }
+    return NBX_OK;
+}
+
+int step_bh(nbx_engine* e, float theta, float dt)
+{
+    int rc = upload(e);
+    if (rc != NBX_OK) return rc;
+    const int slab = e->slab();
+    if (e->n == 0) return NBX_OK;
+    rc = build_and_upload_tree(e);
+    if (rc != NBX_OK) return rc;
+    if (slab == 0) return NBX_OK;
+    rc = grow(&e->d_f2, &e->f2_cap, (size_t)slab);
+    if (rc != NBX_OK) return rc;
+    {
+        ProfScope ps(e, NBX_K_BH_EVAL);
+        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->flat.size(), theta, e->force_mode,
+                                    e->d_f2, e->stream));
+    }
+    {
+        ProfScope ps(e, NBX_K_INTEGRATE);
+        HIP_TRY(nbx::launch_integrate_f2(e->d_posm, e->lo, slab, e->d_vel, e->d_f2, dt, e->force_mode == 0 ? 1 : 0, 1,
+                                         e->stream));
+    }
+    e->host_pos_valid = false;
+    e->host_vel_valid = false;
+    return NBX_OK;
+}
+
+void free_device(nbx_engine* e)
+{
+    if (!e->dev_ready) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& r : e->prof) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    e->prof.clear();
+    if (e->d_posm && !e->posm_external) (void)hipFree(e->d_posm);
+    if (e->d_vel) (void)hipFree(e->d_vel);
+    if (e->d_acc) (void)hipFree(e->d_acc);
+    if (e->d_f2) (void)hipFree(e->d_f2);
+    if (e->d_out4) (void)hipFree(e->d_out4);
+    if (e->d_nodes) (void)hipFree(e->d_nodes);
+    if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
+}
+
+uint64_t entropy_seed()
+{
+    std::random_device rd;
+    return ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+}
+
+void after_host_state_change(nbx_engine* e)
+{
+    e->n = e->host.n();
+    compute_slab(e);
+    e->host_pos_valid = e->host_vel_valid = true;
+    e->dev_valid = false;
+    e->any_z = false;
+    for (int i = 0; i < e->n && !e->any_z; i++)
+        if (e->host.pz[i] != 0.0f || e->host.vz[i] != 0.0f) e->any_z = true;
+}
+
+}  // namespace
+
+// =============================================================================================
+// Level 2
+// =============================================================================================
+extern "C" {
+
+const char* nbx_last_error(void) { return g_last_error.c_str(); }
+const char* nbx_version(void) { return "nbody_mi355x 0.1 (gfx950)"; }
+
+int32_t nbx_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
+}
+
+int32_t nbx_device_info_get(int32_t device, nbx_device_info* out)
+{
+    if (!out) return fail(NBX_ERR_INVALID, "null out");
+    if (device < 0 || device >= nbx_device_count()) return fail(NBX_ERR_NO_DEVICE, "no such device %d", device);
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    std::memset(out, 0, sizeof *out);
+    std::snprintf(out->name, sizeof out->name, "%s", p.name);
+    std::snprintf(out->arch, sizeof out->arch, "%s", p.gcnArchName);
+    out->compute_units = p.multiProcessorCount;
+    out->clock_khz = p.clockRate;
+    out->wavefront_size = p.warpSize;
+    out->lds_bytes_per_cu = (int32_t)p.maxSharedMemoryPerMultiProcessor;
+    out->peak_fp32_flops = (double)p.multiProcessorCount * (double)p.clockRate * 1e3 * 256.0;
+    out->hbm_bytes = (uint64_t)p.totalGlobalMem;
+    return NBX_OK;
+}
+
+int32_t nbx_create(nbx_engine** out, int32_t device)
+{
+    if (!out) return fail(NBX_ERR_INVALID, "null out");
+    nbx_engine* e = new (std::nothrow) nbx_engine();
+    if (!e) return fail(NBX_ERR_ALLOC, "out of memory");
+    e->device = device;
+    *out = e;
+    return NBX_OK;
+}
+
+void nbx_destroy(nbx_engine* e)
+{
+    if (!e) return;
+    free_device(e);
+    delete e;
+}
+
+int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    switch (option) {
+        case NBX_OPT_FORCE_MODE:
+            if (value != 0 && value != 1) return fail(NBX_ERR_INVALID, "force mode must be 0 (fast) or 1 (strict)");
+            e->force_mode = (int)value;
+            return NBX_OK;
+        case NBX_OPT_JSPLIT:
+            if (value < 0 || value > 4096) return fail(NBX_ERR_INVALID, "jsplit out of range");
+            e->jsplit = (int)value;
+            return NBX_OK;
+        case NBX_OPT_BODIES_PER_THREAD:
+            if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NBX_ERR_INVALID, "bodies/thread must be 0,1,2,4");
+            e->bpt = (int)value;
+            return NBX_OK;
+        case NBX_OPT_DIM:
+            if (value != 0 && value != 2 && value != 3) return fail(NBX_ERR_INVALID, "dim must be 0,2,3");
+            e->dim_opt = (int)value;
+            return NBX_OK;
+        case NBX_OPT_PROFILE:
+            e->profile = value ? 1 : 0;
+            return NBX_OK;
+        case NBX_OPT_KERNEL_VARIANT:
+            e->variant = (int)value;
+            return NBX_OK;
+        case NBX_OPT_BH_LEAF_CAP:
+            return NBX_OK;
+        default:
+            return fail(NBX_ERR_INVALID, "unknown option %d", option);
+    }
+}
+
+int64_t nbx_get_option(const nbx_engine* e, int32_t option)
+{
+    if (!e) return NBX_ERR_INVALID;
+    switch (option) {
+        case NBX_OPT_FORCE_MODE: return e->force_mode;
+        case NBX_OPT_JSPLIT: return e->jsplit;
+        case NBX_OPT_BODIES_PER_THREAD: return e->bpt;
+        case NBX_OPT_DIM: return e->dim_opt;
+        case NBX_OPT_PROFILE: return e->profile;
+        case NBX_OPT_KERNEL_VARIANT: return e->variant;
+        default: return NBX_ERR_INVALID;
+    }
+}
+
+int32_t nbx_seed(nbx_engine* e, uint64_t seed)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    e->rng.s = seed;
+    e->seeded = true;
+    return NBX_OK;
+}
+
+static void ensure_seed(nbx_engine* e)
+{
+    if (e->seeded) return;
+    const char* env = std::getenv("NB_SEED");
+    e->rng.s = env ? std::strtoull(env, nullptr, 0) : entropy_seed();
+    e->seeded = true;
+}
+
+int32_t nbx_random_disk(nbx_engine* e, int32_t n)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    ensure_seed(e);
+    nbx::preset_random_disk(e->host, n, e->rng);
+    after_host_state_change(e);
+    return NBX_OK;
+}
+
+int32_t nbx_stable_orbits(nbx_engine* e, int32_t n, float rmin, float rmax)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    ensure_seed(e);
+    nbx::preset_stable_orbits(e->host, n, rmin, rmax, e->rng);
+    after_host_state_change(e);
+    return NBX_OK;
+}
+
+int32_t nbx_num_particles(const nbx_engine* e) { return e ? e->n : NBX_ERR_INVALID; }
+
+int32_t nbx_set_particles3(nbx_engine* e, int32_t n, const float* px, const float* py, const float* pz, const float* vx,
+                           const float* vy, const float* vz, const float* m)
+{
+    if (!e || n < 0) return fail(NBX_ERR_INVALID, "bad engine or n");
+    if (n > 0 && (!px || !py || !vx || !vy || !m)) return fail(NBX_ERR_INVALID, "null input array");
+    e->host.resize(n);
+    for (int i = 0; i < n; i++) {
+        e->host.px[i] = px[i]; e->host.py[i] = py[i]; e->host.pz[i] = pz ? pz[i] : 0.0f;
+        e->host.vx[i] = vx[i]; e->host.vy[i] = vy[i]; e->host.vz[i] = vz ? vz[i] : 0.0f;
+        e->host.m[i] = m[i];
+    }
+    after_host_state_change(e);
+    return NBX_OK;
+}
+
+int32_t nbx_set_particles(nbx_engine* e, int32_t n, const float* px, const float* py, const float* vx, const float* vy,
+                          const float* m)
+{
+    return nbx_set_particles3(e, n, px, py, nullptr, vx, vy, nullptr, m);
+}
+
+int32_t nbx_get_particles3(nbx_engine* e, int32_t cap, float* px, float* py, float* pz, float* vx, float* vy, float* vz,
+                           float* m)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    if (cap < e->n) return fail(NBX_ERR_INVALID, "capacity %d < particle count %d", cap, e->n);
+    int rc = download_positions(e);
+    if (rc != NBX_OK) return rc;
+    rc = download_velocities(e);
+    if (rc != NBX_OK) return rc;
+    const size_t bytes = sizeof(float) * (size_t)e->n;
+    if (px) std::memcpy(px, e->host.px.data(), bytes);
+    if (py) std::memcpy(py, e->host.py.data(), bytes);
+    if (pz) std::memcpy(pz, e->host.pz.data(), bytes);
+    if (vx) std::memcpy(vx, e->host.vx.data(), bytes);
+    if (vy) std::memcpy(vy, e->host.vy.data(), bytes);
+    if (vz) std::memcpy(vz, e->host.vz.data(), bytes);
+    if (m) std::memcpy(m, e->host.m.data(), bytes);
+    return e->n;
+}
+
+int32_t nbx_get_particles(nbx_engine* e, int32_t cap, float* px, float* py, float* vx, float* vy, float* m)
+{
+    return nbx_get_particles3(e, cap, px, py, nullptr, vx, vy, nullptr, m);
+}
+
+int32_t nbx_step_brute_force(nbx_engine* e, float dt)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    return step_brute(e, dt);
+}
+
+int32_t nbx_step_barnes_hut(nbx_engine* e, float theta, float dt, int32_t nthreads)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    if (theta == 0.0f) return step_brute(e, dt);  // nbody.rs:197-200 (exact compare, before anything else)
+    if (nthreads <= 0) return fail(NBX_ERR_INVALID, "nthreads must be >= 1 (the reference divides by it, nbody.rs:426)");
+    return step_bh(e, theta, dt);
+}
+
+int32_t nbx_step_local(nbx_engine* e, float dt)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    return step_brute(e, dt);
+}
+
+int32_t nbx_synchronize(nbx_engine* e)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    if (!e->dev_ready) return NBX_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return NBX_OK;
+}
+
+int32_t nbx_forces(nbx_engine* e, float theta, int32_t cap, float* fx, float* fy, float* fz)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    int rc = upload(e);
+    if (rc != NBX_OK) return rc;
+    const int slab = e->slab();
+    if (cap < slab) return fail(NBX_ERR_INVALID, "capacity %d < slab %d", cap, slab);
+    if (slab == 0) return 0;
+    if (theta == 0.0f && e->force_mode == 0) {
+        rc = launch_forces_fast(e);
+        if (rc != NBX_OK) return rc;
+        rc = grow(&e->d_out4, &e->out4_cap, (size_t)slab);
+        if (rc != NBX_OK) return rc;
+        const int stride = ((slab + kTile - 1) / kTile) * kTile;
+        HIP_TRY(nbx::launch_reduce_forces(e->d_posm, e->lo, slab, e->d_acc, e->last.jsplit, stride, e->d_out4, e->stream));
+        std::vector<float4> tmp((size_t)slab);
+        HIP_TRY(hipMemcpyAsync(tmp.data(), e->d_out4, sizeof(float4) * (size_t)slab, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int i = 0; i < slab; i++) {
+            if (fx) fx[i] = tmp[i].x;
+            if (fy) fy[i] = tmp[i].y;
+            if (fz) fz[i] = tmp[i].z;
+        }
+        return slab;
+    }
+    rc = grow(&e->d_f2, &e->f2_cap, (size_t)slab);
+    if (rc != NBX_OK) return rc;
+    bool is_accel = false;
+    if (theta == 0.0f) {
+        ProfScope ps(e, NBX_K_FORCE);
+        HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream));
+    } else {
+        rc = build_and_upload_tree(e);
+        if (rc != NBX_OK) return rc;
+        ProfScope ps(e, NBX_K_BH_EVAL);
+        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->flat.size(), theta, e->force_mode,
+                                    e->d_f2, e->stream));
+        is_accel = e->force_mode == 0;
+    }
+    std::vector<float2> tmp((size_t)slab);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), e->d_f2, sizeof(float2) * (size_t)slab, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < slab; i++) {
+        const float mi = is_accel ? e->host.m[e->lo + i] : 1.0f;
+        if (fx) fx[i] = is_accel ? mi * tmp[i].x : tmp[i].x;
+        if (fy) fy[i] = is_accel ? mi * tmp[i].y : tmp[i].y;
+        if (fz) fz[i] = 0.0f;
+    }
+    return slab;
+}
+
+int32_t nbx_draw(nbx_engine* e, int32_t w, int32_t h, uint32_t* fb)
+{
+    if (!e || !fb || w <= 0 || h <= 0) return fail(NBX_ERR_INVALID, "bad draw arguments");
+    int rc = download_positions(e);
+    if (rc != NBX_OK) return rc;
+    rc = download_velocities(e);
+    if (rc != NBX_OK) return rc;
+    nbx::draw_particles(e->host.px.data(), e->host.py.data(), e->host.vx.data(), e->host.vy.data(), e->n, w, h, fb);
+    return NBX_OK;
+}
+
+int32_t nbx_bh_tree_dump(nbx_engine* e, float* rows, int32_t cap)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    int rc = download_positions(e);
+    if (rc != NBX_OK) return rc;
+    rc = e->tree.build(e->host.px.data(), e->host.py.data(), e->host.m.data(), e->n);
+    if (rc != NBX_OK) return fail(rc, "quadtree build failed (%d)", rc);
+    return e->tree.dump_preorder(rows, cap);
+}
+
+int32_t nbx_set_shard(nbx_engine* e, int32_t rank, int32_t world)
+{
+    if (!e || world < 1 || rank < 0 || rank >= world) return fail(NBX_ERR_INVALID, "bad shard %d/%d", rank, world);
+    if (e->dev_valid) return fail(NBX_ERR_STATE, "set the shard before the state is uploaded");
+    e->rank = rank;
+    e->world = world;
+    compute_slab(e);
+    return NBX_OK;
+}
+
+int32_t nbx_get_slab(const nbx_engine* e, int32_t* lo, int32_t* hi)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    if (lo) *lo = e->lo;
+    if (hi) *hi = e->hi;
+    return NBX_OK;
+}
+
+size_t nbx_positions_bytes(const nbx_engine* e)
+{
+    if (!e) return 0;
+    int n_pad = ((e->n + kTile - 1) / kTile) * kTile;
+    if (n_pad == 0) n_pad = kTile;
+    return sizeof(float4) * (size_t)n_pad;
+}
+
+int32_t nbx_bind_positions(nbx_engine* e, void* device_ptr, size_t bytes)
+{
+    if (!e || !device_ptr) return fail(NBX_ERR_INVALID, "null argument");
+    if (bytes < nbx_positions_bytes(e)) return fail(NBX_ERR_INVALID, "buffer too small: %zu < %zu", bytes, nbx_positions_bytes(e));
+    int rc = ensure_device(e);
+    if (rc != NBX_OK) return rc;
+    rc = download_positions(e);   // keep whatever the device currently holds
+    if (rc != NBX_OK) return rc;
+    rc = download_velocities(e);
+    if (rc != NBX_OK) return rc;
+    if (e->d_posm && !e->posm_external) HIP_TRY(hipFree(e->d_posm));
+    e->d_posm = static_cast<float4*>(device_ptr);
+    e->posm_external = true;
+    e->posm_cap = bytes / sizeof(float4);
+    e->dev_valid = false;
+    return upload(e);
+}
+
+void* nbx_positions_device(nbx_engine* e)
+{
+    if (!e) return nullptr;
+    if (upload(e) != NBX_OK) return nullptr;
+    return e->d_posm;
+}
+
+int32_t nbx_set_stream(nbx_engine* e, void* hip_stream)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    int rc = ensure_device(e);
+    if (rc != NBX_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->own_stream && e->stream) HIP_TRY(hipStreamDestroy(e->stream));
+    e->stream = static_cast<hipStream_t>(hip_stream);
+    e->own_stream = false;
+    return NBX_OK;
+}
+
+int32_t nbx_profile_reset(nbx_engine* e)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    if (e->dev_ready) {
+        HIP_TRY(hipSetDevice(e->device));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    for (auto& r : e->prof) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    e->prof.clear();
+    return NBX_OK;
+}
+
+int32_t nbx_profile_read(nbx_engine* e, int32_t kernel_id, double* total_ms, int32_t* launches)
+{
+    if (!e || kernel_id < 0 || kernel_id >= NBX_K_COUNT) return fail(NBX_ERR_INVALID, "bad kernel id");
+    double total = 0.0;
+    int count = 0;
+    if (e->dev_ready) {
+        HIP_TRY(hipSetDevice(e->device));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (auto& r : e->prof) {
+            if (r.kernel != kernel_id) continue;
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
+            total += ms;
+            count++;
+        }
+    }
+    if (total_ms) *total_ms = total;
+    if (launches) *launches = count;
+    return NBX_OK;
+}
+
+int32_t nbx_last_launch(const nbx_engine* e, int32_t* grid, int32_t* block, int32_t* jsplit, int32_t* bodies_per_thread,
+                        int32_t* dim)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    if (grid) *grid = e->last.grid;
+    if (block) *block = e->last.block;
+    if (jsplit) *jsplit = e->last.jsplit;
+    if (bodies_per_thread) *bodies_per_thread = e->last.bpt;
+    if (dim) *dim = e->last.dim;
+    return NBX_OK;
+}
+
+// =============================================================================================
+// Level 1: the reference's six symbols on a process-global engine
+// =============================================================================================
+
+static std::mutex g_mutex;           // PARTICLES: Mutex<..> (nbody.rs:28-32)
+static nbx_engine* g_engine = nullptr;
+
+static nbx_engine* global_engine()
+{
+    if (!g_engine) {
+        const char* dev = std::getenv("NB_DEVICE");
+        if (nbx_create(&g_engine, dev ? std::atoi(dev) : 0) != NBX_OK) {
+            std::fprintf(stderr, "nbody_mi355x: cannot create engine: %s\n", nbx_last_error());
+            std::abort();
+        }
+        const char* mode = std::getenv("NB_FORCE_MODE");
+        if (mode && std::strcmp(mode, "strict") == 0) g_engine->force_mode = 1;
+    }
+    return g_engine;
+}
+
+[[noreturn]] static void die(const char* where)
+{
+    // the reference panics (and poisons its mutex) on failure; across the C ABI that is an abort
+    std::fprintf(stderr, "nbody_mi355x: fatal in %s: %s\n", where, nbx_last_error());
+    std::abort();
+}
+
+int32_t nb_num_particles(void)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    return nbx_num_particles(global_engine());
+}
+
+void nb_random_disk(int32_t num_particles)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (nbx_random_disk(global_engine(), num_particles) != NBX_OK) die("nb_random_disk");
+}
+
+void nb_stable_orbits(int32_t num_particles, float rmin, float rmax)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (nbx_stable_orbits(global_engine(), num_particles, rmin, rmax) != NBX_OK) die("nb_stable_orbits");
+}
+
+void nb_step_brute_force(float dt)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    nbx_engine* e = global_engine();
+    if (nbx_step_brute_force(e, dt) != NBX_OK || nbx_synchronize(e) != NBX_OK) die("nb_step_brute_force");
+}
+
+void nb_step_barnes_hut(float theta, float dt, int32_t nthreads)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    nbx_engine* e = global_engine();
+    if (theta != 0.0f && nthreads <= 0) return;  // reference: integer division by zero panic; here a no-op
+    if (nbx_step_barnes_hut(e, theta, dt, nthreads) != NBX_OK || nbx_synchronize(e) != NBX_OK) die("nb_step_barnes_hut");
+}
+
+void nb_draw(int32_t w, int32_t h, uint32_t* fb)
+{
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (w <= 0 || h <= 0 || !fb) return;
+    if (nbx_draw(global_engine(), w, h, fb) != NBX_OK) die("nb_draw");
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+// force_tile.hip -- K1 (all-pairs force tiles) and K2 (reduce + kick-drift) for gfx950 / MI355X.
+//
+// Replaces the hot loop of the reference: nbody.rs:132-144 (for i, for j != i: force()) with
+// force() = nbody.rs:164-184, and the integrator nbody.rs:153-160.
+//
+// Law (reference, NOT Newton): F_ij = m_i m_j d / (|d|^2 + EPS), d = p_j - p_i  (magnitude ~ 1/r).
+// The fast kernels factor m_i out and accumulate the acceleration a_i = sum_j m_j d /(|d|^2+EPS):
+//   d    = p_j - p_i                      3 v_sub            (2 in 2-D)
+//   r2   = fma(dz,dz,fma(dy,dy,fma(dx,dx,EPS)))  3 v_fma     (2)
+//   inv  = v_rcp_f32(r2)                  1 transcendental   (1 ulp; r2 >= EPS > 0 always)
+//   s    = m_j * inv                      1 v_mul
+//   a   += s * d                          3 v_fma            (2)
+// = 11 VALU issues / interaction (8 in 2-D) = 17 algorithmic flops (12), SURVEY.md section 8(d).
+// The self term (and any coincident body) contributes s*0 = exactly 0, as in the reference where
+// f*dx = 0; zero-mass padding sources contribute 0*d = 0.  So no index test in the inner loop.
+//
+// Mapping: one workgroup = 256 threads = 4 wave64; each thread owns B target bodies in registers
+// (B*256 per workgroup); the source range of the launch is cut in `jsplit` contiguous tile ranges;
+// workgroup w handles (target block w / jsplit, source range w % jsplit).  Workgroups are
+// dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), so with jsplit a multiple or
+// divisor of 8 every XCD's private L2 only ever sees its own 1/jsplit of the source array.
+// Sources stream HBM/L2 -> VGPR (one coalesced 16-B float4 load per lane per tile, issued one tile
+// ahead) -> LDS (double buffered, ONE barrier per tile) -> broadcast ds_read_b128 (all lanes read
+// the same address: conflict-free, 4 LDS cycles per wave-instruction).
+#include "kernels.h"
+
+namespace nbx {
+
+template <int DIM>
+__device__ __forceinline__ void interact(const float4 sj, const float xi, const float yi, const float zi,
+                                         float& ax, float& ay, float& az)
+{
+    const float dx = sj.x - xi;
+    const float dy = sj.y - yi;
+    float r2 = __builtin_fmaf(dx, dx, kEps);
+    r2 = __builtin_fmaf(dy, dy, r2);
+    float dz = 0.0f;
+    if (DIM == 3) {
+        dz = sj.z - zi;
+        r2 = __builtin_fmaf(dz, dz, r2);
+    }
+    const float s = sj.w * __builtin_amdgcn_rcpf(r2);
+    ax = __builtin_fmaf(s, dx, ax);
+    ay = __builtin_fmaf(s, dy, ay);
+    if (DIM == 3) az = __builtin_fmaf(s, dz, az);
+}
+
+// variant 0: LDS tiles. B bodies per thread, UNROLL sources per inner-loop trip.
+template <int B, int DIM, int UNROLL>
+__global__ __launch_bounds__(kTile) void k_force_tile(const float4* __restrict__ posm, const int lo,
+                                                      const int n_targets, const int tiles_total,
+                                                      const int jsplit, float4* __restrict__ acc_partial,
+                                                      const int acc_stride)
+{
+    __shared__ float4 tile[2][kTile];
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x % jsplit;
+    const int iblk = blockIdx.x / jsplit;
+    const int t0 = (int)(((long long)tiles_total * split) / jsplit);
+    const int t1 = (int)(((long long)tiles_total * (split + 1)) / jsplit);
+
+    float xi[B], yi[B], zi[B], ax[B], ay[B], az[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int i = iblk * (kTile * B) + b * kTile + tid;
+        i = i < n_targets ? i : n_targets - 1;  // clamp: tail threads compute a duplicate, never store
+        const float4 p = posm[lo + i];
+        xi[b] = p.x; yi[b] = p.y; zi[b] = p.z;
+        ax[b] = 0.0f; ay[b] = 0.0f; az[b] = 0.0f;
+    }
+
+    float4 nxt = posm[(size_t)t0 * kTile + tid];
+    int buf = 0;
+    for (int t = t0; t < t1; t++) {
+        tile[buf][tid] = nxt;
+        __syncthreads();
+        if (t + 1 < t1) nxt = posm[(size_t)(t + 1) * kTile + tid];  // in flight during the tile's math
+#pragma unroll UNROLL
+        for (int k = 0; k < kTile; k++) {
+            const float4 sj = tile[buf][k];
+#pragma unroll
+            for (int b = 0; b < B; b++) interact<DIM>(sj, xi[b], yi[b], zi[b], ax[b], ay[b], az[b]);
+        }
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        const int i = iblk * (kTile * B) + b * kTile + tid;
+        if (i < n_targets) acc_partial[(size_t)split * acc_stride + i] = make_float4(ax[b], ay[b], az[b], 0.0f);
+    }
+}
+
+// variant 2: no LDS. The source index is wave-uniform, so the compiler fetches sources through
+// the scalar cache (s_load_dwordx4..x16 into SGPRs) and feeds them to the VALU as scalar operands.
+template <int B, int DIM, int UNROLL>
+__global__ __launch_bounds__(kTile) void k_force_smem(const float4* __restrict__ posm, const int lo,
+                                                      const int n_targets, const int tiles_total,
+                                                      const int jsplit, float4* __restrict__ acc_partial,
+                                                      const int acc_stride)
+{
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x % jsplit;
+    const int iblk = blockIdx.x / jsplit;
+    const int j0 = (int)(((long long)tiles_total * split) / jsplit) * kTile;
+    const int j1 = (int)(((long long)tiles_total * (split + 1)) / jsplit) * kTile;
+
+    float xi[B], yi[B], zi[B], ax[B], ay[B], az[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        int i = iblk * (kTile * B) + b * kTile + tid;
+        i = i < n_targets ? i : n_targets - 1;
+        const float4 p = posm[lo + i];
+        xi[b] = p.x; yi[b] = p.y; zi[b] = p.z;
+        ax[b] = 0.0f; ay[b] = 0.0f; az[b] = 0.0f;
+    }
+#pragma unroll UNROLL
+    for (int j = j0; j < j1; j++) {
+        const float4 sj = posm[j];
+#pragma unroll
+        for (int b = 0; b < B; b++) interact<DIM>(sj, xi[b], yi[b], zi[b], ax[b], ay[b], az[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        const int i = iblk * (kTile * B) + b * kTile + tid;
+        if (i < n_targets) acc_partial[(size_t)split * acc_stride + i] = make_float4(ax[b], ay[b], az[b], 0.0f);
+    }
+}
+
+// K2: a_i = sum over splits in FIXED ascending order (deterministic), then the reference's
+// kick-drift (nbody.rs:153-160) with F/m == a:  v += dt*a ; p += dt*v_new.  Products and sums are
+// kept unfused (mul then add, as rustc emits them).
+__global__ __launch_bounds__(kTile) void k_integrate(float4* __restrict__ posm, const int lo, const int n_targets,
+                                                     float4* __restrict__ vel,
+                                                     const float4* __restrict__ acc_partial, const int jsplit,
+                                                     const int acc_stride, const float dt)
+{
+    const int i = blockIdx.x * kTile + threadIdx.x;
+    if (i >= n_targets) return;
+    float4 a = acc_partial[i];
+    for (int s = 1; s < jsplit; s++) {
+        const float4 q = acc_partial[(size_t)s * acc_stride + i];
+        a.x += q.x; a.y += q.y; a.z += q.z;
+    }
+    float4 v = vel[i];
+    float4 p = posm[lo + i];
+    v.x = __fadd_rn(v.x, __fmul_rn(dt, a.x));
+    v.y = __fadd_rn(v.y, __fmul_rn(dt, a.y));
+    v.z = __fadd_rn(v.z, __fmul_rn(dt, a.z));
+    p.x = __fadd_rn(p.x, __fmul_rn(dt, v.x));
+    p.y = __fadd_rn(p.y, __fmul_rn(dt, v.y));
+    p.z = __fadd_rn(p.z, __fmul_rn(dt, v.z));
+    vel[i] = v;
+    posm[lo + i] = p;
+}
+
+__global__ __launch_bounds__(kTile) void k_reduce_forces(const float4* __restrict__ posm, const int lo,
+                                                         const int n_targets,
+                                                         const float4* __restrict__ acc_partial, const int jsplit,
+                                                         const int acc_stride, float4* __restrict__ out)
+{
+    const int i = blockIdx.x * kTile + threadIdx.x;
+    if (i >= n_targets) return;
+    float4 a = acc_partial[i];
+    for (int s = 1; s < jsplit; s++) {
+        const float4 q = acc_partial[(size_t)s * acc_stride + i];
+        a.x += q.x; a.y += q.y; a.z += q.z;
+    }
+    const float m = posm[lo + i].w;
+    out[i] = make_float4(m * a.x, m * a.y, m * a.z, 0.0f);
+}
+
+template <int B, int DIM>
+static hipError_t launch_variant(int variant, dim3 grid, hipStream_t stream, const float4* posm, int lo,
+                                 int n_targets, int tiles_total, int jsplit, float4* acc_partial, int acc_stride)
+{
+    if (variant == 2)
+        hipLaunchKernelGGL((k_force_smem<B, DIM, 8>), grid, dim3(kTile), 0, stream, posm, lo, n_targets, tiles_total,
+                           jsplit, acc_partial, acc_stride);
+    else
+        hipLaunchKernelGGL((k_force_tile<B, DIM, 16>), grid, dim3(kTile), 0, stream, posm, lo, n_targets,
+                           tiles_total, jsplit, acc_partial, acc_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tiles_total, int jsplit, int bpt, int dim,
+                             int variant, float4* acc_partial, int acc_stride, hipStream_t stream, ForceLaunch* info)
+{
+    if (n_targets <= 0 || tiles_total <= 0) return hipSuccess;
+    if (jsplit < 1) jsplit = 1;
+    if (jsplit > tiles_total) jsplit = tiles_total;
+    const int iblocks = (n_targets + kTile * bpt - 1) / (kTile * bpt);
+    const dim3 grid((unsigned)(iblocks * jsplit));
+    if (info) *info = ForceLaunch{(int)grid.x, kTile, jsplit, bpt, dim, variant};
+#define NBX_DISPATCH(BB, DD) \
+    return launch_variant<BB, DD>(variant, grid, stream, posm, lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride)
+    if (dim == 3) {
+        if (bpt == 1) NBX_DISPATCH(1, 3);
+        if (bpt == 2) NBX_DISPATCH(2, 3);
+        if (bpt == 4) NBX_DISPATCH(4, 3);
+    } else {
+        if (bpt == 1) NBX_DISPATCH(1, 2);
+        if (bpt == 2) NBX_DISPATCH(2, 2);
+        if (bpt == 4) NBX_DISPATCH(4, 2);
+    }
+#undef NBX_DISPATCH
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_integrate(float4* posm, int lo, int n_targets, float4* vel, const float4* acc_partial, int jsplit,
+                            int acc_stride, float dt, hipStream_t stream)
+{
+    if (n_targets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_integrate, dim3((n_targets + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, lo, n_targets,
+                       vel, acc_partial, jsplit, acc_stride, dt);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_forces(const float4* posm, int lo, int n_targets, const float4* acc_partial, int jsplit,
+                                int acc_stride, float4* out, hipStream_t stream)
+{
+    if (n_targets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_reduce_forces, dim3((n_targets + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, lo,
+                       n_targets, acc_partial, jsplit, acc_stride, out);
+    return hipGetLastError();
+}
+
+}  // namespace nbx

@@ -1,0 +1,306 @@
+// host_ops.cpp -- presets, framebuffer splat and Barnes-Hut quadtree build on the host.
+// COMPILED WITH -ffp-contract=off: the tree's centre-of-mass update and the draw transform must
+// round exactly like the reference (rustc never contracts a*b+c).
+#include "host_ops.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "../../include/nbody_mi355x.h"
+
+namespace nbx {
+
+static constexpr float VP_WDH = 100.0f;   // nbody.rs:13
+static constexpr float VP_ORG_X = 0.0f;   // nbody.rs:14
+static constexpr float VP_ORG_Y = 0.0f;   // nbody.rs:15
+static constexpr float PI_F32 = 3.14159274f;  // std::f32::consts::PI
+
+void HostState::resize(int n)
+{
+    px.resize(n); py.resize(n); pz.resize(n); vx.resize(n); vy.resize(n); vz.resize(n); m.resize(n);
+}
+
+float Rng::next_f32()
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// ---- presets ---------------------------------------------------------------------------------
+
+void preset_random_disk(HostState& st, int n, Rng& rng)
+{
+    st.resize(n > 0 ? n : 0);
+    for (int i = 0; i < n; i++) {
+        const float u0 = rng.range(0.0f, 1.0f);            // nbody.rs:52
+        const float u1 = rng.range(0.0f, 1.0f);            // :53
+        const float r = std::sqrt(u0);                     // :67  uniform_sample_disk
+        const float theta = 2.0f * PI_F32 * u1;            // :68
+        st.px[i] = (r * std::cos(theta)) * 23.0f;          // :69, :55
+        st.py[i] = (r * std::sin(theta)) * 23.0f;          // :70, :56
+        st.pz[i] = 0.0f;
+        st.vx[i] = rng.range(-3.5f, 3.5f);                 // :60
+        st.vy[i] = rng.range(-3.5f, 3.5f);                 // :61
+        st.vz[i] = 0.0f;
+        st.m[i] = rng.range(0.1f, 1.5f);                   // :62
+    }
+}
+
+void preset_stable_orbits(HostState& st, int n, float rmin, float rmax, Rng& rng)
+{
+    const int total = n > 1 ? n : 1;                       // the sun is always pushed (:93), then 0..n-1 planets
+    st.resize(total);
+    const float sun_mass = 1000.0f, planet_mass = 1.0f, g = 1.0f;
+    const float speed = std::sqrt(g * sun_mass);           // :88
+    st.px[0] = st.py[0] = st.pz[0] = st.vx[0] = st.vy[0] = st.vz[0] = 0.0f;
+    st.m[0] = sun_mass;
+    for (int i = 1; i < total; i++) {
+        const float r = (rmax - rmin) * rng.range(0.0f, 1.0f) + rmin;   // :96
+        const float theta = 2.0f * PI_F32 * rng.range(0.0f, 1.0f);      // :97
+        const float c = std::cos(theta), s = std::sin(theta);
+        st.px[i] = r * c;                                  // :98
+        st.py[i] = r * s;                                  // :99
+        st.pz[i] = 0.0f;
+        st.vx[i] = -speed * s;                             // :100
+        st.vy[i] = speed * c;                              // :101
+        st.vz[i] = 0.0f;
+        st.m[i] = planet_mass;                             // :102
+    }
+}
+
+// ---- draw ------------------------------------------------------------------------------------
+
+namespace {
+
+inline int32_t trunc_i32(float v)   // Rust `as i32`: toward zero, saturating, NaN -> 0
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v;
+}
+
+inline uint32_t scale_channel(uint32_t c8, float factor)   // nbody.rs:587 (r as f32 * factor) as u32, clamped :590
+{
+    const float v = (float)c8 * factor;
+    uint32_t u = (v != v || v <= 0.0f) ? 0u : (v >= 4294967296.0f ? UINT32_MAX : (uint32_t)v);
+    return u > 255u ? 255u : u;
+}
+
+inline uint32_t pack_abgr(uint32_t r8, uint32_t g8, uint32_t b8, float factor)   // nbody.rs:585-593
+{
+    return scale_channel(r8, factor) | (scale_channel(g8, factor) << 8) | (scale_channel(b8, factor) << 16);
+}
+
+inline uint32_t sat_add_abgr(uint32_t a, uint32_t b)   // nbody.rs:595-617, channel by channel
+{
+    uint32_t out = 0;
+    for (int sh = 0; sh < 32; sh += 8) {
+        uint32_t c = ((a >> sh) & 0xFFu) + ((b >> sh) & 0xFFu);
+        out |= (c > 255u ? 255u : c) << sh;
+    }
+    return out;
+}
+
+}  // namespace
+
+void draw_particles(const float* px, const float* py, const float* vx, const float* vy, int n, int32_t w, int32_t h,
+                    uint32_t* fb)
+{
+    static const int8_t step[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+    std::memset(fb, 0, sizeof(uint32_t) * (size_t)w * (size_t)h);           // nbody.rs:490
+    const float aspect = (float)h / (float)w;                                // :494
+    const float vx1 = VP_ORG_X - VP_WDH / 2.0f;                              // :497
+    const float vy1 = (VP_ORG_Y - VP_WDH / 2.0f) * aspect;                   // :498
+    const float vx2 = VP_ORG_X + VP_WDH / 2.0f;
+    const float vy2 = (VP_ORG_Y + VP_WDH / 2.0f) * aspect;
+    const float scalex = (1.0f / (vx2 - vx1)) * (float)w;                    // :505
+    const float scaley = (1.0f / (vy2 - vy1)) * (float)h;                    // :506
+    const uint32_t col_body = pack_abgr(255, 215, 130, 0.3f);                // :520
+    const uint32_t col_tail = pack_abgr(255, 215, 130, 0.25f);               // :521
+    for (int k = 0; k < n; k++) {
+        const int32_t xi = trunc_i32((px[k] - vx1) * scalex);                // :525, :536
+        const int32_t yi = trunc_i32((py[k] - vy1) * scaley);                // :526, :537
+        if (xi >= 0 && xi < w && yi >= 0 && yi < h) {                        // :559
+            uint32_t& px0 = fb[xi + yi * w];
+            px0 = sat_add_abgr(px0, col_body);
+        }
+        const float angle = std::atan2(vy[k], vx[k]);                        // :541
+        const int32_t oct = trunc_i32(8.0f * angle / (2.0f * PI_F32) + 8.0f) % 8;  // :542
+        const int32_t xt = xi - step[oct][0], yt = yi - step[oct][1];        // :553-554
+        if (xt >= 0 && xt < w && yt >= 0 && yt < h) {
+            uint32_t& px1 = fb[xt + yt * w];
+            px1 = sat_add_abgr(px1, col_tail);
+        }
+    }
+    if (w >= 3 && h >= 3) {   // :571-577; the reference writes these unchecked (UB for w,h < 3), guarded here
+        const int32_t cx = w / 2, cy = h / 2;
+        fb[cx + cy * w] = 0x00FF00FFu;
+        fb[cx + 1 + cy * w] = 0x00FF00FFu;
+        fb[cx + (cy + 1) * w] = 0x00FF00FFu;
+        fb[cx - 1 + cy * w] = 0x00FF00FFu;
+        fb[cx + (cy - 1) * w] = 0x00FF00FFu;
+    }
+}
+
+// ---- quadtree --------------------------------------------------------------------------------
+//
+// The reference inserts recursively into a Box-linked tree (nbody.rs:226-284). Here the same
+// decisions run as one iterative descent over an index-linked node pool:
+//   interior  -> add_mass, descend to quadrant_from_point, depth+1                 (:234-240)
+//   exterior, empty or within EPS of the resident -> add_mass (merge)              (:249-260)
+//   exterior, occupied -> split: children created, the resident re-inserted (it lands in an empty
+//             child at depth+2), then the newcomer continues from THIS node at depth+1 (:271-281)
+// Depth accounting follows the reference exactly (insert(..., depth+1) on the same node).
+
+namespace {
+
+inline bool add_mass(QuadTree::Node& nd, float px, float py, float m)   // nbody.rs:303-320
+{
+    if (!(m > 0.0f)) return false;                                       // :304
+    if (nd.m == 0.0f) {                                                  // :305 exact copy
+        nd.px = px; nd.py = py; nd.m = m;
+    } else {
+        const float inv_msum = 1.0f / (nd.m + m);                        // :315
+        nd.px = (nd.px * nd.m + px * m) * inv_msum;                      // :316
+        nd.py = (nd.py * nd.m + py * m) * inv_msum;                      // :317
+        nd.m += m;                                                       // :318
+    }
+    return true;
+}
+
+inline int quadrant(const QuadTree::Node& nd, float x, float y)         // nbody.rs:322-331 -> [UL,UR,LL,LR]
+{
+    const float cx = (nd.x1 + nd.x2) * 0.5f;
+    const float cy = (nd.y1 + nd.y2) * 0.5f;
+    return (y < cy ? 2 : 0) + (x < cx ? 0 : 1);
+}
+
+}  // namespace
+
+int QuadTree::build(const float* px, const float* py, const float* m, int n)
+{
+    const float EPS = kEps;
+    nodes.clear();
+    nodes.reserve((size_t)n * 3 + 8);
+    float x1 = 3.40282347e+38f, y1 = 3.40282347e+38f, x2 = -3.40282347e+38f, y2 = -3.40282347e+38f;  // :388-391
+    for (int i = 0; i < n; i++) {                                         // :392-398 strict < / >
+        x1 = px[i] < x1 ? px[i] : x1;
+        y1 = py[i] < y1 ? py[i] : y1;
+        x2 = px[i] > x2 ? px[i] : x2;
+        y2 = py[i] > y2 ? py[i] : y2;
+    }
+    nodes.push_back(Node{x1, y1, x2, y2, 0.0f, 0.0f, 0.0f, -1});          // :410
+
+    auto split = [&](int k) -> int {                                      // create_children, :286-301
+        const Node nd = nodes[k];
+        const float cx = (nd.x1 + nd.x2) * 0.5f;
+        const float cy = (nd.y1 + nd.y2) * 0.5f;
+        if (!(cx > nd.x1 || cx < nd.x2 || cy > nd.y1 || cy < nd.y2)) return NBX_ERR_TREE;  // :293
+        const int c = (int)nodes.size();
+        nodes.push_back(Node{nd.x1, cy, cx, nd.y2, 0.0f, 0.0f, 0.0f, -1});      // UL :296
+        nodes.push_back(Node{cx, cy, nd.x2, nd.y2, 0.0f, 0.0f, 0.0f, -1});      // UR :297
+        nodes.push_back(Node{nd.x1, nd.y1, cx, cy, 0.0f, 0.0f, 0.0f, -1});      // LL :298
+        nodes.push_back(Node{cx, nd.y1, nd.x2, cy, 0.0f, 0.0f, 0.0f, -1});      // LR :299
+        nodes[k].first_child = c;
+        return NBX_OK;
+    };
+
+    for (int i = 0; i < n; i++) {                                         // :413-415 particle-index order
+        const float qx = px[i], qy = py[i], qm = m[i];
+        int k = 0;
+        unsigned depth = 0;
+        for (;;) {
+            if (depth > 50) return NBX_ERR_TREE_DEPTH;                    // :230
+            if (nodes[k].first_child >= 0) {                              // :234
+                if (!add_mass(nodes[k], qx, qy, qm)) return NBX_ERR_TREE; // :236
+                k = nodes[k].first_child + quadrant(nodes[k], qx, qy);    // :237-240
+                depth += 1;
+                continue;
+            }
+            Node& nd = nodes[k];
+            const bool too_close = std::fabs(nd.px - qx) < EPS && std::fabs(nd.py - qy) < EPS;  // :249
+            if (nd.m == 0.0f || too_close) {                              // :250
+                if (!add_mass(nd, qx, qy, qm)) return NBX_ERR_TREE;       // :260
+                break;
+            }
+            if (!(nd.px != qx || nd.py != qy)) return NBX_ERR_TREE;       // :267
+            const float ox = nd.px, oy = nd.py, om = nd.m;                // :271-273
+            nodes[k].px = 0.0f; nodes[k].py = 0.0f; nodes[k].m = 0.0f;    // :274-276
+            const int rc = split(k);                                      // :277 (invalidates `nd`)
+            if (rc != NBX_OK) return rc;
+            // self.insert(original, depth+1)  :278 -> interior branch: add_mass on the emptied node
+            // (exact copy), then the child at depth+2, which is empty -> exact copy again.
+            if (depth + 1 > 50) return NBX_ERR_TREE_DEPTH;
+            if (!add_mass(nodes[k], ox, oy, om)) return NBX_ERR_TREE;
+            if (depth + 2 > 50) return NBX_ERR_TREE_DEPTH;
+            Node& child = nodes[nodes[k].first_child + quadrant(nodes[k], ox, oy)];
+            if (!add_mass(child, ox, oy, om)) return NBX_ERR_TREE;
+            depth += 1;                                                   // :281 self.insert(new, depth+1)
+        }
+    }
+    return NBX_OK;
+}
+
+int QuadTree::dump_preorder(float* rows, int cap) const
+{
+    if (nodes.empty()) return 0;
+    int count = 0;
+    std::vector<int> stack;
+    stack.push_back(0);
+    while (!stack.empty()) {
+        const int k = stack.back();
+        stack.pop_back();
+        const Node& nd = nodes[k];
+        if (count < cap && rows) {
+            float* o = rows + 8 * (size_t)count;
+            o[0] = nd.x1; o[1] = nd.y1; o[2] = nd.x2; o[3] = nd.y2;
+            o[4] = nd.px; o[5] = nd.py; o[6] = nd.m; o[7] = nd.first_child >= 0 ? 1.0f : 0.0f;
+        }
+        count++;
+        if (nd.first_child >= 0)
+            for (int c = 3; c >= 0; c--) stack.push_back(nd.first_child + c);
+    }
+    return count;
+}
+
+void QuadTree::flatten(std::vector<BhNode>& out) const
+{
+    out.clear();
+    if (nodes.empty()) return;
+    out.reserve(nodes.size());
+    // iterative pre-order; a frame remembers the output slot whose skip pointer is patched when
+    // the subtree has been emitted.
+    struct Frame { int node; int slot; int next_child; };
+    std::vector<Frame> st;
+    auto emit = [&](int k) -> int {
+        const Node& nd = nodes[k];
+        BhNode b;
+        b.px = nd.px; b.py = nd.py; b.m = nd.m; b.s = nd.x2 - nd.x1;   // s = x-extent, nbody.rs:341
+        b.skip = 0; b.interior = nd.first_child >= 0 ? 1 : 0; b.pad0 = 0; b.pad1 = 0;
+        out.push_back(b);
+        return (int)out.size() - 1;
+    };
+    const Node& root = nodes[0];
+    if (root.first_child < 0 && root.m == 0.0f) return;   // empty tree
+    st.push_back(Frame{0, emit(0), 0});
+    while (!st.empty()) {
+        Frame& f = st.back();
+        const Node& nd = nodes[f.node];
+        if (nd.first_child < 0 || f.next_child == 4) {
+            out[f.slot].skip = (int)out.size();
+            st.pop_back();
+            continue;
+        }
+        const int c = nd.first_child + f.next_child++;
+        const Node& ch = nodes[c];
+        if (ch.first_child < 0 && ch.m == 0.0f) continue;   // empty exterior: contributes (0,0), nbody.rs:368
+        const int slot = emit(c);
+        st.push_back(Frame{c, slot, 0});
+    }
+}
+
+}  // namespace nbx

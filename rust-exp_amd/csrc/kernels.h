@@ -1,0 +1,51 @@
+// kernels.h -- launch wrappers of the gfx950 kernels (internal; the public ABI is include/nbody_mi355x.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nbx {
+
+constexpr int kTile = 256;   // sources per LDS tile == threads per workgroup (4 wave64)
+constexpr float kEps = 0.0001f;  // nbody.rs:17
+
+// Flattened Barnes-Hut node (pre-order, skip pointers). 32 bytes, two 16-B loads.
+struct BhNode {
+    float px, py, m, s;      // COM / particle position, mass, x-extent (x2-x1; nbody.rs:341)
+    int32_t skip;            // index of the next node when this subtree is not opened
+    int32_t interior;        // 1 = has children (nbody.rs:338), 0 = exterior (leaf)
+    int32_t pad0, pad1;
+};
+
+struct ForceLaunch {
+    int grid, block, jsplit, bpt, dim, variant;
+};
+
+// K1: all-pairs accelerations for slab targets [lo, lo+n_targets) against tiles_total*kTile sources.
+// acc_partial: [jsplit][acc_stride] float4 (ax, ay, az, unused).
+hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tiles_total, int jsplit, int bpt,
+                             int dim, int variant, float4* acc_partial, int acc_stride, hipStream_t stream,
+                             ForceLaunch* info);
+
+// K2: reduce partials in fixed order, kick-drift, write positions in place (slab slot of posm).
+hipError_t launch_integrate(float4* posm, int lo, int n_targets, float4* vel, const float4* acc_partial,
+                            int jsplit, int acc_stride, float dt, hipStream_t stream);
+
+// forces-only readout: F_i = m_i * a_i into float4 out[n_targets]
+hipError_t launch_reduce_forces(const float4* posm, int lo, int n_targets, const float4* acc_partial, int jsplit,
+                                int acc_stride, float4* out, hipStream_t stream);
+
+// strict (bit-exact) pair: one thread per body, ascending j, IEEE divide, no contraction. 2-D.
+hipError_t launch_force_strict(const float4* posm, int n, int lo, int n_targets, float2* force_out,
+                               hipStream_t stream);
+// kick-drift from a per-body force (v += (dt*F)/m, nbody.rs:155) or acceleration (is_accel: v += dt*a),
+// optional velocity kill box (nbody.rs:466-471).
+hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel, const float2* force, float dt,
+                               int is_accel, int killbox, hipStream_t stream);
+
+// K3: Barnes-Hut traversal. mode 0 = fast (sequential pre-order accumulation, rcp),
+// mode 1 = strict (hierarchical summation order of nbody.rs:354-360 via an explicit frame stack,
+// IEEE sqrt/divide): bit-exact with the reference traversal.
+hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
+                          int mode, float2* force_out, hipStream_t stream);
+
+}  // namespace nbx

@@ -1,0 +1,369 @@
+"""ctypes binding of lib/libnbody_mi355x.so (C ABI: include/nbody_mi355x.h).
+
+Mirrors the reference interface: the six `nb_*` functions keep the names and argument meaning of
+rs-src/nbody.rs:34-35,:39-40,:73-74,:106-107,:186-187,:482-483 (as imported by
+hs-src/RustNBodyExperiment.hs:101-106); `NBodyEngine` wraps the additive handle API.
+No CPU fallback: a missing library raises at import, a missing GPU raises at the first step.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, "csrc")
+_SO = os.path.join(_PKG, "lib", "libnbody_mi355x.so")
+
+NBX_OK = 0
+NBX_ERR_INVALID = -1
+NBX_ERR_NO_DEVICE = -2
+NBX_ERR_HIP = -3
+NBX_ERR_TREE_DEPTH = -4
+NBX_ERR_TREE = -5
+NBX_ERR_ALLOC = -6
+NBX_ERR_STATE = -7
+
+NBX_OPT_FORCE_MODE = 0
+NBX_OPT_JSPLIT = 1
+NBX_OPT_BODIES_PER_THREAD = 2
+NBX_OPT_DIM = 3
+NBX_OPT_PROFILE = 4
+NBX_OPT_KERNEL_VARIANT = 5
+
+NBX_K_FORCE = 0
+NBX_K_INTEGRATE = 1
+NBX_K_BH_EVAL = 2
+
+
+class NBodyError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"nbody_mi355x error {code}: {text}")
+        self.code = code
+
+
+class _DeviceInfo(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 128),
+        ("arch", C.c_char * 64),
+        ("compute_units", C.c_int32),
+        ("clock_khz", C.c_int32),
+        ("wavefront_size", C.c_int32),
+        ("lds_bytes_per_cu", C.c_int32),
+        ("peak_fp32_flops", C.c_double),
+        ("hbm_bytes", C.c_uint64),
+    ]
+
+
+def lib_path():
+    return _SO
+
+
+def build(force=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)] + [
+        os.path.join(_PKG, "..", "include", "nbody_mi355x.h")
+    ]
+    stale = not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        if not any(os.access(os.path.join(p, "hipcc"), os.X_OK) for p in os.environ.get("PATH", "").split(os.pathsep)):
+            if os.path.exists(_SO):
+                return _SO  # GPU box without a compiler on PATH: use the prebuilt library that travelled with the tree
+            raise RuntimeError("hipcc not found and libnbody_mi355x.so is not built")
+        subprocess.check_call(["make", "-C", _CSRC, "-s", "-j8"])
+    return _SO
+
+
+_lib = None
+
+_f32p = C.POINTER(C.c_float)
+
+
+def lib():
+    """Load the library (building it if needed). Raises if it cannot be loaded: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_SO)
+    E = C.c_void_p
+    i32 = C.c_int32
+    # level 1
+    L.nb_num_particles.argtypes = []
+    L.nb_num_particles.restype = i32
+    L.nb_random_disk.argtypes = [i32]
+    L.nb_random_disk.restype = None
+    L.nb_stable_orbits.argtypes = [i32, C.c_float, C.c_float]
+    L.nb_stable_orbits.restype = None
+    L.nb_step_brute_force.argtypes = [C.c_float]
+    L.nb_step_brute_force.restype = None
+    L.nb_step_barnes_hut.argtypes = [C.c_float, C.c_float, i32]
+    L.nb_step_barnes_hut.restype = None
+    L.nb_draw.argtypes = [i32, i32, C.c_void_p]
+    L.nb_draw.restype = None
+    # level 2
+    L.nbx_last_error.restype = C.c_char_p
+    L.nbx_version.restype = C.c_char_p
+    L.nbx_device_count.restype = i32
+    L.nbx_device_info_get.argtypes = [i32, C.POINTER(_DeviceInfo)]
+    L.nbx_device_info_get.restype = i32
+    L.nbx_create.argtypes = [C.POINTER(E), i32]
+    L.nbx_create.restype = i32
+    L.nbx_destroy.argtypes = [E]
+    L.nbx_destroy.restype = None
+    L.nbx_set_option.argtypes = [E, i32, C.c_int64]
+    L.nbx_set_option.restype = i32
+    L.nbx_get_option.argtypes = [E, i32]
+    L.nbx_get_option.restype = C.c_int64
+    L.nbx_seed.argtypes = [E, C.c_uint64]
+    L.nbx_seed.restype = i32
+    L.nbx_random_disk.argtypes = [E, i32]
+    L.nbx_random_disk.restype = i32
+    L.nbx_stable_orbits.argtypes = [E, i32, C.c_float, C.c_float]
+    L.nbx_stable_orbits.restype = i32
+    L.nbx_num_particles.argtypes = [E]
+    L.nbx_num_particles.restype = i32
+    L.nbx_set_particles.argtypes = [E, i32] + [C.c_void_p] * 5
+    L.nbx_set_particles.restype = i32
+    L.nbx_set_particles3.argtypes = [E, i32] + [C.c_void_p] * 7
+    L.nbx_set_particles3.restype = i32
+    L.nbx_get_particles.argtypes = [E, i32] + [C.c_void_p] * 5
+    L.nbx_get_particles.restype = i32
+    L.nbx_get_particles3.argtypes = [E, i32] + [C.c_void_p] * 7
+    L.nbx_get_particles3.restype = i32
+    L.nbx_step_brute_force.argtypes = [E, C.c_float]
+    L.nbx_step_brute_force.restype = i32
+    L.nbx_step_barnes_hut.argtypes = [E, C.c_float, C.c_float, i32]
+    L.nbx_step_barnes_hut.restype = i32
+    L.nbx_step_local.argtypes = [E, C.c_float]
+    L.nbx_step_local.restype = i32
+    L.nbx_synchronize.argtypes = [E]
+    L.nbx_synchronize.restype = i32
+    L.nbx_forces.argtypes = [E, C.c_float, i32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.nbx_forces.restype = i32
+    L.nbx_draw.argtypes = [E, i32, i32, C.c_void_p]
+    L.nbx_draw.restype = i32
+    L.nbx_bh_tree_dump.argtypes = [E, C.c_void_p, i32]
+    L.nbx_bh_tree_dump.restype = i32
+    L.nbx_set_shard.argtypes = [E, i32, i32]
+    L.nbx_set_shard.restype = i32
+    L.nbx_get_slab.argtypes = [E, C.POINTER(i32), C.POINTER(i32)]
+    L.nbx_get_slab.restype = i32
+    L.nbx_bind_positions.argtypes = [E, C.c_void_p, C.c_size_t]
+    L.nbx_bind_positions.restype = i32
+    L.nbx_positions_device.argtypes = [E]
+    L.nbx_positions_device.restype = C.c_void_p
+    L.nbx_positions_bytes.argtypes = [E]
+    L.nbx_positions_bytes.restype = C.c_size_t
+    L.nbx_set_stream.argtypes = [E, C.c_void_p]
+    L.nbx_set_stream.restype = i32
+    L.nbx_profile_reset.argtypes = [E]
+    L.nbx_profile_reset.restype = i32
+    L.nbx_profile_read.argtypes = [E, i32, C.POINTER(C.c_double), C.POINTER(i32)]
+    L.nbx_profile_read.restype = i32
+    L.nbx_last_launch.argtypes = [E] + [C.POINTER(i32)] * 5
+    L.nbx_last_launch.restype = i32
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise NBodyError(rc, lib().nbx_last_error().decode(errors="replace"))
+    return rc
+
+
+def device_count():
+    return int(lib().nbx_device_count())
+
+
+def device_info(device=0):
+    info = _DeviceInfo()
+    _check(lib().nbx_device_info_get(device, C.byref(info)))
+    return {
+        "name": info.name.decode(),
+        "arch": info.arch.decode(),
+        "compute_units": info.compute_units,
+        "clock_khz": info.clock_khz,
+        "wavefront_size": info.wavefront_size,
+        "lds_bytes_per_cu": info.lds_bytes_per_cu,
+        "peak_fp32_flops": info.peak_fp32_flops,
+        "hbm_bytes": info.hbm_bytes,
+    }
+
+
+# ---- level 1: the reference's six symbols (process-global state) -----------------------------
+
+def nb_num_particles():
+    return int(lib().nb_num_particles())
+
+
+def nb_random_disk(num_particles):
+    lib().nb_random_disk(num_particles)
+
+
+def nb_stable_orbits(num_particles, rmin, rmax):
+    lib().nb_stable_orbits(num_particles, rmin, rmax)
+
+
+def nb_step_brute_force(dt):
+    lib().nb_step_brute_force(dt)
+
+
+def nb_step_barnes_hut(theta, dt, nthreads):
+    lib().nb_step_barnes_hut(theta, dt, nthreads)
+
+
+def nb_draw(w, h):
+    fb = np.zeros(w * h, np.uint32)
+    lib().nb_draw(w, h, fb.ctypes.data_as(C.c_void_p))
+    return fb.reshape(h, w)
+
+
+# ---- level 2 ---------------------------------------------------------------------------------
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class NBodyEngine:
+    """Handle-based engine. Method names follow the reference entry points without the nb_ prefix."""
+
+    def __init__(self, device=0, mode="fast"):
+        self._L = lib()
+        h = C.c_void_p()
+        _check(self._L.nbx_create(C.byref(h), device))
+        self._h = h
+        self.set_mode(mode)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nbx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # options
+    def set_option(self, opt, value):
+        _check(self._L.nbx_set_option(self._h, opt, int(value)))
+
+    def set_mode(self, mode):
+        self.set_option(NBX_OPT_FORCE_MODE, {"fast": 0, "strict": 1}[mode])
+
+    def set_launch(self, jsplit=0, bodies_per_thread=0, dim=0, variant=0):
+        self.set_option(NBX_OPT_JSPLIT, jsplit)
+        self.set_option(NBX_OPT_BODIES_PER_THREAD, bodies_per_thread)
+        self.set_option(NBX_OPT_DIM, dim)
+        self.set_option(NBX_OPT_KERNEL_VARIANT, variant)
+
+    # presets (nbody.rs:39-104) with a seedable generator
+    def seed(self, seed):
+        _check(self._L.nbx_seed(self._h, seed))
+
+    def random_disk(self, n):
+        _check(self._L.nbx_random_disk(self._h, n))
+
+    def stable_orbits(self, n, rmin, rmax):
+        _check(self._L.nbx_stable_orbits(self._h, n, rmin, rmax))
+
+    def num_particles(self):
+        return _check(self._L.nbx_num_particles(self._h))
+
+    # state
+    def set_particles(self, px, py, vx, vy, m, pz=None, vz=None):
+        px, py, vx, vy, m = map(_f32, (px, py, vx, vy, m))
+        n = len(px)
+        assert all(len(a) == n for a in (py, vx, vy, m))
+        if pz is None and vz is None:
+            _check(self._L.nbx_set_particles(self._h, n, _p(px), _p(py), _p(vx), _p(vy), _p(m)))
+        else:
+            pz = _f32(np.zeros(n) if pz is None else pz)
+            vz = _f32(np.zeros(n) if vz is None else vz)
+            _check(self._L.nbx_set_particles3(self._h, n, _p(px), _p(py), _p(pz), _p(vx), _p(vy), _p(vz), _p(m)))
+
+    def get_particles(self):
+        n = self.num_particles()
+        out = {k: np.zeros(n, np.float32) for k in ("px", "py", "pz", "vx", "vy", "vz", "m")}
+        _check(self._L.nbx_get_particles3(self._h, n, *[_p(out[k]) for k in ("px", "py", "pz", "vx", "vy", "vz", "m")]))
+        return out
+
+    # steps
+    def step_brute_force(self, dt):
+        _check(self._L.nbx_step_brute_force(self._h, dt))
+
+    def step_barnes_hut(self, theta, dt, nthreads=1):
+        _check(self._L.nbx_step_barnes_hut(self._h, theta, dt, nthreads))
+
+    def step_local(self, dt):
+        _check(self._L.nbx_step_local(self._h, dt))
+
+    def synchronize(self):
+        _check(self._L.nbx_synchronize(self._h))
+
+    def forces(self, theta=0.0):
+        lo, hi = self.slab()
+        fx = np.zeros(hi - lo, np.float32)
+        fy = np.zeros(hi - lo, np.float32)
+        fz = np.zeros(hi - lo, np.float32)
+        _check(self._L.nbx_forces(self._h, theta, hi - lo, _p(fx), _p(fy), _p(fz)))
+        return fx, fy, fz
+
+    def draw(self, w, h):
+        fb = np.zeros(w * h, np.uint32)
+        _check(self._L.nbx_draw(self._h, w, h, _p(fb)))
+        return fb.reshape(h, w)
+
+    def bh_tree_dump(self):
+        cnt = _check(self._L.nbx_bh_tree_dump(self._h, None, 0))
+        rows = np.zeros((max(cnt, 1), 8), np.float32)
+        cnt = _check(self._L.nbx_bh_tree_dump(self._h, _p(rows), cnt))
+        return rows[:cnt]
+
+    # sharding
+    def set_shard(self, rank, world):
+        _check(self._L.nbx_set_shard(self._h, rank, world))
+
+    def slab(self):
+        lo, hi = C.c_int32(), C.c_int32()
+        _check(self._L.nbx_get_slab(self._h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def positions_bytes(self):
+        return int(self._L.nbx_positions_bytes(self._h))
+
+    def bind_positions(self, device_ptr, nbytes):
+        _check(self._L.nbx_bind_positions(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def set_stream(self, hip_stream):
+        _check(self._L.nbx_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    # profiling
+    def profile(self, on=True):
+        self.set_option(NBX_OPT_PROFILE, 1 if on else 0)
+
+    def profile_reset(self):
+        _check(self._L.nbx_profile_reset(self._h))
+
+    def profile_read(self, kernel_id):
+        ms, cnt = C.c_double(), C.c_int32()
+        _check(self._L.nbx_profile_read(self._h, kernel_id, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def last_launch(self):
+        v = [C.c_int32() for _ in range(5)]
+        _check(self._L.nbx_last_launch(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("grid", "block", "jsplit", "bodies_per_thread", "dim"), (x.value for x in v)))

@@ -1,0 +1,222 @@
+"""CPU: the C-ABI library loads, exports every symbol include/nbody_mi355x.h declares, refuses to
+step without a GPU (no CPU fallback), and its host-side pieces (presets, draw, quadtree build)
+agree bit for bit with the oracle.  No device compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_bit_equal, golden, particles_from
+
+HEADER = os.path.join(ROOT, "include", "nbody_mi355x.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nbx?_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_six_reference_symbols():
+    # rs-src/nbody.rs:34-35,:39-40,:73-74,:106-107,:186-187,:482-483 / RustNBodyExperiment.hs:101-106
+    six = {"nb_num_particles", "nb_random_disk", "nb_stable_orbits", "nb_step_brute_force", "nb_step_barnes_hut", "nb_draw"}
+    assert six <= set(declared_symbols())
+
+
+def test_library_exports_every_declared_symbol(rx):
+    L = C.CDLL(rx.lib_path())
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in the header but not exported"
+
+
+def test_library_is_the_hip_build(rx):
+    # the product must be the gfx950 code object, not something else
+    blob = open(rx.lib_path(), "rb").read()
+    assert b"gfx950" in blob
+    assert b"k_force_tile" in blob
+
+
+def test_no_cpu_fallback_without_device(rx):
+    if rx.device_count() > 0:
+        pytest.skip("device present")
+    e = rx.NBodyEngine()
+    e.seed(1)
+    e.stable_orbits(64, 0.5, 30.0)
+    with pytest.raises(rx.NBodyError) as ei:
+        e.step_brute_force(0.01)
+    assert ei.value.code == rx.NBX_ERR_NO_DEVICE
+    with pytest.raises(rx.NBodyError):
+        e.step_barnes_hut(0.5, 0.01, 1)
+    with pytest.raises(rx.NBodyError):
+        e.forces()
+    # state untouched by the refused step
+    st = e.get_particles()
+    assert st["m"][0] == 1000.0
+
+
+def test_product_presets_equal_oracle_presets(rx, ob):
+    e = rx.NBodyEngine()
+    e.seed(7)
+    e.random_disk(257)
+    st = e.get_particles()
+    o = ob.random_disk(257, 7)
+    for k in ("px", "py", "vx", "vy", "m"):
+        assert_bit_equal(st[k], o[k], "disk " + k)
+    assert not st["pz"].any() and not st["vz"].any()
+    e.seed(9)
+    e.stable_orbits(100, 0.5, 30.0)
+    st = e.get_particles()
+    o = ob.stable_orbits(100, 0.5, 30.0, 9)
+    for k in ("px", "py", "vx", "vy", "m"):
+        assert_bit_equal(st[k], o[k], "orbits " + k)
+    # reference edge cases: i32 arithmetic, `0..n-1` empty for n <= 1 (nbody.rs:95)
+    e.stable_orbits(0, 1.0, 2.0)
+    assert e.num_particles() == 1
+    e.random_disk(0)
+    assert e.num_particles() == 0
+    e.random_disk(-3)
+    assert e.num_particles() == 0
+    # consecutive presets continue one generator stream, like one thread_rng
+    e.seed(5); e.random_disk(10); e.random_disk(10)
+    a = e.get_particles()["px"].copy()
+    e.seed(5); e.random_disk(10)
+    assert not np.array_equal(a, e.get_particles()["px"])
+
+
+def test_product_presets_match_golden(rx):
+    g = golden("presets")
+    e = rx.NBodyEngine()
+    e.seed(7); e.random_disk(257)
+    st = e.get_particles()
+    got = np.stack([st[k] for k in ("px", "py", "vx", "vy", "m")], axis=1)
+    assert np.array_equal(got.view(np.uint32), g["disk_seed7_n257"].view(np.uint32))
+
+
+def test_set_get_roundtrip_2d_and_3d(rx):
+    rng = np.random.default_rng(3)
+    n = 300
+    a = {k: rng.normal(size=n).astype(np.float32) for k in ("px", "py", "pz", "vx", "vy", "vz")}
+    a["m"] = rng.uniform(0.1, 2, n).astype(np.float32)
+    e = rx.NBodyEngine()
+    e.set_particles(a["px"], a["py"], a["vx"], a["vy"], a["m"], a["pz"], a["vz"])
+    st = e.get_particles()
+    for k in a:
+        assert_bit_equal(st[k], a[k], k)
+    e.set_particles(a["px"], a["py"], a["vx"], a["vy"], a["m"])
+    st = e.get_particles()
+    assert not st["pz"].any() and not st["vz"].any()
+    e.set_particles([], [], [], [], [])
+    assert e.num_particles() == 0
+
+
+@pytest.mark.parametrize("shape", [(64, 48), (512, 512), (100, 37)])
+def test_product_draw_equals_oracle_draw(rx, ob, shape):
+    w, h = shape
+    p = ob.stable_orbits(1024, 0.5, 30.0, 1)
+    e = rx.NBodyEngine()
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    assert np.array_equal(e.draw(w, h), ob.draw(p, w, h))
+    d = ob.random_disk(3000, 8)
+    d["px"][:50] *= 3.0   # push some bodies out of the viewport
+    e.set_particles(d["px"], d["py"], d["vx"], d["vy"], d["m"])
+    assert np.array_equal(e.draw(w, h), ob.draw(d, w, h))
+
+
+def test_product_draw_matches_golden(rx):
+    g = golden("draw_n1024_orbits")
+    e = rx.NBodyEngine()
+    e.set_particles(g["in_px"], g["in_py"], g["in_vx"], g["in_vy"], g["in_m"])
+    assert np.array_equal(e.draw(64, 48), g["fb_64x48"])
+    assert np.array_equal(e.draw(512, 512), g["fb_512x512"])
+
+
+def test_level1_host_entry_points(rx):
+    # the six-symbol surface on the process-global engine (host-side ones only on CPU)
+    os.environ.setdefault("NB_SEED", "42")
+    rx.nb_stable_orbits(500, 0.5, 30.0)
+    assert rx.nb_num_particles() == 500
+    fb = rx.nb_draw(128, 128)
+    assert (fb == 0x00FF00FF).sum() == 5
+    assert (fb != 0).sum() > 100
+    rx.nb_random_disk(123)
+    assert rx.nb_num_particles() == 123
+    rx.nb_random_disk(0)
+    assert rx.nb_num_particles() == 0
+
+
+@pytest.mark.parametrize("make", ["disk", "orbits", "clumps", "line", "merge"])
+def test_product_quadtree_equals_oracle_tree_node_for_node(rx, ob, make):
+    rng = np.random.default_rng(4)
+    if make == "disk":
+        p = ob.random_disk(2000, 31)
+    elif make == "orbits":
+        p = ob.stable_orbits(3000, 0.5, 30.0, 32)
+    elif make == "clumps":
+        c = rng.normal(size=(1500, 2)).astype(np.float32) * 0.01
+        c[:750] += 10.0
+        p = ob.particles(c[:, 0], c[:, 1], np.zeros(1500), np.zeros(1500), rng.uniform(0.5, 2, 1500))
+    elif make == "line":   # degenerate AABB: all y equal (root box has zero height)
+        p = ob.particles(np.linspace(-20, 20, 300), np.zeros(300), np.zeros(300), np.zeros(300), np.ones(300))
+    else:                  # pairs closer than EPS merge into one exterior node (nbody.rs:249-260)
+        x = rng.uniform(-20, 20, 200).astype(np.float32)
+        y = rng.uniform(-20, 20, 200).astype(np.float32)
+        p = ob.particles(np.concatenate([x, x + np.float32(3e-5)]), np.concatenate([y, y]), np.zeros(400),
+                         np.zeros(400), np.ones(400))
+    rc, want = ob.bh_tree_dump(p)
+    assert rc == 0
+    e = rx.NBodyEngine()
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    got = e.bh_tree_dump()
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_product_quadtree_reports_reference_panics(rx, ob):
+    e = rx.NBodyEngine()
+    e.set_particles([0.0, 1e30, 1.0, 1.0003], [0.0, 1e30, 1.0, 1.0], [0] * 4, [0] * 4, [1.0] * 4)
+    with pytest.raises(rx.NBodyError) as ei:
+        e.bh_tree_dump()
+    assert ei.value.code == rx.NBX_ERR_TREE_DEPTH          # nbody.rs:230-232
+    e.set_particles([0.0, 1.0], [0.0, 1.0], [0, 0], [0, 0], [1.0, 0.0])
+    with pytest.raises(rx.NBodyError) as ei:
+        e.bh_tree_dump()
+    assert ei.value.code == rx.NBX_ERR_TREE                # nbody.rs:304
+
+
+def test_reference_slab_split(rx):
+    # nbody.rs:426-428
+    assert rx.reference_slab(10, 0, 3) == (0, 3)
+    assert rx.reference_slab(10, 1, 3) == (3, 6)
+    assert rx.reference_slab(10, 2, 3) == (6, 10)
+    e = rx.NBodyEngine()
+    e.set_shard(2, 3)
+    e.set_particles(np.zeros(10), np.zeros(10), np.zeros(10), np.zeros(10), np.ones(10))
+    assert e.slab() == (6, 10)
+    for n, w in ((262144, 8), (1000, 7), (5, 8)):
+        covered = []
+        for r in range(w):
+            lo, hi = rx.reference_slab(n, r, w)
+            covered += list(range(lo, hi))
+        assert covered == list(range(n))
+
+
+def test_plummer_generator_is_deterministic_and_bounded(rx):
+    a = rx.plummer_sphere(4096)
+    b = rx.plummer_sphere(4096)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    r = np.sqrt(a["px"].astype(np.float64) ** 2 + a["py"] ** 2 + a["pz"] ** 2)
+    assert r.max() <= 45.0 + 1e-3 and np.median(r) > 3.0 and np.median(r) < 9.0
+    assert abs(a["m"].sum() - 1000.0) < 1e-2
+    c = rx.plummer_sphere(4096, dim=2)
+    assert not c["pz"].any() and np.array_equal(c["px"], a["px"])
+    u = rx.splitmix64_uniform(123, 5)
+    import ctypes
+
+    from oracle import binding as ob
+
+    s = ctypes.c_uint64(123)
+    assert [float(x) for x in u] == [float(ob.lib().orc_next_f32(ctypes.byref(s))) for _ in range(5)]
