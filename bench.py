@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- body-pair interactions/s of the brute-force N-body step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one nb_step_brute_force (rs-src/nbody.rs:106-162): all-pairs force + kick-drift over
+the whole synthetic system.  Workload: N = 262 144-body Plummer sphere (3-D float4 kernel,
+17 algorithmic flops / interaction), the configuration the metric is quoted on; it fits one GPU.
+With N GPUs the SAME system is sharded as slabs of targets (strong scaling) with one all-gather of
+(x,y,z,m) per step.  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOPS_PER_INTERACTION = 17   # 3 sub, 3 mul + 2 add, 1 add eps, 1 mul, 1 div, 3 mul, 3 add
+DT = 0.01                    # RustNBodyExperiment.hs:45
+
+
+def cpu_baseline(st, seconds):
+    """Oracle (CPU restatement of nbody.rs:132-144) on the host cores: a bounded i-slice of the same
+    workload (work per target is uniform), threads = all cores with the reference's slab split."""
+    from oracle import binding as ob
+
+    n = len(st["px"])
+    cores = os.cpu_count() or 1
+    p = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])   # the reference law is 2-D: z ignored
+    # calibrate
+    ni = min(n, 16 * cores)
+    t0 = time.perf_counter(); ob.brute_forces(p, 0, ni, nthreads=cores); t1 = time.perf_counter()
+    rate = ni * (n - 1) / max(t1 - t0, 1e-9)
+    ni = int(min(n, max(ni, rate * seconds / (n - 1))))
+    ni -= ni % cores or 0
+    ni = max(ni, cores)
+    t0 = time.perf_counter(); ob.brute_forces(p, 0, ni, nthreads=cores); t1 = time.perf_counter()
+    mt = ni * (n - 1) / (t1 - t0)
+    n1 = max(1, min(n, int(ni / cores)))
+    t0 = time.perf_counter(); ob.brute_forces(p, 0, n1, nthreads=1); t2 = time.perf_counter()
+    st1 = n1 * (n - 1) / (t2 - t0)
+    return {
+        "value": mt, "unit": "interactions/s", "cores": cores, "kind": "port",
+        "sample": f"first {ni} targets x {n} sources (2-D reference law), {cores} threads, reference slab split",
+        "single_thread_value": st1,
+        "single_thread_sample": f"first {n1} targets x {n} sources, 1 thread (the reference's brute force is single-threaded)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=262144)
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--mode", default="fast")
+    ap.add_argument("--jsplit", type=int, default=0)
+    ap.add_argument("--bpt", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import rust_exp_amd as rx
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    n = args.n
+    st = rx.plummer_sphere(n, dim=args.dim)
+
+    if world == 1:
+        eng = rx.NBodyEngine(device=0, mode=args.mode)
+        eng.set_launch(jsplit=args.jsplit, bodies_per_thread=args.bpt, variant=args.variant)
+        eng.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
+
+        def step():
+            eng.step_brute_force(DT)
+
+        def sync():
+            eng.synchronize()
+
+        def barrier():
+            pass
+
+        engine = eng
+    else:
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        slab = rx.sharded.TorchSlabEngine(local_rank, mode=args.mode)
+        slab.eng.set_launch(jsplit=args.jsplit, bodies_per_thread=args.bpt, variant=args.variant)
+        sim = rx.ShardedNBody(slab)
+        sim.set_particles(st)
+
+        def step():
+            sim.step_brute_force(DT)
+
+        def sync():
+            torch.cuda.synchronize()
+
+        def barrier():
+            dist.barrier()
+
+        engine = slab.eng
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    engine.profile(True)
+    engine.profile_reset()
+    barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync(); barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_cnt = engine.profile_read(rx.NBX_K_FORCE)
+    i_ms, _ = engine.profile_read(rx.NBX_K_INTEGRATE)
+    engine.profile(False)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        info = rx.device_info(local_rank)
+        interactions_per_step = float(n) * float(n - 1)
+        value = interactions_per_step * args.steps / elapsed
+        lo, hi = engine.slab()
+        launch = engine.last_launch()
+        # dominant kernel: K1 force tiles. Algorithmic work of ONE launch on this rank:
+        inter_per_launch = float(hi - lo) * float(n - 1)
+        flops_per_inter = FLOPS_PER_INTERACTION if launch["dim"] == 3 else 12
+        k_avg_s = (k_ms / max(k_cnt, 1)) * 1e-3
+        achieved = inter_per_launch * flops_per_inter / k_avg_s / 1e12
+        peak = info["peak_fp32_flops"] / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile) and world == 1 and n == 262144:
+            try:
+                traffic = json.load(open(tfile)).get("k_force_tile_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "body-pair interactions/s at N=262144 (brute-force O(N^2) step)" if n == 262144
+                      else f"body-pair interactions/s at N={n} (brute-force O(N^2) step)",
+            "value": value, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"plummer_sphere_N{n}_brute_force_dim{launch['dim']}_dt{DT}",
+                       "bodies": n, "seed": "0x5EED0001", "force_mode": args.mode,
+                       "sharding": f"slab x{world}, one all-gather of (x,y,z,m) per step" if world > 1 else "single GPU",
+                       "launch": launch},
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "kernel": "k_force_tile", "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_cnt,
+                         "flops_per_interaction": flops_per_inter,
+                         "interactions_per_launch": inter_per_launch,
+                         "hbm_algorithmic_bytes_per_launch": 16.0 * n + 16.0 * (hi - lo) * launch["jsplit"],
+                         "note": "VALU-bound path (arithmetic intensity ~1e5 flop/B): peak = CUs*clock*256 flop/clk "
+                                 "(fp32 vector FMA roofline, = the f32 MFMA rate); HBM is not the bound"},
+            "integrate_kernel_avg_ms": i_ms / max(k_cnt, 1),
+            "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],
+            "clock_khz": info["clock_khz"],
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(st, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

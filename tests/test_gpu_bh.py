@@ -1,0 +1,101 @@
+"""GPU parity: Barnes-Hut (host-built reference-faithful quadtree + HIP traversal) against the
+oracle and the golden vectors. strict = bit exact (hierarchical summation reproduced);
+fast = walk-order accumulation + rcp: accelerations within 2e-5 of max|F|."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal, golden
+
+pytestmark = pytest.mark.gpu
+
+BH = [f"bh_{c}_t{t}" for c in ("n64_disk", "n1024_orbits", "n1000_disk") for t in ("0p5", "0p85")]
+DT = 0.01
+
+
+@pytest.mark.parametrize("name", BH)
+def test_bh_strict_matches_golden_bitwise(rx, name):
+    g = golden(name)
+    e = rx.NBodyEngine(mode="strict")
+    e.set_particles(g["in_px"], g["in_py"], g["in_vx"], g["in_vy"], g["in_m"])
+    fx, fy, _ = e.forces(float(g["theta"]))
+    assert_bit_equal(fx, g["f0_x"], name + " fx"); assert_bit_equal(fy, g["f0_y"], name + " fy")
+    done = 0
+    for s in (1, 10):
+        while done < s:
+            e.step_barnes_hut(float(g["theta"]), float(g["dt"]), 1)
+            done += 1
+        st = e.get_particles()
+        for k in ("px", "py", "vx", "vy"):
+            assert_bit_equal(st[k], g[f"s{s}_{k}"], f"{name} step {s} {k}")
+
+
+@pytest.mark.parametrize("n,seed,theta", [(2, 1, 0.5), (10000, 2, 0.85), (10000, 3, 0.3), (30000, 4, 0.95)])
+def test_bh_strict_matches_oracle_bitwise(rx, ob, n, seed, theta):
+    p = ob.stable_orbits(n, 0.5, 30.0, seed) if seed % 2 == 0 else ob.random_disk(n, seed)
+    e = rx.NBodyEngine(mode="strict")
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    q = p.copy()
+    for _ in range(3):
+        e.step_barnes_hut(theta, DT, 2)
+        assert ob.step_barnes_hut(q, theta, DT, 8) == 0
+    st = e.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        assert_bit_equal(st[k], q[k], k)
+
+
+@pytest.mark.parametrize("name", BH)
+def test_bh_fast_within_tolerance(rx, name):
+    g = golden(name)
+    e = rx.NBodyEngine(mode="fast")
+    e.set_particles(g["in_px"], g["in_py"], g["in_vx"], g["in_vy"], g["in_m"])
+    fx, fy, _ = e.forces(float(g["theta"]))
+    scale = max(np.abs(g["f0_x"]).max(), np.abs(g["f0_y"]).max())
+    assert np.abs(fx - g["f0_x"]).max() <= 2e-5 * scale
+    assert np.abs(fy - g["f0_y"]).max() <= 2e-5 * scale
+    e.step_barnes_hut(float(g["theta"]), float(g["dt"]), 1)
+    st = e.get_particles()
+    assert np.abs(st["px"] - g["s1_px"]).max() <= 1e-5 * max(1.0, np.abs(g["s1_px"]).max())
+    assert np.abs(st["vx"] - g["s1_vx"]).max() <= 5e-4
+
+
+def test_bh_velocity_kill_and_merge_on_gpu(rx, ob):
+    # nbody.rs:466-471 kill box; :249-260 merge; :365 self-skip by position equality
+    p = ob.particles([0.0, 56.0, -10.0, 3.0, 3.00005], [0.0, 0.0, 54.9, 3.0, 3.00005], [0.0, 1.0, 1.0, 0.0, 0.0],
+                     [0.0, 1.0, 1.0, 0.0, 0.0], [1000.0, 1.0, 1.0, 1.0, 2.0])
+    e = rx.NBodyEngine(mode="strict")
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    e.step_barnes_hut(0.5, DT, 1)
+    q = p.copy(); ob.step_barnes_hut(q, 0.5, DT, 1)
+    st = e.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        assert_bit_equal(st[k], q[k], k)
+    assert st["vx"][1] == 0 and st["vy"][1] == 0
+
+
+def test_bh_depth_panic_surfaces_as_error(rx):
+    e = rx.NBodyEngine()
+    e.set_particles([0.0, 1e30, 1.0, 1.0003], [0.0, 1e30, 1.0, 1.0], [0] * 4, [0] * 4, [1.0] * 4)
+    with pytest.raises(rx.NBodyError) as ei:
+        e.step_barnes_hut(0.5, DT, 1)
+    assert ei.value.code == rx.NBX_ERR_TREE_DEPTH
+
+
+def test_bh_small_theta_approaches_brute_force_on_gpu(rx, ob):
+    p = ob.random_disk(2000, 21)
+    e = rx.NBodyEngine(mode="fast")
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    bx, by, _ = e.forces(1e-6)
+    fx, fy, _ = e.forces(0.0)
+    assert np.abs(bx - fx).max() <= 3e-5 * np.abs(fx).max()
+
+
+def test_bh_large_n_force_error_vs_brute_sample(rx):
+    """BASELINE config #4 shape at reduced N for test time: theta=0.5 force error vs all-pairs."""
+    st = rx.plummer_sphere(131072, dim=2)
+    e = rx.NBodyEngine(mode="fast")
+    e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    bx, by, _ = e.forces(0.5)
+    fx, fy, _ = e.forces(0.0)
+    num = np.hypot(bx - fx, by - fy)
+    den = np.hypot(fx, fy) + 1e-12
+    assert np.median(num / den) < 2e-2

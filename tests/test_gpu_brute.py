@@ -1,0 +1,250 @@
+"""GPU parity: the HIP brute-force path (through the C ABI) against the oracle and the golden
+vectors.  strict mode = bit-exact; fast mode = within the stated fp32 tolerance
+(SURVEY.md 8(d) / DESIGN.md section 4):
+    accelerations   max|dF| / max|F|            <= 1e-5
+    1 step          max|dp| <= 1e-5 , max|dv|   <= 1e-5 * max|a| * dt * max(1, sqrt(N)/64)
+    10 steps        max|dp| <= 1e-4 , max|dv|   <= 5e-3
+    vs fp64         GPU error <= 2 x the f32 oracle's own error
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal, golden, particles_from
+
+pytestmark = pytest.mark.gpu
+
+BRUTE = ["brute_n2", "brute_n5_orbits", "brute_n64_disk", "brute_n1024_orbits", "brute_n1000_disk"]
+DT = 0.01
+
+
+def load(e, p, three_d=False):
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+
+
+# ---------------------------------------------------------------- strict = bit exact
+@pytest.mark.parametrize("name", BRUTE)
+def test_strict_matches_golden_bitwise(rx, name):
+    g = golden(name)
+    e = rx.NBodyEngine(mode="strict")
+    e.set_particles(g["in_px"], g["in_py"], g["in_vx"], g["in_vy"], g["in_m"])
+    done = 0
+    for s in (1, 10):
+        while done < s:
+            e.step_brute_force(float(g["dt"]))
+            done += 1
+        st = e.get_particles()
+        for k in ("px", "py", "vx", "vy"):
+            assert_bit_equal(st[k], g[f"s{s}_{k}"], f"{name} step {s} {k}")
+
+
+@pytest.mark.parametrize("n,seed,kind", [(1, 1, "disk"), (3, 2, "disk"), (255, 3, "disk"), (256, 4, "orbits"),
+                                         (257, 5, "disk"), (4096, 6, "orbits"), (10000, 7, "orbits")])
+def test_strict_matches_oracle_bitwise(rx, ob, n, seed, kind):
+    p = ob.random_disk(n, seed) if kind == "disk" else ob.stable_orbits(n, 0.5, 30.0, seed)
+    e = rx.NBodyEngine(mode="strict")
+    load(e, p)
+    fx, fy, _ = e.forces()
+    ofx, ofy = ob.brute_forces(p, nthreads=8)
+    assert_bit_equal(fx, ofx, "fx"); assert_bit_equal(fy, ofy, "fy")
+    q = p.copy()
+    for _ in range(3):
+        e.step_brute_force(DT)
+        ob.step_brute_force(q, DT, nthreads=8)
+    st = e.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        assert_bit_equal(st[k], q[k], k)
+
+
+def test_strict_theta_zero_is_brute_force(rx, ob):
+    # nbody.rs:197-200
+    p = ob.random_disk(500, 9)
+    e = rx.NBodyEngine(mode="strict")
+    load(e, p)
+    e.step_barnes_hut(0.0, DT, 4)
+    q = p.copy()
+    ob.step_brute_force(q, DT)
+    st = e.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        assert_bit_equal(st[k], q[k], k)
+
+
+def test_strict_coincident_and_denormal_inputs(rx, ob):
+    p = ob.particles([1.0, 1.0, 5.0, 1e-39, 0.0], [2.0, 2.0, 5.0, 0.0, 1e-40], [0] * 5, [0] * 5,
+                     [3.0, 4.0, 1.0, 1e-30, 2.0])
+    e = rx.NBodyEngine(mode="strict")
+    load(e, p)
+    fx, fy, _ = e.forces()
+    ofx, ofy = ob.brute_forces(p)
+    assert_bit_equal(fx, ofx); assert_bit_equal(fy, ofy)
+
+
+def test_strict_full_size_slice_65536(rx, ob):
+    """BASELINE config #2 size: compare a 2048-target slice of a 65536-body Plummer (z=0) bit for bit."""
+    st = rx.plummer_sphere(65536, dim=2)
+    p = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    e = rx.NBodyEngine(mode="strict")
+    load(e, p)
+    fx, fy, _ = e.forces()
+    ofx, ofy = ob.brute_forces(p, 0, 2048, nthreads=8)
+    assert_bit_equal(fx[:2048], ofx); assert_bit_equal(fy[:2048], ofy)
+    ofx, ofy = ob.brute_forces(p, 65536 - 64, 65536)
+    assert_bit_equal(fx[-64:], ofx); assert_bit_equal(fy[-64:], ofy)
+
+
+# ---------------------------------------------------------------- fast = stated tolerance
+def rel_err(a, b):
+    return np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("name", BRUTE)
+def test_fast_matches_golden_within_tolerance(rx, name):
+    g = golden(name)
+    n = len(g["in_px"])
+    e = rx.NBodyEngine(mode="fast")
+    e.set_particles(g["in_px"], g["in_py"], g["in_vx"], g["in_vy"], g["in_m"])
+    amax = 2.0e3 if n > 5 else 1.0e3
+    tol_v1 = 1e-5 * amax * float(g["dt"]) * max(1.0, np.sqrt(n) / 64.0)
+    done = 0
+    for s, tp, tv in ((1, 1e-5, tol_v1), (10, 1e-4, 5e-3)):
+        while done < s:
+            e.step_brute_force(float(g["dt"]))
+            done += 1
+        st = e.get_particles()
+        for k, tol in (("px", tp), ("py", tp), ("vx", tv), ("vy", tv)):
+            err = np.abs(st[k].astype(np.float64) - g[f"s{s}_{k}"]).max()
+            assert err <= tol, f"{name} step {s} {k}: {err} > {tol}"
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("bpt", [1, 2, 4])
+@pytest.mark.parametrize("jsplit", [1, 3, 8])
+def test_fast_accelerations_all_launch_shapes(rx, ob, variant, bpt, jsplit):
+    p = ob.stable_orbits(4096 + 37, 0.5, 30.0, 11)
+    ofx, ofy = ob.brute_forces(p, nthreads=8)
+    e = rx.NBodyEngine(mode="fast")
+    load(e, p)
+    e.set_launch(jsplit=jsplit, bodies_per_thread=bpt, variant=variant)
+    fx, fy, fz = e.forces()
+    ll = e.last_launch()
+    assert ll["jsplit"] == jsplit and ll["bodies_per_thread"] == bpt and ll["dim"] == 2
+    assert rel_err(fx, ofx) <= 1e-5 and rel_err(fy, ofy) <= 1e-5
+    assert not fz.any()
+    # the 3-D kernel with z == 0 must reduce to the 2-D law (dz*dz = +0, s*dz = 0)
+    e.set_launch(jsplit=jsplit, bodies_per_thread=bpt, dim=3, variant=variant)
+    gx, gy, gz = e.forces()
+    assert e.last_launch()["dim"] == 3
+    assert rel_err(gx, ofx) <= 1e-5 and rel_err(gy, ofy) <= 1e-5 and not gz.any()
+
+
+def test_fast_error_vs_fp64_no_worse_than_twice_the_f32_oracle(rx, ob):
+    p = ob.stable_orbits(4096, 0.5, 30.0, 12)
+    dfx, dfy = ob.brute_forces_f64(p)
+    ofx, ofy = ob.brute_forces(p, nthreads=8)
+    e = rx.NBodyEngine(mode="fast")
+    load(e, p)
+    fx, fy, _ = e.forces()
+    scale = np.abs(dfx).max()
+    err_gpu = max(np.abs(fx - dfx).max(), np.abs(fy - dfy).max()) / scale
+    err_cpu = max(np.abs(ofx - dfx).max(), np.abs(ofy - dfy).max()) / scale
+    assert err_gpu <= 2.0 * err_cpu + 1e-7, (err_gpu, err_cpu)
+
+
+def test_fast_deterministic_run_to_run(rx, ob):
+    p = ob.random_disk(5000, 13)
+    out = []
+    for _ in range(2):
+        e = rx.NBodyEngine(mode="fast")
+        load(e, p)
+        for _ in range(5):
+            e.step_brute_force(DT)
+        out.append(e.get_particles())
+    for k in ("px", "py", "vx", "vy"):
+        assert_bit_equal(out[0][k], out[1][k], k)
+
+
+def test_fast_3d_against_fp64(rx):
+    st = rx.plummer_sphere(8192)
+    e = rx.NBodyEngine(mode="fast")
+    e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
+    fx, fy, fz = e.forces()
+    assert e.last_launch()["dim"] == 3
+    P = np.stack([st["px"], st["py"], st["pz"]], 1).astype(np.float64)
+    m = st["m"].astype(np.float64)
+    idx = np.arange(0, 8192, 16)
+    d = P[None, :, :] - P[idx, None, :]
+    w = m[None, :] / ((d * d).sum(-1) + 1e-4)
+    F = (w[:, :, None] * d).sum(1) * m[idx, None]
+    scale = np.abs(F).max()
+    got = np.stack([fx[idx], fy[idx], fz[idx]], 1)
+    assert np.abs(got - F).max() / scale <= 1e-5
+
+
+def test_fast_vs_strict_at_full_size_262144(rx):
+    """BASELINE headline size: the fast kernel against the bit-exact kernel on the same GPU
+    (a CPU step at this size takes minutes), plus Newton's third law as a size-independent check."""
+    st = rx.plummer_sphere(262144, dim=2)
+    fast = rx.NBodyEngine(mode="fast")
+    strict = rx.NBodyEngine(mode="strict")
+    for e in (fast, strict):
+        e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    fx, fy, _ = fast.forces()
+    sx, sy, _ = strict.forces()
+    assert rel_err(fx, sx) <= 1e-5 and rel_err(fy, sy) <= 1e-5
+    # sum of all internal forces vanishes (antisymmetry, nbody.rs:174-183)
+    tot = np.array([fx.astype(np.float64).sum(), fy.astype(np.float64).sum()])
+    assert np.all(np.abs(tot) <= 1e-6 * np.abs(fx.astype(np.float64)).sum())
+
+
+def test_step_sequence_mixed_with_state_io(rx, ob):
+    """set -> step -> get -> set -> step keeps host mirror and device state coherent."""
+    p = ob.random_disk(777, 14)
+    e = rx.NBodyEngine(mode="strict")
+    load(e, p)
+    e.step_brute_force(DT)
+    mid = e.get_particles()
+    e2 = rx.NBodyEngine(mode="strict")
+    e2.set_particles(mid["px"], mid["py"], mid["vx"], mid["vy"], mid["m"])
+    e.step_brute_force(DT); e2.step_brute_force(DT)
+    a, b = e.get_particles(), e2.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        assert_bit_equal(a[k], b[k], k)
+    fb = e.draw(64, 64)
+    q = p.copy(); ob.step_brute_force(q, DT); ob.step_brute_force(q, DT)
+    assert np.array_equal(fb, ob.draw(q, 64, 64))
+
+
+def test_empty_and_single_body(rx):
+    e = rx.NBodyEngine()
+    e.set_particles([], [], [], [], [])
+    e.step_brute_force(DT)
+    assert e.num_particles() == 0
+    e.set_particles([1.0], [2.0], [0.5], [-0.5], [3.0])
+    e.step_brute_force(DT)
+    st = e.get_particles()
+    assert st["vx"][0] == np.float32(0.5) and st["px"][0] == np.float32(1.0) + np.float32(DT) * np.float32(0.5)
+
+
+def test_level1_surface_on_gpu(rx, ob):
+    """The six reference symbols exactly as RustNBodyExperiment.hs drives them (process-global)."""
+    rx.nb_stable_orbits(1024, 0.5, 30.0)
+    assert rx.nb_num_particles() == 1024
+    fb0 = rx.nb_draw(256, 256)
+    rx.nb_step_brute_force(DT)
+    rx.nb_step_barnes_hut(0.0, DT, 1)
+    rx.nb_step_barnes_hut(0.85, DT, 1)
+    fb1 = rx.nb_draw(256, 256)
+    assert rx.nb_num_particles() == 1024
+    assert (fb1 == 0x00FF00FF).sum() == 5 and not np.array_equal(fb0, fb1)
+
+
+def test_profile_records_kernel_time(rx, ob):
+    p = ob.random_disk(8192, 15)
+    e = rx.NBodyEngine()
+    load(e, p)
+    e.profile(True)
+    for _ in range(4):
+        e.step_brute_force(DT)
+    ms, cnt = e.profile_read(rx.NBX_K_FORCE)
+    assert cnt == 4 and ms > 0
+    ms2, cnt2 = e.profile_read(rx.NBX_K_INTEGRATE)
+    assert cnt2 == 4 and ms2 > 0 and ms2 < ms
