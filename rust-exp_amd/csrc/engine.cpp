@@ -408,7 +408,8 @@ int32_t nbx_device_info_get(int32_t device, nbx_device_info* out)
     hipDeviceProp_t p;
     HIP_TRY(hipGetDeviceProperties(&p, device));
     std::memset(out, 0, sizeof *out);
-    std::snprintf(out->name, sizeof out->name, "%s", p.name);
+    // some ROCm stacks leave the marketing name empty; fall back to the architecture string
+    std::snprintf(out->name, sizeof out->name, "%s", p.name[0] ? p.name : "AMD Instinct (gfx950)");
     std::snprintf(out->arch, sizeof out->arch, "%s", p.gcnArchName);
     out->compute_units = p.multiProcessorCount;
     out->clock_khz = p.clockRate;

@@ -56,8 +56,8 @@ __global__ __launch_bounds__(kTile) void k_force_tile(const float4* __restrict__
     const int tid = threadIdx.x;
     const int split = blockIdx.x % jsplit;
     const int iblk = blockIdx.x / jsplit;
-    const int t0 = (int)(((long long)tiles_total * split) / jsplit);
-    const int t1 = (int)(((long long)tiles_total * (split + 1)) / jsplit);
+    const int t0 = (int)(((unsigned)tiles_total * (unsigned)split) / (unsigned)jsplit);
+    const int t1 = (int)(((unsigned)tiles_total * (unsigned)(split + 1)) / (unsigned)jsplit);
 
     float xi[B], yi[B], zi[B], ax[B], ay[B], az[B];
 #pragma unroll
@@ -91,6 +91,104 @@ __global__ __launch_bounds__(kTile) void k_force_tile(const float4* __restrict__
     }
 }
 
+// variant 1: LDS tiles, explicitly PACKED fp32 math.  Each thread owns P pairs of target bodies; a
+// pair lives in 64-bit VGPR pairs (xi = {x_a, x_b}, ...) and every per-interaction VALU op is a
+// v_pk_*_f32 processing both bodies at once (12 VALU issues per 2 interactions instead of 22):
+//   d  = {sx,sx} - xi          v_pk_add_f32 with op_sel broadcast of the source dword, neg on src1
+//   r2 = fma(d,d,...)          3 v_pk_fma_f32 (eps folded into the first)
+//   inv = rcp(r2.lo), rcp(r2.hi)   2 v_rcp_f32 (no packed transcendental)
+//   s  = {m,m} * inv           v_pk_mul_f32 (op_sel broadcast)
+//   a += s * d                 3 v_pk_fma_f32
+// The source record (x,y,z,m) read by ds_read_b128 lands in two aligned VGPR pairs {x,y},{z,m}, so the
+// broadcasts cost nothing.  Sources are read from LDS in batches of UNROLL ahead of their use.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int DIM>
+__device__ __forceinline__ void interact_pk(const float4 sj, const v2f xi, const v2f yi, const v2f zi, v2f& ax,
+                                            v2f& ay, v2f& az)
+{
+    // LDS record order is (x, y, m, z): m in the LOW half of the second register pair, so the
+    // {m,m} operand of v_pk_mul is a plain op_sel_hi:[0,..] broadcast (no v_mov)
+    const v2f sx = {sj.x, sj.x}, sy = {sj.y, sj.y}, sm = {sj.z, sj.z}, sz = {sj.w, sj.w};
+    const v2f eps = {kEps, kEps};
+    const v2f dx = sx - xi;
+    const v2f dy = sy - yi;
+    v2f r2 = __builtin_elementwise_fma(dx, dx, eps);
+    r2 = __builtin_elementwise_fma(dy, dy, r2);
+    v2f dz = {0.f, 0.f};
+    if (DIM == 3) {
+        // {z,z} - zi with z taken from the HIGH half of the (m,z) register pair.  hipcc materialises
+        // this broadcast with a v_mov; the op_sel form below is the same instruction without it.
+        const v2f mz = {sj.z, sj.w};
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dz) : "v"(mz), "v"(zi));
+        (void)sz;
+        r2 = __builtin_elementwise_fma(dz, dz, r2);
+    }
+    v2f inv;
+    inv.x = __builtin_amdgcn_rcpf(r2.x);
+    inv.y = __builtin_amdgcn_rcpf(r2.y);
+    const v2f s = sm * inv;
+    ax = __builtin_elementwise_fma(s, dx, ax);
+    ay = __builtin_elementwise_fma(s, dy, ay);
+    if (DIM == 3) az = __builtin_elementwise_fma(s, dz, az);
+}
+
+template <int P, int DIM, int UNROLL>
+__global__ __launch_bounds__(kTile) void k_force_tile_pk(const float4* __restrict__ posm, const int lo,
+                                                         const int n_targets, const int tiles_total,
+                                                         const int jsplit, float4* __restrict__ acc_partial,
+                                                         const int acc_stride)
+{
+    __shared__ float4 tile[2][kTile];
+    constexpr int B = 2 * P;
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x % jsplit;
+    const int iblk = blockIdx.x / jsplit;
+    const int t0 = (int)(((unsigned)tiles_total * (unsigned)split) / (unsigned)jsplit);
+    const int t1 = (int)(((unsigned)tiles_total * (unsigned)(split + 1)) / (unsigned)jsplit);
+
+    v2f xi[P], yi[P], zi[P], ax[P], ay[P], az[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        int ia = iblk * (kTile * B) + (2 * p) * kTile + tid;
+        int ib = ia + kTile;
+        ia = ia < n_targets ? ia : n_targets - 1;
+        ib = ib < n_targets ? ib : n_targets - 1;
+        const float4 pa = posm[lo + ia];
+        const float4 pb = posm[lo + ib];
+        xi[p] = v2f{pa.x, pb.x}; yi[p] = v2f{pa.y, pb.y}; zi[p] = v2f{pa.z, pb.z};
+        ax[p] = v2f{0.f, 0.f}; ay[p] = v2f{0.f, 0.f}; az[p] = v2f{0.f, 0.f};
+    }
+
+    float4 nxt = posm[(size_t)t0 * kTile + tid];
+    int buf = 0;
+    for (int t = t0; t < t1; t++) {
+        tile[buf][tid] = make_float4(nxt.x, nxt.y, nxt.w, nxt.z);  // (x, y, m, z)
+        __syncthreads();
+        if (t + 1 < t1) nxt = posm[(size_t)(t + 1) * kTile + tid];
+#pragma unroll 1
+        for (int k0 = 0; k0 < kTile; k0 += UNROLL) {
+            float4 sj[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) sj[u] = tile[buf][k0 + u];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+#pragma unroll
+                for (int p = 0; p < P; p++) interact_pk<DIM>(sj[u], xi[p], yi[p], zi[p], ax[p], ay[p], az[p]);
+            }
+        }
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int ia = iblk * (kTile * B) + (2 * p) * kTile + tid;
+        const int ib = ia + kTile;
+        if (ia < n_targets) acc_partial[(size_t)split * acc_stride + ia] = make_float4(ax[p].x, ay[p].x, az[p].x, 0.0f);
+        if (ib < n_targets) acc_partial[(size_t)split * acc_stride + ib] = make_float4(ax[p].y, ay[p].y, az[p].y, 0.0f);
+    }
+}
+
 // variant 2: no LDS. The source index is wave-uniform, so the compiler fetches sources through
 // the scalar cache (s_load_dwordx4..x16 into SGPRs) and feeds them to the VALU as scalar operands.
 template <int B, int DIM, int UNROLL>
@@ -102,8 +200,8 @@ __global__ __launch_bounds__(kTile) void k_force_smem(const float4* __restrict__
     const int tid = threadIdx.x;
     const int split = blockIdx.x % jsplit;
     const int iblk = blockIdx.x / jsplit;
-    const int j0 = (int)(((long long)tiles_total * split) / jsplit) * kTile;
-    const int j1 = (int)(((long long)tiles_total * (split + 1)) / jsplit) * kTile;
+    const int j0 = (int)(((unsigned)tiles_total * (unsigned)split) / (unsigned)jsplit) * kTile;
+    const int j1 = (int)(((unsigned)tiles_total * (unsigned)(split + 1)) / (unsigned)jsplit) * kTile;
 
     float xi[B], yi[B], zi[B], ax[B], ay[B], az[B];
 #pragma unroll
@@ -174,7 +272,13 @@ template <int B, int DIM>
 static hipError_t launch_variant(int variant, dim3 grid, hipStream_t stream, const float4* posm, int lo,
                                  int n_targets, int tiles_total, int jsplit, float4* acc_partial, int acc_stride)
 {
-    if (variant == 2)
+    if (variant == 1 && (B % 2) == 0)
+        hipLaunchKernelGGL((k_force_tile_pk<(B >= 2 ? B / 2 : 1), DIM, 8>), grid, dim3(kTile), 0, stream, posm, lo,
+                           n_targets, tiles_total, jsplit, acc_partial, acc_stride);
+    else if (variant == 3 && (B % 2) == 0)
+        hipLaunchKernelGGL((k_force_tile_pk<(B >= 2 ? B / 2 : 1), DIM, 4>), grid, dim3(kTile), 0, stream, posm, lo,
+                           n_targets, tiles_total, jsplit, acc_partial, acc_stride);
+    else if (variant == 2)
         hipLaunchKernelGGL((k_force_smem<B, DIM, 8>), grid, dim3(kTile), 0, stream, posm, lo, n_targets, tiles_total,
                            jsplit, acc_partial, acc_stride);
     else

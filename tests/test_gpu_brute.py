@@ -115,7 +115,7 @@ def test_fast_matches_golden_within_tolerance(rx, name):
             assert err <= tol, f"{name} step {s} {k}: {err} > {tol}"
 
 
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("bpt", [1, 2, 4])
 @pytest.mark.parametrize("jsplit", [1, 3, 8])
 def test_fast_accelerations_all_launch_shapes(rx, ob, variant, bpt, jsplit):
@@ -179,17 +179,31 @@ def test_fast_3d_against_fp64(rx):
     assert np.abs(got - F).max() / scale <= 1e-5
 
 
-def test_fast_vs_strict_at_full_size_262144(rx):
-    """BASELINE headline size: the fast kernel against the bit-exact kernel on the same GPU
-    (a CPU step at this size takes minutes), plus Newton's third law as a size-independent check."""
-    st = rx.plummer_sphere(262144, dim=2)
+def test_fast_vs_strict_at_full_size_262144(rx, ob):
+    """BASELINE headline size (a CPU step here takes minutes): the fast kernel against the bit-exact
+    kernel on the same GPU, both against an fp64 sample, plus Newton's third law as a
+    size-independent check.  Tolerance 1e-5 * max(1, sqrt(N)/64): sequential f32 summation error
+    grows ~sqrt(N) and the strict (reference-order) sum is the LESS accurate of the two."""
+    n = 262144
+    st = rx.plummer_sphere(n, dim=2)
     fast = rx.NBodyEngine(mode="fast")
     strict = rx.NBodyEngine(mode="strict")
     for e in (fast, strict):
         e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
     fx, fy, _ = fast.forces()
     sx, sy, _ = strict.forces()
-    assert rel_err(fx, sx) <= 1e-5 and rel_err(fy, sy) <= 1e-5
+    tol = 1e-5 * max(1.0, np.sqrt(n) / 64.0)
+    assert rel_err(fx, sx) <= tol and rel_err(fy, sy) <= tol
+    # fp64 arbiter on a 512-target sample: the fast kernel is at least as accurate as the reference order
+    p = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    dfx, dfy = ob.brute_forces_f64(p, 1000, 1512)
+    scale = np.abs(sx).max()
+    err_fast = max(np.abs(fx[1000:1512] - dfx).max(), np.abs(fy[1000:1512] - dfy).max()) / scale
+    err_strict = max(np.abs(sx[1000:1512] - dfx).max(), np.abs(sy[1000:1512] - dfy).max()) / scale
+    assert err_fast <= 1e-5 and err_fast <= 2.0 * err_strict + 1e-7, (err_fast, err_strict)
+    # and the strict slice is the oracle's, bit for bit, at this size too
+    ofx, ofy = ob.brute_forces(p, 1000, 1064)
+    assert_bit_equal(sx[1000:1064], ofx); assert_bit_equal(sy[1000:1064], ofy)
     # sum of all internal forces vanishes (antisymmetry, nbody.rs:174-183)
     tot = np.array([fx.astype(np.float64).sum(), fy.astype(np.float64).sum()])
     assert np.all(np.abs(tot) <= 1e-6 * np.abs(fx.astype(np.float64)).sum())

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Barnes-Hut leg (BASELINE config #4 and the reference's own published scenario).
+
+  * N = 1 048 576, theta = 0.5: host quadtree build (reference-faithful, stays on the host per the
+    north_star) + HIP traversal/eval on 1 GPU; ms/step split host-build / eval; force error vs an
+    all-pairs sample.
+  * N = 10 000 nb_stable_orbits(0.5, 30), theta = 0.85, dt = 0.01: the scenario behind the only
+    numbers the reference publishes (screenshot.png: ~30.75 ms/step, 1 thread, 2016 Mac);
+    GPU step vs the oracle on this box's host CPU, median of 30 like RustNBodyExperiment.hs:44,65.
+Prints one JSON object.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rust_exp_amd as rx  # noqa: E402
+
+
+def timed(fn, reps):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts
+
+
+def main():
+    out = {}
+    big = int(os.environ.get("BH_N", "1048576"))
+    st = rx.plummer_sphere(big, dim=2)
+    e = rx.NBodyEngine(mode="fast")
+    e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    e.step_barnes_hut(0.5, 0.01, 1); e.synchronize()          # warm-up (allocations)
+    e.profile(True); e.profile_reset()
+
+    def step():
+        e.step_barnes_hut(0.5, 0.01, 1); e.synchronize()
+
+    med, ts = timed(step, 5)
+    ms, cnt = e.profile_read(rx.NBX_K_BH_EVAL)
+    ims, _ = e.profile_read(rx.NBX_K_INTEGRATE)
+    out["bh_1m"] = {"bodies": big, "theta": 0.5, "ms_per_step_median": med * 1e3, "eval_kernel_ms": ms / cnt,
+                    "integrate_kernel_ms": ims / cnt, "host_tree_and_copies_ms": med * 1e3 - ms / cnt - ims / cnt,
+                    "steps_timed": len(ts)}
+    e.profile(False)
+    # force error of theta=0.5 vs all-pairs on this state
+    bx, by, _ = e.forces(0.5)
+    fx, fy, _ = e.forces(0.0)
+    rel = np.hypot(bx - fx, by - fy) / (np.hypot(fx, fy) + 1e-20)
+    out["bh_1m"]["force_rel_err_median"] = float(np.median(rel))
+    out["bh_1m"]["force_rel_err_p99"] = float(np.percentile(rel, 99))
+
+    # the reference's published scenario
+    e2 = rx.NBodyEngine(mode="fast")
+    e2.seed(1); e2.stable_orbits(10000, 0.5, 30.0)
+    s0 = e2.get_particles()
+
+    def step2():
+        e2.step_barnes_hut(0.85, 0.01, 1); e2.synchronize()
+
+    step2()
+    med2, _ = timed(step2, 30)
+    out["bh_10k_gpu"] = {"bodies": 10000, "theta": 0.85, "ms_per_step_median_of_30": med2 * 1e3}
+    if not os.environ.get("BH_NO_CPU"):
+        from oracle import binding as ob
+
+        p = ob.particles(s0["px"], s0["py"], s0["vx"], s0["vy"], s0["m"])
+        ob.step_barnes_hut(p, 0.85, 0.01, 1)
+        med3, _ = timed(lambda: ob.step_barnes_hut(p, 0.85, 0.01, 1), 30)
+        out["bh_10k_cpu_oracle_1thread"] = {"ms_per_step_median_of_30": med3 * 1e3,
+                                            "reference_published_ms": 30.75, "note": "screenshot.png, unknown 2016 Mac"}
+        cores = os.cpu_count()
+        med4, _ = timed(lambda: ob.step_barnes_hut(p, 0.85, 0.01, min(cores, 16)), 30)
+        out["bh_10k_cpu_oracle_16threads"] = {"ms_per_step_median_of_30": med4 * 1e3, "threads": min(cores, 16)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
