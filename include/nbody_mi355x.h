@@ -88,7 +88,8 @@ enum nbx_option {
     NBX_OPT_BODIES_PER_THREAD = 2, /* register blocking B in {1,2,4}; 0 = auto */
     NBX_OPT_DIM = 3,               /* 2 or 3; 0 = auto (2 when every z and vz is zero) */
     NBX_OPT_PROFILE = 4,           /* 1 = record a HIP event pair around every kernel launch */
-    NBX_OPT_KERNEL_VARIANT = 5,    /* fast force kernel variant; 0 = default */
+    NBX_OPT_KERNEL_VARIANT = 5,    /* fast force kernel: 1 = packed fp32 + LDS tiles (default), 0 = compiler-scheduled
+                                    * LDS tiles, 2 = scalar-cache sources (no LDS), 3 = packed, 4-source batches */
     NBX_OPT_BH_LEAF_CAP = 6        /* reserved */
 };
 
@@ -179,6 +180,10 @@ int32_t nbx_step_local(nbx_engine *e, float dt);
 int32_t nbx_profile_reset(nbx_engine *e);
 /* total milliseconds and launch count recorded for `kernel_id` since the last reset (synchronises) */
 int32_t nbx_profile_read(nbx_engine *e, int32_t kernel_id, double *total_ms, int32_t *launches);
+/* Barnes-Hut host-side phases since the last call (cumulative ms, then reset): ms4 = download of
+ * positions, quadtree build, flatten, upload of the node array; steps = tree builds; nodes = size of
+ * the last flattened tree. */
+int32_t nbx_bh_host_timing(nbx_engine *e, double *ms4, int32_t *steps, int32_t *nodes);
 /* launch geometry the last force launch used (for DESIGN/bench reporting); any pointer may be NULL */
 int32_t nbx_last_launch(const nbx_engine *e, int32_t *grid, int32_t *block, int32_t *jsplit,
                         int32_t *bodies_per_thread, int32_t *dim);

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -85,7 +86,7 @@ struct nbx_engine {
     size_t nodes_cap = 0;
 
     // options
-    int force_mode = 0, jsplit = 0, bpt = 0, dim_opt = 0, profile = 0, variant = 0;
+    int force_mode = 0, jsplit = 0, bpt = 0, dim_opt = 0, profile = 0, variant = 1;
     bool any_z = false;
 
     nbx::Rng rng{0};
@@ -96,6 +97,8 @@ struct nbx_engine {
 
     std::vector<ProfRec> prof;
     nbx::ForceLaunch last{0, 0, 0, 0, 0, 0};
+    double host_ms[4] = {0, 0, 0, 0};  // Barnes-Hut host phases: download, build, flatten, upload (cumulative)
+    int host_steps = 0;
 
     int slab() const { return hi - lo; }
 };
@@ -238,17 +241,20 @@ struct ProfScope {
 
 void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* bpt, int* jsplit, int* dim)
 {
+    // Defaults from the measured launch-shape sweep (profiles/r01_shapes_sweep.txt): register blocking 4
+    // (two packed pairs) once a GPU owns >= 32768 targets, else 2; source split S = the smallest power of
+    // two that yields >= 32 workgroups per CU, capped at 64 and at half the tile count.
     *dim = e->dim_opt ? e->dim_opt : (e->any_z ? 3 : 2);
-    int b = e->bpt ? e->bpt : 2;
+    int b = e->bpt ? e->bpt : (n_targets >= 32768 ? 4 : 2);
     if (b != 1 && b != 2 && b != 4) b = 2;
     *bpt = b;
     int s = e->jsplit;
     if (s <= 0) {
-        // fill the chip: >= 8 workgroups (32 waves) per CU when the problem allows it
         const int iblocks = (n_targets + kTile * b - 1) / (kTile * b);
-        const int want = e->cu_count * 8;
+        const int want = e->cu_count * 32;
         s = 1;
         while (iblocks * s < want && s < 64) s *= 2;
+        s = std::min(s, std::max(1, tiles_total / 2));
     }
     s = std::max(1, std::min(s, tiles_total));
     *jsplit = s;
@@ -303,12 +309,18 @@ int step_brute(nbx_engine* e, float dt)
 // host tree (reference-faithful) -> flatten -> device
 int build_and_upload_tree(nbx_engine* e)
 {
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = clk::now();
     int rc = download_positions(e);
     if (rc != NBX_OK) return rc;
+    const auto t1 = clk::now();
     rc = e->tree.build(e->host.px.data(), e->host.py.data(), e->host.m.data(), e->n);
     if (rc == NBX_ERR_TREE_DEPTH) return fail(rc, "quadtree depth > 50 (the reference panics here, nbody.rs:230-232)");
     if (rc != NBX_OK) return fail(rc, "quadtree build hit a reference assert (nbody.rs:267/:293/:304)");
+    const auto t2 = clk::now();
     e->tree.flatten(e->flat);
+    const auto t3 = clk::now();
     rc = grow(&e->d_nodes, &e->nodes_cap, std::max<size_t>(e->flat.size(), 1));
     if (rc != NBX_OK) return rc;
     if (!e->flat.empty()) {
@@ -316,6 +328,9 @@ int build_and_upload_tree(nbx_engine* e)
                                e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));  // flat is reused next step
     }
+    const auto t4 = clk::now();
+    e->host_ms[0] += ms(t0, t1); e->host_ms[1] += ms(t1, t2); e->host_ms[2] += ms(t2, t3); e->host_ms[3] += ms(t3, t4);
+    e->host_steps++;
     return NBX_OK;
 }
 
@@ -763,6 +778,17 @@ int32_t nbx_profile_read(nbx_engine* e, int32_t kernel_id, double* total_ms, int
     }
     if (total_ms) *total_ms = total;
     if (launches) *launches = count;
+    return NBX_OK;
+}
+
+int32_t nbx_bh_host_timing(nbx_engine* e, double* ms4, int32_t* steps, int32_t* nodes)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    if (ms4) for (int i = 0; i < 4; i++) ms4[i] = e->host_ms[i];
+    if (steps) *steps = e->host_steps;
+    if (nodes) *nodes = (int32_t)e->flat.size();
+    for (int i = 0; i < 4; i++) e->host_ms[i] = 0;
+    e->host_steps = 0;
     return NBX_OK;
 }
 

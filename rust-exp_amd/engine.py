@@ -161,6 +161,8 @@ def lib():
     L.nbx_profile_reset.restype = i32
     L.nbx_profile_read.argtypes = [E, i32, C.POINTER(C.c_double), C.POINTER(i32)]
     L.nbx_profile_read.restype = i32
+    L.nbx_bh_host_timing.argtypes = [E, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(i32)]
+    L.nbx_bh_host_timing.restype = i32
     L.nbx_last_launch.argtypes = [E] + [C.POINTER(i32)] * 5
     L.nbx_last_launch.restype = i32
     _lib = L
@@ -264,7 +266,7 @@ class NBodyEngine:
     def set_mode(self, mode):
         self.set_option(NBX_OPT_FORCE_MODE, {"fast": 0, "strict": 1}[mode])
 
-    def set_launch(self, jsplit=0, bodies_per_thread=0, dim=0, variant=0):
+    def set_launch(self, jsplit=0, bodies_per_thread=0, dim=0, variant=1):
         self.set_option(NBX_OPT_JSPLIT, jsplit)
         self.set_option(NBX_OPT_BODIES_PER_THREAD, bodies_per_thread)
         self.set_option(NBX_OPT_DIM, dim)
@@ -362,6 +364,14 @@ class NBodyEngine:
         ms, cnt = C.c_double(), C.c_int32()
         _check(self._L.nbx_profile_read(self._h, kernel_id, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def bh_host_timing(self):
+        ms = (C.c_double * 4)()
+        steps, nodes = C.c_int32(), C.c_int32()
+        _check(self._L.nbx_bh_host_timing(self._h, ms, C.byref(steps), C.byref(nodes)))
+        k = max(steps.value, 1)
+        return {"download_ms": ms[0] / k, "build_ms": ms[1] / k, "flatten_ms": ms[2] / k, "upload_ms": ms[3] / k,
+                "steps": steps.value, "nodes": nodes.value}
 
     def last_launch(self):
         v = [C.c_int32() for _ in range(5)]

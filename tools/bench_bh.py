@@ -35,7 +35,7 @@ def main():
     e = rx.NBodyEngine(mode="fast")
     e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
     e.step_barnes_hut(0.5, 0.01, 1); e.synchronize()          # warm-up (allocations)
-    e.profile(True); e.profile_reset()
+    e.profile(True); e.profile_reset(); e.bh_host_timing()
 
     def step():
         e.step_barnes_hut(0.5, 0.01, 1); e.synchronize()
@@ -46,6 +46,7 @@ def main():
     out["bh_1m"] = {"bodies": big, "theta": 0.5, "ms_per_step_median": med * 1e3, "eval_kernel_ms": ms / cnt,
                     "integrate_kernel_ms": ims / cnt, "host_tree_and_copies_ms": med * 1e3 - ms / cnt - ims / cnt,
                     "steps_timed": len(ts)}
+    out["bh_1m"]["host_phases"] = e.bh_host_timing()
     e.profile(False)
     # force error of theta=0.5 vs all-pairs on this state
     bx, by, _ = e.forces(0.5)
