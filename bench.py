@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-path", action="store_true",
+                    help="use the multi-GPU code path (torch-owned buffer + torch stream) even on one GPU")
     args = ap.parse_args()
 
     import rust_exp_amd as rx
@@ -80,7 +82,7 @@ def main():
     n = args.n
     st = rx.plummer_sphere(n, dim=args.dim)
 
-    if world == 1:
+    if world == 1 and not args.torch_path:
         eng = rx.NBodyEngine(device=0, mode=args.mode)
         eng.set_launch(jsplit=args.jsplit, bodies_per_thread=args.bpt, variant=args.variant)
         eng.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
@@ -101,7 +103,8 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         slab = rx.sharded.TorchSlabEngine(local_rank, mode=args.mode)
         slab.eng.set_launch(jsplit=args.jsplit, bodies_per_thread=args.bpt, variant=args.variant)
         sim = rx.ShardedNBody(slab)
@@ -114,7 +117,8 @@ def main():
             torch.cuda.synchronize()
 
         def barrier():
-            dist.barrier()
+            if world > 1:
+                dist.barrier()
 
         engine = slab.eng
 

@@ -30,6 +30,16 @@ class TorchSlabEngine:
     """The HIP engine bound to a torch-owned positions buffer on this rank's GPU."""
 
     def __init__(self, device_index, mode="fast"):
+        import sys
+
+        from . import engine as _engine
+
+        if _engine._lib is not None and "torch" not in sys.modules:
+            # The PyTorch-ROCm wheel bundles its own libamdhip64/libhsa-runtime64. Loaded AFTER the
+            # system ROCm runtime that libnbody_mi355x.so pulled in, the process ends up with two HSA
+            # runtimes and torch sees "No HIP GPUs". Loaded FIRST, both share torch's runtime.
+            raise RuntimeError("import torch before the first rust_exp_amd.lib() call in this process "
+                               "(two HIP runtimes would be loaded otherwise)")
         import torch
 
         from .engine import NBodyEngine
@@ -67,11 +77,13 @@ class TorchSlabEngine:
 
 
 class ShardedNBody:
-    def __init__(self, local_engine, group=None):
+    def __init__(self, local_engine, group=None, always_exchange=False):
         import torch.distributed as dist
 
         self.dist = dist
         self.group = group
+        self.always_exchange = always_exchange   # run the collective even at world size 1 (tests)
+        self._staged = False
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.local = local_engine
@@ -86,14 +98,22 @@ class ShardedNBody:
 
     def _exchange(self):
         """One all-gather of the slabs of the (x,y,z,m) array."""
-        if self.world == 1:
+        if self.world == 1 and not (self.always_exchange and self.dist.is_initialized()):
             return
         dist = self.dist
         pos = self.local.positions_array()
         n, w = self.n, self.world
         if n % w == 0:
             body = pos[:n]
-            dist.all_gather_into_tensor(body, body[self.lo:self.hi], group=self.group)  # in place
+            if not self._staged:
+                try:
+                    # in place: the send slab IS the rank's slot of the receive buffer (ncclAllGather
+                    # in-place form: sendbuff == recvbuff + rank * count)
+                    dist.all_gather_into_tensor(body, body[self.lo:self.hi], group=self.group)
+                    return
+                except (RuntimeError, ValueError):
+                    self._staged = True   # backend refuses aliasing: stage the slab once per step
+            dist.all_gather_into_tensor(body, body[self.lo:self.hi].clone(), group=self.group)
         else:
             # ragged last slab (reference split): one broadcast per owner
             for r in range(w):

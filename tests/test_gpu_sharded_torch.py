@@ -1,0 +1,98 @@
+"""GPU: the multi-GPU code path (torch-owned positions buffer, engine on torch's stream, RCCL
+all-gather through torch.distributed) exercised with world_size 1 on the single test GPU, plus the
+per-rank slab kernels of an 8-way shard stitched together on one GPU.  The >1-rank collective itself
+is covered on CPU by tests/test_sharded_gloo.py (gloo) and by the driver's multi-GPU bench."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+WORKER = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["NBX_ROOT"])
+import numpy as np
+import torch                      # BEFORE the HIP library: both then share one HIP runtime
+import torch.distributed as dist
+import rust_exp_amd as rx
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+st = rx.plummer_sphere(16384)
+slab = rx.sharded.TorchSlabEngine(0)
+sim = rx.ShardedNBody(slab, always_exchange=True)
+sim.set_particles(st)
+ref = rx.NBodyEngine()
+ref.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
+for _ in range(4):
+    sim.step_brute_force(0.01)
+    ref.step_brute_force(0.01)
+torch.cuda.synchronize()
+got, want = sim.gather_state(), ref.get_particles()
+bad = [k for k in ("px", "py", "pz", "vx", "vy", "vz")
+       if not np.array_equal(np.asarray(got[k]).view(np.uint32), want[k].view(np.uint32))]
+pos = slab.positions_array()[:16384].cpu().numpy()
+if not np.array_equal(pos[:, 0], want["px"]) or not np.array_equal(pos[:, 3], want["m"]):
+    bad.append("posm")
+moved = float(np.abs(want["px"] - st["px"]).max())
+dist.destroy_process_group()
+print("RESULT " + json.dumps({"bad": bad, "staged": sim._staged, "moved": moved}))
+"""
+
+
+def test_torch_slab_engine_world1_with_rccl_allgather(rx):
+    """Runs in a fresh process: torch must be imported before the HIP library (the wheel bundles its
+    own HIP runtime; see TorchSlabEngine)."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, NBX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-4000:]
+    res = json.loads(lines[-1][7:])
+    assert res["bad"] == [] and res["moved"] > 0, res
+
+
+@pytest.mark.parametrize("world,n", [(8, 32768), (3, 1000)])
+def test_slab_kernels_of_all_ranks_stitch_to_the_single_gpu_step(rx, ob, world, n):
+    """Every rank's nbx_step_local on its own slab (run one after another on this GPU) reproduces the
+    unsharded step: strict mode bit for bit vs the oracle, fast mode within rounding of the unsharded
+    fast step (different j-split per slab size)."""
+    p = ob.random_disk(n, 33)
+    for mode in ("strict", "fast"):
+        news = {k: np.zeros(n, np.float32) for k in ("px", "py", "vx", "vy")}
+        for r in range(world):
+            e = rx.NBodyEngine(mode=mode)
+            e.set_shard(r, world)
+            e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+            lo, hi = e.slab()
+            assert (lo, hi) == rx.reference_slab(n, r, world)
+            e.step_local(0.01)
+            st = e.get_particles()
+            for k in news:
+                news[k][lo:hi] = st[k][lo:hi]
+            # bodies outside the slab are untouched on this rank until the all-gather
+            out = np.ones(n, bool); out[lo:hi] = False
+            assert_bit_equal(st["px"][out], p["px"][out])
+        q = p.copy()
+        ob.step_brute_force(q, 0.01, nthreads=8)
+        if mode == "strict":
+            for k in news:
+                assert_bit_equal(news[k], q[k], k)
+        else:
+            assert np.abs(news["px"] - q["px"]).max() <= 1e-5
+            assert np.abs(news["vx"] - q["vx"]).max() <= 2e-4
