@@ -159,6 +159,11 @@ int32_t nbx_draw(nbx_engine *e, int32_t w, int32_t h, uint32_t *fb);
  * cap rows are written) or a negative status. Runs without a device. */
 int32_t nbx_bh_tree_dump(nbx_engine *e, float *rows, int32_t cap);
 
+/* The flattened tree the GPU traversal walks: pre-order, empty exterior nodes dropped, 32-byte records
+ * {float px, py, m, s; int32 skip, interior, pad, pad}. threaded != 0 uses the host-thread flattener
+ * (same bytes). Returns the node count; writes only when cap >= count. Runs without a device. */
+int32_t nbx_bh_flat_dump(nbx_engine *e, void *rows, int32_t cap, int32_t threaded);
+
 /* ---- multi-GPU: bodies shard as contiguous slabs of targets, the reference's own thread split  */
 /* (range = N/world, last rank takes the remainder; nbody.rs:426-428).  One process per GPU; every */
 /* rank holds the full (x,y,z,m) source array and its own slab's velocities.  Per step:            */

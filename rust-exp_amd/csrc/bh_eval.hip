@@ -83,7 +83,9 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_strict(const float4* __restri
         if (b.y) {
             const float dx = __fsub_rn(a.x, pi.x);                               // :342
             const float dy = __fsub_rn(a.y, pi.y);                               // :343
-            const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));  // :344
+            // sqrtf, NOT __fsqrt_rn: the latter lowers to the 1-ulp native v_sqrt_f32; sqrtf is correctly
+            // rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt) like Rust's f32::sqrt
+            const float d = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));        // :344
             if (a.w / d < theta) {                                               // :345
                 // force(px,py,m, self.px,self.py,self.m)  :348
                 const float ddx = __fsub_rn(a.x, pi.x), ddy = __fsub_rn(a.y, pi.y);

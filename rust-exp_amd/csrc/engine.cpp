@@ -93,7 +93,13 @@ struct nbx_engine {
     bool seeded = false;
 
     nbx::QuadTree tree;
-    std::vector<nbx::BhNode> flat;
+    nbx::QuadTree::FlatPlan plan;
+    std::vector<nbx::BhNode> flat_small;
+    nbx::BhNode* h_nodes = nullptr;   // pinned host staging of the flattened tree
+    size_t h_nodes_cap = 0;
+    size_t n_flat = 0;
+    float4* h_stage = nullptr;        // pinned host staging for position downloads
+    size_t h_stage_cap = 0;
 
     std::vector<ProfRec> prof;
     nbx::ForceLaunch last{0, 0, 0, 0, 0, 0};
@@ -193,8 +199,15 @@ int download_positions(nbx_engine* e)
     if (e->host_pos_valid) return NBX_OK;
     int rc = ensure_device(e);
     if (rc != NBX_OK) return rc;
-    std::vector<float4> tmp((size_t)std::max(e->n, 1));
-    HIP_TRY(hipMemcpyAsync(tmp.data(), e->d_posm, sizeof(float4) * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
+    if ((size_t)e->n > e->h_stage_cap) {
+        if (e->h_stage) HIP_TRY(hipHostFree(e->h_stage));
+        e->h_stage = nullptr;
+        e->h_stage_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage), sizeof(float4) * (size_t)std::max(e->n, 256), hipHostMallocDefault));
+        e->h_stage_cap = (size_t)std::max(e->n, 256);
+    }
+    float4* tmp = e->h_stage;
+    HIP_TRY(hipMemcpyAsync(tmp, e->d_posm, sizeof(float4) * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     for (int i = 0; i < e->n; i++) {
         e->host.px[i] = tmp[i].x; e->host.py[i] = tmp[i].y; e->host.pz[i] = tmp[i].z;
@@ -319,14 +332,33 @@ int build_and_upload_tree(nbx_engine* e)
     if (rc == NBX_ERR_TREE_DEPTH) return fail(rc, "quadtree depth > 50 (the reference panics here, nbody.rs:230-232)");
     if (rc != NBX_OK) return fail(rc, "quadtree build hit a reference assert (nbody.rs:267/:293/:304)");
     const auto t2 = clk::now();
-    e->tree.flatten(e->flat);
+    const bool big = e->tree.forest;
+    size_t count;
+    if (big) {
+        count = e->tree.flatten_prepare(e->plan);
+    } else {
+        e->tree.flatten(e->flat_small);
+        count = e->flat_small.size();
+    }
+    if (count > e->h_nodes_cap) {
+        if (e->h_nodes) HIP_TRY(hipHostFree(e->h_nodes));
+        e->h_nodes = nullptr;
+        e->h_nodes_cap = 0;
+        const size_t want = std::max<size_t>(count + count / 4, 1024);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_nodes), sizeof(nbx::BhNode) * want, hipHostMallocDefault));
+        e->h_nodes_cap = want;
+    }
+    if (big)
+        e->tree.flatten_write(e->plan, e->h_nodes);
+    else if (count)
+        std::memcpy(e->h_nodes, e->flat_small.data(), sizeof(nbx::BhNode) * count);
+    e->n_flat = count;
     const auto t3 = clk::now();
-    rc = grow(&e->d_nodes, &e->nodes_cap, std::max<size_t>(e->flat.size(), 1));
+    rc = grow(&e->d_nodes, &e->nodes_cap, std::max<size_t>(count, 1));
     if (rc != NBX_OK) return rc;
-    if (!e->flat.empty()) {
-        HIP_TRY(hipMemcpyAsync(e->d_nodes, e->flat.data(), sizeof(nbx::BhNode) * e->flat.size(), hipMemcpyHostToDevice,
-                               e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));  // flat is reused next step
+    if (count) {
+        HIP_TRY(hipMemcpyAsync(e->d_nodes, e->h_nodes, sizeof(nbx::BhNode) * count, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));  // the staging buffer is rewritten next step
     }
     const auto t4 = clk::now();
     e->host_ms[0] += ms(t0, t1); e->host_ms[1] += ms(t1, t2); e->host_ms[2] += ms(t2, t3); e->host_ms[3] += ms(t3, t4);
@@ -347,7 +379,7 @@ int step_bh(nbx_engine* e, float theta, float dt)
     if (rc != NBX_OK) return rc;
     {
         ProfScope ps(e, NBX_K_BH_EVAL);
-        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->flat.size(), theta, e->force_mode,
+        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, e->force_mode,
                                     e->d_f2, e->stream));
     }
     {
@@ -376,6 +408,8 @@ void free_device(nbx_engine* e)
     if (e->d_f2) (void)hipFree(e->d_f2);
     if (e->d_out4) (void)hipFree(e->d_out4);
     if (e->d_nodes) (void)hipFree(e->d_nodes);
+    if (e->h_nodes) (void)hipHostFree(e->h_nodes);
+    if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
 }
 
@@ -645,7 +679,7 @@ int32_t nbx_forces(nbx_engine* e, float theta, int32_t cap, float* fx, float* fy
         rc = build_and_upload_tree(e);
         if (rc != NBX_OK) return rc;
         ProfScope ps(e, NBX_K_BH_EVAL);
-        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->flat.size(), theta, e->force_mode,
+        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, e->force_mode,
                                     e->d_f2, e->stream));
         is_accel = e->force_mode == 0;
     }
@@ -680,6 +714,24 @@ int32_t nbx_bh_tree_dump(nbx_engine* e, float* rows, int32_t cap)
     rc = e->tree.build(e->host.px.data(), e->host.py.data(), e->host.m.data(), e->n);
     if (rc != NBX_OK) return fail(rc, "quadtree build failed (%d)", rc);
     return e->tree.dump_preorder(rows, cap);
+}
+
+int32_t nbx_bh_flat_dump(nbx_engine* e, void* rows, int32_t cap, int32_t threaded)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    int rc = download_positions(e);
+    if (rc != NBX_OK) return rc;
+    rc = e->tree.build(e->host.px.data(), e->host.py.data(), e->host.m.data(), e->n);
+    if (rc != NBX_OK) return fail(rc, "quadtree build failed (%d)", rc);
+    if (threaded && e->tree.forest) {
+        const size_t count = e->tree.flatten_prepare(e->plan);
+        if ((size_t)cap >= count && rows) e->tree.flatten_write(e->plan, static_cast<nbx::BhNode*>(rows));
+        return (int32_t)count;
+    }
+    e->tree.flatten(e->flat_small);
+    if ((size_t)cap >= e->flat_small.size() && rows && !e->flat_small.empty())
+        std::memcpy(rows, e->flat_small.data(), sizeof(nbx::BhNode) * e->flat_small.size());
+    return (int32_t)e->flat_small.size();
 }
 
 int32_t nbx_set_shard(nbx_engine* e, int32_t rank, int32_t world)
@@ -786,7 +838,7 @@ int32_t nbx_bh_host_timing(nbx_engine* e, double* ms4, int32_t* steps, int32_t* 
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
     if (ms4) for (int i = 0; i < 4; i++) ms4[i] = e->host_ms[i];
     if (steps) *steps = e->host_steps;
-    if (nodes) *nodes = (int32_t)e->flat.size();
+    if (nodes) *nodes = (int32_t)e->n_flat;
     for (int i = 0; i < 4; i++) e->host_ms[i] = 0;
     e->host_steps = 0;
     return NBX_OK;

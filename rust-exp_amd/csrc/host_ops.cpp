@@ -3,8 +3,14 @@
 // round exactly like the reference (rustc never contracts a*b+c).
 #include "host_ops.h"
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "../../include/nbody_mi355x.h"
 
@@ -181,11 +187,113 @@ inline int quadrant(const QuadTree::Node& nd, float x, float y)         // nbody
 
 }  // namespace
 
+namespace {
+
+using Event = QuadTree::Event;   // one pending Node::insert(px, py, m, depth) call
+
+// The reference insertion (nbody.rs:226-284) as an iterative descent over an index-linked pool.
+// `TOP` mode is the first phase of the threaded build: nodes carry their tree level, and an insert that
+// is about to enter a node at level == limit is not executed but queued on that node's bucket, in
+// arrival order.  Replaying a bucket's queue later, on its own, reproduces the sequential result
+// exactly: a subtree's state depends only on the ordered sequence of inserts that reach its root.
+struct Builder {
+    std::vector<QuadTree::Node>& pool;
+    std::vector<uint8_t>* level = nullptr;               // TOP mode only
+    std::vector<int>* bucket_of = nullptr;               // TOP mode only: node -> bucket id or -1
+    std::vector<std::vector<QuadTree::Event>>* buckets = nullptr;  // TOP mode only (capacity reused across builds)
+    size_t* used = nullptr;                                        // TOP mode only: buckets in use
+    int limit = -1;
+
+    int split(int k)                                                      // create_children, :286-301
+    {
+        const QuadTree::Node nd = pool[k];
+        const float cx = (nd.x1 + nd.x2) * 0.5f;
+        const float cy = (nd.y1 + nd.y2) * 0.5f;
+        if (!(cx > nd.x1 || cx < nd.x2 || cy > nd.y1 || cy < nd.y2)) return NBX_ERR_TREE;  // :293
+        const int c = (int)pool.size();
+        pool.push_back(QuadTree::Node{nd.x1, cy, cx, nd.y2, 0.0f, 0.0f, 0.0f, -1});      // UL :296
+        pool.push_back(QuadTree::Node{cx, cy, nd.x2, nd.y2, 0.0f, 0.0f, 0.0f, -1});      // UR :297
+        pool.push_back(QuadTree::Node{nd.x1, nd.y1, cx, cy, 0.0f, 0.0f, 0.0f, -1});      // LL :298
+        pool.push_back(QuadTree::Node{cx, nd.y1, nd.x2, cy, 0.0f, 0.0f, 0.0f, -1});      // LR :299
+        pool[k].first_child = c;
+        if (level) {
+            const uint8_t lv = (uint8_t)((*level)[k] + 1);
+            for (int q = 0; q < 4; q++) {
+                level->push_back(lv);
+                if (lv == limit) {
+                    bucket_of->push_back((int)*used);
+                    if (*used == buckets->size()) buckets->emplace_back();
+                    ++*used;
+                } else {
+                    bucket_of->push_back(-1);
+                }
+            }
+        }
+        return NBX_OK;
+    }
+
+    template <bool TOP>
+    int insert(int k, const Event ev)
+    {
+        const float EPS = kEps;
+        const float qx = ev.x, qy = ev.y, qm = ev.m;
+        unsigned depth = ev.depth;
+        for (;;) {
+            if (TOP && (*bucket_of)[k] >= 0) {                            // hand over to the subtree's owner
+                (*buckets)[(*bucket_of)[k]].push_back(Event{qx, qy, qm, depth});
+                return NBX_OK;
+            }
+            if (depth > 50) return NBX_ERR_TREE_DEPTH;                    // :230
+            if (pool[k].first_child >= 0) {                               // :234
+                if (!add_mass(pool[k], qx, qy, qm)) return NBX_ERR_TREE;  // :236
+                k = pool[k].first_child + quadrant(pool[k], qx, qy);      // :237-240
+                depth += 1;
+                continue;
+            }
+            QuadTree::Node& nd = pool[k];
+            const bool too_close = std::fabs(nd.px - qx) < EPS && std::fabs(nd.py - qy) < EPS;  // :249
+            if (nd.m == 0.0f || too_close) {                              // :250
+                if (!add_mass(nd, qx, qy, qm)) return NBX_ERR_TREE;       // :260
+                return NBX_OK;
+            }
+            if (!(nd.px != qx || nd.py != qy)) return NBX_ERR_TREE;       // :267
+            const float ox = nd.px, oy = nd.py, om = nd.m;                // :271-273
+            pool[k].px = 0.0f; pool[k].py = 0.0f; pool[k].m = 0.0f;       // :274-276
+            const int rc = split(k);                                      // :277 (invalidates `nd`)
+            if (rc != NBX_OK) return rc;
+            // self.insert(original, depth+1)  :278 -> interior branch: add_mass on the emptied node
+            // (exact copy), then the child at depth+2, which is empty -> exact copy again.
+            if (depth + 1 > 50) return NBX_ERR_TREE_DEPTH;
+            if (!add_mass(pool[k], ox, oy, om)) return NBX_ERR_TREE;
+            const int child = pool[k].first_child + quadrant(pool[k], ox, oy);
+            if (TOP && (*bucket_of)[child] >= 0) {
+                (*buckets)[(*bucket_of)[child]].push_back(Event{ox, oy, om, depth + 2});
+            } else {
+                if (depth + 2 > 50) return NBX_ERR_TREE_DEPTH;
+                if (!add_mass(pool[child], ox, oy, om)) return NBX_ERR_TREE;
+            }
+            depth += 1;                                                   // :281 self.insert(new, depth+1)
+        }
+    }
+};
+
+int host_threads()
+{
+    if (const char* env = std::getenv("NBX_HOST_THREADS")) {
+        const int t = std::atoi(env);
+        if (t >= 1) return t < 256 ? t : 256;
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(hw ? hw : 1, 32);
+}
+
+}  // namespace
+
 int QuadTree::build(const float* px, const float* py, const float* m, int n)
 {
-    const float EPS = kEps;
     nodes.clear();
-    nodes.reserve((size_t)n * 3 + 8);
+    forest = false;
+    n_buckets = 0;
     float x1 = 3.40282347e+38f, y1 = 3.40282347e+38f, x2 = -3.40282347e+38f, y2 = -3.40282347e+38f;  // :388-391
     for (int i = 0; i < n; i++) {                                         // :392-398 strict < / >
         x1 = px[i] < x1 ? px[i] : x1;
@@ -193,68 +301,109 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n)
         x2 = px[i] > x2 ? px[i] : x2;
         y2 = py[i] > y2 ? py[i] : y2;
     }
-    nodes.push_back(Node{x1, y1, x2, y2, 0.0f, 0.0f, 0.0f, -1});          // :410
-
-    auto split = [&](int k) -> int {                                      // create_children, :286-301
-        const Node nd = nodes[k];
-        const float cx = (nd.x1 + nd.x2) * 0.5f;
-        const float cy = (nd.y1 + nd.y2) * 0.5f;
-        if (!(cx > nd.x1 || cx < nd.x2 || cy > nd.y1 || cy < nd.y2)) return NBX_ERR_TREE;  // :293
-        const int c = (int)nodes.size();
-        nodes.push_back(Node{nd.x1, cy, cx, nd.y2, 0.0f, 0.0f, 0.0f, -1});      // UL :296
-        nodes.push_back(Node{cx, cy, nd.x2, nd.y2, 0.0f, 0.0f, 0.0f, -1});      // UR :297
-        nodes.push_back(Node{nd.x1, nd.y1, cx, cy, 0.0f, 0.0f, 0.0f, -1});      // LL :298
-        nodes.push_back(Node{cx, nd.y1, nd.x2, cy, 0.0f, 0.0f, 0.0f, -1});      // LR :299
-        nodes[k].first_child = c;
-        return NBX_OK;
-    };
-
-    for (int i = 0; i < n; i++) {                                         // :413-415 particle-index order
-        const float qx = px[i], qy = py[i], qm = m[i];
-        int k = 0;
-        unsigned depth = 0;
-        for (;;) {
-            if (depth > 50) return NBX_ERR_TREE_DEPTH;                    // :230
-            if (nodes[k].first_child >= 0) {                              // :234
-                if (!add_mass(nodes[k], qx, qy, qm)) return NBX_ERR_TREE; // :236
-                k = nodes[k].first_child + quadrant(nodes[k], qx, qy);    // :237-240
-                depth += 1;
-                continue;
-            }
-            Node& nd = nodes[k];
-            const bool too_close = std::fabs(nd.px - qx) < EPS && std::fabs(nd.py - qy) < EPS;  // :249
-            if (nd.m == 0.0f || too_close) {                              // :250
-                if (!add_mass(nd, qx, qy, qm)) return NBX_ERR_TREE;       // :260
-                break;
-            }
-            if (!(nd.px != qx || nd.py != qy)) return NBX_ERR_TREE;       // :267
-            const float ox = nd.px, oy = nd.py, om = nd.m;                // :271-273
-            nodes[k].px = 0.0f; nodes[k].py = 0.0f; nodes[k].m = 0.0f;    // :274-276
-            const int rc = split(k);                                      // :277 (invalidates `nd`)
+    const int threads = host_threads();
+    if (n < 32768 || threads < 2) {
+        // sequential: exactly the reference's loop (nbody.rs:413-415, particle-index order)
+        nodes.reserve((size_t)n * 3 + 8);
+        nodes.push_back(Node{x1, y1, x2, y2, 0.0f, 0.0f, 0.0f, -1});      // :410
+        Builder b{nodes};
+        for (int i = 0; i < n; i++) {
+            const int rc = b.insert<false>(0, Event{px[i], py[i], m[i], 0});
             if (rc != NBX_OK) return rc;
-            // self.insert(original, depth+1)  :278 -> interior branch: add_mass on the emptied node
-            // (exact copy), then the child at depth+2, which is empty -> exact copy again.
-            if (depth + 1 > 50) return NBX_ERR_TREE_DEPTH;
-            if (!add_mass(nodes[k], ox, oy, om)) return NBX_ERR_TREE;
-            if (depth + 2 > 50) return NBX_ERR_TREE_DEPTH;
-            Node& child = nodes[nodes[k].first_child + quadrant(nodes[k], ox, oy)];
-            if (!add_mass(child, ox, oy, om)) return NBX_ERR_TREE;
-            depth += 1;                                                   // :281 self.insert(new, depth+1)
         }
+        return NBX_OK;
+    }
+
+    // ---- threaded, result-identical build --------------------------------------------------------
+    const bool timing = std::getenv("NBX_TIMING") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
+    // Phase 1 (sequential, particle-index order): the real algorithm on the top `limit` levels only;
+    // inserts reaching a level-`limit` node are queued on that node ("bucket") in arrival order.
+    const int limit = n >= 262144 ? 5 : 4;
+    std::vector<Node>& top = nodes;
+    std::vector<uint8_t> level;
+    bucket_of.clear();
+    for (auto& q : queues) q.clear();
+    size_t used_queues = 0;
+    top.reserve(4096);
+    top.push_back(Node{x1, y1, x2, y2, 0.0f, 0.0f, 0.0f, -1});
+    level.push_back(0);
+    bucket_of.push_back(-1);
+    Builder tb{top, &level, &bucket_of, &queues, &used_queues, limit};
+    for (int i = 0; i < n; i++) {
+        const int rc = tb.insert<true>(0, Event{px[i], py[i], m[i], 0});
+        if (rc != NBX_OK) return rc;
+    }
+    const auto tp1 = std::chrono::steady_clock::now();
+    // Phase 2 (parallel over buckets): replay each queue on a private pool whose node 0 is the bucket root.
+    const int nb = (int)used_queues;
+    root_of.assign(nb, -1);
+    for (int k = 0; k < (int)top.size(); k++)
+        if (bucket_of[k] >= 0) root_of[bucket_of[k]] = k;
+    if ((int)pools.size() < nb) pools.resize(nb);
+    std::vector<int> status(nb, NBX_OK);
+    std::vector<int> order(nb);
+    for (int b = 0; b < nb; b++) order[b] = b;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return queues[a].size() > queues[b].size(); });
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int t = next.fetch_add(1);
+            if (t >= nb) return;
+            const int b = order[t];
+            std::vector<Node>& pool = pools[b];
+            pool.clear();
+            pool.reserve(queues[b].size() * 3 + 8);
+            pool.push_back(top[root_of[b]]);
+            Builder lb{pool};
+            for (const Event& ev : queues[b]) {
+                const int rc = lb.insert<false>(0, ev);
+                if (rc != NBX_OK) { status[b] = rc; break; }
+            }
+        }
+    };
+    const int nt = std::max(1, std::min(threads, nb));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    for (int b = 0; b < nb; b++)
+        if (status[b] != NBX_OK) return status[b];
+    // The tree stays a forest: `nodes` = top levels, pools[b] = subtree of bucket b (local indices,
+    // node 0 = the bucket root, which supersedes nodes[root_of[b]]).  Traversals below understand both.
+    forest = true;
+    n_buckets = nb;
+    if (timing) {
+        const auto tp2 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        size_t big = 0;
+        for (int b = 0; b < nb; b++) big = std::max(big, queues[b].size());
+        std::fprintf(stderr, "[nbx] tree build n=%d threads=%d buckets=%d (largest %zu): top %.2f ms, subtrees %.2f ms\n", n, nt, nb,
+                     big, ms(tp0, tp1), ms(tp1, tp2));
     }
     return NBX_OK;
+}
+
+size_t QuadTree::node_count() const
+{
+    size_t c = nodes.size();
+    if (forest)
+        for (int b = 0; b < n_buckets; b++) c += pools[b].size() - 1;
+    return c;
 }
 
 int QuadTree::dump_preorder(float* rows, int cap) const
 {
     if (nodes.empty()) return 0;
     int count = 0;
-    std::vector<int> stack;
-    stack.push_back(0);
+    struct Ref { int pool; int idx; };   // pool -1 = `nodes`
+    std::vector<Ref> stack;
+    stack.push_back(Ref{-1, 0});
     while (!stack.empty()) {
-        const int k = stack.back();
+        Ref r = stack.back();
         stack.pop_back();
-        const Node& nd = nodes[k];
+        if (r.pool < 0 && forest && bucket_of[r.idx] >= 0) r = Ref{bucket_of[r.idx], 0};
+        const Node& nd = r.pool < 0 ? nodes[r.idx] : pools[r.pool][r.idx];
         if (count < cap && rows) {
             float* o = rows + 8 * (size_t)count;
             o[0] = nd.x1; o[1] = nd.y1; o[2] = nd.x2; o[3] = nd.y2;
@@ -262,45 +411,159 @@ int QuadTree::dump_preorder(float* rows, int cap) const
         }
         count++;
         if (nd.first_child >= 0)
-            for (int c = 3; c >= 0; c--) stack.push_back(nd.first_child + c);
+            for (int c = 3; c >= 0; c--) stack.push_back(Ref{r.pool, nd.first_child + c});
     }
     return count;
 }
 
-void QuadTree::flatten(std::vector<BhNode>& out) const
+// Pre-order flattening with skip pointers, empty exterior nodes dropped (they contribute (0,0),
+// nbody.rs:368).  `base` is added to every skip pointer (position of the subtree in the final array).
+static void flatten_subtree(const std::vector<QuadTree::Node>& nodes, int root, std::vector<BhNode>& out)
 {
-    out.clear();
-    if (nodes.empty()) return;
-    out.reserve(nodes.size());
-    // iterative pre-order; a frame remembers the output slot whose skip pointer is patched when
-    // the subtree has been emitted.
     struct Frame { int node; int slot; int next_child; };
     std::vector<Frame> st;
     auto emit = [&](int k) -> int {
-        const Node& nd = nodes[k];
+        const QuadTree::Node& nd = nodes[k];
         BhNode b;
         b.px = nd.px; b.py = nd.py; b.m = nd.m; b.s = nd.x2 - nd.x1;   // s = x-extent, nbody.rs:341
         b.skip = 0; b.interior = nd.first_child >= 0 ? 1 : 0; b.pad0 = 0; b.pad1 = 0;
         out.push_back(b);
         return (int)out.size() - 1;
     };
-    const Node& root = nodes[0];
-    if (root.first_child < 0 && root.m == 0.0f) return;   // empty tree
-    st.push_back(Frame{0, emit(0), 0});
+    st.push_back(Frame{root, emit(root), 0});
     while (!st.empty()) {
         Frame& f = st.back();
-        const Node& nd = nodes[f.node];
+        const QuadTree::Node& nd = nodes[f.node];
         if (nd.first_child < 0 || f.next_child == 4) {
             out[f.slot].skip = (int)out.size();
             st.pop_back();
             continue;
         }
         const int c = nd.first_child + f.next_child++;
-        const Node& ch = nodes[c];
-        if (ch.first_child < 0 && ch.m == 0.0f) continue;   // empty exterior: contributes (0,0), nbody.rs:368
+        const QuadTree::Node& ch = nodes[c];
+        if (ch.first_child < 0 && ch.m == 0.0f) continue;
         const int slot = emit(c);
         st.push_back(Frame{c, slot, 0});
     }
+}
+
+void QuadTree::flatten(std::vector<BhNode>& out) const
+{
+    out.clear();
+    if (nodes.empty()) return;
+    if (forest) {   // generic path: lay the pieces out serially
+        FlatPlan plan;
+        const size_t count = flatten_prepare(plan);
+        out.resize(count);
+        if (count) flatten_write(plan, out.data());
+        return;
+    }
+    const Node& root = nodes[0];
+    if (root.first_child < 0 && root.m == 0.0f) return;   // empty tree
+    out.reserve(nodes.size());
+    flatten_subtree(nodes, 0, out);
+}
+
+// Threaded flattening of a forest: the top levels are walked serially; every non-empty bucket subtree
+// is an independent job flattened into a private array (relative skips); then all pieces are laid out
+// in pre-order and copied to the destination in parallel (flatten_write).
+size_t QuadTree::flatten_prepare(FlatPlan& plan) const
+{
+    plan.items.clear();
+    plan.total = 0;
+    if (nodes.empty()) return 0;
+    if ((int)plan.pieces.size() < n_buckets) plan.pieces.resize(n_buckets);
+    auto eff = [&](int k) -> const Node& { return (forest && bucket_of[k] >= 0) ? pools[bucket_of[k]][0] : nodes[k]; };
+    const Node& root = eff(0);
+    if (root.first_child < 0 && root.m == 0.0f) return 0;
+    struct Frame { int node; int item; int next_child; };
+    std::vector<Frame> st;
+    auto add_item = [&](int node) -> int {
+        FlatPlan::Item it;
+        it.node = node; it.end_item = -1; it.offset = 0;
+        it.piece = (forest && bucket_of[node] >= 0) ? bucket_of[node] : -1;
+        plan.items.push_back(it);
+        return (int)plan.items.size() - 1;
+    };
+    st.push_back(Frame{0, add_item(0), 0});
+    while (!st.empty()) {
+        Frame& f = st.back();
+        const Node& nd = nodes[f.node];
+        const bool leaf_like = plan.items[f.item].piece >= 0 || nd.first_child < 0;
+        if (leaf_like || f.next_child == 4) {
+            plan.items[f.item].end_item = (int)plan.items.size();
+            st.pop_back();
+            continue;
+        }
+        const int c = nd.first_child + f.next_child++;
+        const Node& ch = eff(c);
+        if (ch.first_child < 0 && ch.m == 0.0f) continue;   // empty exterior: dropped
+        const int item = add_item(c);
+        st.push_back(Frame{c, item, 0});
+    }
+    // parallel: flatten every referenced bucket privately
+    std::vector<int> jobs;
+    for (const auto& it : plan.items)
+        if (it.piece >= 0) jobs.push_back(it.piece);
+    std::sort(jobs.begin(), jobs.end(), [&](int a, int b) { return pools[a].size() > pools[b].size(); });
+    const int nj = (int)jobs.size();
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int j = next.fetch_add(1);
+            if (j >= nj) return;
+            std::vector<BhNode>& pc = plan.pieces[jobs[j]];
+            pc.clear();
+            pc.reserve(pools[jobs[j]].size());
+            flatten_subtree(pools[jobs[j]], 0, pc);
+        }
+    };
+    const int nt = std::max(1, std::min(host_threads(), nj));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    size_t off = 0;
+    for (auto& it : plan.items) {
+        it.offset = off;
+        off += it.piece >= 0 ? plan.pieces[it.piece].size() : 1;
+    }
+    plan.total = off;
+    return off;
+}
+
+void QuadTree::flatten_write(const FlatPlan& plan, BhNode* out) const
+{
+    const int ni = (int)plan.items.size();
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= ni) return;
+            const FlatPlan::Item& it = plan.items[i];
+            if (it.piece < 0) {
+                const Node& nd = nodes[it.node];
+                BhNode b;
+                b.px = nd.px; b.py = nd.py; b.m = nd.m; b.s = nd.x2 - nd.x1;
+                b.interior = nd.first_child >= 0 ? 1 : 0; b.pad0 = 0; b.pad1 = 0;
+                b.skip = (int)(it.end_item < ni ? plan.items[it.end_item].offset : plan.total);
+                out[it.offset] = b;
+            } else {
+                const std::vector<BhNode>& pc = plan.pieces[it.piece];
+                const int base = (int)it.offset;
+                for (size_t k = 0; k < pc.size(); k++) {
+                    BhNode b = pc[k];
+                    b.skip += base;
+                    out[it.offset + k] = b;
+                }
+            }
+        }
+    };
+    const int nt = std::max(1, std::min(host_threads(), ni));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
 }
 
 }  // namespace nbx

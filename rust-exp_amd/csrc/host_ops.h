@@ -41,13 +41,33 @@ struct QuadTree {
         float px, py, m;       // COM + total mass (interior) / particle (exterior)
         int32_t first_child;   // -1 = exterior
     };
-    std::vector<Node> nodes;   // nodes[0] = root
+    struct Event { float x, y, m; unsigned depth; };   // a pending Node::insert(px, py, m, depth)
+    std::vector<Node> nodes;   // nodes[0] = root. Whole tree (forest == false) or its top levels.
+    // Threaded build leaves a forest: the subtree under top node root_of[b] lives in pools[b] with
+    // pool-local child indices; pools[b][0] is that bucket root and supersedes nodes[root_of[b]].
+    bool forest = false;
+    int n_buckets = 0;
+    std::vector<int> bucket_of;                 // top node -> bucket id or -1
+    std::vector<int> root_of;                   // bucket id -> top node
+    std::vector<std::vector<Node>> pools;       // capacity reused from step to step
+    std::vector<std::vector<Event>> queues;     // per-bucket insert queues of the last build (reused)
+    size_t node_count() const;
     // status: 0 ok, else the NBX_ERR_* code standing in for the reference panic
     int build(const float* px, const float* py, const float* m, int n);
     // pre-order, all nodes (including empty exteriors), rows of 8 floats (see nbx_bh_tree_dump)
     int dump_preorder(float* rows, int cap) const;
-    // pre-order with empty exterior nodes dropped + skip pointers, for the GPU traversal
+    // pre-order with empty exterior nodes dropped + skip pointers, for the GPU traversal (serial)
     void flatten(std::vector<BhNode>& out) const;
+    // the same array produced by host threads straight into a caller buffer (e.g. pinned memory):
+    // prepare() returns the node count, write() fills out[0..count)
+    struct FlatPlan {
+        struct Item { int node; int piece; int end_item; size_t offset; };
+        std::vector<Item> items;                  // top-level nodes and subtree pieces, in pre-order
+        std::vector<std::vector<BhNode>> pieces;  // privately flattened subtrees (relative skips)
+        size_t total = 0;
+    };
+    size_t flatten_prepare(FlatPlan& plan) const;
+    void flatten_write(const FlatPlan& plan, BhNode* out) const;
 };
 
 }  // namespace nbx

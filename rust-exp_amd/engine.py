@@ -145,6 +145,8 @@ def lib():
     L.nbx_draw.restype = i32
     L.nbx_bh_tree_dump.argtypes = [E, C.c_void_p, i32]
     L.nbx_bh_tree_dump.restype = i32
+    L.nbx_bh_flat_dump.argtypes = [E, C.c_void_p, i32, i32]
+    L.nbx_bh_flat_dump.restype = i32
     L.nbx_set_shard.argtypes = [E, i32, i32]
     L.nbx_set_shard.restype = i32
     L.nbx_get_slab.argtypes = [E, C.POINTER(i32), C.POINTER(i32)]
@@ -333,6 +335,15 @@ class NBodyEngine:
         cnt = _check(self._L.nbx_bh_tree_dump(self._h, None, 0))
         rows = np.zeros((max(cnt, 1), 8), np.float32)
         cnt = _check(self._L.nbx_bh_tree_dump(self._h, _p(rows), cnt))
+        return rows[:cnt]
+
+    def bh_flat_dump(self, threaded=False):
+        """Flattened tree as a structured array (px, py, m, s, skip, interior)."""
+        dt = np.dtype([("px", "<f4"), ("py", "<f4"), ("m", "<f4"), ("s", "<f4"), ("skip", "<i4"), ("interior", "<i4"),
+                       ("pad0", "<i4"), ("pad1", "<i4")])
+        cnt = _check(self._L.nbx_bh_flat_dump(self._h, None, 0, int(threaded)))
+        rows = np.zeros(max(cnt, 1), dt)
+        cnt = _check(self._L.nbx_bh_flat_dump(self._h, _p(rows), cnt, int(threaded)))
         return rows[:cnt]
 
     # sharding

@@ -175,6 +175,46 @@ def test_product_quadtree_equals_oracle_tree_node_for_node(rx, ob, make):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("threads", ["1", "2", "7", "32"])
+def test_threaded_quadtree_build_is_result_identical(rx, ob, threads, monkeypatch):
+    """n >= 32768 takes the threaded build (top levels sequential, subtrees replayed in parallel):
+    node for node identical to the oracle's sequential tree, for any thread count, including
+    EPS-merged pairs and a dense clump that forces deep subtrees."""
+    monkeypatch.setenv("NBX_HOST_THREADS", threads)
+    rng = np.random.default_rng(5)
+    n = 40000
+    x = rng.normal(size=n).astype(np.float32) * 8
+    y = rng.normal(size=n).astype(np.float32) * 8
+    x[:4000] = x[:4000] * np.float32(0.001) + np.float32(3.0)          # dense clump
+    y[:4000] = y[:4000] * np.float32(0.001) - np.float32(2.0)
+    x[5000:5100] = x[6000:6100] + np.float32(2e-5)                     # pairs closer than EPS: merged
+    y[5000:5100] = y[6000:6100]
+    m = rng.uniform(0.1, 2.0, n).astype(np.float32)
+    p = ob.particles(x, y, np.zeros(n), np.zeros(n), m)
+    rc, want = ob.bh_tree_dump(p)
+    assert rc == 0
+    e = rx.NBodyEngine()
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    got = e.bh_tree_dump()
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_threaded_quadtree_reports_depth_panic(rx, monkeypatch):
+    monkeypatch.setenv("NBX_HOST_THREADS", "4")
+    rng = np.random.default_rng(6)
+    n = 40000
+    x = rng.uniform(-20, 20, n).astype(np.float32)
+    y = rng.uniform(-20, 20, n).astype(np.float32)
+    x[0], y[0] = 1e30, 1e30                                           # huge box: two close bodies need > 50 splits
+    x[1], y[1], x[2], y[2] = 1.0, 1.0, 1.0003, 1.0
+    e = rx.NBodyEngine()
+    e.set_particles(x, y, np.zeros(n), np.zeros(n), np.ones(n))
+    with pytest.raises(rx.NBodyError) as ei:
+        e.bh_tree_dump()
+    assert ei.value.code == rx.NBX_ERR_TREE_DEPTH
+
+
 def test_product_quadtree_reports_reference_panics(rx, ob):
     e = rx.NBodyEngine()
     e.set_particles([0.0, 1e30, 1.0, 1.0003], [0.0, 1e30, 1.0, 1.0], [0] * 4, [0] * 4, [1.0] * 4)
@@ -220,3 +260,25 @@ def test_plummer_generator_is_deterministic_and_bounded(rx):
 
     s = ctypes.c_uint64(123)
     assert [float(x) for x in u] == [float(ob.lib().orc_next_f32(ctypes.byref(s))) for _ in range(5)]
+
+
+def test_threaded_flatten_equals_serial_flatten(rx, ob, monkeypatch):
+    """The array the GPU traversal walks: forest build + host-thread flattener == sequential build +
+    serial flattener, byte for byte, and its structure is a valid pre-order with skip pointers."""
+    p = ob.stable_orbits(60000, 0.5, 30.0, 6)
+    e = rx.NBodyEngine()
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    monkeypatch.setenv("NBX_HOST_THREADS", "1")      # sequential build, one contiguous pool
+    a = e.bh_flat_dump(False)
+    monkeypatch.setenv("NBX_HOST_THREADS", "8")      # forest of bucket pools, threaded flatten
+    b = e.bh_flat_dump(True)
+    c = e.bh_flat_dump(False)
+    assert len(a) > 100000 and a.tobytes() == b.tobytes() and a.tobytes() == c.tobytes()
+    assert a["skip"][0] == len(a) and a["interior"][0] == 1
+    leaves = a[a["interior"] == 0]
+    assert np.all(leaves["m"] > 0)                           # empty exterior nodes are dropped
+    idx = np.arange(len(a))
+    assert np.all(a["skip"] > idx) and np.all(a["skip"] <= len(a))
+    assert np.all(a["skip"][a["interior"] == 0] == idx[a["interior"] == 0] + 1)
+    assert abs(float(a["m"][0]) - float(p["m"].astype(np.float64).sum())) < 1e-2 * 60000
+    assert len(leaves) <= 60000

@@ -29,7 +29,8 @@ def test_bh_strict_matches_golden_bitwise(rx, name):
             assert_bit_equal(st[k], g[f"s{s}_{k}"], f"{name} step {s} {k}")
 
 
-@pytest.mark.parametrize("n,seed,theta", [(2, 1, 0.5), (10000, 2, 0.85), (10000, 3, 0.3), (30000, 4, 0.95)])
+@pytest.mark.parametrize("n,seed,theta", [(2, 1, 0.5), (10000, 2, 0.85), (10000, 3, 0.3), (30000, 4, 0.95),
+                                          (100000, 6, 0.5), (150001, 7, 0.7)])
 def test_bh_strict_matches_oracle_bitwise(rx, ob, n, seed, theta):
     p = ob.stable_orbits(n, 0.5, 30.0, seed) if seed % 2 == 0 else ob.random_disk(n, seed)
     e = rx.NBodyEngine(mode="strict")

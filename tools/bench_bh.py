@@ -55,6 +55,13 @@ def main():
     out["bh_1m"]["force_rel_err_median"] = float(np.median(rel))
     out["bh_1m"]["force_rel_err_p99"] = float(np.percentile(rel, 99))
 
+    if not os.environ.get("BH_NO_CPU"):
+        from oracle import binding as ob
+
+        p1 = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+        t0 = time.perf_counter(); rc = ob.step_barnes_hut(p1, 0.5, 0.01, 16); t1 = time.perf_counter()
+        out["bh_1m_cpu_oracle_16threads"] = {"ms_per_step": (t1 - t0) * 1e3, "rc": rc,
+                                             "note": "oracle restatement of nbody.rs:186-480, serial tree build + 16 traversal threads (the caller's maximum, hs:94-97)"}
     # the reference's published scenario
     e2 = rx.NBodyEngine(mode="fast")
     e2.seed(1); e2.stable_orbits(10000, 0.5, 30.0)
