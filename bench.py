@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--mode", default="fast")
     ap.add_argument("--jsplit", type=int, default=0)
     ap.add_argument("--bpt", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-path", action="store_true",
@@ -175,7 +175,7 @@ def main():
                        "launch": launch},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "kernel": {0: "k_force_tile", 1: "k_force_tile_pk", 2: "k_force_smem", 3: "k_force_tile_pk"}.get(args.variant, "k_force_tile"), "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_cnt,
+                         "kernel": {0: "k_force_tile", 1: "k_force_tile_pk", 2: "k_force_smem", 3: "k_force_tile_pk", 4: "k_force_tile_pkb", -1: "k_force_tile_pk"}.get(args.variant, "k_force_tile"), "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_cnt,
                          "flops_per_interaction": flops_per_inter,
                          "interactions_per_launch": inter_per_launch,
                          "hbm_algorithmic_bytes_per_launch": 16.0 * n + 16.0 * (hi - lo) * launch["jsplit"],

@@ -88,8 +88,10 @@ enum nbx_option {
     NBX_OPT_BODIES_PER_THREAD = 2, /* register blocking B in {1,2,4}; 0 = auto */
     NBX_OPT_DIM = 3,               /* 2 or 3; 0 = auto (2 when every z and vz is zero) */
     NBX_OPT_PROFILE = 4,           /* 1 = record a HIP event pair around every kernel launch */
-    NBX_OPT_KERNEL_VARIANT = 5,    /* fast force kernel: 1 = packed fp32 + LDS tiles (default), 0 = compiler-scheduled
-                                    * LDS tiles, 2 = scalar-cache sources (no LDS), 3 = packed, 4-source batches */
+    NBX_OPT_KERNEL_VARIANT = 5,    /* fast force kernel: -1 = auto (= 1), 1 = packed fp32 + LDS tiles, 4 = 1 + batched
+                                    * reciprocals (guarded by max|coord| <= 1e4, else the plain sweep runs; same
+                                    * wall time as 1 because the chip is power-limited here), 0 = compiler-scheduled
+                                    * LDS tiles, 2 = scalar-cache sources (no LDS), 3 = packed, 4-source LDS batches */
     NBX_OPT_BH_LEAF_CAP = 6        /* reserved */
 };
 

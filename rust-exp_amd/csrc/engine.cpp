@@ -84,9 +84,11 @@ struct nbx_engine {
     size_t out4_cap = 0;
     nbx::BhNode* d_nodes = nullptr;
     size_t nodes_cap = 0;
+    unsigned* d_guard = nullptr;   // max|coord| word for the batched-reciprocal kernel
+    size_t guard_cap = 0;
 
     // options
-    int force_mode = 0, jsplit = 0, bpt = 0, dim_opt = 0, profile = 0, variant = 1;
+    int force_mode = 0, jsplit = 0, bpt = 0, dim_opt = 0, profile = 0, variant = -1;
     bool any_z = false;
 
     nbx::Rng rng{0};
@@ -282,10 +284,19 @@ int launch_forces_fast(nbx_engine* e)
     const int stride = ((slab + kTile - 1) / kTile) * kTile;
     int rc = grow(&e->d_acc, &e->acc_cap, (size_t)jsplit * (size_t)std::max(stride, kTile));
     if (rc != NBX_OK) return rc;
+    // variant -1 = auto = the plain packed kernel (1).  The batched-reciprocal kernel (4) issues 7 % fewer
+    // VALU cycles but the chip is power-limited on this instruction mix: its clock drops by the same 6-7 %
+    // (2.17 -> 2.03 GHz, profiles/r01_variant1_vs_4_pmc.txt) and wall time is identical, so it buys nothing.
+    int variant = e->variant;
+    if (variant < 0) variant = 1;
+    if (variant == 4) {
+        rc = grow(&e->d_guard, &e->guard_cap, 1);
+        if (rc != NBX_OK) return rc;
+    }
     {
         ProfScope ps(e, NBX_K_FORCE);
-        HIP_TRY(nbx::launch_force_tile(e->d_posm, e->lo, slab, tiles_total, jsplit, bpt, dim, e->variant, e->d_acc,
-                                       stride, e->stream, &e->last));
+        HIP_TRY(nbx::launch_force_tile(e->d_posm, e->lo, slab, tiles_total, jsplit, bpt, dim, variant, e->d_acc, stride,
+                                       variant == 4 ? e->d_guard : nullptr, e->stream, &e->last));
     }
     return NBX_OK;
 }
@@ -408,6 +419,7 @@ void free_device(nbx_engine* e)
     if (e->d_f2) (void)hipFree(e->d_f2);
     if (e->d_out4) (void)hipFree(e->d_out4);
     if (e->d_nodes) (void)hipFree(e->d_nodes);
+    if (e->d_guard) (void)hipFree(e->d_guard);
     if (e->h_nodes) (void)hipHostFree(e->h_nodes);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);

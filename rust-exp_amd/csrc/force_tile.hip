@@ -133,6 +133,151 @@ __device__ __forceinline__ void interact_pk(const float4 sj, const v2f xi, const
     if (DIM == 3) az = __builtin_elementwise_fma(s, dz, az);
 }
 
+// variant 4: as variant 1 with BATCHED reciprocals.  v_rcp_f32 is a quarter-rate transcendental (8
+// cycles per wave64 vs 4 for a packed op, 2 for a plain VALU op; profiles/r01_ubench_banks.txt) and has
+// no packed form, so the 2 (P=1) or 4 (P=2) reciprocals a thread needs per source are obtained from ONE:
+//     t = product of the r2 values          q = rcp(t)        qm = q * m_j
+//     s_k = qm * (product of the OTHER r2 values) = m_j / r2_k
+// P=2: 4 rcp + 2 pk_mul  ->  1 rcp + 2 v_mul + 4 pk_mul   (-9 % issue cycles per source)
+// Valid while the product of four softened squared distances stays inside fp32 range, i.e. for
+// |d| < 6.5e4 (eps^4 = 1e-16 is far from underflow); the engine only selects this variant while every
+// coordinate is inside +-1e4 (it tracks max|coord| on the device) and falls back to variant 1 otherwise.
+template <int DIM>
+__device__ __forceinline__ void sep_r2(const float4 sj, const v2f xi, const v2f yi, const v2f zi, v2f& dx, v2f& dy,
+                                       v2f& dz, v2f& r2)
+{
+    const v2f sx = {sj.x, sj.x}, sy = {sj.y, sj.y};
+    const v2f eps = {kEps, kEps};
+    dx = sx - xi;
+    dy = sy - yi;
+    r2 = __builtin_elementwise_fma(dx, dx, eps);
+    r2 = __builtin_elementwise_fma(dy, dy, r2);
+    dz = v2f{0.f, 0.f};
+    if (DIM == 3) {
+        const v2f mz = {sj.z, sj.w};
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dz) : "v"(mz), "v"(zi));
+        r2 = __builtin_elementwise_fma(dz, dz, r2);
+    }
+}
+
+template <int DIM>
+__device__ __forceinline__ void accumulate(const v2f s, const v2f dx, const v2f dy, const v2f dz, v2f& ax, v2f& ay,
+                                           v2f& az)
+{
+    ax = __builtin_elementwise_fma(s, dx, ax);
+    ay = __builtin_elementwise_fma(s, dy, ay);
+    if (DIM == 3) az = __builtin_elementwise_fma(s, dz, az);
+}
+
+// max |coordinate| a batched launch may see (float bits; non-negative floats order like unsigned ints)
+constexpr unsigned kBatchGuardBits = 0x461C4000u;   // 1.0e4f
+
+template <int P, int DIM, int UNROLL, bool BATCH>
+__device__ __forceinline__ void tile_sweep(const float4* __restrict__ posm, float4 (*tile)[kTile], const int tid,
+                                           const int t0, const int t1, const v2f (&xi)[P], const v2f (&yi)[P],
+                                           const v2f (&zi)[P], v2f (&ax)[P], v2f (&ay)[P], v2f (&az)[P])
+{
+    float4 nxt = posm[(size_t)t0 * kTile + tid];
+    int buf = 0;
+    for (int t = t0; t < t1; t++) {
+        tile[buf][tid] = make_float4(nxt.x, nxt.y, nxt.w, nxt.z);  // (x, y, m, z)
+        __syncthreads();
+        if (t + 1 < t1) nxt = posm[(size_t)(t + 1) * kTile + tid];
+#pragma unroll 1
+        for (int k0 = 0; k0 < kTile; k0 += UNROLL) {
+            float4 sj[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) sj[u] = tile[buf][k0 + u];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const float mj = sj[u].z;
+                if (!BATCH) {
+#pragma unroll
+                    for (int p = 0; p < P; p++) interact_pk<DIM>(sj[u], xi[p], yi[p], zi[p], ax[p], ay[p], az[p]);
+                } else if (P == 1) {
+                    v2f dx, dy, dz, r2;
+                    sep_r2<DIM>(sj[u], xi[0], yi[0], zi[0], dx, dy, dz, r2);
+                    const float qm = __builtin_amdgcn_rcpf(r2.x * r2.y) * mj;
+                    const v2f s = v2f{qm, qm} * v2f{r2.y, r2.x};
+                    accumulate<DIM>(s, dx, dy, dz, ax[0], ay[0], az[0]);
+                } else {
+                    v2f dxa, dya, dza, ra, dxb, dyb, dzb, rb;
+                    sep_r2<DIM>(sj[u], xi[0], yi[0], zi[0], dxa, dya, dza, ra);
+                    sep_r2<DIM>(sj[u], xi[P - 1], yi[P - 1], zi[P - 1], dxb, dyb, dzb, rb);
+                    const v2f pr = ra * rb;                                     // {a0 b0, a1 b1}
+                    const float qm = __builtin_amdgcn_rcpf(pr.x * pr.y) * mj;   // m / (a0 b0 a1 b1)
+                    const v2f u2 = v2f{qm, qm} * v2f{pr.y, pr.x};               // {m/(a0 b0), m/(a1 b1)}
+                    const v2f sa = u2 * rb;                                     // {m/a0, m/a1}
+                    const v2f sb = u2 * ra;                                     // {m/b0, m/b1}
+                    accumulate<DIM>(sa, dxa, dya, dza, ax[0], ay[0], az[0]);
+                    accumulate<DIM>(sb, dxb, dyb, dzb, ax[P - 1], ay[P - 1], az[P - 1]);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+// `guard` points at the device word holding max|coordinate| of the CURRENT source array (float bits,
+// written by k_max_coord on the same stream just before this launch): the batched sweep runs only while
+// it is <= 1e4, otherwise the plain packed sweep does the work.
+template <int P, int DIM, int UNROLL, bool BATCH>
+__global__ __launch_bounds__(kTile) void k_force_tile_pkb(const float4* __restrict__ posm, const int lo,
+                                                          const int n_targets, const int tiles_total,
+                                                          const int jsplit, float4* __restrict__ acc_partial,
+                                                          const int acc_stride, const unsigned* __restrict__ guard)
+{
+    // Two instantiations are launched back to back; exactly one of them does the work (wave-uniform test
+    // of the guard word), the other returns at once.  Keeping the sweeps in separate kernels lets each
+    // have its own register budget (100 vs 156 VGPRs).
+    if ((guard[0] <= kBatchGuardBits) != BATCH) return;
+    __shared__ float4 tile[2][kTile];
+    constexpr int B = 2 * P;
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x % jsplit;
+    const int iblk = blockIdx.x / jsplit;
+    const int t0 = (int)(((unsigned)tiles_total * (unsigned)split) / (unsigned)jsplit);
+    const int t1 = (int)(((unsigned)tiles_total * (unsigned)(split + 1)) / (unsigned)jsplit);
+
+    v2f xi[P], yi[P], zi[P], ax[P], ay[P], az[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        int ia = iblk * (kTile * B) + (2 * p) * kTile + tid;
+        int ib = ia + kTile;
+        ia = ia < n_targets ? ia : n_targets - 1;
+        ib = ib < n_targets ? ib : n_targets - 1;
+        const float4 pa = posm[lo + ia];
+        const float4 pb = posm[lo + ib];
+        xi[p] = v2f{pa.x, pb.x}; yi[p] = v2f{pa.y, pb.y}; zi[p] = v2f{pa.z, pb.z};
+        ax[p] = v2f{0.f, 0.f}; ay[p] = v2f{0.f, 0.f}; az[p] = v2f{0.f, 0.f};
+    }
+
+    tile_sweep<P, DIM, UNROLL, BATCH>(posm, tile, tid, t0, t1, xi, yi, zi, ax, ay, az);
+
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int ia = iblk * (kTile * B) + (2 * p) * kTile + tid;
+        const int ib = ia + kTile;
+        if (ia < n_targets) acc_partial[(size_t)split * acc_stride + ia] = make_float4(ax[p].x, ay[p].x, az[p].x, 0.0f);
+        if (ib < n_targets) acc_partial[(size_t)split * acc_stride + ib] = make_float4(ax[p].y, ay[p].y, az[p].y, 0.0f);
+    }
+}
+
+// max over all sources of max(|x|,|y|,|z|) as float bits (NaN counts as +inf), into *out (pre-zeroed)
+__global__ __launch_bounds__(kTile) void k_max_coord(const float4* __restrict__ posm, const int n, unsigned* out)
+{
+    float m = 0.0f;
+    for (int i = blockIdx.x * kTile + threadIdx.x; i < n; i += gridDim.x * kTile) {
+        const float4 p = posm[i];
+        float c = fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z));
+        if (!(c == c) || !(p.x == p.x) || !(p.y == p.y) || !(p.z == p.z)) c = __builtin_inff();
+        m = fmaxf(m, c);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 template <int P, int DIM, int UNROLL>
 __global__ __launch_bounds__(kTile) void k_force_tile_pk(const float4* __restrict__ posm, const int lo,
                                                          const int n_targets, const int tiles_total,
@@ -270,9 +415,23 @@ __global__ __launch_bounds__(kTile) void k_reduce_forces(const float4* __restric
 
 template <int B, int DIM>
 static hipError_t launch_variant(int variant, dim3 grid, hipStream_t stream, const float4* posm, int lo,
-                                 int n_targets, int tiles_total, int jsplit, float4* acc_partial, int acc_stride)
+                                 int n_targets, int tiles_total, int jsplit, float4* acc_partial, int acc_stride,
+                                 unsigned* guard)
 {
     if (variant == 1 && (B % 2) == 0)
+        hipLaunchKernelGGL((k_force_tile_pk<(B >= 2 ? B / 2 : 1), DIM, 8>), grid, dim3(kTile), 0, stream, posm, lo,
+                           n_targets, tiles_total, jsplit, acc_partial, acc_stride);
+    else if (variant == 4 && (B % 2) == 0 && guard) {
+        // refresh max|coord| of the source array this launch will read, on the same stream
+        hipError_t e = hipMemsetAsync(guard, 0, sizeof(unsigned), stream);
+        if (e != hipSuccess) return e;
+        const int mblocks = tiles_total < 256 ? tiles_total : 256;
+        hipLaunchKernelGGL(k_max_coord, dim3(mblocks), dim3(kTile), 0, stream, posm, tiles_total * kTile, guard);
+        hipLaunchKernelGGL((k_force_tile_pkb<(B >= 2 ? B / 2 : 1), DIM, 8, true>), grid, dim3(kTile), 0, stream, posm,
+                           lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride, guard);
+        hipLaunchKernelGGL((k_force_tile_pkb<(B >= 2 ? B / 2 : 1), DIM, 8, false>), grid, dim3(kTile), 0, stream, posm,
+                           lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride, guard);
+    } else if (variant == 4 && (B % 2) == 0)
         hipLaunchKernelGGL((k_force_tile_pk<(B >= 2 ? B / 2 : 1), DIM, 8>), grid, dim3(kTile), 0, stream, posm, lo,
                            n_targets, tiles_total, jsplit, acc_partial, acc_stride);
     else if (variant == 3 && (B % 2) == 0)
@@ -288,7 +447,8 @@ static hipError_t launch_variant(int variant, dim3 grid, hipStream_t stream, con
 }
 
 hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tiles_total, int jsplit, int bpt, int dim,
-                             int variant, float4* acc_partial, int acc_stride, hipStream_t stream, ForceLaunch* info)
+                             int variant, float4* acc_partial, int acc_stride, unsigned* guard, hipStream_t stream,
+                             ForceLaunch* info)
 {
     if (n_targets <= 0 || tiles_total <= 0) return hipSuccess;
     if (jsplit < 1) jsplit = 1;
@@ -297,7 +457,7 @@ hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tile
     const dim3 grid((unsigned)(iblocks * jsplit));
     if (info) *info = ForceLaunch{(int)grid.x, kTile, jsplit, bpt, dim, variant};
 #define NBX_DISPATCH(BB, DD) \
-    return launch_variant<BB, DD>(variant, grid, stream, posm, lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride)
+    return launch_variant<BB, DD>(variant, grid, stream, posm, lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride, guard)
     if (dim == 3) {
         if (bpt == 1) NBX_DISPATCH(1, 3);
         if (bpt == 2) NBX_DISPATCH(2, 3);

@@ -22,9 +22,11 @@ struct ForceLaunch {
 
 // K1: all-pairs accelerations for slab targets [lo, lo+n_targets) against tiles_total*kTile sources.
 // acc_partial: [jsplit][acc_stride] float4 (ax, ay, az, unused).
+// guard: device word for variant 4 (batched reciprocals): refreshed with max|coord| of posm before the
+// launch; the kernel falls back to the plain packed sweep when it exceeds 1e4. May be null (-> variant 1).
 hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tiles_total, int jsplit, int bpt,
-                             int dim, int variant, float4* acc_partial, int acc_stride, hipStream_t stream,
-                             ForceLaunch* info);
+                             int dim, int variant, float4* acc_partial, int acc_stride, unsigned* guard,
+                             hipStream_t stream, ForceLaunch* info);
 
 // K2: reduce partials in fixed order, kick-drift, write positions in place (slab slot of posm).
 hipError_t launch_integrate(float4* posm, int lo, int n_targets, float4* vel, const float4* acc_partial,
