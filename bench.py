@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="plummer", choices=["plummer", "two_galaxies"])
+    ap.add_argument("--source-bits", type=int, default=32, choices=[16, 32],
+                    help="16 = fp16 source copy / fp32 accumulators (BASELINE config #5)")
     ap.add_argument("--torch-path", action="store_true",
                     help="use the multi-GPU code path (torch-owned buffer + torch stream) even on one GPU")
     args = ap.parse_args()
@@ -80,10 +83,11 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     n = args.n
-    st = rx.plummer_sphere(n, dim=args.dim)
+    st = rx.plummer_sphere(n, dim=args.dim) if args.workload == "plummer" else rx.two_galaxies(n)
 
     if world == 1 and not args.torch_path:
         eng = rx.NBodyEngine(device=0, mode=args.mode)
+        eng.set_source_precision(args.source_bits)
         eng.set_launch(jsplit=args.jsplit, bodies_per_thread=args.bpt, variant=args.variant)
         eng.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
 
@@ -105,7 +109,7 @@ def main():
         torch.cuda.set_device(local_rank)
         if world > 1:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        slab = rx.sharded.TorchSlabEngine(local_rank, mode=args.mode)
+        slab = rx.sharded.TorchSlabEngine(local_rank, mode=args.mode, source_half=args.source_bits == 16)
         slab.eng.set_launch(jsplit=args.jsplit, bodies_per_thread=args.bpt, variant=args.variant)
         sim = rx.ShardedNBody(slab)
         sim.set_particles(st)
@@ -168,8 +172,9 @@ def main():
                       else f"body-pair interactions/s at N={n} (brute-force O(N^2) step)",
             "value": value, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"plummer_sphere_N{n}_brute_force_dim{launch['dim']}_dt{DT}",
+            "vs_baseline": None, "dtype": "f32" if args.source_bits == 32 else "f32 (fp16 source copy)", "data": "synthetic",
+            "config": {"workload": f"{'plummer_sphere' if args.workload == 'plummer' else 'two_galaxies'}_N{n}_brute_force_dim{launch['dim']}_dt{DT}"
+                                   + ("_fp16sources" if args.source_bits == 16 else ""),
                        "bodies": n, "seed": "0x5EED0001", "force_mode": args.mode,
                        "sharding": f"slab x{world}, one all-gather of (x,y,z,m) per step" if world > 1 else "single GPU",
                        "launch": launch},

@@ -92,7 +92,8 @@ enum nbx_option {
                                     * reciprocals (guarded by max|coord| <= 1e4, else the plain sweep runs; same
                                     * wall time as 1 because the chip is power-limited here), 0 = compiler-scheduled
                                     * LDS tiles, 2 = scalar-cache sources (no LDS), 3 = packed, 4-source LDS batches */
-    NBX_OPT_BH_LEAF_CAP = 6        /* reserved */
+    NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
+                                    * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };
 
 enum nbx_kernel_id {
@@ -176,6 +177,10 @@ int32_t nbx_get_slab(const nbx_engine *e, int32_t *lo, int32_t *hi);
  * (x,y,z,m) float4 array instead of an engine-owned one. bytes >= nbx_positions_bytes(). Call
  * after set_particles; the engine copies its current positions into it. */
 int32_t nbx_bind_positions(nbx_engine *e, void *device_ptr, size_t bytes);
+/* fp16 source copy (NBX_OPT_SOURCE_PRECISION = 16): in sharded runs THIS buffer is what the per-step
+ * all-gather moves (half the bytes); bind a caller-owned device buffer of >= nbx_half_sources_bytes(). */
+size_t nbx_half_sources_bytes(const nbx_engine *e); /* n_padded * 8 */
+int32_t nbx_bind_half_sources(nbx_engine *e, void *device_ptr, size_t bytes);
 void *nbx_positions_device(nbx_engine *e); /* device pointer of the float4 (x,y,z,m) array */
 size_t nbx_positions_bytes(const nbx_engine *e); /* n_padded * 16 */
 int32_t nbx_set_stream(nbx_engine *e, void *hip_stream); /* run on a caller-owned hipStream_t */

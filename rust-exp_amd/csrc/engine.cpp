@@ -86,6 +86,10 @@ struct nbx_engine {
     size_t nodes_cap = 0;
     unsigned* d_guard = nullptr;   // max|coord| word for the batched-reciprocal kernel
     size_t guard_cap = 0;
+    void* d_posh = nullptr;        // half4 (x,y,z,m) source copy (NBX_OPT_SOURCE_PRECISION = 16)
+    bool posh_external = false;
+    size_t posh_cap = 0;           // records
+    int source_half = 0;
 
     // options
     int force_mode = 0, jsplit = 0, bpt = 0, dim_opt = 0, profile = 0, variant = -1;
@@ -163,6 +167,23 @@ int grow(T** ptr, size_t* cap, size_t need)
     return NBX_OK;
 }
 
+// (re)build the fp16 source copy for records [first, first+count) from the fp32 array
+int refresh_half_sources(nbx_engine* e, int first, int count)
+{
+    if (!e->posh_external && (size_t)e->n_pad > e->posh_cap) {
+        if (e->d_posh) HIP_TRY(hipFree(e->d_posh));
+        e->d_posh = nullptr;
+        e->posh_cap = 0;
+        HIP_TRY(hipMalloc(&e->d_posh, (size_t)e->n_pad * 8));
+        e->posh_cap = (size_t)e->n_pad;
+        first = 0;
+        count = e->n_pad;
+    }
+    if (e->posh_external && (size_t)e->n_pad > e->posh_cap) return fail(NBX_ERR_STATE, "bound half-source buffer too small");
+    HIP_TRY(nbx::launch_pack_half(e->d_posm, e->d_posh, first, count, e->stream));
+    return NBX_OK;
+}
+
 int upload(nbx_engine* e)
 {
     int rc = ensure_device(e);
@@ -193,6 +214,10 @@ int upload(nbx_engine* e)
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
     e->dev_valid = true;
+    if (e->source_half) {
+        rc = refresh_half_sources(e, 0, e->n_pad);
+        if (rc != NBX_OK) return rc;
+    }
     return NBX_OK;
 }
 
@@ -293,6 +318,12 @@ int launch_forces_fast(nbx_engine* e)
         rc = grow(&e->d_guard, &e->guard_cap, 1);
         if (rc != NBX_OK) return rc;
     }
+    if (e->source_half) {
+        ProfScope ps(e, NBX_K_FORCE);
+        HIP_TRY(nbx::launch_force_tile_half(e->d_posm, e->d_posh, e->lo, slab, tiles_total, jsplit, bpt, dim, e->d_acc,
+                                            stride, e->stream, &e->last));
+        return NBX_OK;
+    }
     {
         ProfScope ps(e, NBX_K_FORCE);
         HIP_TRY(nbx::launch_force_tile(e->d_posm, e->lo, slab, tiles_total, jsplit, bpt, dim, variant, e->d_acc, stride,
@@ -324,6 +355,10 @@ int step_brute(nbx_engine* e, float dt)
         ProfScope ps(e, NBX_K_INTEGRATE);
         HIP_TRY(nbx::launch_integrate(e->d_posm, e->lo, slab, e->d_vel, e->d_acc, e->last.jsplit, stride, dt,
                                       e->stream));
+        if (e->source_half) {   // refresh this slab's slot of the fp16 source copy (the all-gather send slot)
+            rc = refresh_half_sources(e, e->lo, slab);
+            if (rc != NBX_OK) return rc;
+        }
     }
     e->host_pos_valid = false;
     e->host_vel_valid = false;
@@ -420,6 +455,7 @@ void free_device(nbx_engine* e)
     if (e->d_out4) (void)hipFree(e->d_out4);
     if (e->d_nodes) (void)hipFree(e->d_nodes);
     if (e->d_guard) (void)hipFree(e->d_guard);
+    if (e->d_posh && !e->posh_external) (void)hipFree(e->d_posh);
     if (e->h_nodes) (void)hipHostFree(e->h_nodes);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -524,7 +560,14 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
         case NBX_OPT_KERNEL_VARIANT:
             e->variant = (int)value;
             return NBX_OK;
-        case NBX_OPT_BH_LEAF_CAP:
+        case NBX_OPT_SOURCE_PRECISION:
+            if (value != 16 && value != 32) return fail(NBX_ERR_INVALID, "source precision must be 16 or 32");
+            e->source_half = value == 16;
+            if (e->source_half && e->dev_valid) {   // device state is live: build the fp16 copy from it now
+                int rc = ensure_device(e);
+                if (rc != NBX_OK) return rc;
+                return refresh_half_sources(e, 0, e->n_pad);
+            }
             return NBX_OK;
         default:
             return fail(NBX_ERR_INVALID, "unknown option %d", option);
@@ -541,6 +584,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_DIM: return e->dim_opt;
         case NBX_OPT_PROFILE: return e->profile;
         case NBX_OPT_KERNEL_VARIANT: return e->variant;
+        case NBX_OPT_SOURCE_PRECISION: return e->source_half ? 16 : 32;
         default: return NBX_ERR_INVALID;
     }
 }
@@ -788,6 +832,23 @@ int32_t nbx_bind_positions(nbx_engine* e, void* device_ptr, size_t bytes)
     e->posm_cap = bytes / sizeof(float4);
     e->dev_valid = false;
     return upload(e);
+}
+
+size_t nbx_half_sources_bytes(const nbx_engine* e) { return nbx_positions_bytes(e) / 2; }
+
+int32_t nbx_bind_half_sources(nbx_engine* e, void* device_ptr, size_t bytes)
+{
+    if (!e || !device_ptr) return fail(NBX_ERR_INVALID, "null argument");
+    if (!e->source_half) return fail(NBX_ERR_STATE, "set NBX_OPT_SOURCE_PRECISION to 16 first");
+    if (bytes < nbx_half_sources_bytes(e)) return fail(NBX_ERR_INVALID, "buffer too small: %zu < %zu", bytes, nbx_half_sources_bytes(e));
+    int rc = upload(e);
+    if (rc != NBX_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->d_posh && !e->posh_external) HIP_TRY(hipFree(e->d_posh));
+    e->d_posh = device_ptr;
+    e->posh_external = true;
+    e->posh_cap = bytes / 8;
+    return refresh_half_sources(e, 0, e->n_pad);
 }
 
 void* nbx_positions_device(nbx_engine* e)

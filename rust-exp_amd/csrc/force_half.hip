@@ -1,0 +1,186 @@
+// force_half.hip -- K4: all-pairs force tiles with an fp16 SOURCE copy (BASELINE config #5:
+// "fp16 positions / fp32 accumulators").  The integrated state stays fp32: each GPU keeps fp32 (x,y,z,m)
+// and velocities for its own slab of targets; what every GPU holds for ALL bodies -- and what the
+// per-step all-gather moves -- is a half4 (x,y,z,m) record, 8 B per body instead of 16.
+//
+// Arithmetic is the packed fp32 sweep of force_tile.hip (variant 1): sources are widened to fp32 when the
+// tile is written to LDS, so the inner loop, its 12 VALU / 2 interactions and its fp32 accumulators are
+// unchanged; only global/L2 source bytes and all-gather bytes halve (the kernel stays VALU-bound: the
+// "HBM-bound" label of config #5 does not hold for an all-pairs sweep).
+//
+// Accuracy class (looser than fp32, stated in DESIGN.md section 4): source coordinates carry 11
+// significant bits (spacing 2^-6 = 0.016 at |x| in [16,32)), masses likewise.  A body's own fp16 image
+// is NOT at its fp32 position, so the self term is no longer an exact zero: it is recomputed once per
+// target with the same arithmetic and subtracted after the sweep.
+#include <hip/hip_fp16.h>
+
+#include "kernels.h"
+
+namespace nbx {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 widen_xymz(const h4 v)   // LDS record order (x, y, m, z), see force_tile.hip
+{
+    return make_float4((float)v.x, (float)v.y, (float)v.w, (float)v.z);
+}
+
+template <int DIM>
+__device__ __forceinline__ void interact_pk_h(const float4 sj, const v2f xi, const v2f yi, const v2f zi, v2f& ax,
+                                              v2f& ay, v2f& az)
+{
+    const v2f sx = {sj.x, sj.x}, sy = {sj.y, sj.y}, sm = {sj.z, sj.z};
+    const v2f eps = {kEps, kEps};
+    const v2f dx = sx - xi;
+    const v2f dy = sy - yi;
+    v2f r2 = __builtin_elementwise_fma(dx, dx, eps);
+    r2 = __builtin_elementwise_fma(dy, dy, r2);
+    v2f dz = {0.f, 0.f};
+    if (DIM == 3) {
+        const v2f mz = {sj.z, sj.w};
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dz) : "v"(mz), "v"(zi));
+        r2 = __builtin_elementwise_fma(dz, dz, r2);
+    }
+    v2f inv;
+    inv.x = __builtin_amdgcn_rcpf(r2.x);
+    inv.y = __builtin_amdgcn_rcpf(r2.y);
+    const v2f s = sm * inv;
+    ax = __builtin_elementwise_fma(s, dx, ax);
+    ay = __builtin_elementwise_fma(s, dy, ay);
+    if (DIM == 3) az = __builtin_elementwise_fma(s, dz, az);
+}
+
+template <int P, int DIM, int UNROLL>
+__global__ __launch_bounds__(kTile) void k_force_tile_pk_h(const float4* __restrict__ posm, const h4* __restrict__ posh,
+                                                           const int lo, const int n_targets, const int tiles_total,
+                                                           const int jsplit, float4* __restrict__ acc_partial,
+                                                           const int acc_stride)
+{
+    __shared__ float4 tile[2][kTile];
+    constexpr int B = 2 * P;
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x % jsplit;
+    const int iblk = blockIdx.x / jsplit;
+    const int t0 = (int)(((unsigned)tiles_total * (unsigned)split) / (unsigned)jsplit);
+    const int t1 = (int)(((unsigned)tiles_total * (unsigned)(split + 1)) / (unsigned)jsplit);
+
+    v2f xi[P], yi[P], zi[P], ax[P], ay[P], az[P];
+    int gi[P][2];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        int ia = iblk * (kTile * B) + (2 * p) * kTile + tid;
+        int ib = ia + kTile;
+        ia = ia < n_targets ? ia : n_targets - 1;
+        ib = ib < n_targets ? ib : n_targets - 1;
+        gi[p][0] = lo + ia;
+        gi[p][1] = lo + ib;
+        const float4 pa = posm[lo + ia];   // targets: full fp32
+        const float4 pb = posm[lo + ib];
+        xi[p] = v2f{pa.x, pb.x}; yi[p] = v2f{pa.y, pb.y}; zi[p] = v2f{pa.z, pb.z};
+        ax[p] = v2f{0.f, 0.f}; ay[p] = v2f{0.f, 0.f}; az[p] = v2f{0.f, 0.f};
+    }
+
+    h4 nxt = posh[(size_t)t0 * kTile + tid];
+    int buf = 0;
+    for (int t = t0; t < t1; t++) {
+        tile[buf][tid] = widen_xymz(nxt);
+        __syncthreads();
+        if (t + 1 < t1) nxt = posh[(size_t)(t + 1) * kTile + tid];
+#pragma unroll 1
+        for (int k0 = 0; k0 < kTile; k0 += UNROLL) {
+            float4 sj[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) sj[u] = tile[buf][k0 + u];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+#pragma unroll
+                for (int p = 0; p < P; p++) interact_pk_h<DIM>(sj[u], xi[p], yi[p], zi[p], ax[p], ay[p], az[p]);
+            }
+        }
+        buf ^= 1;
+    }
+
+    // remove each target's interaction with its OWN fp16 image (same arithmetic as the sweep)
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int g = gi[p][h];
+            if (g >= t0 * kTile && g < t1 * kTile) {
+                const float4 sj = widen_xymz(posh[g]);
+                const float x = h ? xi[p].y : xi[p].x, y = h ? yi[p].y : yi[p].x, z = h ? zi[p].y : zi[p].x;
+                const float dx = sj.x - x, dy = sj.y - y;
+                float r2 = __builtin_fmaf(dx, dx, kEps);
+                r2 = __builtin_fmaf(dy, dy, r2);
+                float dz = 0.f;
+                if (DIM == 3) {
+                    dz = sj.w - z;
+                    r2 = __builtin_fmaf(dz, dz, r2);
+                }
+                const float s = sj.z * __builtin_amdgcn_rcpf(r2);
+                if (h) {
+                    ax[p].y = __builtin_fmaf(-s, dx, ax[p].y); ay[p].y = __builtin_fmaf(-s, dy, ay[p].y);
+                    if (DIM == 3) az[p].y = __builtin_fmaf(-s, dz, az[p].y);
+                } else {
+                    ax[p].x = __builtin_fmaf(-s, dx, ax[p].x); ay[p].x = __builtin_fmaf(-s, dy, ay[p].x);
+                    if (DIM == 3) az[p].x = __builtin_fmaf(-s, dz, az[p].x);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int ia = iblk * (kTile * B) + (2 * p) * kTile + tid;
+        const int ib = ia + kTile;
+        if (ia < n_targets) acc_partial[(size_t)split * acc_stride + ia] = make_float4(ax[p].x, ay[p].x, az[p].x, 0.0f);
+        if (ib < n_targets) acc_partial[(size_t)split * acc_stride + ib] = make_float4(ax[p].y, ay[p].y, az[p].y, 0.0f);
+    }
+}
+
+// fp32 (x,y,z,m) -> half4, round to nearest even, for records [first, first+count)
+__global__ __launch_bounds__(kTile) void k_pack_half(const float4* __restrict__ posm, h4* __restrict__ posh,
+                                                     const int first, const int count)
+{
+    const int i = blockIdx.x * kTile + threadIdx.x;
+    if (i >= count) return;
+    const float4 p = posm[first + i];
+    h4 v;
+    v.x = (_Float16)p.x; v.y = (_Float16)p.y; v.z = (_Float16)p.z; v.w = (_Float16)p.w;
+    posh[first + i] = v;
+}
+
+hipError_t launch_pack_half(const float4* posm, void* posh, int first, int count, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_half, dim3((count + kTile - 1) / kTile), dim3(kTile), 0, stream, posm,
+                       static_cast<h4*>(posh), first, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_force_tile_half(const float4* posm, const void* posh, int lo, int n_targets, int tiles_total,
+                                  int jsplit, int bpt, int dim, float4* acc_partial, int acc_stride, hipStream_t stream,
+                                  ForceLaunch* info)
+{
+    if (n_targets <= 0 || tiles_total <= 0) return hipSuccess;
+    if (jsplit < 1) jsplit = 1;
+    if (jsplit > tiles_total) jsplit = tiles_total;
+    if (bpt != 4) bpt = 2;
+    const int iblocks = (n_targets + kTile * bpt - 1) / (kTile * bpt);
+    const dim3 grid((unsigned)(iblocks * jsplit));
+    if (info) *info = ForceLaunch{(int)grid.x, kTile, jsplit, bpt, dim, 16};
+    const h4* src = static_cast<const h4*>(posh);
+#define NBX_H(PP, DD)                                                                                              \
+    hipLaunchKernelGGL((k_force_tile_pk_h<PP, DD, 8>), grid, dim3(kTile), 0, stream, posm, src, lo, n_targets,      \
+                       tiles_total, jsplit, acc_partial, acc_stride)
+    if (dim == 3) {
+        if (bpt == 4) NBX_H(2, 3); else NBX_H(1, 3);
+    } else {
+        if (bpt == 4) NBX_H(2, 2); else NBX_H(1, 2);
+    }
+#undef NBX_H
+    return hipGetLastError();
+}
+
+}  // namespace nbx

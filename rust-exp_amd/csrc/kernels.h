@@ -28,6 +28,13 @@ hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tile
                              int dim, int variant, float4* acc_partial, int acc_stride, unsigned* guard,
                              hipStream_t stream, ForceLaunch* info);
 
+// K4: the packed sweep with sources read from a half4 (x,y,z,m) copy (8 B/body), targets fp32.
+hipError_t launch_force_tile_half(const float4* posm, const void* posh, int lo, int n_targets, int tiles_total,
+                                  int jsplit, int bpt, int dim, float4* acc_partial, int acc_stride, hipStream_t stream,
+                                  ForceLaunch* info);
+// posh[first..first+count) = half(posm[...]) (round to nearest even)
+hipError_t launch_pack_half(const float4* posm, void* posh, int first, int count, hipStream_t stream);
+
 // K2: reduce partials in fixed order, kick-drift, write positions in place (slab slot of posm).
 hipError_t launch_integrate(float4* posm, int lo, int n_targets, float4* vel, const float4* acc_partial,
                             int jsplit, int acc_stride, float dt, hipStream_t stream);

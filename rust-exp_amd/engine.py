@@ -30,6 +30,7 @@ NBX_OPT_BODIES_PER_THREAD = 2
 NBX_OPT_DIM = 3
 NBX_OPT_PROFILE = 4
 NBX_OPT_KERNEL_VARIANT = 5
+NBX_OPT_SOURCE_PRECISION = 6
 
 NBX_K_FORCE = 0
 NBX_K_INTEGRATE = 1
@@ -153,6 +154,10 @@ def lib():
     L.nbx_get_slab.restype = i32
     L.nbx_bind_positions.argtypes = [E, C.c_void_p, C.c_size_t]
     L.nbx_bind_positions.restype = i32
+    L.nbx_half_sources_bytes.argtypes = [E]
+    L.nbx_half_sources_bytes.restype = C.c_size_t
+    L.nbx_bind_half_sources.argtypes = [E, C.c_void_p, C.c_size_t]
+    L.nbx_bind_half_sources.restype = i32
     L.nbx_positions_device.argtypes = [E]
     L.nbx_positions_device.restype = C.c_void_p
     L.nbx_positions_bytes.argtypes = [E]
@@ -360,6 +365,16 @@ class NBodyEngine:
 
     def bind_positions(self, device_ptr, nbytes):
         _check(self._L.nbx_bind_positions(self._h, C.c_void_p(device_ptr), nbytes))
+
+    def set_source_precision(self, bits):
+        """16: all-pairs sources come from a half4 copy (BASELINE config #5); 32: default."""
+        self.set_option(NBX_OPT_SOURCE_PRECISION, bits)
+
+    def half_sources_bytes(self):
+        return int(self._L.nbx_half_sources_bytes(self._h))
+
+    def bind_half_sources(self, device_ptr, nbytes):
+        _check(self._L.nbx_bind_half_sources(self._h, C.c_void_p(device_ptr), nbytes))
 
     def set_stream(self, hip_stream):
         _check(self._L.nbx_set_stream(self._h, C.c_void_p(hip_stream)))

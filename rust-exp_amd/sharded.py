@@ -29,7 +29,7 @@ def reference_slab(n, rank, world):
 class TorchSlabEngine:
     """The HIP engine bound to a torch-owned positions buffer on this rank's GPU."""
 
-    def __init__(self, device_index, mode="fast"):
+    def __init__(self, device_index, mode="fast", source_half=False):
         import sys
 
         from . import engine as _engine
@@ -48,7 +48,11 @@ class TorchSlabEngine:
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
         self.eng = NBodyEngine(device=device_index, mode=mode)
+        self.source_half = bool(source_half)
+        if self.source_half:
+            self.eng.set_source_precision(16)
         self.posm = None
+        self.posh = None
 
     def set_shard(self, rank, world):
         self.eng.set_shard(rank, world)
@@ -61,6 +65,10 @@ class TorchSlabEngine:
         # kernels run on torch's current stream so that collectives issued by torch order after them
         self.eng.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.eng.bind_positions(self.posm.data_ptr(), nbytes)
+        if self.source_half:
+            # the exchanged array is the half4 source copy: 8 B per body on the wire instead of 16
+            self.posh = torch.zeros(nbytes // 16, 4, dtype=torch.float16, device=self.device)
+            self.eng.bind_half_sources(self.posh.data_ptr(), nbytes // 2)
         torch.cuda.synchronize(self.device)
 
     def slab(self):
@@ -70,7 +78,12 @@ class TorchSlabEngine:
         self.eng.step_local(dt)
 
     def positions_array(self):
-        return self.posm  # [n_pad, 4] float32 (x, y, z, m)
+        """The array the per-step all-gather moves: [n_pad, 4] (x, y, z, m), float32 or float16."""
+        return self.posh if self.source_half else self.posm
+
+    @property
+    def positions_replicated(self):
+        return not self.source_half   # fp16 mode: other ranks' fp32 positions are not kept current
 
     def get_particles(self):
         return self.eng.get_particles()
@@ -128,21 +141,26 @@ class ShardedNBody:
         self._exchange()
 
     def gather_state(self):
-        """Full state on every rank (positions are already replicated; velocities are gathered)."""
+        """Full fp32 state on every rank: velocities always live only on their owner; positions too when the
+        exchanged array is the fp16 copy."""
         import torch
 
         st = self.local.get_particles()
         if self.world == 1:
             return st
         out = dict(st)
-        for k in ("vx", "vy", "vz"):
+        keys = ["vx", "vy", "vz"]
+        if not getattr(self.local, "positions_replicated", True):
+            keys += ["px", "py", "pz"]
+        nccl = self.dist.get_backend(self.group) == "nccl"
+        for k in keys:
             full = torch.from_numpy(np.array(st[k], dtype=np.float32))
             for r in range(self.world):
                 lo, hi = reference_slab(self.n, r, self.world)
                 if hi > lo:
                     src = self.dist.get_global_rank(self.group, r) if self.group is not None else r
                     part = full[lo:hi].clone()
-                    if part.device.type == "cpu" and self.dist.get_backend(self.group) == "nccl":
+                    if nccl:
                         part = part.cuda()
                         self.dist.broadcast(part, src=src, group=self.group)
                         full[lo:hi] = part.cpu()

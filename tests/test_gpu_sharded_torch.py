@@ -45,6 +45,23 @@ pos = slab.positions_array()[:16384].cpu().numpy()
 if not np.array_equal(pos[:, 0], want["px"]) or not np.array_equal(pos[:, 3], want["m"]):
     bad.append("posm")
 moved = float(np.abs(want["px"] - st["px"]).max())
+# BASELINE config #5 numerics: the exchanged array is the half4 source copy
+st2 = rx.two_galaxies(8192)
+slab2 = rx.sharded.TorchSlabEngine(0, source_half=True)
+sim2 = rx.ShardedNBody(slab2, always_exchange=True)
+sim2.set_particles(st2)
+ref2 = rx.NBodyEngine()
+ref2.set_source_precision(16)
+ref2.set_particles(st2["px"], st2["py"], st2["vx"], st2["vy"], st2["m"])
+for _ in range(3):
+    sim2.step_brute_force(0.01)
+    ref2.step_brute_force(0.01)
+torch.cuda.synchronize()
+got2, want2 = sim2.gather_state(), ref2.get_particles()
+bad += ["half_" + k for k in ("px", "py", "vx", "vy")
+        if not np.array_equal(np.asarray(got2[k]).view(np.uint32), want2[k].view(np.uint32))]
+if slab2.positions_array().dtype != torch.float16:
+    bad.append("half_dtype")
 dist.destroy_process_group()
 print("RESULT " + json.dumps({"bad": bad, "staged": sim._staged, "moved": moved}))
 """
