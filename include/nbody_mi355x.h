@@ -88,10 +88,12 @@ enum nbx_option {
     NBX_OPT_BODIES_PER_THREAD = 2, /* register blocking B in {1,2,4}; 0 = auto */
     NBX_OPT_DIM = 3,               /* 2 or 3; 0 = auto (2 when every z and vz is zero) */
     NBX_OPT_PROFILE = 4,           /* 1 = record a HIP event pair around every kernel launch */
-    NBX_OPT_KERNEL_VARIANT = 5,    /* fast force kernel: -1 = auto (= 1), 1 = packed fp32 + LDS tiles, 4 = 1 + batched
-                                    * reciprocals (guarded by max|coord| <= 1e4, else the plain sweep runs; same
-                                    * wall time as 1 because the chip is power-limited here), 0 = compiler-scheduled
-                                    * LDS tiles, 2 = scalar-cache sources (no LDS), 3 = packed, 4-source LDS batches */
+    NBX_OPT_KERNEL_VARIANT = 5,    /* fast force kernel; -1 = auto (default: 5 for >= 32768 sources, else 1):
+                                    *  5 = packed fp32, sources through the scalar cache as SGPR operands (no LDS)
+                                    *  1 = packed fp32, sources staged through LDS tiles
+                                    *  4 = 1 + batched reciprocals (guarded by max|coord| <= 1e4)
+                                    *  0 = compiler-scheduled LDS tiles, 2 = scalar-cache scalar math,
+                                    *  3 = 1 with 4-source LDS batches            (all A/B'd in DESIGN.md 6) */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };
@@ -198,7 +200,7 @@ int32_t nbx_profile_read(nbx_engine *e, int32_t kernel_id, double *total_ms, int
 int32_t nbx_bh_host_timing(nbx_engine *e, double *ms4, int32_t *steps, int32_t *nodes);
 /* launch geometry the last force launch used (for DESIGN/bench reporting); any pointer may be NULL */
 int32_t nbx_last_launch(const nbx_engine *e, int32_t *grid, int32_t *block, int32_t *jsplit,
-                        int32_t *bodies_per_thread, int32_t *dim);
+                        int32_t *bodies_per_thread, int32_t *dim, int32_t *variant);
 
 #ifdef __cplusplus
 }

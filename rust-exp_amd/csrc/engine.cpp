@@ -279,19 +279,25 @@ struct ProfScope {
     }
 };
 
-void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* bpt, int* jsplit, int* dim)
+void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* variant, int* bpt, int* jsplit, int* dim)
 {
-    // Defaults from the measured launch-shape sweep (profiles/r01_shapes_sweep.txt): register blocking 4
-    // (two packed pairs) once a GPU owns >= 32768 targets, else 2; source split S = the smallest power of
-    // two that yields >= 32 workgroups per CU, capped at 64 and at half the tile count.
+    // Defaults from the measured launch-shape sweeps (profiles/r01_shapes_sweep*.txt):
+    //  * kernel: scalar-cache sources + packed math (variant 5) once the source array has >= 32768 bodies
+    //    (no LDS traffic -> +2.4 % clock under the power cap, +3.5 % throughput); LDS tiles (variant 1) below.
+    //  * register blocking 4 (two packed pairs) when a GPU owns >= 131072 targets (variant 5) / 32768 (variant 1).
+    //  * source split S = smallest power of two giving >= 64 (variant 5) / 32 (variant 1) workgroups per CU,
+    //    capped at 64 and at half the tile count.
     *dim = e->dim_opt ? e->dim_opt : (e->any_z ? 3 : 2);
-    int b = e->bpt ? e->bpt : (n_targets >= 32768 ? 4 : 2);
+    int v = e->variant;
+    if (v < 0) v = (tiles_total * kTile >= 32768) ? 5 : 1;
+    *variant = v;
+    int b = e->bpt ? e->bpt : (v == 5 ? (n_targets >= 131072 ? 4 : 2) : (n_targets >= 32768 ? 4 : 2));
     if (b != 1 && b != 2 && b != 4) b = 2;
     *bpt = b;
     int s = e->jsplit;
     if (s <= 0) {
         const int iblocks = (n_targets + kTile * b - 1) / (kTile * b);
-        const int want = e->cu_count * 32;
+        const int want = e->cu_count * (v == 5 ? 64 : 32);
         s = 1;
         while (iblocks * s < want && s < 64) s *= 2;
         s = std::min(s, std::max(1, tiles_total / 2));
@@ -304,16 +310,11 @@ int launch_forces_fast(nbx_engine* e)
 {
     const int slab = e->slab();
     const int tiles_total = e->n_pad / kTile;
-    int bpt, jsplit, dim;
-    choose_launch(e, slab, tiles_total, &bpt, &jsplit, &dim);
+    int variant, bpt, jsplit, dim;
+    choose_launch(e, slab, tiles_total, &variant, &bpt, &jsplit, &dim);
     const int stride = ((slab + kTile - 1) / kTile) * kTile;
     int rc = grow(&e->d_acc, &e->acc_cap, (size_t)jsplit * (size_t)std::max(stride, kTile));
     if (rc != NBX_OK) return rc;
-    // variant -1 = auto = the plain packed kernel (1).  The batched-reciprocal kernel (4) issues 7 % fewer
-    // VALU cycles but the chip is power-limited on this instruction mix: its clock drops by the same 6-7 %
-    // (2.17 -> 2.03 GHz, profiles/r01_variant1_vs_4_pmc.txt) and wall time is identical, so it buys nothing.
-    int variant = e->variant;
-    if (variant < 0) variant = 1;
     if (variant == 4) {
         rc = grow(&e->d_guard, &e->guard_cap, 1);
         if (rc != NBX_OK) return rc;
@@ -918,8 +919,9 @@ int32_t nbx_bh_host_timing(nbx_engine* e, double* ms4, int32_t* steps, int32_t* 
 }
 
 int32_t nbx_last_launch(const nbx_engine* e, int32_t* grid, int32_t* block, int32_t* jsplit, int32_t* bodies_per_thread,
-                        int32_t* dim)
+                        int32_t* dim, int32_t* variant)
 {
+    if (e && variant) *variant = e->last.variant;
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
     if (grid) *grid = e->last.grid;
     if (block) *block = e->last.block;

@@ -334,6 +334,66 @@ __global__ __launch_bounds__(kTile) void k_force_tile_pk(const float4* __restric
     }
 }
 
+// variant 5: packed math with sources through the SCALAR cache (no LDS, no barriers): posm[j] with a
+// wave-uniform j becomes s_load_dwordx4 and the source record feeds v_pk_* as an SGPR-pair operand.
+template <int P, int DIM, int UNROLL>
+__global__ __launch_bounds__(kTile) void k_force_smem_pk(const float4* __restrict__ posm, const int lo,
+                                                         const int n_targets, const int tiles_total,
+                                                         const int jsplit, float4* __restrict__ acc_partial,
+                                                         const int acc_stride)
+{
+    constexpr int B = 2 * P;
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x % jsplit;
+    const int iblk = blockIdx.x / jsplit;
+    const int j0 = (int)(((unsigned)tiles_total * (unsigned)split) / (unsigned)jsplit) * kTile;
+    const int j1 = (int)(((unsigned)tiles_total * (unsigned)(split + 1)) / (unsigned)jsplit) * kTile;
+    v2f xi[P], yi[P], zi[P], ax[P], ay[P], az[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        int ia = iblk * (kTile * B) + (2 * p) * kTile + tid;
+        int ib = ia + kTile;
+        ia = ia < n_targets ? ia : n_targets - 1;
+        ib = ib < n_targets ? ib : n_targets - 1;
+        const float4 pa = posm[lo + ia];
+        const float4 pb = posm[lo + ib];
+        xi[p] = v2f{pa.x, pb.x}; yi[p] = v2f{pa.y, pb.y}; zi[p] = v2f{pa.z, pb.z};
+        ax[p] = v2f{0.f, 0.f}; ay[p] = v2f{0.f, 0.f}; az[p] = v2f{0.f, 0.f};
+    }
+#pragma unroll UNROLL
+    for (int j = j0; j < j1; j++) {
+        const float4 s = posm[j];
+        const v2f sx = {s.x, s.x}, sy = {s.y, s.y}, sz = {s.z, s.z}, sm = {s.w, s.w};
+        const v2f eps = {kEps, kEps};
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const v2f dx = sx - xi[p];
+            const v2f dy = sy - yi[p];
+            v2f r2 = __builtin_elementwise_fma(dx, dx, eps);
+            r2 = __builtin_elementwise_fma(dy, dy, r2);
+            v2f dz = {0.f, 0.f};
+            if (DIM == 3) {
+                dz = sz - zi[p];
+                r2 = __builtin_elementwise_fma(dz, dz, r2);
+            }
+            v2f inv;
+            inv.x = __builtin_amdgcn_rcpf(r2.x);
+            inv.y = __builtin_amdgcn_rcpf(r2.y);
+            const v2f sc = sm * inv;
+            ax[p] = __builtin_elementwise_fma(sc, dx, ax[p]);
+            ay[p] = __builtin_elementwise_fma(sc, dy, ay[p]);
+            if (DIM == 3) az[p] = __builtin_elementwise_fma(sc, dz, az[p]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int ia = iblk * (kTile * B) + (2 * p) * kTile + tid;
+        const int ib = ia + kTile;
+        if (ia < n_targets) acc_partial[(size_t)split * acc_stride + ia] = make_float4(ax[p].x, ay[p].x, az[p].x, 0.0f);
+        if (ib < n_targets) acc_partial[(size_t)split * acc_stride + ib] = make_float4(ax[p].y, ay[p].y, az[p].y, 0.0f);
+    }
+}
+
 // variant 2: no LDS. The source index is wave-uniform, so the compiler fetches sources through
 // the scalar cache (s_load_dwordx4..x16 into SGPRs) and feeds them to the VALU as scalar operands.
 template <int B, int DIM, int UNROLL>
@@ -433,6 +493,9 @@ static hipError_t launch_variant(int variant, dim3 grid, hipStream_t stream, con
                            lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride, guard);
     } else if (variant == 4 && (B % 2) == 0)
         hipLaunchKernelGGL((k_force_tile_pk<(B >= 2 ? B / 2 : 1), DIM, 8>), grid, dim3(kTile), 0, stream, posm, lo,
+                           n_targets, tiles_total, jsplit, acc_partial, acc_stride);
+    else if (variant == 5 && (B % 2) == 0)
+        hipLaunchKernelGGL((k_force_smem_pk<(B >= 2 ? B / 2 : 1), DIM, 8>), grid, dim3(kTile), 0, stream, posm, lo,
                            n_targets, tiles_total, jsplit, acc_partial, acc_stride);
     else if (variant == 3 && (B % 2) == 0)
         hipLaunchKernelGGL((k_force_tile_pk<(B >= 2 ? B / 2 : 1), DIM, 4>), grid, dim3(kTile), 0, stream, posm, lo,

@@ -170,7 +170,7 @@ def lib():
     L.nbx_profile_read.restype = i32
     L.nbx_bh_host_timing.argtypes = [E, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(i32)]
     L.nbx_bh_host_timing.restype = i32
-    L.nbx_last_launch.argtypes = [E] + [C.POINTER(i32)] * 5
+    L.nbx_last_launch.argtypes = [E] + [C.POINTER(i32)] * 6
     L.nbx_last_launch.restype = i32
     _lib = L
     return L
@@ -400,6 +400,6 @@ class NBodyEngine:
                 "steps": steps.value, "nodes": nodes.value}
 
     def last_launch(self):
-        v = [C.c_int32() for _ in range(5)]
+        v = [C.c_int32() for _ in range(6)]
         _check(self._L.nbx_last_launch(self._h, *[C.byref(x) for x in v]))
-        return dict(zip(("grid", "block", "jsplit", "bodies_per_thread", "dim"), (x.value for x in v)))
+        return dict(zip(("grid", "block", "jsplit", "bodies_per_thread", "dim", "variant"), (x.value for x in v)))

@@ -115,7 +115,7 @@ def test_fast_matches_golden_within_tolerance(rx, name):
             assert err <= tol, f"{name} step {s} {k}: {err} > {tol}"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("bpt", [1, 2, 4])
 @pytest.mark.parametrize("jsplit", [1, 3, 8])
 def test_fast_accelerations_all_launch_shapes(rx, ob, variant, bpt, jsplit):

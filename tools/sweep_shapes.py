@@ -17,7 +17,7 @@ if len(sys.argv) > 1:
 for n, world in shapes:
     st = rx.plummer_sphere(n)
     best = None
-    for variant, bpt, s in itertools.product((1,), (2, 4), (0, 1, 2, 4, 8, 16, 32, 64)):
+    for variant, bpt, s in itertools.product(tuple(int(v) for v in os.environ.get("VARIANTS", "1").split(",")), (2, 4), (0, 8, 16, 32, 64)):
         e = rx.NBodyEngine()
         e.set_shard(0, world)
         e.set_launch(jsplit=s, bodies_per_thread=bpt, variant=variant)
