@@ -34,7 +34,8 @@ extern "C" {
 /* Level 1: drop-in replacements (process-global engine, internally serialised by a mutex like  */
 /* the reference's `PARTICLES: Mutex<Vec<Particle>>`, nbody.rs:28-32).                          */
 /* Environment knobs read once at first use: NB_DEVICE (ordinal, default 0), NB_SEED (u64,      */
-/* default: OS entropy, as the reference's thread_rng), NB_FORCE_MODE=fast|strict.              */
+/* default: OS entropy, as the reference's thread_rng), NB_FORCE_MODE=fast|strict,                */
+/* NB_DRAW=host|device.                                                                          */
 
 /* replaces nbody.rs:34-37   pub extern fn nb_num_particles() -> i32 */
 int32_t nb_num_particles(void);
@@ -94,6 +95,9 @@ enum nbx_option {
                                     *  4 = 1 + batched reciprocals (guarded by max|coord| <= 1e4)
                                     *  0 = compiler-scheduled LDS tiles, 2 = scalar-cache scalar math,
                                     *  3 = 1 with 4-source LDS batches            (all A/B'd in DESIGN.md 6) */
+    NBX_OPT_DRAW_DEVICE = 7,       /* 1: nbx_draw/nb_draw splat on the GPU (count + resolve kernels, one w*h*4 B
+                                    * download) instead of downloading the state; body pixels identical, a tail may
+                                    * move one octant when v is within ~1e-6 rad of a multiple of 45 deg. Default 0 */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };
@@ -146,6 +150,11 @@ int32_t nbx_set_particles3(nbx_engine *e, int32_t n, const float *px, const floa
 int32_t nbx_get_particles(nbx_engine *e, int32_t cap, float *px, float *py, float *vx, float *vy, float *m);
 int32_t nbx_get_particles3(nbx_engine *e, int32_t cap, float *px, float *py, float *pz, float *vx, float *vy,
                            float *vz, float *m);
+
+/* Checkpoint to / resume from a file (additive; the reference has no persistence). Format: "NBXCKPT1",
+ * int32 n, int32 0, then px py pz vx vy vz m as n little-endian f32 each. load returns the particle count. */
+int32_t nbx_save(nbx_engine *e, const char *path);
+int32_t nbx_load(nbx_engine *e, const char *path);
 
 /* Steps. Asynchronous on the engine's stream; nbx_synchronize / get / draw wait. */
 int32_t nbx_step_brute_force(nbx_engine *e, float dt);

@@ -86,6 +86,11 @@ struct nbx_engine {
     size_t nodes_cap = 0;
     unsigned* d_guard = nullptr;   // max|coord| word for the batched-reciprocal kernel
     size_t guard_cap = 0;
+    void* d_counts = nullptr;      // device draw: uint2 hit counters per pixel
+    size_t counts_cap = 0;         // pixels
+    unsigned* d_fb = nullptr;
+    size_t fb_cap = 0;
+    int draw_device = 0;
     void* d_posh = nullptr;        // half4 (x,y,z,m) source copy (NBX_OPT_SOURCE_PRECISION = 16)
     bool posh_external = false;
     size_t posh_cap = 0;           // records
@@ -456,6 +461,8 @@ void free_device(nbx_engine* e)
     if (e->d_out4) (void)hipFree(e->d_out4);
     if (e->d_nodes) (void)hipFree(e->d_nodes);
     if (e->d_guard) (void)hipFree(e->d_guard);
+    if (e->d_counts) (void)hipFree(e->d_counts);
+    if (e->d_fb) (void)hipFree(e->d_fb);
     if (e->d_posh && !e->posh_external) (void)hipFree(e->d_posh);
     if (e->h_nodes) (void)hipHostFree(e->h_nodes);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -561,6 +568,9 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
         case NBX_OPT_KERNEL_VARIANT:
             e->variant = (int)value;
             return NBX_OK;
+        case NBX_OPT_DRAW_DEVICE:
+            e->draw_device = value ? 1 : 0;
+            return NBX_OK;
         case NBX_OPT_SOURCE_PRECISION:
             if (value != 16 && value != 32) return fail(NBX_ERR_INVALID, "source precision must be 16 or 32");
             e->source_half = value == 16;
@@ -586,6 +596,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_PROFILE: return e->profile;
         case NBX_OPT_KERNEL_VARIANT: return e->variant;
         case NBX_OPT_SOURCE_PRECISION: return e->source_half ? 16 : 32;
+        case NBX_OPT_DRAW_DEVICE: return e->draw_device;
         default: return NBX_ERR_INVALID;
     }
 }
@@ -752,9 +763,38 @@ int32_t nbx_forces(nbx_engine* e, float theta, int32_t cap, float* fx, float* fy
     return slab;
 }
 
+// device splat (draw.hip): needs the whole state on this GPU (unsharded) and a live device
+static int draw_on_device(nbx_engine* e, int32_t w, int32_t h, uint32_t* fb)
+{
+    int rc = upload(e);
+    if (rc != NBX_OK) return rc;
+    const size_t px = (size_t)w * (size_t)h;
+    if (px > e->counts_cap) {
+        if (e->d_counts) HIP_TRY(hipFree(e->d_counts));
+        if (e->d_fb) HIP_TRY(hipFree(e->d_fb));
+        e->d_counts = nullptr; e->d_fb = nullptr; e->counts_cap = e->fb_cap = 0;
+        HIP_TRY(hipMalloc(&e->d_counts, px * 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_fb), px * 4));
+        e->counts_cap = e->fb_cap = px;
+    }
+    // viewport transform evaluated on the host exactly as nbody.rs:494-506 does (f32, same order)
+    const float aspect = (float)h / (float)w;
+    const float x1 = 0.0f - 100.0f / 2.0f, y1 = (0.0f - 100.0f / 2.0f) * aspect;
+    const float x2 = 0.0f + 100.0f / 2.0f, y2 = (0.0f + 100.0f / 2.0f) * aspect;
+    const float scalex = (1.0f / (x2 - x1)) * (float)w, scaley = (1.0f / (y2 - y1)) * (float)h;
+    HIP_TRY(nbx::launch_draw(e->d_posm, e->d_vel, e->n, w, h, x1, y1, scalex, scaley, e->d_counts, e->d_fb, e->stream));
+    HIP_TRY(hipMemcpyAsync(fb, e->d_fb, px * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return NBX_OK;
+}
+
 int32_t nbx_draw(nbx_engine* e, int32_t w, int32_t h, uint32_t* fb)
 {
     if (!e || !fb || w <= 0 || h <= 0) return fail(NBX_ERR_INVALID, "bad draw arguments");
+    if (e->draw_device) {
+        if (e->world != 1) return fail(NBX_ERR_STATE, "device draw needs the whole state on one GPU");
+        return draw_on_device(e, w, h, fb);
+    }
     int rc = download_positions(e);
     if (rc != NBX_OK) return rc;
     rc = download_velocities(e);
@@ -789,6 +829,48 @@ int32_t nbx_bh_flat_dump(nbx_engine* e, void* rows, int32_t cap, int32_t threade
     if ((size_t)cap >= e->flat_small.size() && rows && !e->flat_small.empty())
         std::memcpy(rows, e->flat_small.data(), sizeof(nbx::BhNode) * e->flat_small.size());
     return (int32_t)e->flat_small.size();
+}
+
+// ---- checkpoint: the reference has none (state is lost on every experiment switch) ----
+// File = "NBXCKPT1" | int32 n | int32 reserved | 7 arrays of n little-endian f32: px py pz vx vy vz m
+int32_t nbx_save(nbx_engine* e, const char* path)
+{
+    if (!e || !path) return fail(NBX_ERR_INVALID, "null argument");
+    if (e->world != 1) return fail(NBX_ERR_STATE, "save the gathered state from rank 0 of a sharded run via get/set");
+    int rc = download_positions(e);
+    if (rc != NBX_OK) return rc;
+    rc = download_velocities(e);
+    if (rc != NBX_OK) return rc;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(NBX_ERR_INVALID, "cannot open %s for writing", path);
+    const int32_t hdr[2] = {e->n, 0};
+    bool ok = std::fwrite("NBXCKPT1", 1, 8, f) == 8 && std::fwrite(hdr, sizeof hdr, 1, f) == 1;
+    const std::vector<float>* arrs[7] = {&e->host.px, &e->host.py, &e->host.pz, &e->host.vx, &e->host.vy, &e->host.vz, &e->host.m};
+    for (auto* a : arrs) ok = ok && (e->n == 0 || std::fwrite(a->data(), sizeof(float), (size_t)e->n, f) == (size_t)e->n);
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? NBX_OK : fail(NBX_ERR_INVALID, "short write to %s", path);
+}
+
+int32_t nbx_load(nbx_engine* e, const char* path)
+{
+    if (!e || !path) return fail(NBX_ERR_INVALID, "null argument");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(NBX_ERR_INVALID, "cannot open %s", path);
+    char magic[8];
+    int32_t hdr[2] = {0, 0};
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "NBXCKPT1", 8) == 0 && std::fread(hdr, sizeof hdr, 1, f) == 1 &&
+              hdr[0] >= 0;
+    nbx::HostState st;
+    if (ok) {
+        st.resize(hdr[0]);
+        std::vector<float>* arrs[7] = {&st.px, &st.py, &st.pz, &st.vx, &st.vy, &st.vz, &st.m};
+        for (auto* a : arrs) ok = ok && (hdr[0] == 0 || std::fread(a->data(), sizeof(float), (size_t)hdr[0], f) == (size_t)hdr[0]);
+    }
+    std::fclose(f);
+    if (!ok) return fail(NBX_ERR_INVALID, "%s is not a valid NBXCKPT1 checkpoint", path);
+    e->host = std::move(st);
+    after_host_state_change(e);
+    return e->n;
 }
 
 int32_t nbx_set_shard(nbx_engine* e, int32_t rank, int32_t world)
@@ -948,6 +1030,8 @@ static nbx_engine* global_engine()
         }
         const char* mode = std::getenv("NB_FORCE_MODE");
         if (mode && std::strcmp(mode, "strict") == 0) g_engine->force_mode = 1;
+        const char* draw = std::getenv("NB_DRAW");
+        if (draw && std::strcmp(draw, "device") == 0) g_engine->draw_device = 1;
     }
     return g_engine;
 }

@@ -57,4 +57,8 @@ hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel,
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
                           int mode, float2* force_out, hipStream_t stream);
 
+// nb_draw on the device: counts (uint2 per pixel: body hits, tail hits) -> ABGR framebuffer
+hipError_t launch_draw(const float4* posm, const float4* vel, int n, int w, int h, float x1, float y1, float scalex,
+                       float scaley, void* counts, unsigned* fb, hipStream_t stream);
+
 }  // namespace nbx

@@ -31,6 +31,7 @@ NBX_OPT_DIM = 3
 NBX_OPT_PROFILE = 4
 NBX_OPT_KERNEL_VARIANT = 5
 NBX_OPT_SOURCE_PRECISION = 6
+NBX_OPT_DRAW_DEVICE = 7
 
 NBX_K_FORCE = 0
 NBX_K_INTEGRATE = 1
@@ -132,6 +133,10 @@ def lib():
     L.nbx_get_particles.restype = i32
     L.nbx_get_particles3.argtypes = [E, i32] + [C.c_void_p] * 7
     L.nbx_get_particles3.restype = i32
+    L.nbx_save.argtypes = [E, C.c_char_p]
+    L.nbx_save.restype = i32
+    L.nbx_load.argtypes = [E, C.c_char_p]
+    L.nbx_load.restype = i32
     L.nbx_step_brute_force.argtypes = [E, C.c_float]
     L.nbx_step_brute_force.restype = i32
     L.nbx_step_barnes_hut.argtypes = [E, C.c_float, C.c_float, i32]
@@ -310,6 +315,12 @@ class NBodyEngine:
         _check(self._L.nbx_get_particles3(self._h, n, *[_p(out[k]) for k in ("px", "py", "pz", "vx", "vy", "vz", "m")]))
         return out
 
+    def save(self, path):
+        _check(self._L.nbx_save(self._h, os.fsencode(path)))
+
+    def load(self, path):
+        return _check(self._L.nbx_load(self._h, os.fsencode(path)))
+
     # steps
     def step_brute_force(self, dt):
         _check(self._L.nbx_step_brute_force(self._h, dt))
@@ -330,6 +341,9 @@ class NBodyEngine:
         fz = np.zeros(hi - lo, np.float32)
         _check(self._L.nbx_forces(self._h, theta, hi - lo, _p(fx), _p(fy), _p(fz)))
         return fx, fy, fz
+
+    def set_draw_device(self, on=True):
+        self.set_option(NBX_OPT_DRAW_DEVICE, 1 if on else 0)
 
     def draw(self, w, h):
         fb = np.zeros(w * h, np.uint32)

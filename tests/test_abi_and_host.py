@@ -282,3 +282,28 @@ def test_threaded_flatten_equals_serial_flatten(rx, ob, monkeypatch):
     assert np.all(a["skip"][a["interior"] == 0] == idx[a["interior"] == 0] + 1)
     assert abs(float(a["m"][0]) - float(p["m"].astype(np.float64).sum())) < 1e-2 * 60000
     assert len(leaves) <= 60000
+
+
+def test_checkpoint_roundtrip(rx, tmp_path):
+    rng = np.random.default_rng(9)
+    n = 777
+    a = {k: rng.normal(size=n).astype(np.float32) for k in ("px", "py", "pz", "vx", "vy", "vz")}
+    a["m"] = rng.uniform(0.1, 2, n).astype(np.float32)
+    e = rx.NBodyEngine()
+    e.set_particles(a["px"], a["py"], a["vx"], a["vy"], a["m"], a["pz"], a["vz"])
+    path = str(tmp_path / "state.nbx")
+    e.save(path)
+    assert open(path, "rb").read(8) == b"NBXCKPT1"
+    f = rx.NBodyEngine()
+    assert f.load(path) == n
+    st = f.get_particles()
+    for k in a:
+        assert_bit_equal(st[k], a[k], k)
+    bad = str(tmp_path / "bad.nbx")
+    open(bad, "wb").write(b"not a checkpoint")
+    with pytest.raises(rx.NBodyError):
+        f.load(bad)
+    assert f.num_particles() == n           # a failed load leaves the state alone
+    e.set_particles([], [], [], [], [])
+    e.save(path)
+    assert f.load(path) == 0
