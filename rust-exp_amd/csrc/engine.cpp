@@ -289,14 +289,14 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
     // Defaults from the measured launch-shape sweeps (profiles/r01_shapes_sweep*.txt):
     //  * kernel: scalar-cache sources + packed math (variant 5) once the source array has >= 32768 bodies
     //    (no LDS traffic -> +2.4 % clock under the power cap, +3.5 % throughput); LDS tiles (variant 1) below.
-    //  * register blocking 4 (two packed pairs) when a GPU owns >= 131072 targets (variant 5) / 32768 (variant 1).
+    //  * register blocking 4 (two packed pairs) when a GPU owns >= 32768 targets, else 2.
     //  * source split S = smallest power of two giving >= 64 (variant 5) / 32 (variant 1) workgroups per CU,
     //    capped at 64 and at half the tile count.
     *dim = e->dim_opt ? e->dim_opt : (e->any_z ? 3 : 2);
     int v = e->variant;
     if (v < 0) v = (tiles_total * kTile >= 32768) ? 5 : 1;
     *variant = v;
-    int b = e->bpt ? e->bpt : (v == 5 ? (n_targets >= 131072 ? 4 : 2) : (n_targets >= 32768 ? 4 : 2));
+    int b = e->bpt ? e->bpt : (n_targets >= 32768 ? 4 : 2);
     if (b != 1 && b != 2 && b != 4) b = 2;
     *bpt = b;
     int s = e->jsplit;
