@@ -77,6 +77,11 @@ class TorchSlabEngine:
     def step_local(self, dt):
         self.eng.step_local(dt)
 
+    def step_local_barnes_hut(self, theta, dt):
+        # every rank rebuilds the (identical) quadtree on its host from the gathered positions and evaluates
+        # only its slab of targets on its GPU (tree replicas + slab of targets per GPU)
+        self.eng.step_barnes_hut(theta, dt, 1)
+
     def positions_array(self):
         """The array the per-step all-gather moves: [n_pad, 4] (x, y, z, m), float32 or float16."""
         return self.posh if self.source_half else self.posm
@@ -138,6 +143,16 @@ class ShardedNBody:
     def step_brute_force(self, dt):
         """nb_step_brute_force (nbody.rs:106-162) across all ranks."""
         self.local.step_local(dt)
+        self._exchange()
+
+    def step_barnes_hut(self, theta, dt, nthreads=1):
+        """nb_step_barnes_hut (nbody.rs:186-480) across all ranks: theta == 0 delegates to brute force
+        (nbody.rs:197-200); otherwise tree replicas + slab of targets per rank, same single exchange."""
+        if theta == 0.0:
+            return self.step_brute_force(dt)
+        if not getattr(self.local, "positions_replicated", True):
+            raise RuntimeError("Barnes-Hut needs replicated fp32 positions (not the fp16 source copy)")
+        self.local.step_local_barnes_hut(theta, dt)
         self._exchange()
 
     def gather_state(self):

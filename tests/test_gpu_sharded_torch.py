@@ -85,6 +85,26 @@ def test_torch_slab_engine_world1_with_rccl_allgather(rx):
 
 
 @pytest.mark.parametrize("world,n", [(8, 32768), (3, 1000)])
+def test_barnes_hut_slabs_stitch_bitwise(rx, ob, world, n):
+    """Strict Barnes-Hut evaluated slab by slab (tree replica per rank) == the oracle's step, bit for bit."""
+    p = ob.random_disk(n, 34)
+    news = {k: np.zeros(n, np.float32) for k in ("px", "py", "vx", "vy")}
+    for r in range(world):
+        e = rx.NBodyEngine(mode="strict")
+        e.set_shard(r, world)
+        e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+        lo, hi = e.slab()
+        e.step_barnes_hut(0.7, 0.01, 1)
+        st = e.get_particles()
+        for k in news:
+            news[k][lo:hi] = st[k][lo:hi]
+    q = p.copy()
+    assert ob.step_barnes_hut(q, 0.7, 0.01, 4) == 0
+    for k in news:
+        assert_bit_equal(news[k], q[k], k)
+
+
+@pytest.mark.parametrize("world,n", [(8, 32768), (3, 1000)])
 def test_slab_kernels_of_all_ranks_stitch_to_the_single_gpu_step(rx, ob, world, n):
     """Every rank's nbx_step_local on its own slab (run one after another on this GPU) reproduces the
     unsharded step: strict mode bit for bit vs the oracle, fast mode within rounding of the unsharded

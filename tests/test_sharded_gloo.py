@@ -54,6 +54,22 @@ class OracleSlabEngine:
         pos[sl, 0] = pos[sl, 0] + dt * self.vx[sl]              # nbody.rs:158
         pos[sl, 1] = pos[sl, 1] + dt * self.vy[sl]
 
+    def step_local_barnes_hut(self, theta, dt):
+        pos = self.pos.numpy()
+        p = self.ob.particles(pos[:, 0], pos[:, 1], self.vx, self.vy, self.m)
+        rc, fx, fy = self.ob.bh_forces(p, theta)
+        assert rc == 0
+        dt = np.float32(dt)
+        sl = slice(self.lo, self.hi)
+        self.vx[sl] = self.vx[sl] + (dt * fx[sl]) / self.m[sl]     # nbody.rs:453
+        self.vy[sl] = self.vy[sl] + (dt * fy[sl]) / self.m[sl]
+        pos[sl, 0] = pos[sl, 0] + dt * self.vx[sl]                 # nbody.rs:457
+        pos[sl, 1] = pos[sl, 1] + dt * self.vy[sl]
+        kill = (np.abs(np.float32(0.0) - pos[sl, 0]) > np.float32(100.0) * np.float32(0.55)) | \
+               (np.abs(np.float32(0.0) - pos[sl, 1]) > np.float32(100.0) * np.float32(0.55))   # nbody.rs:466-471
+        self.vx[sl][kill] = 0.0
+        self.vy[sl][kill] = 0.0
+
     def positions_array(self):
         return self.pos
 
@@ -64,7 +80,7 @@ class OracleSlabEngine:
                 "vz": z.copy(), "m": self.m.copy()}
 
 
-def _worker(rank, world, port, n, steps, q):
+def _worker(rank, world, port, n, steps, q, theta=0.0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -81,7 +97,7 @@ def _worker(rank, world, port, n, steps, q):
         sim = rx.ShardedNBody(OracleSlabEngine())
         sim.set_particles(st)
         for _ in range(steps):
-            sim.step_brute_force(0.01)
+            sim.step_barnes_hut(theta, 0.01, 1)      # theta == 0 -> brute force (nbody.rs:197-200)
         full = sim.gather_state()
         q.put((rank, sim.lo, sim.hi, {k: np.array(full[k]) for k in ("px", "py", "vx", "vy")}))
     finally:
@@ -96,8 +112,8 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("world,n", [(2, 512), (2, 301), (3, 100)])
-def test_sharded_step_equals_single_process_oracle(world, n):
+@pytest.mark.parametrize("world,n,theta", [(2, 512, 0.0), (2, 301, 0.0), (3, 100, 0.0), (2, 400, 0.85), (3, 333, 0.5)])
+def test_sharded_step_equals_single_process_oracle(world, n, theta):
     import torch.multiprocessing as mp
 
     from oracle import binding as ob
@@ -106,7 +122,7 @@ def test_sharded_step_equals_single_process_oracle(world, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, steps, q, theta)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in range(world)]
@@ -115,7 +131,7 @@ def test_sharded_step_equals_single_process_oracle(world, n):
         assert p.exitcode == 0
     ref = ob.random_disk(n, 77)
     for _ in range(steps):
-        ob.step_brute_force(ref, 0.01)
+        assert ob.step_barnes_hut(ref, theta, 0.01, 1) == 0
     slabs = sorted((lo, hi) for _, lo, hi, _ in results)
     assert slabs[0][0] == 0 and slabs[-1][1] == n and all(a[1] == b[0] for a, b in zip(slabs, slabs[1:]))
     for rank, lo, hi, stt in results:
