@@ -98,6 +98,9 @@ enum nbx_option {
     NBX_OPT_DRAW_DEVICE = 7,       /* 1: nbx_draw/nb_draw splat on the GPU (count + resolve kernels, one w*h*4 B
                                     * download) instead of downloading the state; body pixels identical, a tail may
                                     * move one octant when v is within ~1e-6 rad of a multiple of 45 deg. Default 0 */
+    NBX_OPT_BH_TREE = 8,           /* Barnes-Hut tree: 0 = built on the host exactly like the reference (default;
+                                    * required by strict mode), 1 = built on the device (same node set; interior
+                                    * centres of mass folded per child, no EPS merge: own tolerance class) */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };
@@ -174,8 +177,8 @@ int32_t nbx_draw(nbx_engine *e, int32_t w, int32_t h, uint32_t *fb);
 int32_t nbx_bh_tree_dump(nbx_engine *e, float *rows, int32_t cap);
 
 /* The flattened tree the GPU traversal walks: pre-order, empty exterior nodes dropped, 32-byte records
- * {float px, py, m, s; int32 skip, interior, pad, pad}. threaded != 0 uses the host-thread flattener
- * (same bytes). Returns the node count; writes only when cap >= count. Runs without a device. */
+ * {float px, py, m, s; int32 skip, interior, pad, pad}. threaded = 1 uses the host-thread flattener
+ * (same bytes), 2 dumps the DEVICE-built tree (needs a GPU). Returns the node count; writes only when cap >= count. Runs without a device. */
 int32_t nbx_bh_flat_dump(nbx_engine *e, void *rows, int32_t cap, int32_t threaded);
 
 /* ---- multi-GPU: bodies shard as contiguous slabs of targets, the reference's own thread split  */

@@ -28,10 +28,13 @@ constexpr int kMaxFrames = 56;
 __global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict__ posm, const int lo,
                                                         const int n_targets, const BhNode* __restrict__ nodes,
                                                         const int n_nodes, const float theta,
-                                                        float2* __restrict__ out)
+                                                        float2* __restrict__ out, const unsigned* __restrict__ perm)
 {
-    const int it = blockIdx.x * kTile + threadIdx.x;
-    if (it >= n_targets) return;
+    const int t = blockIdx.x * kTile + threadIdx.x;
+    if (t >= n_targets) return;
+    // perm (optional): a spatial (Morton) order of the bodies, so the 64 lanes of a wave walk nearly the same
+    // nodes; it only changes which thread handles which body, never a result
+    const int it = perm ? (int)perm[t] : t;
     const float4 pi = posm[lo + it];
     float ax = 0.0f, ay = 0.0f;
     int i = 0;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(kTile) void k_integrate_f2(float4* __restrict__ pos
 }
 
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
-                          int mode, float2* force_out, hipStream_t stream)
+                          int mode, float2* force_out, hipStream_t stream, const unsigned* perm)
 {
     if (n_targets <= 0) return hipSuccess;
     const dim3 grid((n_targets + kTile - 1) / kTile);
@@ -156,7 +159,7 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
                            force_out);
     else
         hipLaunchKernelGGL(k_bh_eval_fast, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
-                           force_out);
+                           force_out, perm);
     return hipGetLastError();
 }
 

@@ -86,6 +86,12 @@ struct nbx_engine {
     size_t nodes_cap = 0;
     unsigned* d_guard = nullptr;   // max|coord| word for the batched-reciprocal kernel
     size_t guard_cap = 0;
+    void* d_tree_ws = nullptr;     // device tree build workspace (NBX_OPT_BH_TREE = 1)
+    size_t tree_ws_bytes = 0;
+    int* h_counters = nullptr;     // pinned: per-level node counters of the device build
+    const unsigned* d_perm = nullptr;   // spatial body order produced by the device build
+    int bh_tree_device = 0;
+    int bh_fallbacks = 0;          // device builds that fell back to the host (node pool exhausted)
     void* d_counts = nullptr;      // device draw: uint2 hit counters per pixel
     size_t counts_cap = 0;         // pixels
     unsigned* d_fb = nullptr;
@@ -418,21 +424,62 @@ int build_and_upload_tree(nbx_engine* e)
     return NBX_OK;
 }
 
+// quadtree on the device (bh_build.hip); falls back to the host build when the node pool overflows
+int build_tree_on_device(nbx_engine* e, bool* done)
+{
+    using clk = std::chrono::steady_clock;
+    *done = false;
+    const auto t0 = clk::now();
+    const int node_cap = 4 * e->n + 1024;
+    size_t sort_tmp = 0;
+    const size_t need = nbx::device_tree_workspace_bytes(e->n, node_cap, &sort_tmp);
+    if (need > e->tree_ws_bytes) {
+        if (e->d_tree_ws) HIP_TRY(hipFree(e->d_tree_ws));
+        e->d_tree_ws = nullptr;
+        e->tree_ws_bytes = 0;
+        HIP_TRY(hipMalloc(&e->d_tree_ws, need));
+        e->tree_ws_bytes = need;
+    }
+    if (!e->h_counters) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_counters), 64, hipHostMallocDefault));
+    int rc = grow(&e->d_nodes, &e->nodes_cap, (size_t)node_cap);
+    if (rc != NBX_OK) return rc;
+    int n_nodes = 0, status = 0;
+    HIP_TRY(nbx::device_tree_build(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes, e->h_counters,
+                                   &n_nodes, &e->d_perm, &status, e->stream));
+    if (status != 0) {
+        e->bh_fallbacks++;
+        e->d_perm = nullptr;
+        return NBX_OK;   // caller takes the host path
+    }
+    e->n_flat = (size_t)n_nodes;
+    e->host_ms[1] += std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+    e->host_steps++;
+    *done = true;
+    return NBX_OK;
+}
+
 int step_bh(nbx_engine* e, float theta, float dt)
 {
     int rc = upload(e);
     if (rc != NBX_OK) return rc;
     const int slab = e->slab();
     if (e->n == 0) return NBX_OK;
-    rc = build_and_upload_tree(e);
-    if (rc != NBX_OK) return rc;
+    bool on_device = false;
+    if (e->bh_tree_device && e->force_mode == 0) {
+        rc = build_tree_on_device(e, &on_device);
+        if (rc != NBX_OK) return rc;
+    }
+    if (!on_device) {
+        rc = build_and_upload_tree(e);
+        if (rc != NBX_OK) return rc;
+    }
     if (slab == 0) return NBX_OK;
     rc = grow(&e->d_f2, &e->f2_cap, (size_t)slab);
     if (rc != NBX_OK) return rc;
     {
         ProfScope ps(e, NBX_K_BH_EVAL);
-        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, e->force_mode,
-                                    e->d_f2, e->stream));
+        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, e->force_mode, e->d_f2,
+                                    e->stream, (on_device && e->world == 1) ? e->d_perm : nullptr));
     }
     {
         ProfScope ps(e, NBX_K_INTEGRATE);
@@ -461,6 +508,8 @@ void free_device(nbx_engine* e)
     if (e->d_out4) (void)hipFree(e->d_out4);
     if (e->d_nodes) (void)hipFree(e->d_nodes);
     if (e->d_guard) (void)hipFree(e->d_guard);
+    if (e->d_tree_ws) (void)hipFree(e->d_tree_ws);
+    if (e->h_counters) (void)hipHostFree(e->h_counters);
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_fb) (void)hipFree(e->d_fb);
     if (e->d_posh && !e->posh_external) (void)hipFree(e->d_posh);
@@ -571,6 +620,10 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
         case NBX_OPT_DRAW_DEVICE:
             e->draw_device = value ? 1 : 0;
             return NBX_OK;
+        case NBX_OPT_BH_TREE:
+            if (value != 0 && value != 1) return fail(NBX_ERR_INVALID, "bh tree must be 0 (host) or 1 (device)");
+            e->bh_tree_device = (int)value;
+            return NBX_OK;
         case NBX_OPT_SOURCE_PRECISION:
             if (value != 16 && value != 32) return fail(NBX_ERR_INVALID, "source precision must be 16 or 32");
             e->source_half = value == 16;
@@ -597,6 +650,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_KERNEL_VARIANT: return e->variant;
         case NBX_OPT_SOURCE_PRECISION: return e->source_half ? 16 : 32;
         case NBX_OPT_DRAW_DEVICE: return e->draw_device;
+        case NBX_OPT_BH_TREE: return e->bh_tree_device;
         default: return NBX_ERR_INVALID;
     }
 }
@@ -744,11 +798,18 @@ int32_t nbx_forces(nbx_engine* e, float theta, int32_t cap, float* fx, float* fy
         ProfScope ps(e, NBX_K_FORCE);
         HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream));
     } else {
-        rc = build_and_upload_tree(e);
-        if (rc != NBX_OK) return rc;
+        bool on_device = false;
+        if (e->bh_tree_device && e->force_mode == 0) {
+            rc = build_tree_on_device(e, &on_device);
+            if (rc != NBX_OK) return rc;
+        }
+        if (!on_device) {
+            rc = build_and_upload_tree(e);
+            if (rc != NBX_OK) return rc;
+        }
         ProfScope ps(e, NBX_K_BH_EVAL);
-        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, e->force_mode,
-                                    e->d_f2, e->stream));
+        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, e->force_mode, e->d_f2,
+                                    e->stream, (on_device && e->world == 1) ? e->d_perm : nullptr));
         is_accel = e->force_mode == 0;
     }
     std::vector<float2> tmp((size_t)slab);
@@ -816,6 +877,19 @@ int32_t nbx_bh_tree_dump(nbx_engine* e, float* rows, int32_t cap)
 int32_t nbx_bh_flat_dump(nbx_engine* e, void* rows, int32_t cap, int32_t threaded)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    if (threaded == 2) {   // the DEVICE-built tree (needs a GPU)
+        int rc0 = upload(e);
+        if (rc0 != NBX_OK) return rc0;
+        bool done = false;
+        rc0 = build_tree_on_device(e, &done);
+        if (rc0 != NBX_OK) return rc0;
+        if (!done) return fail(NBX_ERR_STATE, "device tree build fell back (node pool exhausted)");
+        if ((size_t)cap >= e->n_flat && rows && e->n_flat) {
+            HIP_TRY(hipMemcpyAsync(rows, e->d_nodes, sizeof(nbx::BhNode) * e->n_flat, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+        }
+        return (int32_t)e->n_flat;
+    }
     int rc = download_positions(e);
     if (rc != NBX_OK) return rc;
     rc = e->tree.build(e->host.px.data(), e->host.py.data(), e->host.m.data(), e->n);

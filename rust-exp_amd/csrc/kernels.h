@@ -54,8 +54,15 @@ hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel,
 // K3: Barnes-Hut traversal. mode 0 = fast (sequential pre-order accumulation, rcp),
 // mode 1 = strict (hierarchical summation order of nbody.rs:354-360 via an explicit frame stack,
 // IEEE sqrt/divide): bit-exact with the reference traversal.
+// perm (fast mode only, optional): thread t evaluates body perm[t] (spatial order => coherent waves)
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
-                          int mode, float2* force_out, hipStream_t stream);
+                          int mode, float2* force_out, hipStream_t stream, const unsigned* perm = nullptr);
+
+// Quadtree build on the device (bh_build.hip): same node set as the host build, flattened straight into `out`.
+size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes);
+hipError_t device_tree_build(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
+                             int* host_counters, int* n_nodes_host, const unsigned** perm_dev, int* status,
+                             hipStream_t stream);
 
 // nb_draw on the device: counts (uint2 per pixel: body hits, tail hits) -> ABGR framebuffer
 hipError_t launch_draw(const float4* posm, const float4* vel, int n, int w, int h, float x1, float y1, float scalex,

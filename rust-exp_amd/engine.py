@@ -32,6 +32,7 @@ NBX_OPT_PROFILE = 4
 NBX_OPT_KERNEL_VARIANT = 5
 NBX_OPT_SOURCE_PRECISION = 6
 NBX_OPT_DRAW_DEVICE = 7
+NBX_OPT_BH_TREE = 8
 
 NBX_K_FORCE = 0
 NBX_K_INTEGRATE = 1
@@ -342,6 +343,10 @@ class NBodyEngine:
         _check(self._L.nbx_forces(self._h, theta, hi - lo, _p(fx), _p(fy), _p(fz)))
         return fx, fy, fz
 
+    def set_bh_tree(self, where):
+        """'host' (reference-faithful, default) or 'device' (bh_build.hip)."""
+        self.set_option(NBX_OPT_BH_TREE, {"host": 0, "device": 1}[where])
+
     def set_draw_device(self, on=True):
         self.set_option(NBX_OPT_DRAW_DEVICE, 1 if on else 0)
 
@@ -360,9 +365,10 @@ class NBodyEngine:
         """Flattened tree as a structured array (px, py, m, s, skip, interior)."""
         dt = np.dtype([("px", "<f4"), ("py", "<f4"), ("m", "<f4"), ("s", "<f4"), ("skip", "<i4"), ("interior", "<i4"),
                        ("pad0", "<i4"), ("pad1", "<i4")])
-        cnt = _check(self._L.nbx_bh_flat_dump(self._h, None, 0, int(threaded)))
+        mode = 2 if threaded == "device" else int(bool(threaded))
+        cnt = _check(self._L.nbx_bh_flat_dump(self._h, None, 0, mode))
         rows = np.zeros(max(cnt, 1), dt)
-        cnt = _check(self._L.nbx_bh_flat_dump(self._h, _p(rows), cnt, int(threaded)))
+        cnt = _check(self._L.nbx_bh_flat_dump(self._h, _p(rows), cnt, mode))
         return rows[:cnt]
 
     # sharding

@@ -55,6 +55,30 @@ def main():
     out["bh_1m"]["force_rel_err_median"] = float(np.median(rel))
     out["bh_1m"]["force_rel_err_p99"] = float(np.percentile(rel, 99))
 
+    # the same step with the quadtree built on the device (bh_build.hip): no host round trip
+    cur = e.get_particles()            # the state the host-tree errors above were measured on
+    d = rx.NBodyEngine(mode="fast")
+    d.set_bh_tree("device")
+    d.set_particles(cur["px"], cur["py"], cur["vx"], cur["vy"], cur["m"])
+    dx, dy, _ = d.forces(0.5)
+    rel = np.hypot(dx - fx, dy - fy) / (np.hypot(fx, fy) + 1e-20)
+    relh = np.hypot(dx - bx, dy - by) / (np.hypot(bx, by) + 1e-20)
+    dev_err = {"force_rel_err_median": float(np.median(rel)), "force_rel_err_p99": float(np.percentile(rel, 99)),
+               "vs_host_tree_rel_median": float(np.median(relh)), "vs_host_tree_rel_p999": float(np.percentile(relh, 99.9))}
+    d.step_barnes_hut(0.5, 0.01, 1); d.synchronize()
+    d.profile(True); d.profile_reset(); d.bh_host_timing()
+
+    def dstep():
+        d.step_barnes_hut(0.5, 0.01, 1); d.synchronize()
+
+    dmed, dts = timed(dstep, 10)
+    dms, dcnt = d.profile_read(rx.NBX_K_BH_EVAL)
+    ht = d.bh_host_timing()
+    out["bh_1m_device_tree"] = {"ms_per_step_median": dmed * 1e3, "eval_kernel_ms": dms / dcnt, "tree_build_ms": ht["build_ms"],
+                                "nodes": ht["nodes"], "steps_timed": len(dts)}
+    d.profile(False)
+    out["bh_1m_device_tree"].update(dev_err)
+
     if not os.environ.get("BH_NO_CPU"):
         from oracle import binding as ob
 
