@@ -35,7 +35,7 @@ extern "C" {
 /* the reference's `PARTICLES: Mutex<Vec<Particle>>`, nbody.rs:28-32).                          */
 /* Environment knobs read once at first use: NB_DEVICE (ordinal, default 0), NB_SEED (u64,      */
 /* default: OS entropy, as the reference's thread_rng), NB_FORCE_MODE=fast|strict,                */
-/* NB_DRAW=host|device.                                                                          */
+/* NB_DRAW=host|device, NB_BH_TREE=host|device.                                                  */
 
 /* replaces nbody.rs:34-37   pub extern fn nb_num_particles() -> i32 */
 int32_t nb_num_particles(void);
@@ -210,6 +210,9 @@ int32_t nbx_profile_read(nbx_engine *e, int32_t kernel_id, double *total_ms, int
  * positions, quadtree build, flatten, upload of the node array; steps = tree builds; nodes = size of
  * the last flattened tree. */
 int32_t nbx_bh_host_timing(nbx_engine *e, double *ms4, int32_t *steps, int32_t *nodes);
+/* Work of one Barnes-Hut evaluation on the current state: tree nodes visited and pair laws evaluated, summed
+ * over this engine's slab (for roofline accounting; runs a counting traversal, no state change). */
+int32_t nbx_bh_work(nbx_engine *e, float theta, uint64_t *node_visits, uint64_t *pair_evals);
 /* launch geometry the last force launch used (for DESIGN/bench reporting); any pointer may be NULL */
 int32_t nbx_last_launch(const nbx_engine *e, int32_t *grid, int32_t *block, int32_t *jsplit,
                         int32_t *bodies_per_thread, int32_t *dim, int32_t *variant);

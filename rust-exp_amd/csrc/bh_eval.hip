@@ -149,6 +149,48 @@ __global__ __launch_bounds__(kTile) void k_integrate_f2(float4* __restrict__ pos
     posm[lo + i] = p;
 }
 
+// Work counter for the roofline note in DESIGN.md: nodes visited and pair evaluations per launch
+__global__ __launch_bounds__(kTile) void k_bh_count(const float4* __restrict__ posm, const int lo, const int n_targets,
+                                                    const BhNode* __restrict__ nodes, const int n_nodes, const float theta,
+                                                    unsigned long long* __restrict__ totals)
+{
+    const int it = blockIdx.x * kTile + threadIdx.x;
+    unsigned visits = 0, pairs = 0;
+    if (it < n_targets) {
+        const float4 pi = posm[lo + it];
+        int i = 0;
+        while (i < n_nodes) {
+            const float4 a = *reinterpret_cast<const float4*>(&nodes[i]);
+            const int2 b = *reinterpret_cast<const int2*>(&nodes[i].skip);
+            const float dx = a.x - pi.x, dy = a.y - pi.y;
+            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+            const bool take = b.y ? (a.w < theta * __builtin_sqrtf(d2)) : !(a.x == pi.x && a.y == pi.y);
+            visits++;
+            pairs += take ? 1u : 0u;
+            i = (b.y && !take) ? i + 1 : b.x;
+        }
+    }
+    unsigned long long v = visits, q = pairs;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_xor(v, off);
+        q += __shfl_xor(q, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&totals[0], v);
+        atomicAdd(&totals[1], q);
+    }
+}
+
+hipError_t launch_bh_count(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
+                           unsigned long long* totals, hipStream_t stream)
+{
+    if (n_targets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bh_count, dim3((n_targets + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, lo, n_targets, nodes,
+                       n_nodes, theta, totals);
+    return hipGetLastError();
+}
+
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
                           int mode, float2* force_out, hipStream_t stream, const unsigned* perm)
 {

@@ -1063,6 +1063,33 @@ int32_t nbx_profile_read(nbx_engine* e, int32_t kernel_id, double* total_ms, int
     return NBX_OK;
 }
 
+int32_t nbx_bh_work(nbx_engine* e, float theta, uint64_t* node_visits, uint64_t* pair_evals)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    int rc = upload(e);
+    if (rc != NBX_OK) return rc;
+    bool on_device = false;
+    if (e->bh_tree_device && e->force_mode == 0) {
+        rc = build_tree_on_device(e, &on_device);
+        if (rc != NBX_OK) return rc;
+    }
+    if (!on_device) {
+        rc = build_and_upload_tree(e);
+        if (rc != NBX_OK) return rc;
+    }
+    unsigned long long* d_tot = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tot), 16));
+    HIP_TRY(hipMemsetAsync(d_tot, 0, 16, e->stream));
+    HIP_TRY(nbx::launch_bh_count(e->d_posm, e->lo, e->slab(), e->d_nodes, (int)e->n_flat, theta, d_tot, e->stream));
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h, d_tot, 16, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipFree(d_tot));
+    if (node_visits) *node_visits = h[0];
+    if (pair_evals) *pair_evals = h[1];
+    return NBX_OK;
+}
+
 int32_t nbx_bh_host_timing(nbx_engine* e, double* ms4, int32_t* steps, int32_t* nodes)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
@@ -1104,6 +1131,8 @@ static nbx_engine* global_engine()
         }
         const char* mode = std::getenv("NB_FORCE_MODE");
         if (mode && std::strcmp(mode, "strict") == 0) g_engine->force_mode = 1;
+        const char* tree = std::getenv("NB_BH_TREE");
+        if (tree && std::strcmp(tree, "device") == 0) g_engine->bh_tree_device = 1;
         const char* draw = std::getenv("NB_DRAW");
         if (draw && std::strcmp(draw, "device") == 0) g_engine->draw_device = 1;
     }

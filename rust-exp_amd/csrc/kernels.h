@@ -58,6 +58,9 @@ hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel,
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
                           int mode, float2* force_out, hipStream_t stream, const unsigned* perm = nullptr);
 
+hipError_t launch_bh_count(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
+                           unsigned long long* totals, hipStream_t stream);
+
 // Quadtree build on the device (bh_build.hip): same node set as the host build, flattened straight into `out`.
 size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes);
 hipError_t device_tree_build(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,

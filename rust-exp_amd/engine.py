@@ -174,6 +174,8 @@ def lib():
     L.nbx_profile_reset.restype = i32
     L.nbx_profile_read.argtypes = [E, i32, C.POINTER(C.c_double), C.POINTER(i32)]
     L.nbx_profile_read.restype = i32
+    L.nbx_bh_work.argtypes = [E, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.nbx_bh_work.restype = i32
     L.nbx_bh_host_timing.argtypes = [E, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(i32)]
     L.nbx_bh_host_timing.restype = i32
     L.nbx_last_launch.argtypes = [E] + [C.POINTER(i32)] * 6
@@ -410,6 +412,11 @@ class NBodyEngine:
         ms, cnt = C.c_double(), C.c_int32()
         _check(self._L.nbx_profile_read(self._h, kernel_id, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def bh_work(self, theta):
+        v, q = C.c_uint64(), C.c_uint64()
+        _check(self._L.nbx_bh_work(self._h, theta, C.byref(v), C.byref(q)))
+        return {"node_visits": v.value, "pair_evals": q.value}
 
     def bh_host_timing(self):
         ms = (C.c_double * 4)()

@@ -78,6 +78,13 @@ def main():
                                 "nodes": ht["nodes"], "steps_timed": len(dts)}
     d.profile(False)
     out["bh_1m_device_tree"].update(dev_err)
+    wk = d.bh_work(0.5)
+    kms = out["bh_1m_device_tree"]["eval_kernel_ms"]
+    out["bh_1m_device_tree"]["work"] = {
+        "node_visits_per_body": wk["node_visits"] / big, "pair_evals_per_body": wk["pair_evals"] / big,
+        "node_bytes_per_launch": wk["node_visits"] * 32.0,
+        "node_read_rate_GBps": wk["node_visits"] * 32.0 / (kms * 1e-3) / 1e9,
+        "visits_per_second": wk["node_visits"] / (kms * 1e-3)}
 
     if not os.environ.get("BH_NO_CPU"):
         from oracle import binding as ob
