@@ -33,7 +33,8 @@ extern "C" {
 /* ------------------------------------------------------------------------------------------- */
 /* Level 1: drop-in replacements (process-global engine, internally serialised by a mutex like  */
 /* the reference's `PARTICLES: Mutex<Vec<Particle>>`, nbody.rs:28-32).                          */
-/* Environment knobs read once at first use: NB_DEVICE (ordinal, default 0), NB_SEED (u64,      */
+/* Environment knobs read once at first use: NB_DEVICE (ordinal, default 0), NB_GPUS (n | all:   */
+/* single-process multi-GPU group, see nbx_group_*), NB_SEED (u64,                               */
 /* default: OS entropy, as the reference's thread_rng), NB_FORCE_MODE=fast|strict,                */
 /* NB_DRAW=host|device, NB_BH_TREE=host|device.                                                  */
 
@@ -201,6 +202,28 @@ int32_t nbx_set_stream(nbx_engine *e, void *hip_stream); /* run on a caller-owne
 /* force + integrate for this rank's slab only, writing the new positions into the slab's slot of
  * the positions buffer. The caller then performs the all-gather on the same stream. */
 int32_t nbx_step_local(nbx_engine *e, float dt);
+
+/* ---- single-process multi-GPU group: G engines (one per device) behind one handle, for hosts that cannot run
+ * one process per GPU (the unmodified Haskell caller: set NB_GPUS=<n>|all and the six nb_* symbols use it).
+ * Same slab sharding and the same single exchange per step as above, but the all-gather is issued by the
+ * library itself through RCCL (ncclCommInitAll; librccl is dlopen'ed on first use). devices may be NULL
+ * (0..count-1). Per-engine calls (options, profiling, forces) remain available through nbx_group_engine. */
+typedef struct nbx_group nbx_group;
+int32_t nbx_group_create(nbx_group **out, const int32_t *devices, int32_t count);
+void nbx_group_destroy(nbx_group *g);
+int32_t nbx_group_size(const nbx_group *g);
+nbx_engine *nbx_group_engine(nbx_group *g, int32_t i);
+int32_t nbx_group_set_option(nbx_group *g, int32_t option, int64_t value);
+int32_t nbx_group_num_particles(const nbx_group *g);
+int32_t nbx_group_set_particles3(nbx_group *g, int32_t n, const float *px, const float *py, const float *pz,
+                                 const float *vx, const float *vy, const float *vz, const float *m);
+int32_t nbx_group_get_particles3(nbx_group *g, int32_t cap, float *px, float *py, float *pz, float *vx, float *vy,
+                                 float *vz, float *m);
+int32_t nbx_group_step_brute_force(nbx_group *g, float dt);
+int32_t nbx_group_step_barnes_hut(nbx_group *g, float theta, float dt, int32_t nthreads);
+int32_t nbx_group_synchronize(nbx_group *g);
+int32_t nbx_group_draw(nbx_group *g, int32_t w, int32_t h, uint32_t *fb);
+int32_t nbx_group_exchanges(const nbx_group *g); /* all-gathers issued so far */
 
 /* ---- profiling: HIP event pairs on the engine's stream around each kernel launch -------------- */
 int32_t nbx_profile_reset(nbx_engine *e);

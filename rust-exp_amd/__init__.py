@@ -25,6 +25,7 @@ from .engine import (  # noqa: F401
     NBX_K_INTEGRATE,
     NBodyEngine,
     NBodyError,
+    NBodyGroup,
     build,
     device_count,
     device_info,

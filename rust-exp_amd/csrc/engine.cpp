@@ -1114,36 +1114,297 @@ int32_t nbx_last_launch(const nbx_engine* e, int32_t* grid, int32_t* block, int3
     return NBX_OK;
 }
 
+
+// =============================================================================================
+// Single-process multi-GPU group: what the unmodified Haskell caller needs to use every GPU of a node.
+// G engines, one per device, slab-sharded exactly like the multi-process path (nbody.rs:426-428 split);
+// per step every device runs K1+K2 on its slab on its own stream, then ONE RCCL all-gather of the
+// (x,y,z,m) array (ncclCommInitAll communicators, one group call).  RCCL is dlopen'ed on first use so that
+// single-GPU users carry no dependency on it.
+// =============================================================================================
+}  // extern "C"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only; the functions are resolved at run time
+
+namespace {
+
+struct RcclApi {
+    void* so = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+RcclApi* rccl_api()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (so) {
+            api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(so, "ncclCommInitAll"));
+            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(so, "ncclCommDestroy"));
+            api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(so, "ncclAllGather"));
+            api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(so, "ncclBroadcast"));
+            api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(so, "ncclGroupStart"));
+            api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(so, "ncclGroupEnd"));
+            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(so, "ncclGetErrorString"));
+            if (api.CommInitAll && api.CommDestroy && api.AllGather && api.Broadcast && api.GroupStart && api.GroupEnd &&
+                api.GetErrorString)
+                api.so = so;
+        }
+    }
+    return api.so ? &api : nullptr;
+}
+
+#define RCCL_TRY(api, expr)                                                                         \
+    do {                                                                                            \
+        ncclResult_t _r = (expr);                                                                   \
+        if (_r != ncclSuccess) return fail(NBX_ERR_HIP, "%s failed: %s", #expr, (api)->GetErrorString(_r)); \
+    } while (0)
+
+}  // namespace
+
+struct nbx_group {
+    std::vector<nbx_engine*> eng;
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+    int exchanges = 0;
+};
+
+namespace {
+
+int group_comms(nbx_group* g)
+{
+    if (!g->comms.empty()) return NBX_OK;
+    RcclApi* api = rccl_api();
+    if (!api) return fail(NBX_ERR_HIP, "librccl.so could not be loaded: %s", dlerror());
+    g->comms.resize(g->eng.size());
+    RCCL_TRY(api, api->CommInitAll(g->comms.data(), (int)g->eng.size(), g->devices.data()));
+    return NBX_OK;
+}
+
+// one all-gather of the (x,y,z,m) slabs: in place, sendbuff = recvbuff + lo (per device), same stream as the kernels
+int group_exchange(nbx_group* g)
+{
+    const int G = (int)g->eng.size();
+    int rc = group_comms(g);
+    if (rc != NBX_OK) return rc;
+    RcclApi* api = rccl_api();
+    const int n = g->eng[0]->n;
+    if (n == 0) return NBX_OK;
+    RCCL_TRY(api, api->GroupStart());
+    if (n % G == 0) {
+        for (int d = 0; d < G; d++) {
+            nbx_engine* e = g->eng[d];
+            RCCL_TRY(api, api->AllGather(e->d_posm + e->lo, e->d_posm, (size_t)e->slab() * 4, ncclFloat32, g->comms[d], e->stream));
+        }
+    } else {   // ragged last slab (reference split): one broadcast per owner
+        for (int r = 0; r < G; r++) {
+            const int lo = g->eng[r]->lo, cnt = g->eng[r]->slab();
+            if (cnt == 0) continue;
+            for (int d = 0; d < G; d++) {
+                nbx_engine* e = g->eng[d];
+                RCCL_TRY(api, api->Broadcast(e->d_posm + lo, e->d_posm + lo, (size_t)cnt * 4, ncclFloat32, r, g->comms[d], e->stream));
+            }
+        }
+    }
+    RCCL_TRY(api, api->GroupEnd());
+    for (nbx_engine* e : g->eng) e->host_pos_valid = false;
+    g->exchanges++;
+    return NBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t nbx_group_create(nbx_group** out, const int32_t* devices, int32_t count)
+{
+    if (!out || count < 1) return fail(NBX_ERR_INVALID, "bad group arguments");
+    const int present = nbx_device_count();
+    nbx_group* g = new (std::nothrow) nbx_group();
+    if (!g) return fail(NBX_ERR_ALLOC, "out of memory");
+    for (int i = 0; i < count; i++) {
+        const int dev = devices ? devices[i] : i;
+        for (int j = 0; j < i; j++)
+            if (g->devices[j] == dev) { nbx_group_destroy(g); return fail(NBX_ERR_INVALID, "device %d listed twice", dev); }
+        if (present > 0 && (dev < 0 || dev >= present)) { nbx_group_destroy(g); return fail(NBX_ERR_NO_DEVICE, "no device %d (%d present)", dev, present); }
+        nbx_engine* e = nullptr;
+        if (nbx_create(&e, dev) != NBX_OK) { nbx_group_destroy(g); return NBX_ERR_ALLOC; }
+        e->rank = i;
+        e->world = count;
+        g->eng.push_back(e);
+        g->devices.push_back(dev);
+    }
+    *out = g;
+    return NBX_OK;
+}
+
+void nbx_group_destroy(nbx_group* g)
+{
+    if (!g) return;
+    for (nbx_engine* e : g->eng)
+        if (e && e->dev_ready) { (void)hipSetDevice(e->device); (void)hipStreamSynchronize(e->stream); }
+    if (!g->comms.empty())
+        if (RcclApi* api = rccl_api())
+            for (ncclComm_t c : g->comms) (void)api->CommDestroy(c);
+    for (nbx_engine* e : g->eng) nbx_destroy(e);
+    delete g;
+}
+
+int32_t nbx_group_size(const nbx_group* g) { return g ? (int32_t)g->eng.size() : NBX_ERR_INVALID; }
+nbx_engine* nbx_group_engine(nbx_group* g, int32_t i) { return (g && i >= 0 && i < (int)g->eng.size()) ? g->eng[i] : nullptr; }
+
+int32_t nbx_group_set_option(nbx_group* g, int32_t option, int64_t value)
+{
+    if (!g) return fail(NBX_ERR_INVALID, "null group");
+    for (nbx_engine* e : g->eng) {
+        const int rc = nbx_set_option(e, option, value);
+        if (rc != NBX_OK) return rc;
+    }
+    return NBX_OK;
+}
+
+int32_t nbx_group_num_particles(const nbx_group* g) { return g ? g->eng[0]->n : NBX_ERR_INVALID; }
+
+int32_t nbx_group_set_particles3(nbx_group* g, int32_t n, const float* px, const float* py, const float* pz, const float* vx,
+                                 const float* vy, const float* vz, const float* m)
+{
+    if (!g) return fail(NBX_ERR_INVALID, "null group");
+    for (nbx_engine* e : g->eng) {
+        const int rc = nbx_set_particles3(e, n, px, py, pz, vx, vy, vz, m);
+        if (rc != NBX_OK) return rc;
+    }
+    return NBX_OK;
+}
+
+int32_t nbx_group_get_particles3(nbx_group* g, int32_t cap, float* px, float* py, float* pz, float* vx, float* vy, float* vz,
+                                 float* m)
+{
+    if (!g) return fail(NBX_ERR_INVALID, "null group");
+    nbx_engine* e0 = g->eng[0];
+    if (cap < e0->n) return fail(NBX_ERR_INVALID, "capacity %d < particle count %d", cap, e0->n);
+    int rc = nbx_get_particles3(e0, cap, px, py, pz, vx, vy, vz, m);   // positions are replicated after the all-gather
+    if (rc < 0) return rc;
+    for (size_t d = 1; d < g->eng.size(); d++) {                        // velocities live on their owner
+        nbx_engine* e = g->eng[d];
+        rc = download_velocities(e);
+        if (rc != NBX_OK) return rc;
+        const size_t bytes = sizeof(float) * (size_t)e->slab();
+        if (vx) std::memcpy(vx + e->lo, e->host.vx.data() + e->lo, bytes);
+        if (vy) std::memcpy(vy + e->lo, e->host.vy.data() + e->lo, bytes);
+        if (vz) std::memcpy(vz + e->lo, e->host.vz.data() + e->lo, bytes);
+    }
+    return e0->n;
+}
+
+int32_t nbx_group_step_brute_force(nbx_group* g, float dt)
+{
+    if (!g) return fail(NBX_ERR_INVALID, "null group");
+    for (nbx_engine* e : g->eng) {   // asynchronous: every device works on its slab concurrently
+        const int rc = step_brute(e, dt);
+        if (rc != NBX_OK) return rc;
+    }
+    return group_exchange(g);
+}
+
+int32_t nbx_group_step_barnes_hut(nbx_group* g, float theta, float dt, int32_t nthreads)
+{
+    if (!g) return fail(NBX_ERR_INVALID, "null group");
+    if (theta == 0.0f) return nbx_group_step_brute_force(g, dt);   // nbody.rs:197-200
+    if (nthreads <= 0) return fail(NBX_ERR_INVALID, "nthreads must be >= 1");
+    for (nbx_engine* e : g->eng) {   // tree replica per device; each evaluates its slab
+        const int rc = step_bh(e, theta, dt);
+        if (rc != NBX_OK) return rc;
+    }
+    return group_exchange(g);
+}
+
+int32_t nbx_group_synchronize(nbx_group* g)
+{
+    if (!g) return fail(NBX_ERR_INVALID, "null group");
+    for (nbx_engine* e : g->eng) {
+        const int rc = nbx_synchronize(e);
+        if (rc != NBX_OK) return rc;
+    }
+    return NBX_OK;
+}
+
+int32_t nbx_group_draw(nbx_group* g, int32_t w, int32_t h, uint32_t* fb)
+{
+    if (!g || !fb || w <= 0 || h <= 0) return fail(NBX_ERR_INVALID, "bad draw arguments");
+    const int n = g->eng[0]->n;
+    std::vector<float> px(n), py(n), vx(n), vy(n);
+    const int rc = nbx_group_get_particles3(g, n, px.data(), py.data(), nullptr, vx.data(), vy.data(), nullptr, nullptr);
+    if (rc < 0) return rc;
+    nbx::draw_particles(px.data(), py.data(), vx.data(), vy.data(), n, w, h, fb);
+    return NBX_OK;
+}
+
+int32_t nbx_group_exchanges(const nbx_group* g) { return g ? g->exchanges : NBX_ERR_INVALID; }
+
 // =============================================================================================
 // Level 1: the reference's six symbols on a process-global engine
 // =============================================================================================
 
 static std::mutex g_mutex;           // PARTICLES: Mutex<..> (nbody.rs:28-32)
 static nbx_engine* g_engine = nullptr;
-
-static nbx_engine* global_engine()
-{
-    if (!g_engine) {
-        const char* dev = std::getenv("NB_DEVICE");
-        if (nbx_create(&g_engine, dev ? std::atoi(dev) : 0) != NBX_OK) {
-            std::fprintf(stderr, "nbody_mi355x: cannot create engine: %s\n", nbx_last_error());
-            std::abort();
-        }
-        const char* mode = std::getenv("NB_FORCE_MODE");
-        if (mode && std::strcmp(mode, "strict") == 0) g_engine->force_mode = 1;
-        const char* tree = std::getenv("NB_BH_TREE");
-        if (tree && std::strcmp(tree, "device") == 0) g_engine->bh_tree_device = 1;
-        const char* draw = std::getenv("NB_DRAW");
-        if (draw && std::strcmp(draw, "device") == 0) g_engine->draw_device = 1;
-    }
-    return g_engine;
-}
+static nbx_group* g_group = nullptr;   // NB_GPUS > 1: every call below is served by the multi-GPU group
 
 [[noreturn]] static void die(const char* where)
 {
     // the reference panics (and poisons its mutex) on failure; across the C ABI that is an abort
     std::fprintf(stderr, "nbody_mi355x: fatal in %s: %s\n", where, nbx_last_error());
     std::abort();
+}
+
+static void apply_env(nbx_engine* e)
+{
+    const char* mode = std::getenv("NB_FORCE_MODE");
+    if (mode && std::strcmp(mode, "strict") == 0) e->force_mode = 1;
+    const char* tree = std::getenv("NB_BH_TREE");
+    if (tree && std::strcmp(tree, "device") == 0) e->bh_tree_device = 1;
+    const char* draw = std::getenv("NB_DRAW");
+    if (draw && std::strcmp(draw, "device") == 0) e->draw_device = 1;
+}
+
+static nbx_engine* global_engine()   // engine 0 of the group when NB_GPUS > 1
+{
+    if (!g_engine) {
+        const char* gpus = std::getenv("NB_GPUS");
+        int want = gpus ? (std::strcmp(gpus, "all") == 0 ? nbx_device_count() : std::atoi(gpus)) : 1;
+        if (want > 1) {
+            if (nbx_group_create(&g_group, nullptr, want) != NBX_OK) die("NB_GPUS group creation");
+            for (nbx_engine* e : g_group->eng) apply_env(e);
+            g_engine = g_group->eng[0];
+            return g_engine;
+        }
+        const char* dev = std::getenv("NB_DEVICE");
+        if (nbx_create(&g_engine, dev ? std::atoi(dev) : 0) != NBX_OK) die("engine creation");
+        apply_env(g_engine);
+    }
+    return g_engine;
+}
+
+// after a preset ran on engine 0 (host side), replicate its state to the other engines of the group
+static int replicate_preset()
+{
+    if (!g_group) return NBX_OK;
+    nbx_engine* e0 = g_group->eng[0];
+    for (size_t d = 1; d < g_group->eng.size(); d++) {
+        const int rc = nbx_set_particles3(g_group->eng[d], e0->n, e0->host.px.data(), e0->host.py.data(), e0->host.pz.data(),
+                                          e0->host.vx.data(), e0->host.vy.data(), e0->host.vz.data(), e0->host.m.data());
+        if (rc != NBX_OK) return rc;
+    }
+    return NBX_OK;
 }
 
 int32_t nb_num_particles(void)
@@ -1155,19 +1416,24 @@ int32_t nb_num_particles(void)
 void nb_random_disk(int32_t num_particles)
 {
     std::lock_guard<std::mutex> lk(g_mutex);
-    if (nbx_random_disk(global_engine(), num_particles) != NBX_OK) die("nb_random_disk");
+    if (nbx_random_disk(global_engine(), num_particles) != NBX_OK || replicate_preset() != NBX_OK) die("nb_random_disk");
 }
 
 void nb_stable_orbits(int32_t num_particles, float rmin, float rmax)
 {
     std::lock_guard<std::mutex> lk(g_mutex);
-    if (nbx_stable_orbits(global_engine(), num_particles, rmin, rmax) != NBX_OK) die("nb_stable_orbits");
+    if (nbx_stable_orbits(global_engine(), num_particles, rmin, rmax) != NBX_OK || replicate_preset() != NBX_OK)
+        die("nb_stable_orbits");
 }
 
 void nb_step_brute_force(float dt)
 {
     std::lock_guard<std::mutex> lk(g_mutex);
     nbx_engine* e = global_engine();
+    if (g_group) {
+        if (nbx_group_step_brute_force(g_group, dt) != NBX_OK || nbx_group_synchronize(g_group) != NBX_OK) die("nb_step_brute_force");
+        return;
+    }
     if (nbx_step_brute_force(e, dt) != NBX_OK || nbx_synchronize(e) != NBX_OK) die("nb_step_brute_force");
 }
 
@@ -1176,6 +1442,11 @@ void nb_step_barnes_hut(float theta, float dt, int32_t nthreads)
     std::lock_guard<std::mutex> lk(g_mutex);
     nbx_engine* e = global_engine();
     if (theta != 0.0f && nthreads <= 0) return;  // reference: integer division by zero panic; here a no-op
+    if (g_group) {
+        if (nbx_group_step_barnes_hut(g_group, theta, dt, nthreads) != NBX_OK || nbx_group_synchronize(g_group) != NBX_OK)
+            die("nb_step_barnes_hut");
+        return;
+    }
     if (nbx_step_barnes_hut(e, theta, dt, nthreads) != NBX_OK || nbx_synchronize(e) != NBX_OK) die("nb_step_barnes_hut");
 }
 
@@ -1183,7 +1454,12 @@ void nb_draw(int32_t w, int32_t h, uint32_t* fb)
 {
     std::lock_guard<std::mutex> lk(g_mutex);
     if (w <= 0 || h <= 0 || !fb) return;
-    if (nbx_draw(global_engine(), w, h, fb) != NBX_OK) die("nb_draw");
+    nbx_engine* e = global_engine();
+    if (g_group) {
+        if (nbx_group_draw(g_group, w, h, fb) != NBX_OK) die("nb_draw");
+        return;
+    }
+    if (nbx_draw(e, w, h, fb) != NBX_OK) die("nb_draw");
 }
 
 }  // extern "C"

@@ -170,6 +170,33 @@ def lib():
     L.nbx_positions_bytes.restype = C.c_size_t
     L.nbx_set_stream.argtypes = [E, C.c_void_p]
     L.nbx_set_stream.restype = i32
+    G = C.c_void_p
+    L.nbx_group_create.argtypes = [C.POINTER(G), C.POINTER(i32), i32]
+    L.nbx_group_create.restype = i32
+    L.nbx_group_destroy.argtypes = [G]
+    L.nbx_group_destroy.restype = None
+    L.nbx_group_size.argtypes = [G]
+    L.nbx_group_size.restype = i32
+    L.nbx_group_engine.argtypes = [G, i32]
+    L.nbx_group_engine.restype = C.c_void_p
+    L.nbx_group_set_option.argtypes = [G, i32, C.c_int64]
+    L.nbx_group_set_option.restype = i32
+    L.nbx_group_num_particles.argtypes = [G]
+    L.nbx_group_num_particles.restype = i32
+    L.nbx_group_set_particles3.argtypes = [G, i32] + [C.c_void_p] * 7
+    L.nbx_group_set_particles3.restype = i32
+    L.nbx_group_get_particles3.argtypes = [G, i32] + [C.c_void_p] * 7
+    L.nbx_group_get_particles3.restype = i32
+    L.nbx_group_step_brute_force.argtypes = [G, C.c_float]
+    L.nbx_group_step_brute_force.restype = i32
+    L.nbx_group_step_barnes_hut.argtypes = [G, C.c_float, C.c_float, i32]
+    L.nbx_group_step_barnes_hut.restype = i32
+    L.nbx_group_synchronize.argtypes = [G]
+    L.nbx_group_synchronize.restype = i32
+    L.nbx_group_draw.argtypes = [G, i32, i32, C.c_void_p]
+    L.nbx_group_draw.restype = i32
+    L.nbx_group_exchanges.argtypes = [G]
+    L.nbx_group_exchanges.restype = i32
     L.nbx_profile_reset.argtypes = [E]
     L.nbx_profile_reset.restype = i32
     L.nbx_profile_read.argtypes = [E, i32, C.POINTER(C.c_double), C.POINTER(i32)]
@@ -430,3 +457,67 @@ class NBodyEngine:
         v = [C.c_int32() for _ in range(6)]
         _check(self._L.nbx_last_launch(self._h, *[C.byref(x) for x in v]))
         return dict(zip(("grid", "block", "jsplit", "bodies_per_thread", "dim", "variant"), (x.value for x in v)))
+
+
+class NBodyGroup:
+    """Single-process multi-GPU group (nbx_group_*): G engines, slab-sharded, one RCCL all-gather per step
+    issued by the library. What NB_GPUS=<n> gives the six nb_* symbols."""
+
+    def __init__(self, devices, mode="fast"):
+        self._L = lib()
+        devs = list(devices)
+        arr = (C.c_int32 * len(devs))(*devs)
+        h = C.c_void_p()
+        _check(self._L.nbx_group_create(C.byref(h), arr, len(devs)))
+        self._h = h
+        self.set_option(NBX_OPT_FORCE_MODE, {"fast": 0, "strict": 1}[mode])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nbx_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return _check(self._L.nbx_group_size(self._h))
+
+    def set_option(self, opt, value):
+        _check(self._L.nbx_group_set_option(self._h, opt, int(value)))
+
+    def num_particles(self):
+        return _check(self._L.nbx_group_num_particles(self._h))
+
+    def set_particles(self, px, py, vx, vy, m, pz=None, vz=None):
+        px, py, vx, vy, m = map(_f32, (px, py, vx, vy, m))
+        n = len(px)
+        pz = _f32(np.zeros(n) if pz is None else pz)
+        vz = _f32(np.zeros(n) if vz is None else vz)
+        _check(self._L.nbx_group_set_particles3(self._h, n, _p(px), _p(py), _p(pz), _p(vx), _p(vy), _p(vz), _p(m)))
+
+    def get_particles(self):
+        n = self.num_particles()
+        out = {k: np.zeros(n, np.float32) for k in ("px", "py", "pz", "vx", "vy", "vz", "m")}
+        _check(self._L.nbx_group_get_particles3(self._h, n, *[_p(out[k]) for k in ("px", "py", "pz", "vx", "vy", "vz", "m")]))
+        return out
+
+    def step_brute_force(self, dt):
+        _check(self._L.nbx_group_step_brute_force(self._h, dt))
+
+    def step_barnes_hut(self, theta, dt, nthreads=1):
+        _check(self._L.nbx_group_step_barnes_hut(self._h, theta, dt, nthreads))
+
+    def synchronize(self):
+        _check(self._L.nbx_group_synchronize(self._h))
+
+    def draw(self, w, h):
+        fb = np.zeros(w * h, np.uint32)
+        _check(self._L.nbx_group_draw(self._h, w, h, _p(fb)))
+        return fb.reshape(h, w)
+
+    def exchanges(self):
+        return _check(self._L.nbx_group_exchanges(self._h))

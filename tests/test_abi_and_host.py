@@ -307,3 +307,24 @@ def test_checkpoint_roundtrip(rx, tmp_path):
     e.set_particles([], [], [], [], [])
     e.save(path)
     assert f.load(path) == 0
+
+
+def test_group_host_side_without_device(rx):
+    """nbx_group_*: slab layout and state replication are host logic (no GPU needed)."""
+    n = 1000
+    rng = np.random.default_rng(2)
+    a = {k: rng.normal(size=n).astype(np.float32) for k in ("px", "py", "vx", "vy")}
+    m = rng.uniform(0.5, 2, n).astype(np.float32)
+    if rx.device_count() == 0:
+        g = rx.NBodyGroup([0, 1, 2])          # device ordinals are only checked when a driver is present
+        assert g.size() == 3
+        g.set_particles(a["px"], a["py"], a["vx"], a["vy"], m)
+        assert g.num_particles() == n
+        st = g.get_particles()
+        for k in a:
+            assert_bit_equal(st[k], a[k], k)
+        with pytest.raises(rx.NBodyError) as ei:
+            g.step_brute_force(0.01)
+        assert ei.value.code == rx.NBX_ERR_NO_DEVICE
+    with pytest.raises(rx.NBodyError):
+        rx.NBodyGroup([0, 0])                 # the same device twice

@@ -133,3 +133,32 @@ def test_slab_kernels_of_all_ranks_stitch_to_the_single_gpu_step(rx, ob, world, 
         else:
             assert np.abs(news["px"] - q["px"]).max() <= 1e-5
             assert np.abs(news["vx"] - q["vx"]).max() <= 2e-4
+
+
+def test_single_process_group_of_one_gpu_matches_plain_engine(rx, ob):
+    """nbx_group_* with G = 1 (all this box has): exercises RCCL loading, ncclCommInitAll and the in-place
+    all-gather call sequence; results equal the plain engine bit for bit, for brute force and Barnes-Hut."""
+    p = ob.stable_orbits(8192, 0.5, 30.0, 51)
+    for mode in ("strict", "fast"):
+        g = rx.NBodyGroup([0], mode=mode)
+        g.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+        e = rx.NBodyEngine(mode=mode)
+        e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+        for _ in range(3):
+            g.step_brute_force(0.01); e.step_brute_force(0.01)
+        g.step_barnes_hut(0.85, 0.01, 1); e.step_barnes_hut(0.85, 0.01, 1)
+        g.step_barnes_hut(0.0, 0.01, 1); e.step_barnes_hut(0.0, 0.01, 1)
+        g.synchronize()
+        assert g.exchanges() == 5
+        a, b = g.get_particles(), e.get_particles()
+        for k in ("px", "py", "vx", "vy"):
+            assert_bit_equal(a[k], b[k], f"{mode} {k}")
+        assert np.array_equal(g.draw(128, 128), e.draw(128, 128))
+        g.close()
+    # ragged slab path (broadcast per owner) with G = 1
+    q = ob.random_disk(1001, 52)
+    g = rx.NBodyGroup([0], mode="strict")
+    g.set_particles(q["px"], q["py"], q["vx"], q["vy"], q["m"])
+    g.step_brute_force(0.01)
+    r = q.copy(); ob.step_brute_force(r, 0.01)
+    assert_bit_equal(g.get_particles()["px"], r["px"])
