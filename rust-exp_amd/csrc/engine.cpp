@@ -296,8 +296,8 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
     //  * kernel: scalar-cache sources + packed math (variant 5) once the source array has >= 32768 bodies
     //    (no LDS traffic -> +2.4 % clock under the power cap, +3.5 % throughput); LDS tiles (variant 1) below.
     //  * register blocking 4 (two packed pairs) when a GPU owns >= 32768 targets, else 2.
-    //  * source split S = smallest power of two giving >= 64 (variant 5) / 32 (variant 1) workgroups per CU,
-    //    capped at 64 and at half the tile count.
+    //  * source split S = smallest power of two giving >= 32 workgroups per CU (64 for variant 5 with < 131072
+    //    targets per GPU), capped at 64 and at half the tile count.
     *dim = e->dim_opt ? e->dim_opt : (e->any_z ? 3 : 2);
     int v = e->variant;
     if (v < 0) v = (tiles_total * kTile >= 32768) ? 5 : 1;
@@ -308,7 +308,9 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
     int s = e->jsplit;
     if (s <= 0) {
         const int iblocks = (n_targets + kTile * b - 1) / (kTile * b);
-        const int want = e->cu_count * (v == 5 ? 64 : 32);
+        // 64 workgroups per CU only where targets are scarce (sharded shapes: tail effect); 32 otherwise --
+        // same speed at N = 262144 on one GPU and half the partial-slab traffic
+        const int want = e->cu_count * ((v == 5 && n_targets < 131072) ? 64 : 32);
         s = 1;
         while (iblocks * s < want && s < 64) s *= 2;
         s = std::min(s, std::max(1, tiles_total / 2));
