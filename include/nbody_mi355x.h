@@ -67,6 +67,8 @@ void nb_draw(int32_t w, int32_t h, uint32_t *fb);
 /* ------------------------------------------------------------------------------------------- */
 /* Level 2: handle API                                                                          */
 
+/* An engine is NOT internally synchronised: use one engine from one thread at a time (different engines may be
+ * used from different threads; the level-1 symbols serialise themselves with a mutex like the reference). */
 typedef struct nbx_engine nbx_engine;
 
 enum nbx_status {

@@ -360,8 +360,14 @@ int step_brute(nbx_engine* e, float dt)
             HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream));
             e->last = nbx::ForceLaunch{(slab + kTile - 1) / kTile, kTile, 1, 1, 2, -1};
         }
-        ProfScope ps(e, NBX_K_INTEGRATE);
-        HIP_TRY(nbx::launch_integrate_f2(e->d_posm, e->lo, slab, e->d_vel, e->d_f2, dt, 0, 0, e->stream));
+        {
+            ProfScope ps(e, NBX_K_INTEGRATE);
+            HIP_TRY(nbx::launch_integrate_f2(e->d_posm, e->lo, slab, e->d_vel, e->d_f2, dt, 0, 0, e->stream));
+        }
+        if (e->source_half) {   // keep the fp16 source copy coherent even when a bit-exact step moved the bodies
+            rc = refresh_half_sources(e, e->lo, slab);
+            if (rc != NBX_OK) return rc;
+        }
     } else {
         rc = launch_forces_fast(e);
         if (rc != NBX_OK) return rc;
@@ -487,6 +493,10 @@ int step_bh(nbx_engine* e, float theta, float dt)
         ProfScope ps(e, NBX_K_INTEGRATE);
         HIP_TRY(nbx::launch_integrate_f2(e->d_posm, e->lo, slab, e->d_vel, e->d_f2, dt, e->force_mode == 0 ? 1 : 0, 1,
                                          e->stream));
+    }
+    if (e->source_half) {
+        rc = refresh_half_sources(e, e->lo, slab);
+        if (rc != NBX_OK) return rc;
     }
     e->host_pos_valid = false;
     e->host_vel_valid = false;

@@ -92,3 +92,17 @@ def test_switching_precision_on_a_live_engine(rx):
     e.step_brute_force(0.01)
     p = e.get_particles()
     assert np.isfinite(p["px"]).all() and np.abs(p["px"] - st["px"]).max() > 0
+
+
+def test_half_copy_stays_coherent_across_barnes_hut_and_strict_steps(rx):
+    """Steps that do not use the fp16 copy (Barnes-Hut, bit-exact brute force) still refresh it, so a later
+    fp16-source step sees the current positions."""
+    st = rx.two_galaxies(4096)
+    a = rx.NBodyEngine(); a.set_source_precision(16)
+    a.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    a.step_barnes_hut(0.5, 0.01, 1)
+    mid = a.get_particles()
+    b = rx.NBodyEngine(); b.set_source_precision(16)
+    b.set_particles(mid["px"], mid["py"], mid["vx"], mid["vy"], mid["m"])
+    fa = a.forces(); fb = b.forces()
+    assert np.array_equal(fa[0], fb[0]) and np.array_equal(fa[1], fb[1])
