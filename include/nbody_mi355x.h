@@ -104,6 +104,9 @@ enum nbx_option {
     NBX_OPT_BH_TREE = 8,           /* Barnes-Hut tree: 0 = built on the host exactly like the reference (default;
                                     * required by strict mode), 1 = built on the device (same node set; interior
                                     * centres of mass folded per child, no EPS merge: own tolerance class) */
+    NBX_OPT_BH_WAVE = 9,           /* 1 (default): with the device-built tree, walk the tree once per WAVE (node
+                                    * records through the scalar cache, lanes park on accepted subtrees); 0: one
+                                    * independent walk per lane. Bit-identical results either way */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };

@@ -60,6 +60,60 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict
     out[it] = make_float2(ax, ay);
 }
 
+// Wave-uniform variant of the fast walk (used when the bodies arrive in a spatial order, i.e. with the device-built
+// tree's Morton permutation): the 64 lanes of a wave walk ONE node sequence -- the union of what their bodies
+// need -- so the node record comes through the scalar cache (s_load, no per-lane address divergence) and the
+// dependent-load chain is per wave, not per lane.  Per-lane semantics are unchanged: a lane that accepted a node
+// (or passed a leaf) parks until the walk leaves that subtree (resume index r = skip), so every body still makes
+// exactly the decisions of nbody.rs:333-377 and accumulates its contributions in the same (walk) order as
+// k_bh_eval_fast => bit-identical results to it.
+__global__ __launch_bounds__(kTile) void k_bh_eval_fast_wave(const float4* __restrict__ posm, const int lo,
+                                                             const int n_targets, const BhNode* __restrict__ nodes,
+                                                             const int n_nodes, const float theta,
+                                                             float2* __restrict__ out, const unsigned* __restrict__ perm)
+{
+    const int t = blockIdx.x * kTile + threadIdx.x;
+    const bool valid = t < n_targets;
+    const int it = valid ? (perm ? (int)perm[t] : t) : 0;
+    const float4 pi = posm[lo + it];
+    float ax = 0.0f, ay = 0.0f;
+    int r = valid ? 0 : 0x7FFFFFFF;   // resume index: the lane takes part in node i iff r <= i
+    int i = 0;
+    // (fetching node i+1 ahead of the decision was tried and is slower: 1.47 vs 1.14 ms at 1 M bodies)
+    while (i < n_nodes) {
+        i = __builtin_amdgcn_readfirstlane(i);
+        const bool active = r <= i;
+        if (__ballot(active) == 0ull) {          // every lane is parked beyond i: jump to the earliest resume point
+            int m = r;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const int o = __shfl_xor(m, off);
+                m = o < m ? o : m;
+            }
+            i = __builtin_amdgcn_readfirstlane(m);
+            continue;
+        }
+        const float4 a = *reinterpret_cast<const float4*>(&nodes[i]);      // wave-uniform address: scalar loads
+        const int2 b = *reinterpret_cast<const int2*>(&nodes[i].skip);
+        bool open = false;
+        if (active) {
+            const float dx = a.x - pi.x;
+            const float dy = a.y - pi.y;
+            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+            const bool take = b.y ? (a.w < theta * __builtin_sqrtf(d2)) : !(a.x == pi.x && a.y == pi.y);
+            if (take) {
+                const float s = a.z * __builtin_amdgcn_rcpf(d2 + kEps);
+                ax = __builtin_fmaf(s, dx, ax);
+                ay = __builtin_fmaf(s, dy, ay);
+            }
+            open = b.y && !take;
+            if (!open) r = b.x;                  // done with this subtree
+        }
+        i = (__ballot(open) != 0ull) ? i + 1 : b.x;
+    }
+    if (valid) out[it] = make_float2(ax, ay);
+}
+
 __global__ __launch_bounds__(kTile) void k_bh_eval_strict(const float4* __restrict__ posm, const int lo,
                                                           const int n_targets, const BhNode* __restrict__ nodes,
                                                           const int n_nodes, const float theta,
@@ -199,6 +253,9 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
     if (mode == 1)
         hipLaunchKernelGGL(k_bh_eval_strict, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
                            force_out);
+    else if (mode == 2 && perm)
+        hipLaunchKernelGGL(k_bh_eval_fast_wave, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
+                           force_out, perm);
     else
         hipLaunchKernelGGL(k_bh_eval_fast, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
                            force_out, perm);

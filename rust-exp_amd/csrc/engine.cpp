@@ -91,6 +91,7 @@ struct nbx_engine {
     int* h_counters = nullptr;     // pinned: per-level node counters of the device build
     const unsigned* d_perm = nullptr;   // spatial body order produced by the device build
     int bh_tree_device = 0;
+    int bh_wave = 1;               // wave-uniform traversal when a spatial body order is available
     int bh_fallbacks = 0;          // device builds that fell back to the host (node pool exhausted)
     void* d_counts = nullptr;      // device draw: uint2 hit counters per pixel
     size_t counts_cap = 0;         // pixels
@@ -486,8 +487,9 @@ int step_bh(nbx_engine* e, float theta, float dt)
     if (rc != NBX_OK) return rc;
     {
         ProfScope ps(e, NBX_K_BH_EVAL);
-        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, e->force_mode, e->d_f2,
-                                    e->stream, (on_device && e->world == 1) ? e->d_perm : nullptr));
+        const unsigned* perm = (on_device && e->world == 1) ? e->d_perm : nullptr;
+        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta,
+                                    (e->force_mode == 0 && perm && e->bh_wave) ? 2 : e->force_mode, e->d_f2, e->stream, perm));
     }
     {
         ProfScope ps(e, NBX_K_INTEGRATE);
@@ -632,6 +634,9 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
         case NBX_OPT_DRAW_DEVICE:
             e->draw_device = value ? 1 : 0;
             return NBX_OK;
+        case NBX_OPT_BH_WAVE:
+            e->bh_wave = value ? 1 : 0;
+            return NBX_OK;
         case NBX_OPT_BH_TREE:
             if (value != 0 && value != 1) return fail(NBX_ERR_INVALID, "bh tree must be 0 (host) or 1 (device)");
             e->bh_tree_device = (int)value;
@@ -663,6 +668,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_SOURCE_PRECISION: return e->source_half ? 16 : 32;
         case NBX_OPT_DRAW_DEVICE: return e->draw_device;
         case NBX_OPT_BH_TREE: return e->bh_tree_device;
+        case NBX_OPT_BH_WAVE: return e->bh_wave;
         default: return NBX_ERR_INVALID;
     }
 }
@@ -820,8 +826,9 @@ int32_t nbx_forces(nbx_engine* e, float theta, int32_t cap, float* fx, float* fy
             if (rc != NBX_OK) return rc;
         }
         ProfScope ps(e, NBX_K_BH_EVAL);
-        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, e->force_mode, e->d_f2,
-                                    e->stream, (on_device && e->world == 1) ? e->d_perm : nullptr));
+        const unsigned* perm = (on_device && e->world == 1) ? e->d_perm : nullptr;
+        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta,
+                                    (e->force_mode == 0 && perm && e->bh_wave) ? 2 : e->force_mode, e->d_f2, e->stream, perm));
         is_accel = e->force_mode == 0;
     }
     std::vector<float2> tmp((size_t)slab);

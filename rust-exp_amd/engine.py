@@ -33,6 +33,7 @@ NBX_OPT_KERNEL_VARIANT = 5
 NBX_OPT_SOURCE_PRECISION = 6
 NBX_OPT_DRAW_DEVICE = 7
 NBX_OPT_BH_TREE = 8
+NBX_OPT_BH_WAVE = 9
 
 NBX_K_FORCE = 0
 NBX_K_INTEGRATE = 1

@@ -145,3 +145,23 @@ def test_device_tree_node_pool_overflow_falls_back_to_host_build(rx, ob):
         assert np.median(rel) <= 1e-5
     b.step_barnes_hut(0.5, 0.01, 1)
     assert np.isfinite(b.get_particles()["px"]).all()
+
+
+@pytest.mark.parametrize("n,theta", [(1, 0.5), (70, 0.5), (5000, 0.3), (100000, 0.85)])
+def test_wave_uniform_walk_is_bit_identical_to_the_per_lane_walk(rx, ob, n, theta):
+    """NBX_OPT_BH_WAVE: one walk per wave (scalar node loads, lanes parked on accepted subtrees) must make every
+    body's decisions and sums exactly as the per-lane walk does."""
+    from rust_exp_amd.engine import NBX_OPT_BH_WAVE
+
+    p = ob.stable_orbits(n, 0.5, 30.0, 61) if n > 1 else ob.random_disk(1, 61)
+    res = []
+    for wave in (0, 1):
+        e = engines(rx, p)
+        e.set_bh_tree("device")
+        e.set_option(NBX_OPT_BH_WAVE, wave)
+        fx, fy, _ = e.forces(theta)
+        e.step_barnes_hut(theta, 0.01, 1)
+        st = e.get_particles()
+        res.append((fx, fy, st["px"], st["vx"]))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -78,6 +78,15 @@ def main():
                                 "nodes": ht["nodes"], "steps_timed": len(dts)}
     d.profile(False)
     out["bh_1m_device_tree"].update(dev_err)
+    from rust_exp_amd.engine import NBX_OPT_BH_WAVE
+    d.set_option(NBX_OPT_BH_WAVE, 0)
+    d.profile(True); d.profile_reset()
+    for _ in range(5):
+        dstep()
+    pms, pcnt = d.profile_read(rx.NBX_K_BH_EVAL)
+    out["bh_1m_device_tree"]["eval_kernel_ms_per_lane_walk"] = pms / pcnt
+    d.profile(False)
+    d.set_option(NBX_OPT_BH_WAVE, 1)
     wk = d.bh_work(0.5)
     kms = out["bh_1m_device_tree"]["eval_kernel_ms"]
     out["bh_1m_device_tree"]["work"] = {
