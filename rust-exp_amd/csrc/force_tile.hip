@@ -1,27 +1,33 @@
-// force_tile.hip -- K1 (all-pairs force tiles) and K2 (reduce + kick-drift) for gfx950 / MI355X.
+// force_tile.hip -- K1 (all-pairs force sweeps) and K2 (reduce + kick-drift) for gfx950 / MI355X.
 //
 // Replaces the hot loop of the reference: nbody.rs:132-144 (for i, for j != i: force()) with
 // force() = nbody.rs:164-184, and the integrator nbody.rs:153-160.
 //
 // Law (reference, NOT Newton): F_ij = m_i m_j d / (|d|^2 + EPS), d = p_j - p_i  (magnitude ~ 1/r).
 // The fast kernels factor m_i out and accumulate the acceleration a_i = sum_j m_j d /(|d|^2+EPS):
-//   d    = p_j - p_i                      3 v_sub            (2 in 2-D)
-//   r2   = fma(dz,dz,fma(dy,dy,fma(dx,dx,EPS)))  3 v_fma     (2)
+//   d    = p_j - p_i                      3 sub              (2 in 2-D)
+//   r2   = fma(dz,dz,fma(dy,dy,fma(dx,dx,EPS)))  3 fma       (2)
 //   inv  = v_rcp_f32(r2)                  1 transcendental   (1 ulp; r2 >= EPS > 0 always)
-//   s    = m_j * inv                      1 v_mul
-//   a   += s * d                          3 v_fma            (2)
-// = 11 VALU issues / interaction (8 in 2-D) = 17 algorithmic flops (12), SURVEY.md section 8(d).
+//   s    = m_j * inv                      1 mul
+//   a   += s * d                          3 fma              (2)
+// = 17 algorithmic flops / interaction (12 in 2-D), SURVEY.md section 8(d).  The shipped kernels do this for
+// PAIRS of target bodies with v_pk_*_f32: 12 VALU issues per 2 interactions (10 packed + 2 v_rcp_f32).
 // The self term (and any coincident body) contributes s*0 = exactly 0, as in the reference where
 // f*dx = 0; zero-mass padding sources contribute 0*d = 0.  So no index test in the inner loop.
 //
-// Mapping: one workgroup = 256 threads = 4 wave64; each thread owns B target bodies in registers
-// (B*256 per workgroup); the source range of the launch is cut in `jsplit` contiguous tile ranges;
-// workgroup w handles (target block w / jsplit, source range w % jsplit).  Workgroups are
-// dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), so with jsplit a multiple or
-// divisor of 8 every XCD's private L2 only ever sees its own 1/jsplit of the source array.
-// Sources stream HBM/L2 -> VGPR (one coalesced 16-B float4 load per lane per tile, issued one tile
-// ahead) -> LDS (double buffered, ONE barrier per tile) -> broadcast ds_read_b128 (all lanes read
-// the same address: conflict-free, 4 LDS cycles per wave-instruction).
+// Mapping (all variants): one workgroup = 256 threads = 4 wave64; each thread owns B target bodies in
+// registers (B*256 per workgroup); the source range of the launch is cut in `jsplit` contiguous tile ranges;
+// workgroup w handles (target block w / jsplit, source range w % jsplit).  Workgroups are dispatched
+// round-robin over the 8 XCDs (block b -> XCD b % 8), so with jsplit a multiple or divisor of 8 every XCD's
+// private L2 only ever sees its own 1/jsplit of the source array.
+//
+// Variants (NBX_OPT_KERNEL_VARIANT; A/B evidence in DESIGN.md section 6 and profiles/):
+//   5  k_force_smem_pk   packed math, sources through the scalar cache as SGPR operands   <- default, >= 32768 sources
+//   1  k_force_tile_pk   packed math, sources staged through LDS tiles                   <- default below that
+//   4  k_force_tile_pkb  variant 1 + batched reciprocals (guarded)      3  variant 1, 4-source LDS batches
+//   0  k_force_tile      compiler-scheduled scalar math, LDS tiles      2  k_force_smem: scalar math, scalar cache
+// LDS variants: sources stream HBM/L2 -> VGPR (one coalesced 16-B float4 load per lane per tile, issued one
+// tile ahead) -> LDS (double buffered, ONE barrier per tile) -> broadcast ds_read_b128 (conflict free).
 #include "kernels.h"
 
 namespace nbx {
