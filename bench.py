@@ -54,7 +54,18 @@ def cpu_baseline(st, seconds):
     }
 
 
+def _claim_stdout():
+    """RCCL (and other C libraries) print banners to the C stdout ("RCCL version : ..." at communicator
+    creation, flushed at exit). The contract is ONE JSON line on stdout, so keep a private handle to the real
+    stdout for that line and point file descriptor 1 at stderr for everything else in this process."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
+
+
 def main():
+    real_stdout = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -193,7 +204,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(st, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         import torch.distributed as dist
 
