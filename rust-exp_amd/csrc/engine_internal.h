@@ -1,0 +1,163 @@
+// engine_internal.h -- shared internals of libnbody_mi355x.so's host layer (NOT part of the ABI; the public
+// interface is include/nbody_mi355x.h).  engine.cpp = state owner + step drivers, c_api.cpp = level-2 nbx_*,
+// group.cpp = single-process multi-GPU group, level1.cpp = the six reference symbols.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only (ncclComm_t); RCCL itself is dlopen'ed by group.cpp
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nbody_mi355x.h"
+#include "host_ops.h"
+#include "kernels.h"
+
+struct ProfRec {
+    int kernel;
+    hipEvent_t start, stop;
+};
+
+struct nbx_engine {
+    int device = 0;
+    bool dev_ready = false;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int cu_count = 256;
+
+    nbx::HostState host;
+    bool host_pos_valid = true, host_vel_valid = true;  // host mirror current?
+    bool dev_valid = false;                             // device arrays current?
+    int n = 0, n_pad = 0;
+    int rank = 0, world = 1, lo = 0, hi = 0;
+
+    float4* d_posm = nullptr;
+    bool posm_external = false;
+    size_t posm_cap = 0;  // records
+    float4* d_vel = nullptr;
+    size_t vel_cap = 0;
+    float4* d_acc = nullptr;
+    size_t acc_cap = 0;
+    float2* d_f2 = nullptr;
+    size_t f2_cap = 0;
+    float4* d_out4 = nullptr;
+    size_t out4_cap = 0;
+    nbx::BhNode* d_nodes = nullptr;
+    size_t nodes_cap = 0;
+    unsigned* d_guard = nullptr;   // max|coord| word for the batched-reciprocal kernel
+    size_t guard_cap = 0;
+    void* d_tree_ws = nullptr;     // device tree build workspace (NBX_OPT_BH_TREE = 1)
+    size_t tree_ws_bytes = 0;
+    int* h_counters = nullptr;     // pinned: per-level node counters of the device build
+    const unsigned* d_perm = nullptr;   // spatial body order produced by the device build
+    int bh_tree_device = 0;
+    int bh_wave = 1;               // wave-uniform traversal when a spatial body order is available
+    int bh_fallbacks = 0;          // device builds that fell back to the host (node pool exhausted)
+    void* d_counts = nullptr;      // device draw: uint2 hit counters per pixel
+    size_t counts_cap = 0;         // pixels
+    unsigned* d_fb = nullptr;
+    size_t fb_cap = 0;
+    int draw_device = 0;
+    void* d_posh = nullptr;        // half4 (x,y,z,m) source copy (NBX_OPT_SOURCE_PRECISION = 16)
+    bool posh_external = false;
+    size_t posh_cap = 0;           // records
+    int source_half = 0;
+
+    // options
+    int force_mode = 0, jsplit = 0, bpt = 0, dim_opt = 0, profile = 0, variant = -1;
+    bool any_z = false;
+
+    nbx::Rng rng{0};
+    bool seeded = false;
+
+    nbx::QuadTree tree;
+    nbx::QuadTree::FlatPlan plan;
+    std::vector<nbx::BhNode> flat_small;
+    nbx::BhNode* h_nodes = nullptr;   // pinned host staging of the flattened tree
+    size_t h_nodes_cap = 0;
+    size_t n_flat = 0;
+    float4* h_stage = nullptr;        // pinned host staging for position downloads
+    size_t h_stage_cap = 0;
+
+    std::vector<ProfRec> prof;
+    nbx::ForceLaunch last{0, 0, 0, 0, 0, 0};
+    double host_ms[4] = {0, 0, 0, 0};  // Barnes-Hut host phases: download, build, flatten, upload (cumulative)
+    int host_steps = 0;
+
+    int slab() const { return hi - lo; }
+};
+
+struct nbx_group {
+    std::vector<nbx_engine*> eng;
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+    int exchanges = 0;
+};
+
+namespace nbxi {
+
+using nbx::kTile;
+
+extern thread_local std::string g_last_error;
+int fail(int code, const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return nbxi::fail(NBX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int grow(T** ptr, size_t* cap, size_t need)
+{
+    if (need <= *cap && *ptr) return NBX_OK;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    const size_t want = std::max<size_t>(need, 256);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(ptr), want * sizeof(T)));
+    *cap = want;
+    return NBX_OK;
+}
+
+struct ProfScope {
+    nbx_engine* e;
+    int idx = -1;
+    ProfScope(nbx_engine* eng, int kernel) : e(eng)
+    {
+        if (!e->profile) return;
+        ProfRec r{kernel, nullptr, nullptr};
+        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+        (void)hipEventRecord(r.start, e->stream);
+        e->prof.push_back(r);
+        idx = (int)e->prof.size() - 1;
+    }
+    ~ProfScope()
+    {
+        if (idx >= 0) (void)hipEventRecord(e->prof[idx].stop, e->stream);
+    }
+};
+
+void compute_slab(nbx_engine* e);
+int ensure_device(nbx_engine* e);
+int refresh_half_sources(nbx_engine* e, int first, int count);
+int upload(nbx_engine* e);
+int download_positions(nbx_engine* e);
+int download_velocities(nbx_engine* e);
+void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* variant, int* bpt, int* jsplit, int* dim);
+int launch_forces_fast(nbx_engine* e);
+int step_brute(nbx_engine* e, float dt);
+int build_and_upload_tree(nbx_engine* e);
+int build_tree_on_device(nbx_engine* e, bool* done);
+int step_bh(nbx_engine* e, float theta, float dt);
+void free_device(nbx_engine* e);
+uint64_t entropy_seed();
+void after_host_state_change(nbx_engine* e);
+
+}  // namespace nbxi

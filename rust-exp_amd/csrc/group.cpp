@@ -1,0 +1,234 @@
+// group.cpp -- single-process multi-GPU group (nbx_group_*), RCCL resolved with dlopen.
+#include <dlfcn.h>
+
+#include "engine_internal.h"
+
+using namespace nbxi;
+
+// =============================================================================================
+// Single-process multi-GPU group: what the unmodified Haskell caller needs to use every GPU of a node.
+// G engines, one per device, slab-sharded exactly like the multi-process path (nbody.rs:426-428 split);
+// per step every device runs K1+K2 on its slab on its own stream, then ONE RCCL all-gather of the
+// (x,y,z,m) array (ncclCommInitAll communicators, one group call).  RCCL is dlopen'ed on first use so that
+// single-GPU users carry no dependency on it.
+// =============================================================================================
+
+namespace {
+
+struct RcclApi {
+    void* so = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+RcclApi* rccl_api()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (so) {
+            api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(so, "ncclCommInitAll"));
+            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(so, "ncclCommDestroy"));
+            api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(so, "ncclAllGather"));
+            api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(so, "ncclBroadcast"));
+            api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(so, "ncclGroupStart"));
+            api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(so, "ncclGroupEnd"));
+            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(so, "ncclGetErrorString"));
+            if (api.CommInitAll && api.CommDestroy && api.AllGather && api.Broadcast && api.GroupStart && api.GroupEnd &&
+                api.GetErrorString)
+                api.so = so;
+        }
+    }
+    return api.so ? &api : nullptr;
+}
+
+#define RCCL_TRY(api, expr)                                                                         \
+    do {                                                                                            \
+        ncclResult_t _r = (expr);                                                                   \
+        if (_r != ncclSuccess) return fail(NBX_ERR_HIP, "%s failed: %s", #expr, (api)->GetErrorString(_r)); \
+    } while (0)
+
+}  // namespace
+
+
+namespace {
+
+int group_comms(nbx_group* g)
+{
+    if (!g->comms.empty()) return NBX_OK;
+    RcclApi* api = rccl_api();
+    if (!api) return fail(NBX_ERR_HIP, "librccl.so could not be loaded: %s", dlerror());
+    g->comms.resize(g->eng.size());
+    RCCL_TRY(api, api->CommInitAll(g->comms.data(), (int)g->eng.size(), g->devices.data()));
+    return NBX_OK;
+}
+
+// one all-gather of the (x,y,z,m) slabs: in place, sendbuff = recvbuff + lo (per device), same stream as the kernels
+int group_exchange(nbx_group* g)
+{
+    const int G = (int)g->eng.size();
+    int rc = group_comms(g);
+    if (rc != NBX_OK) return rc;
+    RcclApi* api = rccl_api();
+    const int n = g->eng[0]->n;
+    if (n == 0) return NBX_OK;
+    RCCL_TRY(api, api->GroupStart());
+    if (n % G == 0) {
+        for (int d = 0; d < G; d++) {
+            nbx_engine* e = g->eng[d];
+            RCCL_TRY(api, api->AllGather(e->d_posm + e->lo, e->d_posm, (size_t)e->slab() * 4, ncclFloat32, g->comms[d], e->stream));
+        }
+    } else {   // ragged last slab (reference split): one broadcast per owner
+        for (int r = 0; r < G; r++) {
+            const int lo = g->eng[r]->lo, cnt = g->eng[r]->slab();
+            if (cnt == 0) continue;
+            for (int d = 0; d < G; d++) {
+                nbx_engine* e = g->eng[d];
+                RCCL_TRY(api, api->Broadcast(e->d_posm + lo, e->d_posm + lo, (size_t)cnt * 4, ncclFloat32, r, g->comms[d], e->stream));
+            }
+        }
+    }
+    RCCL_TRY(api, api->GroupEnd());
+    for (nbx_engine* e : g->eng) e->host_pos_valid = false;
+    g->exchanges++;
+    return NBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t nbx_group_create(nbx_group** out, const int32_t* devices, int32_t count)
+{
+    if (!out || count < 1) return fail(NBX_ERR_INVALID, "bad group arguments");
+    const int present = nbx_device_count();
+    nbx_group* g = new (std::nothrow) nbx_group();
+    if (!g) return fail(NBX_ERR_ALLOC, "out of memory");
+    for (int i = 0; i < count; i++) {
+        const int dev = devices ? devices[i] : i;
+        for (int j = 0; j < i; j++)
+            if (g->devices[j] == dev) { nbx_group_destroy(g); return fail(NBX_ERR_INVALID, "device %d listed twice", dev); }
+        if (present > 0 && (dev < 0 || dev >= present)) { nbx_group_destroy(g); return fail(NBX_ERR_NO_DEVICE, "no device %d (%d present)", dev, present); }
+        nbx_engine* e = nullptr;
+        if (nbx_create(&e, dev) != NBX_OK) { nbx_group_destroy(g); return NBX_ERR_ALLOC; }
+        e->rank = i;
+        e->world = count;
+        g->eng.push_back(e);
+        g->devices.push_back(dev);
+    }
+    *out = g;
+    return NBX_OK;
+}
+
+void nbx_group_destroy(nbx_group* g)
+{
+    if (!g) return;
+    for (nbx_engine* e : g->eng)
+        if (e && e->dev_ready) { (void)hipSetDevice(e->device); (void)hipStreamSynchronize(e->stream); }
+    if (!g->comms.empty())
+        if (RcclApi* api = rccl_api())
+            for (ncclComm_t c : g->comms) (void)api->CommDestroy(c);
+    for (nbx_engine* e : g->eng) nbx_destroy(e);
+    delete g;
+}
+
+int32_t nbx_group_size(const nbx_group* g) { return g ? (int32_t)g->eng.size() : NBX_ERR_INVALID; }
+nbx_engine* nbx_group_engine(nbx_group* g, int32_t i) { return (g && i >= 0 && i < (int)g->eng.size()) ? g->eng[i] : nullptr; }
+
+int32_t nbx_group_set_option(nbx_group* g, int32_t option, int64_t value)
+{
+    if (!g) return fail(NBX_ERR_INVALID, "null group");
+    for (nbx_engine* e : g->eng) {
+        const int rc = nbx_set_option(e, option, value);
+        if (rc != NBX_OK) return rc;
+    }
+    return NBX_OK;
+}
+
+int32_t nbx_group_num_particles(const nbx_group* g) { return g ? g->eng[0]->n : NBX_ERR_INVALID; }
+
+int32_t nbx_group_set_particles3(nbx_group* g, int32_t n, const float* px, const float* py, const float* pz, const float* vx,
+                                 const float* vy, const float* vz, const float* m)
+{
+    if (!g) return fail(NBX_ERR_INVALID, "null group");
+    for (nbx_engine* e : g->eng) {
+        const int rc = nbx_set_particles3(e, n, px, py, pz, vx, vy, vz, m);
+        if (rc != NBX_OK) return rc;
+    }
+    return NBX_OK;
+}
+
+int32_t nbx_group_get_particles3(nbx_group* g, int32_t cap, float* px, float* py, float* pz, float* vx, float* vy, float* vz,
+                                 float* m)
+{
+    if (!g) return fail(NBX_ERR_INVALID, "null group");
+    nbx_engine* e0 = g->eng[0];
+    if (cap < e0->n) return fail(NBX_ERR_INVALID, "capacity %d < particle count %d", cap, e0->n);
+    int rc = nbx_get_particles3(e0, cap, px, py, pz, vx, vy, vz, m);   // positions are replicated after the all-gather
+    if (rc < 0) return rc;
+    for (size_t d = 1; d < g->eng.size(); d++) {                        // velocities live on their owner
+        nbx_engine* e = g->eng[d];
+        rc = download_velocities(e);
+        if (rc != NBX_OK) return rc;
+        const size_t bytes = sizeof(float) * (size_t)e->slab();
+        if (vx) std::memcpy(vx + e->lo, e->host.vx.data() + e->lo, bytes);
+        if (vy) std::memcpy(vy + e->lo, e->host.vy.data() + e->lo, bytes);
+        if (vz) std::memcpy(vz + e->lo, e->host.vz.data() + e->lo, bytes);
+    }
+    return e0->n;
+}
+
+int32_t nbx_group_step_brute_force(nbx_group* g, float dt)
+{
+    if (!g) return fail(NBX_ERR_INVALID, "null group");
+    for (nbx_engine* e : g->eng) {   // asynchronous: every device works on its slab concurrently
+        const int rc = step_brute(e, dt);
+        if (rc != NBX_OK) return rc;
+    }
+    return group_exchange(g);
+}
+
+int32_t nbx_group_step_barnes_hut(nbx_group* g, float theta, float dt, int32_t nthreads)
+{
+    if (!g) return fail(NBX_ERR_INVALID, "null group");
+    if (theta == 0.0f) return nbx_group_step_brute_force(g, dt);   // nbody.rs:197-200
+    if (nthreads <= 0) return fail(NBX_ERR_INVALID, "nthreads must be >= 1");
+    for (nbx_engine* e : g->eng) {   // tree replica per device; each evaluates its slab
+        const int rc = step_bh(e, theta, dt);
+        if (rc != NBX_OK) return rc;
+    }
+    return group_exchange(g);
+}
+
+int32_t nbx_group_synchronize(nbx_group* g)
+{
+    if (!g) return fail(NBX_ERR_INVALID, "null group");
+    for (nbx_engine* e : g->eng) {
+        const int rc = nbx_synchronize(e);
+        if (rc != NBX_OK) return rc;
+    }
+    return NBX_OK;
+}
+
+int32_t nbx_group_draw(nbx_group* g, int32_t w, int32_t h, uint32_t* fb)
+{
+    if (!g || !fb || w <= 0 || h <= 0) return fail(NBX_ERR_INVALID, "bad draw arguments");
+    const int n = g->eng[0]->n;
+    std::vector<float> px(n), py(n), vx(n), vy(n);
+    const int rc = nbx_group_get_particles3(g, n, px.data(), py.data(), nullptr, vx.data(), vy.data(), nullptr, nullptr);
+    if (rc < 0) return rc;
+    nbx::draw_particles(px.data(), py.data(), vx.data(), vy.data(), n, w, h, fb);
+    return NBX_OK;
+}
+
+int32_t nbx_group_exchanges(const nbx_group* g) { return g ? g->exchanges : NBX_ERR_INVALID; }
+
+}  // extern "C"
