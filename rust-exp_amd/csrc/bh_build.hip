@@ -238,6 +238,39 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     return bytes;
 }
 
+// Spatial (Morton, reference quadrant order) permutation of the bodies only: bbox + path keys + radix sort.
+// Used to make the traversal of a HOST-built tree wave-coherent. *perm_dev points into the workspace.
+hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size_t workspace_bytes, const unsigned** perm_dev,
+                                hipStream_t stream)
+{
+    *perm_dev = nullptr;
+    if (n <= 0) return hipSuccess;
+    size_t sort_tmp = 0;
+    if (device_tree_workspace_bytes(n, 1, &sort_tmp) > workspace_bytes) return hipErrorInvalidValue;
+    char* w = static_cast<char*>(workspace);
+    auto take = [&](size_t b) { char* p = w; w += (b + 255) & ~(size_t)255; return p; };
+    unsigned long long* keys0 = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * (size_t)n * 2));
+    unsigned long long* keys1 = keys0 + n;
+    unsigned* idx0 = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * (size_t)n * 2));
+    unsigned* idx1 = idx0 + n;
+    void* tmp = take(sort_tmp);
+    int* ints = reinterpret_cast<int*>(take(sizeof(int) * 7));
+    (void)take(sizeof(float4));
+    int* counters = reinterpret_cast<int*>(take(256));
+    unsigned* box = reinterpret_cast<unsigned*>(counters + 4);
+    TreeArrays t;
+    t.lo = ints; t.hi = ints + 1; t.level = ints + 2; t.child0 = ints + 3; t.nchild = ints + 4; t.size = ints + 5; t.offset = ints + 6;
+    t.com = nullptr;
+    const int nb = (n + kTile - 1) / kTile;
+    hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, stream, t, n, counters, counters + 1, box);
+    hipLaunchKernelGGL(k_bbox, dim3(nb < 1024 ? nb : 1024), dim3(kTile), 0, stream, posm, n, box);
+    hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, box, keys0, idx0);
+    hipError_t e = rocprim::radix_sort_pairs(tmp, sort_tmp, keys0, keys1, idx0, idx1, (size_t)n, 0, 2 * kLevels, stream);
+    if (e != hipSuccess) return e;
+    *perm_dev = idx1;
+    return hipGetLastError();
+}
+
 // Builds the flattened tree for posm[0..n) into `out` (capacity node_cap records). Returns the node count in
 // *n_nodes_host (host, valid after the stream work the function waits for) and the sorted body order in
 // *perm_dev (device pointer inside the workspace: body handled by thread t = perm[t], a Morton order).

@@ -338,6 +338,22 @@ int build_tree_on_device(nbx_engine* e, bool* done)
     return NBX_OK;
 }
 
+// Morton permutation of the bodies on the device (for the traversal of a host-built tree)
+int spatial_order(nbx_engine* e)
+{
+    size_t sort_tmp = 0;
+    const size_t need = nbx::device_tree_workspace_bytes(e->n, 1, &sort_tmp);
+    if (need > e->tree_ws_bytes) {
+        if (e->d_tree_ws) HIP_TRY(hipFree(e->d_tree_ws));
+        e->d_tree_ws = nullptr;
+        e->tree_ws_bytes = 0;
+        HIP_TRY(hipMalloc(&e->d_tree_ws, need));
+        e->tree_ws_bytes = need;
+    }
+    HIP_TRY(nbx::device_spatial_order(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, &e->d_perm, e->stream));
+    return NBX_OK;
+}
+
 int step_bh(nbx_engine* e, float theta, float dt)
 {
     int rc = upload(e);
@@ -349,16 +365,24 @@ int step_bh(nbx_engine* e, float theta, float dt)
         rc = build_tree_on_device(e, &on_device);
         if (rc != NBX_OK) return rc;
     }
+    bool have_perm = on_device;
     if (!on_device) {
         rc = build_and_upload_tree(e);
         if (rc != NBX_OK) return rc;
+        // host tree, fast walk, big system on one GPU: a Morton order of the bodies (0.4 ms at 1 M) makes the walk
+        // wave-coherent and lets it take the wave-uniform form (4.4 -> 1.2 ms). Results are unaffected.
+        if (e->force_mode == 0 && e->world == 1 && e->bh_wave && e->n >= 65536) {
+            rc = spatial_order(e);
+            if (rc != NBX_OK) return rc;
+            have_perm = e->d_perm != nullptr;
+        }
     }
     if (slab == 0) return NBX_OK;
     rc = grow(&e->d_f2, &e->f2_cap, (size_t)slab);
     if (rc != NBX_OK) return rc;
     {
         ProfScope ps(e, NBX_K_BH_EVAL);
-        const unsigned* perm = (on_device && e->world == 1) ? e->d_perm : nullptr;
+        const unsigned* perm = (have_perm && e->world == 1) ? e->d_perm : nullptr;
         HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta,
                                     (e->force_mode == 0 && perm && e->bh_wave) ? 2 : e->force_mode, e->d_f2, e->stream, perm));
     }

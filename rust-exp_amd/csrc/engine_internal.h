@@ -155,6 +155,7 @@ int launch_forces_fast(nbx_engine* e);
 int step_brute(nbx_engine* e, float dt);
 int build_and_upload_tree(nbx_engine* e);
 int build_tree_on_device(nbx_engine* e, bool* done);
+int spatial_order(nbx_engine* e);
 int step_bh(nbx_engine* e, float theta, float dt);
 void free_device(nbx_engine* e);
 uint64_t entropy_seed();

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <thread>
 
 #include "../../include/nbody_mi355x.h"
@@ -315,71 +316,177 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n)
     }
 
     // ---- threaded, result-identical build --------------------------------------------------------
+    // A subtree's final state depends only on the ordered sequence of insert() calls that reach its root, and
+    // an interior node only folds the passing particle into its centre of mass and forwards it by geometry.
+    // So:
+    //   phase 0 (sequential, exact): the first `warm` particles run the real algorithm on the top `limit`
+    //            levels; inserts reaching a level-`limit` node are queued on it ("bucket").
+    //   freeze : every top node that is still exterior becomes a bucket too (its state = the pool root).  All
+    //            remaining top nodes are interior and stay interior: they are pure pass-through from now on.
+    //   phase 1 (parallel): (a) route every remaining particle by geometry to its bucket; (b) per top level, a
+    //            thread folds the particles into that level's pass-through nodes IN INDEX ORDER (nodes of one
+    //            level are disjoint, levels are independent); (c) a stable counting sort by bucket appends the
+    //            particles to the bucket queues in index order with depth = bucket level (no split can happen
+    //            on the way, so the reference's depth counter is just the number of descents).
+    //   phase 2 (parallel over buckets): replay each queue on a private pool (node 0 = the bucket root).
     const bool timing = std::getenv("NBX_TIMING") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
-    // Phase 1 (sequential, particle-index order): the real algorithm on the top `limit` levels only;
-    // inserts reaching a level-`limit` node are queued on that node ("bucket") in arrival order.
-    const int limit = n >= 262144 ? 5 : 4;
+    const int limit = n >= 262144 ? 6 : (n >= 65536 ? 5 : 4);
+    const int warm = std::min(n, 8192);
     std::vector<Node>& top = nodes;
     std::vector<uint8_t> level;
     bucket_of.clear();
     for (auto& q : queues) q.clear();
     size_t used_queues = 0;
-    top.reserve(4096);
+    top.reserve(8192);
     top.push_back(Node{x1, y1, x2, y2, 0.0f, 0.0f, 0.0f, -1});
     level.push_back(0);
     bucket_of.push_back(-1);
-    Builder tb{top, &level, &bucket_of, &queues, &used_queues, limit};
-    for (int i = 0; i < n; i++) {
-        const int rc = tb.insert<true>(0, Event{px[i], py[i], m[i], 0});
-        if (rc != NBX_OK) return rc;
+    {
+        Builder tb{top, &level, &bucket_of, &queues, &used_queues, limit};
+        for (int i = 0; i < warm; i++) {
+            const int rc = tb.insert<true>(0, Event{px[i], py[i], m[i], 0});
+            if (rc != NBX_OK) return rc;
+        }
     }
-    const auto tp1 = std::chrono::steady_clock::now();
-    // Phase 2 (parallel over buckets): replay each queue on a private pool whose node 0 is the bucket root.
+    // freeze: exterior top nodes above the limit become buckets as they are
+    const int ntop = (int)top.size();
+    for (int k = 0; k < ntop; k++) {
+        if (bucket_of[k] < 0 && top[k].first_child < 0) {
+            bucket_of[k] = (int)used_queues;
+            if (used_queues == queues.size()) queues.emplace_back();
+            ++used_queues;
+        }
+    }
     const int nb = (int)used_queues;
     root_of.assign(nb, -1);
-    for (int k = 0; k < (int)top.size(); k++)
+    for (int k = 0; k < ntop; k++)
         if (bucket_of[k] >= 0) root_of[bucket_of[k]] = k;
+    const auto tp1 = std::chrono::steady_clock::now();
+
+    const int rest = n - warm;
+    pbucket.resize((size_t)rest);                    // bucket of particle warm+i (scratch reused across builds)
+    std::vector<int> parent(ntop, -1);
+    for (int k = 0; k < ntop; k++)
+        if (top[k].first_child >= 0 && bucket_of[k] < 0)
+            for (int c = 0; c < 4; c++) parent[top[k].first_child + c] = k;
+    std::atomic<int> bad_mass{0};
+    const int nt = std::max(1, threads);
+    auto run_threads = [&](int count, const std::function<void(int)>& fn) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < count; t++) th.emplace_back(fn, t);
+        fn(0);
+        for (auto& t : th) t.join();
+    };
+    // (a) routing
+    run_threads(nt, [&](int t) {
+        const int lo = (int)((long long)rest * t / nt), hi = (int)((long long)rest * (t + 1) / nt);
+        for (int i = lo; i < hi; i++) {
+            const float qx = px[warm + i], qy = py[warm + i];
+            if (!(m[warm + i] > 0.0f)) bad_mass.store(1);
+            int k = 0;
+            while (bucket_of[k] < 0) k = top[k].first_child + quadrant(top[k], qx, qy);
+            pbucket[i] = bucket_of[k];
+        }
+    });
+    if (bad_mass.load()) return NBX_ERR_TREE;                              // nbody.rs:304
+    const auto tpa = std::chrono::steady_clock::now();
+    // ancestors of every bucket root, per level (anc[b][l] = pass-through node at level l, or -1)
+    int max_level = 0;
+    for (int k = 0; k < ntop; k++) max_level = std::max<int>(max_level, level[k]);
+    std::vector<int> anc((size_t)nb * (size_t)(max_level + 1), -1);
+    for (int b2 = 0; b2 < nb; b2++)
+        for (int k = parent[root_of[b2]]; k >= 0; k = parent[k]) anc[(size_t)b2 * (max_level + 1) + level[k]] = k;
+    // (b) folds, one thread per (level, slice of that level's nodes); (c) counting sort -- run concurrently
+    auto tpb = tpa;
+    std::vector<size_t> offset((size_t)nb + 1, 0);
+    sorted.resize((size_t)rest);
+    std::vector<std::vector<size_t>> hist(nt, std::vector<size_t>((size_t)nb, 0));
+    const int fold_levels = max_level;                                   // pass-through nodes live on levels 0..max_level-1
+    const int slices = std::max(1, std::min(4, nt / std::max(1, fold_levels)));
+    auto fold = [&](int lvl, int slice) {
+        const size_t stride = (size_t)(max_level + 1);
+        // work on a private copy: 32-byte nodes of different levels share cache lines in `top`, and every fold
+        // thread writes its nodes a million times (false sharing cost 5x here)
+        std::vector<Node> mine(top.begin(), top.begin() + ntop);
+        for (int i = 0; i < rest; i++) {
+            const int k = anc[(size_t)pbucket[i] * stride + lvl];
+            if (k < 0 || (lvl > 0 && (k % slices) != slice)) continue;
+            add_mass(mine[k], px[warm + i], py[warm + i], m[warm + i]);   // interior: nbody.rs:236, index order
+        }
+        for (int k = 0; k < ntop; k++)
+            if (level[k] == lvl && bucket_of[k] < 0 && top[k].first_child >= 0 && (lvl == 0 || (k % slices) == slice))
+                top[k] = mine[k];
+    };
+    {
+        std::vector<std::thread> th;
+        for (int lvl = 0; lvl < fold_levels; lvl++)
+            for (int sl = 0; sl < (lvl == 0 ? 1 : slices); sl++) th.emplace_back(fold, lvl, sl);
+        // meanwhile: histogram + stable scatter of the particles into per-bucket queues (index order kept)
+        run_threads(nt, [&](int t) {
+            const int lo = (int)((long long)rest * t / nt), hi = (int)((long long)rest * (t + 1) / nt);
+            for (int i = lo; i < hi; i++) hist[t][(size_t)pbucket[i]]++;
+        });
+        size_t run = 0;
+        for (int b2 = 0; b2 < nb; b2++) {
+            offset[b2] = run;
+            for (int t = 0; t < nt; t++) { const size_t c = hist[t][(size_t)b2]; hist[t][(size_t)b2] = run; run += c; }
+        }
+        offset[nb] = run;
+        run_threads(nt, [&](int t) {
+            const int lo = (int)((long long)rest * t / nt), hi = (int)((long long)rest * (t + 1) / nt);
+            for (int i = lo; i < hi; i++) {
+                const int b2 = pbucket[i];
+                sorted[hist[t][(size_t)b2]++] = Event{px[warm + i], py[warm + i], m[warm + i], (unsigned)level[root_of[b2]]};
+            }
+        });
+        tpb = std::chrono::steady_clock::now();
+        for (auto& t : th) t.join();
+    }
+    const auto tp2 = std::chrono::steady_clock::now();
+
+    // Phase 2 (parallel over buckets): replay each queue on a private pool whose node 0 is the bucket root.
     if ((int)pools.size() < nb) pools.resize(nb);
     std::vector<int> status(nb, NBX_OK);
     std::vector<int> order(nb);
-    for (int b = 0; b < nb; b++) order[b] = b;
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return queues[a].size() > queues[b].size(); });
+    for (int b2 = 0; b2 < nb; b2++) order[b2] = b2;
+    auto qsize = [&](int b2) { return queues[b2].size() + (offset[b2 + 1] - offset[b2]); };
+    std::sort(order.begin(), order.end(), [&](int a2, int b2) { return qsize(a2) > qsize(b2); });
     std::atomic<int> next{0};
-    auto work = [&]() {
+    run_threads(std::max(1, std::min(nt, nb)), [&](int) {
         for (;;) {
             const int t = next.fetch_add(1);
             if (t >= nb) return;
-            const int b = order[t];
-            std::vector<Node>& pool = pools[b];
+            const int b2 = order[t];
+            std::vector<Node>& pool = pools[b2];
             pool.clear();
-            pool.reserve(queues[b].size() * 3 + 8);
-            pool.push_back(top[root_of[b]]);
+            pool.reserve(qsize(b2) * 3 + 8);
+            pool.push_back(top[root_of[b2]]);
             Builder lb{pool};
-            for (const Event& ev : queues[b]) {
-                const int rc = lb.insert<false>(0, ev);
-                if (rc != NBX_OK) { status[b] = rc; break; }
+            int rc = NBX_OK;
+            for (const Event& ev : queues[b2]) {                          // phase-0 arrivals first ...
+                rc = lb.insert<false>(0, ev);
+                if (rc != NBX_OK) break;
             }
+            for (size_t i = offset[b2]; rc == NBX_OK && i < offset[b2 + 1]; i++) rc = lb.insert<false>(0, sorted[i]);  // ... then the rest
+            status[b2] = rc;
         }
-    };
-    const int nt = std::max(1, std::min(threads, nb));
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
-    for (int b = 0; b < nb; b++)
-        if (status[b] != NBX_OK) return status[b];
+    });
+    for (int b2 = 0; b2 < nb; b2++)
+        if (status[b2] != NBX_OK) return status[b2];
     // The tree stays a forest: `nodes` = top levels, pools[b] = subtree of bucket b (local indices,
     // node 0 = the bucket root, which supersedes nodes[root_of[b]]).  Traversals below understand both.
     forest = true;
     n_buckets = nb;
     if (timing) {
-        const auto tp2 = std::chrono::steady_clock::now();
-        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a2, auto b2) { return std::chrono::duration<double, std::milli>(b2 - a2).count(); };
         size_t big = 0;
-        for (int b = 0; b < nb; b++) big = std::max(big, queues[b].size());
-        std::fprintf(stderr, "[nbx] tree build n=%d threads=%d buckets=%d (largest %zu): top %.2f ms, subtrees %.2f ms\n", n, nt, nb,
-                     big, ms(tp0, tp1), ms(tp1, tp2));
+        for (int b2 = 0; b2 < nb; b2++) big = std::max(big, qsize(b2));
+        std::fprintf(stderr,
+                     "[nbx] tree build n=%d threads=%d limit=%d buckets=%d (largest %zu): warm-up %.2f ms, route %.2f ms, scatter %.2f ms, "
+                     "folds (remaining) %.2f ms, subtrees %.2f ms\n",
+                     n, nt, limit, nb, big, ms(tp0, tp1), ms(tp1, tpa), ms(tpa, tpb), ms(tpb, tp2), ms(tp2, tp3));
     }
     return NBX_OK;
 }

@@ -51,6 +51,8 @@ struct QuadTree {
     std::vector<int> root_of;                   // bucket id -> top node
     std::vector<std::vector<Node>> pools;       // capacity reused from step to step
     std::vector<std::vector<Event>> queues;     // per-bucket insert queues of the last build (reused)
+    std::vector<int> pbucket;                   // scratch of the threaded build (reused)
+    std::vector<Event> sorted;                  // scratch: particles grouped by bucket, index order kept
     size_t node_count() const;
     // status: 0 ok, else the NBX_ERR_* code standing in for the reference panic
     int build(const float* px, const float* py, const float* m, int n);

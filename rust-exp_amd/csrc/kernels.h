@@ -63,6 +63,8 @@ hipError_t launch_bh_count(const float4* posm, int lo, int n_targets, const BhNo
 
 // Quadtree build on the device (bh_build.hip): same node set as the host build, flattened straight into `out`.
 size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes);
+hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size_t workspace_bytes, const unsigned** perm_dev,
+                                hipStream_t stream);
 hipError_t device_tree_build(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                              int* host_counters, int* n_nodes_host, const unsigned** perm_dev, int* status,
                              hipStream_t stream);

@@ -200,6 +200,61 @@ def test_threaded_quadtree_build_is_result_identical(rx, ob, threads, monkeypatc
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("case", ["limit5_random", "limit6_plummer", "corner_first", "sorted_x", "sparse_ring", "two_clumps"])
+def test_threaded_build_parallel_top_phase_is_result_identical(rx, ob, case, monkeypatch):
+    """The warm-up / freeze / route-fold-scatter scheme (host_ops.cpp) for every bucket depth, for orders that
+    leave many top nodes exterior at the freeze, and for very unbalanced buckets: node-for-node the oracle tree."""
+    monkeypatch.setenv("NBX_HOST_THREADS", "12")
+    rng = np.random.default_rng(11)
+    if case == "limit5_random":
+        n = 70000
+        x = rng.uniform(-40, 40, n); y = rng.uniform(-25, 25, n)
+    elif case == "limit6_plummer":
+        st = rx.plummer_sphere(270000, dim=2)
+        x, y = st["px"], st["py"]; n = len(x)
+    elif case == "corner_first":      # the first 8192 bodies sit in one corner: most of the box is exterior at the freeze
+        n = 80000
+        x = rng.uniform(-40, 40, n); y = rng.uniform(-40, 40, n)
+        x[:9000] = rng.uniform(35, 40, 9000); y[:9000] = rng.uniform(35, 40, 9000)
+    elif case == "sorted_x":
+        n = 66000
+        x = np.sort(rng.normal(0, 10, n)); y = rng.normal(0, 10, n)
+    elif case == "sparse_ring":
+        n = 68000
+        a = rng.uniform(0, 2 * np.pi, n); r = 30 + rng.normal(0, 0.01, n)
+        x = r * np.cos(a); y = r * np.sin(a)
+    else:
+        n = 90000
+        x = np.concatenate([rng.normal(-20, 0.05, n // 2), rng.normal(20, 3, n - n // 2)])
+        y = np.concatenate([rng.normal(5, 0.05, n // 2), rng.normal(-5, 3, n - n // 2)])
+    m = rng.uniform(0.1, 2.0, n).astype(np.float32)
+    p = ob.particles(x, y, np.zeros(n), np.zeros(n), m)
+    rc, want = ob.bh_tree_dump(p)
+    assert rc == 0
+    e = rx.NBodyEngine()
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    got = e.bh_tree_dump()
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    monkeypatch.setenv("NBX_HOST_THREADS", "1")
+    a = e.bh_flat_dump(False)
+    monkeypatch.setenv("NBX_HOST_THREADS", "12")
+    b = e.bh_flat_dump(True)
+    assert a.tobytes() == b.tobytes()
+
+
+def test_threaded_build_reports_nonpositive_mass(rx, monkeypatch):
+    monkeypatch.setenv("NBX_HOST_THREADS", "4")
+    rng = np.random.default_rng(12)
+    n = 50000
+    m = np.ones(n, np.float32); m[30000] = 0.0
+    e = rx.NBodyEngine()
+    e.set_particles(rng.uniform(-9, 9, n), rng.uniform(-9, 9, n), np.zeros(n), np.zeros(n), m)
+    with pytest.raises(rx.NBodyError) as ei:
+        e.bh_tree_dump()
+    assert ei.value.code == rx.NBX_ERR_TREE      # nbody.rs:304
+
+
 def test_threaded_quadtree_reports_depth_panic(rx, monkeypatch):
     monkeypatch.setenv("NBX_HOST_THREADS", "4")
     rng = np.random.default_rng(6)
