@@ -2,7 +2,7 @@
 //
 // Replaces Node::compute_force (nbody.rs:333-377), evaluated per body by the reference's worker
 // threads (nbody.rs:443-447).  The quadtree itself is built on the host exactly as the reference
-// builds it (bh_tree.cpp; nbody.rs:388-415) and flattened in PRE-ORDER (children UL,UR,LL,LR,
+// builds it (host_ops.cpp; nbody.rs:388-415) -- or, opt-in, on the device (bh_build.hip) -- and flattened in PRE-ORDER (children UL,UR,LL,LR,
 // empty exterior nodes dropped) with a skip pointer per node, so the recursive descent becomes a
 // stackless walk:  open a node -> next index;  accept / leaf -> skip[index].
 //
@@ -16,9 +16,10 @@
 //                  sum of its four children, :354-360) reproduced with an explicit frame stack
 //                  (depth <= 52, the reference panics beyond depth 50).  Output = force, bit-exact.
 //
-// One thread per body; bodies arrive in particle-index order (a Morton reorder would improve wave
-// coherence but would change nothing numerically; see DESIGN.md "next").  Tree nodes are read-only
-// 32-B records (two 16-B loads) served by L1/L2.
+// One lane per body.  k_bh_eval_fast / k_bh_eval_strict: every lane walks on its own (bodies in particle-index
+// order, or in a Morton order when `perm` is given).  k_bh_eval_fast_wave: the 64 lanes of a wave share one walk
+// (see there) -- used whenever a spatial order of the bodies is available (device-built tree, or host tree with
+// n >= 65536); results are bit-identical to the per-lane walk.  Tree nodes are read-only 32-B records.
 #include "kernels.h"
 
 namespace nbx {
