@@ -117,9 +117,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one rank per GPU. (NBX_DIST_BACKEND=gloo lets several ranks share one GPU: the builder's only way to
+        # run this multi-rank path on a single-GPU box; the driver's launch uses the default, nccl = RCCL.)
+        backend = os.environ.get("NBX_DIST_BACKEND", "nccl")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         if world > 1:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
         slab = rx.sharded.TorchSlabEngine(local_rank, mode=args.mode, source_half=args.source_bits == 16)
         slab.eng.set_launch(jsplit=args.jsplit, bodies_per_thread=args.bpt, variant=args.variant)
         sim = rx.ShardedNBody(slab)

@@ -162,3 +162,69 @@ def test_single_process_group_of_one_gpu_matches_plain_engine(rx, ob):
     g.step_brute_force(0.01)
     r = q.copy(); ob.step_brute_force(r, 0.01)
     assert_bit_equal(g.get_particles()["px"], r["px"])
+
+
+WORKER2 = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["NBX_ROOT"])
+import numpy as np
+import torch
+import torch.distributed as dist
+import rust_exp_amd as rx
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = int(os.environ["NBX_N"])
+st = rx.plummer_sphere(n)
+slab = rx.sharded.TorchSlabEngine(0)          # both ranks share the one GPU of the test box
+sim = rx.ShardedNBody(slab)
+sim.set_particles(st)
+for _ in range(3):
+    sim.step_brute_force(0.01)
+torch.cuda.synchronize()
+full = sim.gather_state()
+bad = []
+if rank == 0:
+    ref = rx.NBodyEngine()
+    ref.set_launch(jsplit=slab.eng.last_launch()["jsplit"], bodies_per_thread=slab.eng.last_launch()["bodies_per_thread"],
+                   variant=slab.eng.last_launch()["variant"])
+    ref.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
+    for _ in range(3):
+        ref.step_brute_force(0.01)
+    want = ref.get_particles()
+    for k in ("px", "py", "pz", "vx", "vy", "vz"):
+        err = float(np.abs(np.asarray(full[k]) - want[k]).max())
+        if err > (1e-5 if k[0] == "p" else 2e-3):
+            bad.append((k, err))
+dist.barrier()
+dist.destroy_process_group()
+if rank == 0:
+    print("RESULT " + json.dumps({"bad": bad, "slab": list(sim.local.slab())}))
+"""
+
+
+@pytest.mark.parametrize("world,n", [(2, 16384), (3, 10000)])
+def test_two_and_three_ranks_share_the_gpu_over_gloo(rx, world, n):
+    """The real multi-process path (TorchSlabEngine on torch-owned device memory, slab kernels of several ranks,
+    one all-gather per step, velocity gather) with world size > 1: the ranks share the single test GPU and
+    exchange over gloo (RCCL refuses two ranks on one device). Even (2 x 8192) and ragged (3 ranks) slabs."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, NBX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r),
+                   WORLD_SIZE=str(world), NBX_N=str(n))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER2], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-3000:] for o in outs)
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("RESULT ")]
+    assert lines, outs[0][0][-2000:] + outs[0][1][-3000:]
+    res = json.loads(lines[-1][7:])
+    assert res["bad"] == [], res
