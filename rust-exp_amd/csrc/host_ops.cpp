@@ -554,6 +554,38 @@ static void flatten_subtree(const std::vector<QuadTree::Node>& nodes, int root, 
     }
 }
 
+// same walk, written straight into `out` (which must hold the subtree's live-node count); skips are absolute:
+// `base` = position of the subtree root in the final array
+static void flatten_subtree_into(const std::vector<QuadTree::Node>& nodes, int root, BhNode* out, int base)
+{
+    struct Frame { int node; int slot; int next_child; };
+    Frame st[128];   // depth <= 52 (the build rejects deeper trees)
+    int sp = 0, count = 0;
+    auto emit = [&](int k) -> int {
+        const QuadTree::Node& nd = nodes[k];
+        BhNode b;
+        b.px = nd.px; b.py = nd.py; b.m = nd.m; b.s = nd.x2 - nd.x1;
+        b.skip = 0; b.interior = nd.first_child >= 0 ? 1 : 0; b.pad0 = 0; b.pad1 = 0;
+        out[count] = b;
+        return count++;
+    };
+    st[sp++] = Frame{root, emit(root), 0};
+    while (sp > 0) {
+        Frame& f = st[sp - 1];
+        const QuadTree::Node& nd = nodes[f.node];
+        if (nd.first_child < 0 || f.next_child == 4) {
+            out[f.slot].skip = base + count;
+            sp--;
+            continue;
+        }
+        const int c = nd.first_child + f.next_child++;
+        const QuadTree::Node& ch = nodes[c];
+        if (ch.first_child < 0 && ch.m == 0.0f) continue;
+        const int slot = emit(c);
+        st[sp++] = Frame{c, slot, 0};
+    }
+}
+
 void QuadTree::flatten(std::vector<BhNode>& out) const
 {
     out.clear();
@@ -571,15 +603,14 @@ void QuadTree::flatten(std::vector<BhNode>& out) const
     flatten_subtree(nodes, 0, out);
 }
 
-// Threaded flattening of a forest: the top levels are walked serially; every non-empty bucket subtree
-// is an independent job flattened into a private array (relative skips); then all pieces are laid out
-// in pre-order and copied to the destination in parallel (flatten_write).
+// Threaded flattening of a forest: prepare() walks the top levels serially and counts the live nodes of every
+// bucket subtree in parallel, which fixes each piece's position in the pre-order array; write() then flattens
+// every bucket subtree straight into its span of the destination (e.g. pinned memory), in parallel.
 size_t QuadTree::flatten_prepare(FlatPlan& plan) const
 {
     plan.items.clear();
     plan.total = 0;
     if (nodes.empty()) return 0;
-    if ((int)plan.pieces.size() < n_buckets) plan.pieces.resize(n_buckets);
     auto eff = [&](int k) -> const Node& { return (forest && bucket_of[k] >= 0) ? pools[bucket_of[k]][0] : nodes[k]; };
     const Node& root = eff(0);
     if (root.first_child < 0 && root.m == 0.0f) return 0;
@@ -608,21 +639,21 @@ size_t QuadTree::flatten_prepare(FlatPlan& plan) const
         const int item = add_item(c);
         st.push_back(Frame{c, item, 0});
     }
-    // parallel: flatten every referenced bucket privately
+    // parallel: live-node count of every referenced bucket (what its flattened piece will hold)
     std::vector<int> jobs;
     for (const auto& it : plan.items)
         if (it.piece >= 0) jobs.push_back(it.piece);
-    std::sort(jobs.begin(), jobs.end(), [&](int a, int b) { return pools[a].size() > pools[b].size(); });
+    plan.piece_size.assign((size_t)n_buckets, 0);
     const int nj = (int)jobs.size();
     std::atomic<int> next{0};
     auto work = [&]() {
         for (;;) {
             const int j = next.fetch_add(1);
             if (j >= nj) return;
-            std::vector<BhNode>& pc = plan.pieces[jobs[j]];
-            pc.clear();
-            pc.reserve(pools[jobs[j]].size());
-            flatten_subtree(pools[jobs[j]], 0, pc);
+            const std::vector<Node>& pool = pools[jobs[j]];
+            size_t live = 0;
+            for (const Node& nd : pool) live += (nd.first_child >= 0 || nd.m != 0.0f) ? 1 : 0;
+            plan.piece_size[(size_t)jobs[j]] = live;
         }
     };
     const int nt = std::max(1, std::min(host_threads(), nj));
@@ -633,7 +664,7 @@ size_t QuadTree::flatten_prepare(FlatPlan& plan) const
     size_t off = 0;
     for (auto& it : plan.items) {
         it.offset = off;
-        off += it.piece >= 0 ? plan.pieces[it.piece].size() : 1;
+        off += it.piece >= 0 ? plan.piece_size[(size_t)it.piece] : 1;
     }
     plan.total = off;
     return off;
@@ -656,13 +687,7 @@ void QuadTree::flatten_write(const FlatPlan& plan, BhNode* out) const
                 b.skip = (int)(it.end_item < ni ? plan.items[it.end_item].offset : plan.total);
                 out[it.offset] = b;
             } else {
-                const std::vector<BhNode>& pc = plan.pieces[it.piece];
-                const int base = (int)it.offset;
-                for (size_t k = 0; k < pc.size(); k++) {
-                    BhNode b = pc[k];
-                    b.skip += base;
-                    out[it.offset + k] = b;
-                }
+                flatten_subtree_into(pools[it.piece], 0, out + it.offset, (int)it.offset);
             }
         }
     };

@@ -64,8 +64,8 @@ struct QuadTree {
     // prepare() returns the node count, write() fills out[0..count)
     struct FlatPlan {
         struct Item { int node; int piece; int end_item; size_t offset; };
-        std::vector<Item> items;                  // top-level nodes and subtree pieces, in pre-order
-        std::vector<std::vector<BhNode>> pieces;  // privately flattened subtrees (relative skips)
+        std::vector<Item> items;                  // top-level nodes and bucket subtrees, in pre-order
+        std::vector<size_t> piece_size;           // live nodes of every bucket subtree (its span in the array)
         size_t total = 0;
     };
     size_t flatten_prepare(FlatPlan& plan) const;
