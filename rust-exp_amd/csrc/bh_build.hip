@@ -233,7 +233,7 @@ __global__ void k_init_root(TreeArrays t, const int n, int* node_count, int* ove
 size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
 {
     size_t tmp = 0;
-    rocprim::radix_sort_pairs(nullptr, tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
                               (unsigned*)nullptr, (size_t)n, 0, 2 * kLevels, (hipStream_t)0);
     if (sort_tmp_bytes) *sort_tmp_bytes = tmp;
     size_t bytes = 0;
