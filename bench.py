@@ -26,13 +26,36 @@ FLOPS_PER_INTERACTION = 17   # 3 sub, 3 mul + 2 add, 1 add eps, 
 DT = 0.01                    # RustNBodyExperiment.hs:45
 
 
+def effective_cores():
+    """Cores this process may actually use: scheduler affinity, capped by a cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / p + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(st, seconds):
     """Oracle (CPU restatement of nbody.rs:132-144) on the host cores: a bounded i-slice of the same
     workload (work per target is uniform), threads = all cores with the reference's slab split."""
     from oracle import binding as ob
 
     n = len(st["px"])
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     p = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])   # the reference law is 2-D: z ignored
     # calibrate
     ni = min(n, 16 * cores)
@@ -47,7 +70,7 @@ def cpu_baseline(st, seconds):
     t0 = time.perf_counter(); ob.brute_forces(p, 0, n1, nthreads=1); t2 = time.perf_counter()
     st1 = n1 * (n - 1) / (t2 - t0)
     return {
-        "value": mt, "unit": "interactions/s", "cores": cores, "kind": "port",
+        "value": mt, "unit": "interactions/s", "cores": cores, "kind": "port", "logical_cpus": os.cpu_count(),
         "sample": f"first {ni} targets x {n} sources (2-D reference law), {cores} threads, reference slab split",
         "single_thread_value": st1,
         "single_thread_sample": f"first {n1} targets x {n} sources, 1 thread (the reference's brute force is single-threaded)",

@@ -284,6 +284,9 @@ int host_threads()
         const int t = std::atoi(env);
         if (t >= 1) return t < 256 ? t : 256;
     }
+    // Up to 32 threads even under a smaller cgroup CPU quota: the build is a ~15 ms burst and a CFS quota is a
+    // budget per 100 ms period, so the burst may use more CPUs than the long-run average allows (measured on a
+    // 16-CPU quota: 32 threads 6 ms for the subtree phase, 16 threads 11 ms).
     const unsigned hw = std::thread::hardware_concurrency();
     return (int)std::min<unsigned>(hw ? hw : 1, 32);
 }
