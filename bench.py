@@ -89,6 +89,8 @@ def _claim_stdout():
 
 def main():
     real_stdout = _claim_stdout()
+    # multi-process GPU work on this stack needs dmabuf IPC (exported by the driver; harmless to restate)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
