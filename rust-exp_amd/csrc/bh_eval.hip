@@ -94,8 +94,11 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_fast_wave(const float4* __res
             i = __builtin_amdgcn_readfirstlane(m);
             continue;
         }
-        const float4 a = *reinterpret_cast<const float4*>(&nodes[i]);      // wave-uniform address: scalar loads
-        const int2 b = *reinterpret_cast<const int2*>(&nodes[i].skip);
+        // wave-uniform address: the whole 32-B record comes in one scalar load (s_load_dwordx8)
+        typedef float f8 __attribute__((ext_vector_type(8)));
+        const f8 rec = *reinterpret_cast<const f8*>(&nodes[i]);
+        const float4 a = make_float4(rec[0], rec[1], rec[2], rec[3]);
+        const int2 b = make_int2(__float_as_int(rec[4]), __float_as_int(rec[5]));
         bool open = false;
         if (active) {
             const float dx = a.x - pi.x;
