@@ -231,6 +231,13 @@ int launch_forces_fast(nbx_engine* e)
     return NBX_OK;
 }
 
+// NBX_LOG=1: one stderr line per step (the reference has no logging on this path; its Haskell shell has Trace.hs)
+static bool log_enabled()
+{
+    static const bool on = std::getenv("NBX_LOG") != nullptr;
+    return on;
+}
+
 int step_brute(nbx_engine* e, float dt)
 {
     int rc = upload(e);
@@ -267,6 +274,10 @@ int step_brute(nbx_engine* e, float dt)
     }
     e->host_pos_valid = false;
     e->host_vel_valid = false;
+    if (log_enabled())
+        std::fprintf(stderr, "[nbx] step_brute_force dev=%d n=%d slab=[%d,%d) dt=%g mode=%s variant=%d grid=%d S=%d B=%d dim=%d%s\n", e->device,
+                     e->n, e->lo, e->hi, (double)dt, e->force_mode ? "strict" : "fast", e->last.variant, e->last.grid, e->last.jsplit,
+                     e->last.bpt, e->last.dim, e->source_half ? " fp16-sources" : "");
     return NBX_OK;
 }
 
@@ -410,6 +421,10 @@ int step_bh(nbx_engine* e, float theta, float dt)
     }
     e->host_pos_valid = false;
     e->host_vel_valid = false;
+    if (log_enabled())
+        std::fprintf(stderr, "[nbx] step_barnes_hut dev=%d n=%d slab=[%d,%d) theta=%g dt=%g mode=%s tree=%s nodes=%zu walk=%s\n", e->device, e->n,
+                     e->lo, e->hi, (double)theta, (double)dt, e->force_mode ? "strict" : "fast", on_device ? "device" : "host", e->n_flat,
+                     (have_perm && e->world == 1 && e->force_mode == 0 && e->bh_wave) ? "wave" : "lane");
     return NBX_OK;
 }
 
