@@ -25,9 +25,16 @@ ORC_PANIC_NTHREADS = -5
 
 
 def build(force=False):
+    import fcntl
+
     src = os.path.join(_HERE, "nbody_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:   # several test processes may build at once
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+                subprocess.check_call(["make", "-C", _HERE, "-s"])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return _SO
 
 

@@ -64,17 +64,28 @@ def lib_path():
 
 
 def build(force=False):
-    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)] + [
-        os.path.join(_PKG, "..", "include", "nbody_mi355x.h")
-    ]
-    stale = not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
-    if force or stale:
-        if not any(os.access(os.path.join(p, "hipcc"), os.X_OK) for p in os.environ.get("PATH", "").split(os.pathsep)):
-            if os.path.exists(_SO):
-                return _SO  # GPU box without a compiler on PATH: use the prebuilt library that travelled with the tree
-            raise RuntimeError("hipcc not found and libnbody_mi355x.so is not built")
-        subprocess.check_call(["make", "-C", _CSRC, "-s", "-j8"])
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU).
+    Serialised with a file lock: the ranks of a multi-GPU launch may all get here at once."""
+    import fcntl
+
+    os.makedirs(os.path.join(_PKG, "lib"), exist_ok=True)
+    with open(os.path.join(_PKG, "lib", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if not f.startswith(".")] + [
+                os.path.join(_PKG, "..", "include", "nbody_mi355x.h")
+            ]
+            stale = not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+            if force or stale:
+                have_hipcc = any(os.access(os.path.join(p, "hipcc"), os.X_OK)
+                                 for p in os.environ.get("PATH", "").split(os.pathsep))
+                if not have_hipcc:
+                    if os.path.exists(_SO):
+                        return _SO  # box without a compiler on PATH: use the prebuilt library that travelled with the tree
+                    raise RuntimeError("hipcc not found and libnbody_mi355x.so is not built")
+                subprocess.check_call(["make", "-C", _CSRC, "-s", "-j8"])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return _SO
 
 
