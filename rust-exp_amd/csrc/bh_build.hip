@@ -9,16 +9,17 @@
 //      reference's own f32 midpoint arithmetic (cx = (x1+x2)*0.5, nbody.rs:289-290, :324-331) for 31 levels
 //      -> 62-bit key, 2 bits per level, quadrant order [UL,UR,LL,LR] = 0..3 like the reference's child array
 //   3. radix sort (rocPRIM) of (key, body index)
-//   4. breadth-first: a node = a range of the sorted bodies sharing a key prefix; a node with >= 2 bodies is
-//      interior (like the reference: it splits as soon as a second, non-merged particle arrives) and its
-//      non-empty children are found by binary search on the next 2-bit digit
-//   5. bottom-up: subtree sizes and centres of mass (children folded left to right with the reference's
-//      running formula (p*m + p'*m') * (1/(m+m')), nbody.rs:315-318)
-//   6. top-down: pre-order offsets;  7. emit the flattened BhNode array the traversal kernels already walk.
+//   4. nodes straight from the sorted keys: every node is (first body a, depth l); how many nodes start at each body
+//      follows from the digits it shares with its two neighbours, an exclusive scan of those counts gives every node's
+//      PRE-ORDER slot, and a node's skip pointer is the slot of the first node after its bodies (see "the tree from
+//      the sorted keys" below) -- no level-by-level sweep, no host round trips, one read-back of the node count
+//   5. centres of mass from deterministic fp64 prefix sums over the sorted bodies (exact products, one rounding to
+//      f32 per node); node sizes by replaying the first body's path with the reference's f32 midpoints
 //
 // Same node set, same s = x2-x1 per node (box replayed with the same f32 arithmetic), same leaf records as the
 // host build + flatten.  What differs (its own tolerance class): interior centres of
-// mass are folded child by child instead of particle by particle in index order (rounding-level), bodies
+// mass are the f32 rounding of the exact weighted mean instead of the reference's particle-by-particle f32 running
+// fold (nbody.rs:303-320, which drifts by up to ~6e-4 relative at 100 k bodies), bodies
 // closer than EPS are NOT merged (nbody.rs:249-260 merges them in arrival order; here they get their own
 // leaves a few levels deeper), bodies identical down to level 31 share one leaf, and there is no depth-50
 // panic.  Hence: fast mode only; the bit-exact mode keeps the host build.
@@ -96,56 +97,154 @@ __global__ __launch_bounds__(kTile) void k_keys(const float4* __restrict__ posm,
     idx[i] = (unsigned)i;
 }
 
-struct TreeArrays {
-    int* lo;       // first sorted body of the node
-    int* hi;       // one past the last
-    int* level;
-    int* child0;   // first child node id (children are consecutive, quadrant order) or -1
-    int* nchild;
-    int* size;     // nodes in the subtree (pre-order span)
-    int* offset;   // pre-order position
-    float4* com;   // px, py, m, -
-};
+// ---- the tree from the sorted keys, without a level-by-level sweep --------------------------------------------------
+//
+// With the keys sorted, every tree node is a pair (a, l): the bodies that share the first l digits of key[a], where a is
+// the FIRST body of that group.  Let c(j) = number of leading digits key[j-1] and key[j] have in common (c(0) = c(n) = -1).
+//   * the deepest node starting at a is a's leaf, at depth leaf(a) = min(31, 1 + max(c(a), c(a+1))): one level below the
+//     depth at which a still shares a node with a neighbour (the reference splits a node as soon as it holds two bodies,
+//     nbody.rs:262-283, so the leaf sits exactly there);
+//   * the shallowest node starting at a has depth c(a)+1 (one digit deeper than what a shares with its left neighbour);
+//   * every depth in between starts at a too (single-child chain nodes included, as in the reference's tree).
+// So body a contributes cnt(a) = leaf(a) - c(a) nodes (0 for a body whose key equals its left neighbour's: it lives in
+// that neighbour's level-31 leaf), and in PRE-ORDER all nodes starting at a precede all nodes starting at a+1, shallow
+// to deep.  An exclusive scan of cnt therefore gives every node's pre-order slot, and a node's skip pointer -- the slot
+// after its subtree -- is simply base[b], b = first body outside the node (found by galloping over the sorted keys).
+// Centres of mass come from fp64 prefix sums over the sorted bodies (direct fp64 sums for nodes of <= 8 bodies).
 
-__device__ __forceinline__ int lower_bound_digit(const unsigned long long* keys, int lo, int hi, int shift, unsigned d)
+__device__ __forceinline__ int common_digits(const unsigned long long x, const unsigned long long y)
 {
-    while (lo < hi) {   // first index whose digit >= d
-        const int mid = (lo + hi) >> 1;
-        if (((unsigned)(keys[mid] >> shift) & 3u) < d) lo = mid + 1; else hi = mid;
-    }
-    return lo;
+    const unsigned long long d = x ^ y;
+    if (d == 0ull) return kLevels;              // identical down to level 31
+    return (__clzll((long long)d) - 2) >> 1;    // keys occupy the low 62 bits, digit l = bits 61-2l, 60-2l
 }
 
-// split the nodes [first, last) of one level; children are appended at *node_count
-__global__ __launch_bounds__(kTile) void k_split_level(const unsigned long long* __restrict__ keys, TreeArrays t,
-                                                       const int first, const int last, int* node_count, const int cap,
-                                                       int* overflow)
+struct ScanItem {
+    double m, mx, my;
+    int cnt;
+};
+__device__ __forceinline__ ScanItem scan_add(const ScanItem& a, const ScanItem& b)
 {
-    const int k = first + blockIdx.x * kTile + threadIdx.x;
-    if (k >= last) return;
-    const int lo = t.lo[k], hi = t.hi[k], lvl = t.level[k];
-    t.child0[k] = -1;
-    t.nchild[k] = 0;
-    if (hi - lo < 2 || lvl >= kLevels) return;   // exterior (single body, or bodies identical to 31 levels)
-    const int shift = 2 * (kLevels - 1 - lvl);
-    int b[5];
-    b[0] = lo; b[4] = hi;
-    b[1] = lower_bound_digit(keys, lo, hi, shift, 1u);
-    b[2] = lower_bound_digit(keys, b[1], hi, shift, 2u);
-    b[3] = lower_bound_digit(keys, b[2], hi, shift, 3u);
-    int cnt = 0;
+    return ScanItem{a.m + b.m, a.mx + b.mx, a.my + b.my, a.cnt + b.cnt};
+}
+constexpr int kScanPerThread = 4;
+constexpr int kScanBlock = kTile * kScanPerThread;
+
+// sorted body j: record (x, y, z, m) gathered into sb, and the number of tree nodes that start at j
+__device__ __forceinline__ int nodes_starting_at(const unsigned long long* __restrict__ keys, const int j, const int n)
+{
+    const unsigned long long k = keys[j];
+    const int cl = j == 0 ? -1 : common_digits(keys[j - 1], k);
+    if (j > 0 && cl >= kLevels) return 0;
+    const int cr = j == n - 1 ? -1 : common_digits(k, keys[j + 1]);
+    int leaf = 1 + (cl > cr ? cl : cr);
+    if (leaf > kLevels) leaf = kLevels;
+    return leaf - cl;
+}
+
+__global__ __launch_bounds__(kTile) void k_gather(const float4* __restrict__ posm, const unsigned* __restrict__ idx,
+                                                  const int n, float4* __restrict__ sb)
+{
+    const int j = blockIdx.x * kTile + threadIdx.x;
+    if (j < n) sb[j] = posm[idx[j]];
+}
+
+__device__ __forceinline__ ScanItem scan_item(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
+                                              const int j, const int n)
+{
+    if (j >= n) return ScanItem{0.0, 0.0, 0.0, 0};
+    const float4 p = sb[j];
+    return ScanItem{(double)p.w, (double)p.w * (double)p.x, (double)p.w * (double)p.y, nodes_starting_at(keys, j, n)};
+}
+
+// Deterministic three-kernel exclusive scan (fixed summation tree: the same inputs give the same bits on every run,
+// which a decoupled-look-back scan does not guarantee for floating point).
+__device__ __forceinline__ ScanItem block_exclusive(const ScanItem mine, ScanItem* total)
+{
+    __shared__ ScanItem wsum[kTile / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ScanItem inc = mine;
 #pragma unroll
-    for (int q = 0; q < 4; q++) cnt += b[q + 1] > b[q];
-    const int base = atomicAdd(node_count, cnt);
-    if (base + cnt > cap) { *overflow = 1; return; }
-    t.child0[k] = base;
-    t.nchild[k] = cnt;
-    int c = base;
+    for (int off = 1; off < 64; off <<= 1) {
+        ScanItem o;
+        o.m = __shfl_up(inc.m, off); o.mx = __shfl_up(inc.mx, off); o.my = __shfl_up(inc.my, off); o.cnt = __shfl_up(inc.cnt, off);
+        if (lane >= off) inc = scan_add(o, inc);
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    ScanItem before{0.0, 0.0, 0.0, 0};
+    ScanItem all{0.0, 0.0, 0.0, 0};
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        if (b[q + 1] > b[q]) {
-            t.lo[c] = b[q]; t.hi[c] = b[q + 1]; t.level[c] = lvl + 1;
-            c++;
+    for (int w = 0; w < kTile / 64; w++) {
+        if (w < wave) before = scan_add(before, wsum[w]);
+        all = scan_add(all, wsum[w]);
+    }
+    __syncthreads();
+    if (total) *total = all;
+    // exclusive = everything before this wave + the wave-inclusive value minus this thread's own item
+    ScanItem ex;
+    ex.m = __shfl_up(inc.m, 1); ex.mx = __shfl_up(inc.mx, 1); ex.my = __shfl_up(inc.my, 1); ex.cnt = __shfl_up(inc.cnt, 1);
+    if (lane == 0) ex = ScanItem{0.0, 0.0, 0.0, 0};
+    return scan_add(before, ex);
+}
+
+__global__ __launch_bounds__(kTile) void k_scan_reduce(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
+                                                       const int n, ScanItem* __restrict__ block_sums)
+{
+    const int j0 = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
+    ScanItem s = scan_item(sb, keys, j0, n);
+#pragma unroll
+    for (int u = 1; u < kScanPerThread; u++) s = scan_add(s, scan_item(sb, keys, j0 + u, n));
+    ScanItem total;
+    (void)block_exclusive(s, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// one workgroup: exclusive scan of the block sums in place; block_sums[nb] = grand total
+__global__ __launch_bounds__(kTile) void k_scan_blocks(ScanItem* __restrict__ block_sums, const int nb)
+{
+    const int chunk = (nb + kTile - 1) / kTile;
+    const int a = threadIdx.x * chunk, b = min(a + chunk, nb);
+    ScanItem s{0.0, 0.0, 0.0, 0};
+    for (int i = a; i < b; i++) s = scan_add(s, block_sums[i]);
+    ScanItem total;
+    ScanItem run = block_exclusive(s, &total);
+    for (int i = a; i < b; i++) {
+        const ScanItem v = block_sums[i];
+        block_sums[i] = run;
+        run = scan_add(run, v);
+    }
+    if (threadIdx.x == 0) block_sums[nb] = total;
+}
+
+struct Prefix {
+    double* m;    // [n+1] exclusive prefix sums over the sorted bodies
+    double* mx;
+    double* my;
+    int* base;    // [n+1] pre-order slot of the first node starting at body j; base[n] = number of nodes
+};
+
+__global__ __launch_bounds__(kTile) void k_scan_write(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
+                                                      const int n, const ScanItem* __restrict__ block_sums, Prefix p,
+                                                      int* __restrict__ counters)
+{
+    const int j0 = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
+    ScanItem it[kScanPerThread];
+    ScanItem s{0.0, 0.0, 0.0, 0};
+#pragma unroll
+    for (int u = 0; u < kScanPerThread; u++) {
+        it[u] = scan_item(sb, keys, j0 + u, n);
+        s = scan_add(s, it[u]);
+    }
+    ScanItem run = scan_add(block_sums[blockIdx.x], block_exclusive(s, nullptr));
+#pragma unroll
+    for (int u = 0; u < kScanPerThread; u++) {
+        const int j = j0 + u;
+        if (j < n) { p.m[j] = run.m; p.mx[j] = run.mx; p.my[j] = run.my; p.base[j] = run.cnt; }
+        run = scan_add(run, it[u]);
+        if (j == n - 1) {
+            p.m[n] = run.m; p.mx[n] = run.mx; p.my[n] = run.my; p.base[n] = run.cnt;
+            counters[0] = run.cnt;
         }
     }
 }
@@ -159,93 +258,150 @@ __device__ __forceinline__ void fold_mass(float& px, float& py, float& m, const 
     m = __fadd_rn(m, qm);                                                 // :318
 }
 
-// bottom-up over one level: subtree size + centre of mass
-__global__ __launch_bounds__(kTile) void k_up_level(const float4* __restrict__ posm, const unsigned* __restrict__ idx,
-                                                    TreeArrays t, const int first, const int last)
+// first body j >= b that does NOT share its first `level` digits with body a (bodies [a, b) are known to)
+__device__ __forceinline__ int group_end(const unsigned long long* __restrict__ keys, const unsigned long long ka, int b,
+                                         const int n, const int level)
 {
-    const int k = first + blockIdx.x * kTile + threadIdx.x;
-    if (k >= last) return;
-    float px = 0.f, py = 0.f, m = 0.f;
-    int size = 1;
-    const int nc = t.nchild[k];
-    if (nc == 0) {
-        for (int i = t.lo[k]; i < t.hi[k]; i++) {   // one body, or several identical to 31 levels
-            const float4 p = posm[idx[i]];
-            fold_mass(px, py, m, p.x, p.y, p.w);
-        }
-    } else {
-        const int c0 = t.child0[k];
-        for (int c = c0; c < c0 + nc; c++) {
-            const float4 q = t.com[c];
-            fold_mass(px, py, m, q.x, q.y, q.z);
-            size += t.size[c];
-        }
+    const int sh = 2 * (kLevels - level);   // level 0: shift 62 -> every key matches
+    const unsigned long long pa = ka >> sh;
+    if (b >= n || (keys[b] >> sh) != pa) return b;
+    int lo = b, step = 1;                   // keys[lo] matches
+    while (lo + step < n && (keys[lo + step] >> sh) == pa) { lo += step; step <<= 1; }
+    int hi = lo + step < n ? lo + step : n; // first known mismatch (n = past the end)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((keys[mid] >> sh) == pa) lo = mid; else hi = mid;
     }
-    t.com[k] = make_float4(px, py, m, 0.f);
-    t.size[k] = size;
+    return hi;
 }
 
-// top-down over one level: pre-order offsets of the children
-__global__ __launch_bounds__(kTile) void k_down_level(TreeArrays t, const int first, const int last)
+// one thread per sorted body a: writes all nodes that start at a (pre-order slots base[a] ...)
+__global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
+                                                const unsigned* __restrict__ box, const Prefix pre, const int n,
+                                                const int node_cap, BhNode* __restrict__ out)
 {
-    const int k = first + blockIdx.x * kTile + threadIdx.x;
-    if (k >= last) return;
-    const int nc = t.nchild[k];
-    if (nc == 0) return;
-    int run = t.offset[k] + 1;
-    const int c0 = t.child0[k];
-    for (int c = c0; c < c0 + nc; c++) {
-        t.offset[c] = run;
-        run += t.size[c];
-    }
-}
-
-__global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ posm, const unsigned* __restrict__ idx,
-                                                const unsigned* __restrict__ box, TreeArrays t, const int n_nodes,
-                                                BhNode* __restrict__ out)
-{
-    const int k = blockIdx.x * kTile + threadIdx.x;
-    if (k >= n_nodes) return;
-    // the node's AABB: replay the first body's path for `level` steps (same arithmetic as the host tree)
+    const int a = blockIdx.x * kTile + threadIdx.x;
+    if (a >= n) return;
+    const int first = pre.base[a];
+    const int count = pre.base[a + 1] - first;
+    if (count == 0 || pre.base[n] > node_cap) return;
+    const unsigned long long ka = keys[a];
+    const int top = a == 0 ? 0 : common_digits(keys[a - 1], ka) + 1;   // depth of the shallowest node starting here
+    const int leaf = top + count - 1;
+    const float4 p = sb[a];
+    // node sizes: replay the body's path with the reference's f32 midpoints (nbody.rs:289-300)
     float x1 = dec_f32(box[0]), y1 = dec_f32(box[1]), x2 = dec_f32(box[2]), y2 = dec_f32(box[3]);
-    const float4 p = posm[idx[t.lo[k]]];
-    const int lvl = t.level[k];
 #pragma unroll 1
-    for (int l = 0; l < lvl; l++) descend(x1, y1, x2, y2, p.x, p.y);
-    const float4 c = t.com[k];
-    BhNode b;
-    b.px = c.x; b.py = c.y; b.m = c.z; b.s = __fsub_rn(x2, x1);   // nbody.rs:341
-    const int off = t.offset[k];
-    b.skip = off + t.size[k];
-    b.interior = t.nchild[k] > 0 ? 1 : 0;
-    b.pad0 = 0; b.pad1 = 0;
-    out[off] = b;
+    for (int l = 0; l < top; l++) descend(x1, y1, x2, y2, p.x, p.y);
+#pragma unroll 1
+    for (int l = top; l <= leaf; l++) {
+        out[first + (l - top)].s = __fsub_rn(x2, x1);   // nbody.rs:341
+        if (l < leaf) descend(x1, y1, x2, y2, p.x, p.y);
+    }
+    // the leaf: this body, or the bodies whose keys agree with it down to level 31
+    int b = group_end(keys, ka, a + 1, n, leaf);
+    {
+        float px = p.x, py = p.y, m = p.w;
+        for (int j = a + 1; j < b; j++) {
+            const float4 q = sb[j];
+            fold_mass(px, py, m, q.x, q.y, q.w);
+        }
+        BhNode* o = &out[first + count - 1];
+        o->px = px; o->py = py; o->m = m;
+        o->skip = first + count;
+        o->interior = 0; o->pad0 = 0; o->pad1 = 0;
+    }
+    // interior nodes, deepest first: the group only grows as the prefix gets shorter
+#pragma unroll 1
+    for (int l = leaf - 1; l >= top; l--) {
+        b = group_end(keys, ka, b, n, l);
+        double m, mx, my;
+        if (b - a <= 8) {
+            m = 0.0; mx = 0.0; my = 0.0;
+            for (int j = a; j < b; j++) {
+                const float4 q = sb[j];
+                m += (double)q.w; mx += (double)q.w * (double)q.x; my += (double)q.w * (double)q.y;
+            }
+        } else {
+            m = pre.m[b] - pre.m[a]; mx = pre.mx[b] - pre.mx[a]; my = pre.my[b] - pre.my[a];
+        }
+        BhNode* o = &out[first + (l - top)];
+        if (m != 0.0) { o->px = (float)(mx / m); o->py = (float)(my / m); }
+        else          { o->px = p.x; o->py = p.y; }       // massless group: any position, zero contribution
+        o->m = (float)m;
+        o->skip = pre.base[b];
+        o->interior = 1; o->pad0 = 0; o->pad1 = 0;
+    }
 }
 
-__global__ void k_init_root(TreeArrays t, const int n, int* node_count, int* overflow, unsigned* box)
+__global__ void k_init_box(unsigned* box)
 {
-    t.lo[0] = 0; t.hi[0] = n; t.level[0] = 0; t.offset[0] = 0;
-    *node_count = 1;
-    *overflow = 0;
     box[0] = 0xFFFFFFFFu; box[1] = 0xFFFFFFFFu; box[2] = 0u; box[3] = 0u;
 }
 
 size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
 {
+    (void)node_cap;   // the build needs no per-node scratch: nodes are written straight into the caller's array
     size_t tmp = 0;
     (void)rocprim::radix_sort_pairs(nullptr, tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
                               (unsigned*)nullptr, (size_t)n, 0, 2 * kLevels, (hipStream_t)0);
     if (sort_tmp_bytes) *sort_tmp_bytes = tmp;
+    const size_t nb = ((size_t)n + kScanBlock - 1) / kScanBlock;
     size_t bytes = 0;
     auto add = [&](size_t b) { bytes += (b + 255) & ~(size_t)255; };
     add(sizeof(unsigned long long) * (size_t)n * 2);   // keys in/out
     add(sizeof(unsigned) * (size_t)n * 2);             // idx in/out
     add(tmp);
-    add(sizeof(int) * (size_t)node_cap * 7);           // lo hi level child0 nchild size offset
-    add(sizeof(float4) * (size_t)node_cap);            // com
+    add(sizeof(float4) * (size_t)n);                   // sorted bodies
+    add(sizeof(double) * ((size_t)n + 1) * 3);         // prefix sums m, m*x, m*y
+    add(sizeof(int) * ((size_t)n + 1));                // pre-order base
+    add(sizeof(ScanItem) * (nb + 1));                  // block sums
     add(256);                                          // counters + box
     return bytes;
 }
+
+namespace {
+struct Workspace {
+    unsigned long long *keys0, *keys1;
+    unsigned *idx0, *idx1;
+    void* sort_tmp;
+    float4* sb;
+    Prefix pre;
+    ScanItem* block_sums;
+    int* counters;   // [0] node count; [4..7] box (as unsigned)
+    unsigned* box;
+};
+Workspace carve(void* workspace, int n, size_t sort_tmp)
+{
+    char* w = static_cast<char*>(workspace);
+    auto take = [&](size_t b) { char* p = w; w += (b + 255) & ~(size_t)255; return p; };
+    const size_t nb = ((size_t)n + kScanBlock - 1) / kScanBlock;
+    Workspace k;
+    k.keys0 = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * (size_t)n * 2));
+    k.keys1 = k.keys0 + n;
+    k.idx0 = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * (size_t)n * 2));
+    k.idx1 = k.idx0 + n;
+    k.sort_tmp = take(sort_tmp);
+    k.sb = reinterpret_cast<float4*>(take(sizeof(float4) * (size_t)n));
+    double* d = reinterpret_cast<double*>(take(sizeof(double) * ((size_t)n + 1) * 3));
+    k.pre.m = d; k.pre.mx = d + (size_t)n + 1; k.pre.my = d + 2 * ((size_t)n + 1);
+    k.pre.base = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)n + 1)));
+    k.block_sums = reinterpret_cast<ScanItem*>(take(sizeof(ScanItem) * (nb + 1)));
+    k.counters = reinterpret_cast<int*>(take(256));
+    k.box = reinterpret_cast<unsigned*>(k.counters + 4);
+    return k;
+}
+
+// root AABB -> path keys -> sorted (key, body) pairs in keys1 / idx1
+hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sort_tmp, hipStream_t stream)
+{
+    const int nb = (n + kTile - 1) / kTile;
+    hipLaunchKernelGGL(k_init_box, dim3(1), dim3(1), 0, stream, k.box);
+    hipLaunchKernelGGL(k_bbox, dim3(nb < 256 ? nb : 256), dim3(kTile), 0, stream, posm, n, k.box);
+    hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, k.box, k.keys0, k.idx0);
+    return rocprim::radix_sort_pairs(k.sort_tmp, sort_tmp, k.keys0, k.keys1, k.idx0, k.idx1, (size_t)n, 0, 2 * kLevels, stream);
+}
+}  // namespace
 
 // Spatial (Morton, reference quadrant order) permutation of the bodies only: bbox + path keys + radix sort.
 // Used to make the traversal of a HOST-built tree wave-coherent. *perm_dev points into the workspace.
@@ -256,33 +412,17 @@ hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size
     if (n <= 0) return hipSuccess;
     size_t sort_tmp = 0;
     if (device_tree_workspace_bytes(n, 1, &sort_tmp) > workspace_bytes) return hipErrorInvalidValue;
-    char* w = static_cast<char*>(workspace);
-    auto take = [&](size_t b) { char* p = w; w += (b + 255) & ~(size_t)255; return p; };
-    unsigned long long* keys0 = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * (size_t)n * 2));
-    unsigned long long* keys1 = keys0 + n;
-    unsigned* idx0 = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * (size_t)n * 2));
-    unsigned* idx1 = idx0 + n;
-    void* tmp = take(sort_tmp);
-    int* ints = reinterpret_cast<int*>(take(sizeof(int) * 7));
-    (void)take(sizeof(float4));
-    int* counters = reinterpret_cast<int*>(take(256));
-    unsigned* box = reinterpret_cast<unsigned*>(counters + 4);
-    TreeArrays t;
-    t.lo = ints; t.hi = ints + 1; t.level = ints + 2; t.child0 = ints + 3; t.nchild = ints + 4; t.size = ints + 5; t.offset = ints + 6;
-    t.com = nullptr;
-    const int nb = (n + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, stream, t, n, counters, counters + 1, box);
-    hipLaunchKernelGGL(k_bbox, dim3(nb < 256 ? nb : 256), dim3(kTile), 0, stream, posm, n, box);
-    hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, box, keys0, idx0);
-    hipError_t e = rocprim::radix_sort_pairs(tmp, sort_tmp, keys0, keys1, idx0, idx1, (size_t)n, 0, 2 * kLevels, stream);
+    const Workspace k = carve(workspace, n, sort_tmp);
+    const hipError_t e = sort_bodies(posm, n, k, sort_tmp, stream);
     if (e != hipSuccess) return e;
-    *perm_dev = idx1;
+    *perm_dev = k.idx1;
     return hipGetLastError();
 }
 
 // Builds the flattened tree for posm[0..n) into `out` (capacity node_cap records). Returns the node count in
-// *n_nodes_host (host, valid after the stream work the function waits for) and the sorted body order in
-// *perm_dev (device pointer inside the workspace: body handled by thread t = perm[t], a Morton order).
+// *n_nodes_host (read back through the pinned host_counters; the function waits for the stream once, at its end) and
+// the sorted body order in *perm_dev (device pointer inside the workspace: body handled by thread t = perm[t]).
+// *status = 1 when the tree needs more than node_cap nodes (nothing usable was written).
 hipError_t device_tree_build(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                              int* host_counters /* pinned, >= 4 ints */, int* n_nodes_host, const unsigned** perm_dev,
                              int* status, hipStream_t stream)
@@ -292,59 +432,23 @@ hipError_t device_tree_build(const float4* posm, int n, void* workspace, size_t 
     if (n <= 0) return hipSuccess;
     size_t sort_tmp = 0;
     if (device_tree_workspace_bytes(n, node_cap, &sort_tmp) > workspace_bytes) return hipErrorInvalidValue;
-    char* w = static_cast<char*>(workspace);
-    auto take = [&](size_t b) { char* p = w; w += (b + 255) & ~(size_t)255; return p; };
-    unsigned long long* keys0 = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * (size_t)n * 2));
-    unsigned long long* keys1 = keys0 + n;
-    unsigned* idx0 = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * (size_t)n * 2));
-    unsigned* idx1 = idx0 + n;
-    void* tmp = take(sort_tmp);
-    int* ints = reinterpret_cast<int*>(take(sizeof(int) * (size_t)node_cap * 7));
-    TreeArrays t;
-    t.lo = ints; t.hi = ints + node_cap; t.level = ints + 2 * (size_t)node_cap; t.child0 = ints + 3 * (size_t)node_cap;
-    t.nchild = ints + 4 * (size_t)node_cap; t.size = ints + 5 * (size_t)node_cap; t.offset = ints + 6 * (size_t)node_cap;
-    t.com = reinterpret_cast<float4*>(take(sizeof(float4) * (size_t)node_cap));
-    int* counters = reinterpret_cast<int*>(take(256));   // [0] node_count, [1] overflow, [4..7] box (as unsigned)
-    unsigned* box = reinterpret_cast<unsigned*>(counters + 4);
-
-    const int nb = (n + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, stream, t, n, counters, counters + 1, box);
-    hipLaunchKernelGGL(k_bbox, dim3(nb < 256 ? nb : 256), dim3(kTile), 0, stream, posm, n, box);
-    hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, box, keys0, idx0);
-    hipError_t e = rocprim::radix_sort_pairs(tmp, sort_tmp, keys0, keys1, idx0, idx1, (size_t)n, 0, 2 * kLevels, stream);
+    const Workspace k = carve(workspace, n, sort_tmp);
+    hipError_t e = sort_bodies(posm, n, k, sort_tmp, stream);
     if (e != hipSuccess) return e;
-    *perm_dev = idx1;
-
-    // breadth-first splitting, one launch per level; the level's node range comes back through pinned memory
-    int level_first[kLevels + 4];
-    int first = 0, last = 1, levels = 0;
-    level_first[0] = 0;
-    while (first < last && levels <= kLevels) {
-        hipLaunchKernelGGL(k_split_level, dim3((last - first + kTile - 1) / kTile), dim3(kTile), 0, stream, keys1, t, first,
-                           last, counters, node_cap, counters + 1);
-        e = hipMemcpyAsync(host_counters, counters, 2 * sizeof(int), hipMemcpyDeviceToHost, stream);
-        if (e != hipSuccess) return e;
-        e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) return e;
-        if (host_counters[1]) { *status = 1; return hipSuccess; }   // node pool exhausted (pathological input)
-        levels++;
-        level_first[levels] = last;
-        first = last;
-        last = host_counters[0];
-    }
-    const int n_nodes = last;
-    level_first[levels + 1] = n_nodes;
-    for (int l = levels; l >= 0; l--) {
-        const int a = level_first[l], b = l == levels ? n_nodes : level_first[l + 1];
-        if (b > a)
-            hipLaunchKernelGGL(k_up_level, dim3((b - a + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, idx1, t, a, b);
-    }
-    for (int l = 0; l <= levels; l++) {
-        const int a = level_first[l], b = l == levels ? n_nodes : level_first[l + 1];
-        if (b > a) hipLaunchKernelGGL(k_down_level, dim3((b - a + kTile - 1) / kTile), dim3(kTile), 0, stream, t, a, b);
-    }
-    hipLaunchKernelGGL(k_emit, dim3((n_nodes + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, idx1, box, t, n_nodes, out);
-    *n_nodes_host = n_nodes;
+    *perm_dev = k.idx1;
+    const int nb = (n + kTile - 1) / kTile;
+    const int sb = (n + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(k_gather, dim3(nb), dim3(kTile), 0, stream, posm, k.idx1, n, k.sb);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, k.sb, k.keys1, n, k.block_sums);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kTile), 0, stream, k.block_sums, sb);
+    hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, k.sb, k.keys1, n, k.block_sums, k.pre, k.counters);
+    hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kTile), 0, stream, k.sb, k.keys1, k.box, k.pre, n, node_cap, out);
+    e = hipMemcpyAsync(host_counters, k.counters, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    if (host_counters[0] > node_cap) { *status = 1; return hipSuccess; }   // node pool exhausted (pathological input)
+    *n_nodes_host = host_counters[0];
     return hipGetLastError();
 }
 
