@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
         BhNode* o = &out[first + count - 1];
         o->px = px; o->py = py; o->m = m;
         o->skip = first + count;
-        o->interior = 0; o->pad0 = 0; o->pad1 = 0;
+        o->interior = 0; o->q = -1.0f; o->pad1 = 0;
     }
     // interior nodes, deepest first: the group only grows as the prefix gets shorter
 #pragma unroll 1
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
         else          { o->px = p.x; o->py = p.y; }       // massless group: any position, zero contribution
         o->m = (float)m;
         o->skip = pre.base[b];
-        o->interior = 1; o->pad0 = 0; o->pad1 = 0;
+        o->interior = 1; o->q = __fmul_rn(o->s, o->s); o->pad1 = 0;
     }
 }
 

@@ -9,7 +9,7 @@
 //   interior:  s = x2-x1 ; d = sqrt(dx^2+dy^2) ; if s/d < theta -> force(body, COM) else open   (:341-360)
 //   exterior:  skip if position bit-equal to the body (:365), else force(body, particle)        (:371)
 //
-// mode 0 (fast):   test as s < theta*d (same truth table incl. d = 0, s = 0), v_rcp_f32 pair law,
+// mode 0 (fast):   test as q < theta^2 * d^2 (q = s*s or -1 for a leaf: no sqrt, no node-type branch), v_rcp_f32 pair law,
 //                  contributions accumulated in walk order.  Output = acceleration.
 // mode 1 (strict): IEEE sqrt and divide, force() in the reference's expression order, and the
 //                  reference's HIERARCHICAL summation (every opened node returns the left-to-right
@@ -26,6 +26,15 @@ namespace nbx {
 
 constexpr int kMaxFrames = 56;
 
+// The fast kernels test the opening criterion without the square root and without a node-type branch:
+//     take = q < theta^2 * d^2,   q = s*s (interior)  or  -1 (leaf)            (BhNode::q, set when the tree is flattened)
+// interior: s/d < theta <=> s*s < theta^2 d^2 for s, d >= 0 (d = 0 -> open, as in the reference where s/0 = +inf; a
+// non-positive theta accepts nothing).  Same truth table away from the rounding boundary; a body whose s/d sits within
+// ~1e-7 of theta may open one node more or less than the reference -- well inside the fast mode's tolerance class (the
+// bit-exact kernel keeps sqrt and divide).  leaf: always taken; the reference's self-skip (position bit-equal,
+// nbody.rs:365) needs no test here because a coincident leaf contributes m * 0 / (0 + EPS) = exactly 0.
+// A node that is not taken adds an exact zero (scale 0), so both walks below produce identical bits.
+
 __global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict__ posm, const int lo,
                                                         const int n_targets, const BhNode* __restrict__ nodes,
                                                         const int n_nodes, const float theta,
@@ -37,83 +46,67 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict
     // nodes; it only changes which thread handles which body, never a result
     const int it = perm ? (int)perm[t] : t;
     const float4 pi = posm[lo + it];
+    const float th2 = theta > 0.0f ? theta * theta : 0.0f;
     float ax = 0.0f, ay = 0.0f;
     int i = 0;
     while (i < n_nodes) {
         const float4 a = *reinterpret_cast<const float4*>(&nodes[i]);         // px,py,m,s
-        const int2 b = *reinterpret_cast<const int2*>(&nodes[i].skip);        // skip, interior
+        const float4 c = *reinterpret_cast<const float4*>(&nodes[i].skip);    // skip, interior, q, -
+        const int skip = __float_as_int(c.x);
+        const float q = c.z;
         const float dx = a.x - pi.x;
         const float dy = a.y - pi.y;
         const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-        bool take;
-        if (b.y) {
-            take = a.w < theta * __builtin_sqrtf(d2);      // s/d < theta  (d=0 -> open)
-        } else {
-            take = !(a.x == pi.x && a.y == pi.y);          // nbody.rs:365
-        }
-        if (take) {
-            const float s = a.z * __builtin_amdgcn_rcpf(d2 + kEps);
-            ax = __builtin_fmaf(s, dx, ax);
-            ay = __builtin_fmaf(s, dy, ay);
-        }
-        i = (b.y && !take) ? i + 1 : b.x;
+        const bool take = q < th2 * d2;
+        const float s = take ? a.z * __builtin_amdgcn_rcpf(d2 + kEps) : 0.0f;
+        ax = __builtin_fmaf(s, dx, ax);
+        ay = __builtin_fmaf(s, dy, ay);
+        i = take ? skip : i + 1;
     }
     out[it] = make_float2(ax, ay);
 }
 
 // Wave-uniform variant of the fast walk (used when the bodies arrive in a spatial order, i.e. with the device-built
 // tree's Morton permutation): the 64 lanes of a wave walk ONE node sequence -- the union of what their bodies
-// need -- so the node record comes through the scalar cache (s_load, no per-lane address divergence) and the
-// dependent-load chain is per wave, not per lane.  Per-lane semantics are unchanged: a lane that accepted a node
-// (or passed a leaf) parks until the walk leaves that subtree (resume index r = skip), so every body still makes
-// exactly the decisions of nbody.rs:333-377 and accumulates its contributions in the same (walk) order as
-// k_bh_eval_fast => bit-identical results to it.
-__global__ __launch_bounds__(kTile) void k_bh_eval_fast_wave(const float4* __restrict__ posm, const int lo,
-                                                             const int n_targets, const BhNode* __restrict__ nodes,
-                                                             const int n_nodes, const float theta,
-                                                             float2* __restrict__ out, const unsigned* __restrict__ perm)
+// need -- so the node record comes through the scalar cache (one s_load_dwordx8, no per-lane address divergence) and
+// the walk index and the loop branch live on the scalar unit.  Per-lane semantics are unchanged: a lane that took a
+// node parks until the walk leaves that subtree (resume index r = skip), so every body still makes exactly the
+// decisions of k_bh_eval_fast and accumulates its contributions in the same (walk) order => bit-identical results.
+// (At least one lane is active at every visited node: lanes that open a node stay active at i+1, and when nobody
+// opens, the active lanes all resume at skip = the next i.)
+// One wave per workgroup: walks differ in length (dense core vs outskirts).
+constexpr int kWaveBlock = 64;
+__global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* __restrict__ posm, const int lo,
+                                                                  const int n_targets, const BhNode* __restrict__ nodes,
+                                                                  const int n_nodes, const float theta,
+                                                                  float2* __restrict__ out, const unsigned* __restrict__ perm)
 {
-    const int t = blockIdx.x * kTile + threadIdx.x;
+    const int t = blockIdx.x * kWaveBlock + threadIdx.x;
     const bool valid = t < n_targets;
+    if (__ballot(valid) == 0ull) return;
     const int it = valid ? (perm ? (int)perm[t] : t) : 0;
     const float4 pi = posm[lo + it];
+    const float th2 = theta > 0.0f ? theta * theta : 0.0f;
     float ax = 0.0f, ay = 0.0f;
     int r = valid ? 0 : 0x7FFFFFFF;   // resume index: the lane takes part in node i iff r <= i
-    int i = 0;
-    // (fetching node i+1 ahead of the decision was tried and is slower: 1.47 vs 1.14 ms at 1 M bodies)
+    int i = 0;                        // wave-uniform
+    // (fetching node i+1 ahead of the decision was tried and is slower)
     while (i < n_nodes) {
-        i = __builtin_amdgcn_readfirstlane(i);
-        const bool active = r <= i;
-        if (__ballot(active) == 0ull) {          // every lane is parked beyond i: jump to the earliest resume point
-            int m = r;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const int o = __shfl_xor(m, off);
-                m = o < m ? o : m;
-            }
-            i = __builtin_amdgcn_readfirstlane(m);
-            continue;
-        }
-        // wave-uniform address: the whole 32-B record comes in one scalar load (s_load_dwordx8)
         typedef float f8 __attribute__((ext_vector_type(8)));
-        const f8 rec = *reinterpret_cast<const f8*>(&nodes[i]);
-        const float4 a = make_float4(rec[0], rec[1], rec[2], rec[3]);
-        const int2 b = make_int2(__float_as_int(rec[4]), __float_as_int(rec[5]));
-        bool open = false;
-        if (active) {
-            const float dx = a.x - pi.x;
-            const float dy = a.y - pi.y;
-            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-            const bool take = b.y ? (a.w < theta * __builtin_sqrtf(d2)) : !(a.x == pi.x && a.y == pi.y);
-            if (take) {
-                const float s = a.z * __builtin_amdgcn_rcpf(d2 + kEps);
-                ax = __builtin_fmaf(s, dx, ax);
-                ay = __builtin_fmaf(s, dy, ay);
-            }
-            open = b.y && !take;
-            if (!open) r = b.x;                  // done with this subtree
-        }
-        i = (__ballot(open) != 0ull) ? i + 1 : b.x;
+        const f8 rec = *reinterpret_cast<const f8*>(&nodes[(unsigned)__builtin_amdgcn_readfirstlane(i)]);
+        const float nx = rec[0], ny = rec[1], nm = rec[2];
+        const int skip = __float_as_int(rec[4]);
+        const float q = rec[6];
+        const float dx = nx - pi.x;
+        const float dy = ny - pi.y;
+        const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+        const bool take = (r <= i) && (q < th2 * d2);   // parked lanes (r > i) take nothing
+        const float s = take ? nm * __builtin_amdgcn_rcpf(d2 + kEps) : 0.0f;
+        ax = __builtin_fmaf(s, dx, ax);
+        ay = __builtin_fmaf(s, dy, ay);
+        r = take ? skip : r;                            // done with this subtree
+        // lanes still at or before i are the active ones that did not take the node: they want it opened
+        i = (__ballot(r <= i) != 0ull) ? i + 1 : skip;
     }
     if (valid) out[it] = make_float2(ax, ay);
 }
@@ -216,16 +209,17 @@ __global__ __launch_bounds__(kTile) void k_bh_count(const float4* __restrict__ p
     unsigned visits = 0, pairs = 0;
     if (it < n_targets) {
         const float4 pi = posm[lo + it];
+        const float th2 = theta > 0.0f ? theta * theta : 0.0f;
         int i = 0;
         while (i < n_nodes) {
             const float4 a = *reinterpret_cast<const float4*>(&nodes[i]);
-            const int2 b = *reinterpret_cast<const int2*>(&nodes[i].skip);
+            const float4 c = *reinterpret_cast<const float4*>(&nodes[i].skip);
             const float dx = a.x - pi.x, dy = a.y - pi.y;
             const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-            const bool take = b.y ? (a.w < theta * __builtin_sqrtf(d2)) : !(a.x == pi.x && a.y == pi.y);
+            const bool take = c.z < th2 * d2;
             visits++;
             pairs += take ? 1u : 0u;
-            i = (b.y && !take) ? i + 1 : b.x;
+            i = take ? __float_as_int(c.x) : i + 1;
         }
     }
     unsigned long long v = visits, q = pairs;
@@ -258,8 +252,8 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
         hipLaunchKernelGGL(k_bh_eval_strict, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
                            force_out);
     else if (mode == 2 && perm)
-        hipLaunchKernelGGL(k_bh_eval_fast_wave, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
-                           force_out, perm);
+        hipLaunchKernelGGL(k_bh_eval_fast_wave, dim3((n_targets + kWaveBlock - 1) / kWaveBlock), dim3(kWaveBlock), 0, stream,
+                           posm, lo, n_targets, nodes, n_nodes, theta, force_out, perm);
     else
         hipLaunchKernelGGL(k_bh_eval_fast, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
                            force_out, perm);

@@ -536,7 +536,7 @@ static void flatten_subtree(const std::vector<QuadTree::Node>& nodes, int root, 
         const QuadTree::Node& nd = nodes[k];
         BhNode b;
         b.px = nd.px; b.py = nd.py; b.m = nd.m; b.s = nd.x2 - nd.x1;   // s = x-extent, nbody.rs:341
-        b.skip = 0; b.interior = nd.first_child >= 0 ? 1 : 0; b.pad0 = 0; b.pad1 = 0;
+        b.skip = 0; b.interior = nd.first_child >= 0 ? 1 : 0; b.q = bh_node_q(b.s, b.interior != 0); b.pad1 = 0;
         out.push_back(b);
         return (int)out.size() - 1;
     };
@@ -568,7 +568,7 @@ static void flatten_subtree_into(const std::vector<QuadTree::Node>& nodes, int r
         const QuadTree::Node& nd = nodes[k];
         BhNode b;
         b.px = nd.px; b.py = nd.py; b.m = nd.m; b.s = nd.x2 - nd.x1;
-        b.skip = 0; b.interior = nd.first_child >= 0 ? 1 : 0; b.pad0 = 0; b.pad1 = 0;
+        b.skip = 0; b.interior = nd.first_child >= 0 ? 1 : 0; b.q = bh_node_q(b.s, b.interior != 0); b.pad1 = 0;
         out[count] = b;
         return count++;
     };
@@ -686,7 +686,7 @@ void QuadTree::flatten_write(const FlatPlan& plan, BhNode* out) const
                 const Node& nd = nodes[it.node];
                 BhNode b;
                 b.px = nd.px; b.py = nd.py; b.m = nd.m; b.s = nd.x2 - nd.x1;
-                b.interior = nd.first_child >= 0 ? 1 : 0; b.pad0 = 0; b.pad1 = 0;
+                b.interior = nd.first_child >= 0 ? 1 : 0; b.q = bh_node_q(b.s, b.interior != 0); b.pad1 = 0;
                 b.skip = (int)(it.end_item < ni ? plan.items[it.end_item].offset : plan.total);
                 out[it.offset] = b;
             } else {

@@ -13,8 +13,11 @@ struct BhNode {
     float px, py, m, s;      // COM / particle position, mass, x-extent (x2-x1; nbody.rs:341)
     int32_t skip;            // index of the next node when this subtree is not opened
     int32_t interior;        // 1 = has children (nbody.rs:338), 0 = exterior (leaf)
-    int32_t pad0, pad1;
+    float q;                 // opening threshold of the fast walks: s*s for an interior node, -1 for a leaf, so that
+                             // "q < theta^2 * d^2" is the MAC for interior nodes and always true for leaves
+    int32_t pad1;
 };
+inline __host__ __device__ float bh_node_q(float s, bool interior) { return interior ? s * s : -1.0f; }
 
 struct ForceLaunch {
     int grid, block, jsplit, bpt, dim, variant;

@@ -405,7 +405,7 @@ class NBodyEngine:
     def bh_flat_dump(self, threaded=False):
         """Flattened tree as a structured array (px, py, m, s, skip, interior)."""
         dt = np.dtype([("px", "<f4"), ("py", "<f4"), ("m", "<f4"), ("s", "<f4"), ("skip", "<i4"), ("interior", "<i4"),
-                       ("pad0", "<i4"), ("pad1", "<i4")])
+                       ("q", "<f4"), ("pad1", "<i4")])
         mode = 2 if threaded == "device" else int(bool(threaded))
         cnt = _check(self._L.nbx_bh_flat_dump(self._h, None, 0, mode))
         rows = np.zeros(max(cnt, 1), dt)
