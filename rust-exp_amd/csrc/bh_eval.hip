@@ -234,6 +234,26 @@ __global__ __launch_bounds__(kTile) void k_bh_count(const float4* __restrict__ p
     }
 }
 
+// (x, y) of every body as two planar arrays, written straight into pinned host memory (zero-copy, coalesced 256-B
+// segments): all the host quadtree build needs from the device each step -- 8 of the 16 bytes per body, no host-side
+// de-interleave.
+__global__ __launch_bounds__(kTile) void k_split_xy(const float4* __restrict__ posm, const int n, float* __restrict__ xs,
+                                                    float* __restrict__ ys)
+{
+    const int i = blockIdx.x * kTile + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = posm[i];
+    xs[i] = p.x;
+    ys[i] = p.y;
+}
+
+hipError_t launch_split_xy(const float4* posm, int n, float* xs_host_pinned, float* ys_host_pinned, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_split_xy, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, n, xs_host_pinned, ys_host_pinned);
+    return hipGetLastError();
+}
+
 hipError_t launch_bh_count(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
                            unsigned long long* totals, hipStream_t stream)
 {

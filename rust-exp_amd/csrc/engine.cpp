@@ -287,10 +287,41 @@ int build_and_upload_tree(nbx_engine* e)
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = clk::now();
-    int rc = download_positions(e);
-    if (rc != NBX_OK) return rc;
+    int rc = NBX_OK;
+    const float *bx = e->host.px.data(), *by = e->host.py.data();
+    if (!e->host_pos_valid) {
+        // the build needs (x, y) only (masses never change): the device writes them as planar arrays into pinned host
+        // memory; the full host mirror is refreshed lazily by whoever asks for it (get_particles, host draw, ...)
+        if ((size_t)e->n > e->h_xy_cap) {
+            if (e->h_xy) HIP_TRY(hipHostFree(e->h_xy));
+            e->h_xy = nullptr;
+            e->h_xy_cap = 0;
+            const size_t want = std::max<size_t>((size_t)e->n + (size_t)e->n / 8, 1024);
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_xy), sizeof(float) * 2 * want, hipHostMallocDefault));
+            e->h_xy_cap = want;
+        }
+        HIP_TRY(nbx::launch_split_xy(e->d_posm, e->n, e->h_xy, e->h_xy + e->h_xy_cap, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        // into the (cacheable) host mirror: the build makes several scattered passes over the positions, which is
+        // slow straight out of the pinned, device-visible allocation
+        const float* sx = e->h_xy;
+        const float* sy = e->h_xy + e->h_xy_cap;
+        float* dx = e->host.px.data();
+        float* dy = e->host.py.data();
+        const size_t n = (size_t)e->n;
+        if (n >= 262144) {
+            std::thread t1([&] { std::memcpy(dx + n / 2, sx + n / 2, sizeof(float) * (n - n / 2)); });
+            std::thread t2([&] { std::memcpy(dy, sy, sizeof(float) * (n / 2)); });
+            std::thread t3([&] { std::memcpy(dy + n / 2, sy + n / 2, sizeof(float) * (n - n / 2)); });
+            std::memcpy(dx, sx, sizeof(float) * (n / 2));
+            t1.join(); t2.join(); t3.join();
+        } else {
+            std::memcpy(dx, sx, sizeof(float) * n);
+            std::memcpy(dy, sy, sizeof(float) * n);
+        }
+    }
     const auto t1 = clk::now();
-    rc = e->tree.build(e->host.px.data(), e->host.py.data(), e->host.m.data(), e->n);
+    rc = e->tree.build(bx, by, e->host.m.data(), e->n);
     if (rc == NBX_ERR_TREE_DEPTH) return fail(rc, "quadtree depth > 50 (the reference panics here, nbody.rs:230-232)");
     if (rc != NBX_OK) return fail(rc, "quadtree build hit a reference assert (nbody.rs:267/:293/:304)");
     const auto t2 = clk::now();
@@ -310,18 +341,24 @@ int build_and_upload_tree(nbx_engine* e)
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_nodes), sizeof(nbx::BhNode) * want, hipHostMallocDefault));
         e->h_nodes_cap = want;
     }
-    if (big)
-        e->tree.flatten_write(e->plan, e->h_nodes);
-    else if (count)
-        std::memcpy(e->h_nodes, e->flat_small.data(), sizeof(nbx::BhNode) * count);
-    e->n_flat = count;
-    const auto t3 = clk::now();
     rc = grow(&e->d_nodes, &e->nodes_cap, std::max<size_t>(count, 1));
     if (rc != NBX_OK) return rc;
-    if (count) {
-        HIP_TRY(hipMemcpyAsync(e->d_nodes, e->h_nodes, sizeof(nbx::BhNode) * count, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));  // the staging buffer is rewritten next step
+    hipError_t copy_err = hipSuccess;
+    if (big) {
+        // the host-to-device copy of every finished prefix of the array starts while the rest is still being written
+        e->tree.flatten_write(e->plan, e->h_nodes, [&](size_t a, size_t b) {
+            const hipError_t ce = hipMemcpyAsync(e->d_nodes + a, e->h_nodes + a, sizeof(nbx::BhNode) * (b - a),
+                                                 hipMemcpyHostToDevice, e->stream);
+            if (ce != hipSuccess && copy_err == hipSuccess) copy_err = ce;
+        });
+    } else if (count) {
+        std::memcpy(e->h_nodes, e->flat_small.data(), sizeof(nbx::BhNode) * count);
+        copy_err = hipMemcpyAsync(e->d_nodes, e->h_nodes, sizeof(nbx::BhNode) * count, hipMemcpyHostToDevice, e->stream);
     }
+    e->n_flat = count;
+    const auto t3 = clk::now();
+    HIP_TRY(copy_err);
+    if (count) HIP_TRY(hipStreamSynchronize(e->stream));  // the staging buffer is rewritten next step
     const auto t4 = clk::now();
     e->host_ms[0] += ms(t0, t1); e->host_ms[1] += ms(t1, t2); e->host_ms[2] += ms(t2, t3); e->host_ms[3] += ms(t3, t4);
     e->host_steps++;
@@ -452,6 +489,7 @@ void free_device(nbx_engine* e)
     if (e->d_posh && !e->posh_external) (void)hipFree(e->d_posh);
     if (e->h_nodes) (void)hipHostFree(e->h_nodes);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
+    if (e->h_xy) (void)hipHostFree(e->h_xy);
     if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
 }
 

@@ -83,6 +83,8 @@ struct nbx_engine {
     size_t n_flat = 0;
     float4* h_stage = nullptr;        // pinned host staging for position downloads
     size_t h_stage_cap = 0;
+    float* h_xy = nullptr;            // pinned, device-visible: planar x[cap], y[cap] for the host tree build
+    size_t h_xy_cap = 0;
 
     std::vector<ProfRec> prof;
     nbx::ForceLaunch last{0, 0, 0, 0, 0, 0};

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <thread>
 
 #include "../../include/nbody_mi355x.h"
@@ -581,6 +582,18 @@ static void flatten_subtree_into(const std::vector<QuadTree::Node>& nodes, int r
             sp--;
             continue;
         }
+        if (f.next_child == 0) {
+            // the pool is in creation order, the walk is depth-first: every children block (4 nodes = 2 cache
+            // lines) is a likely miss. Ask for the four grandchildren blocks now; all but the first are only
+            // needed after whole subtrees have been written.
+            for (int g = 0; g < 4; g++) {
+                const int gc = nodes[nd.first_child + g].first_child;
+                if (gc >= 0) {
+                    __builtin_prefetch(&nodes[gc]);
+                    __builtin_prefetch(&nodes[gc + 2]);
+                }
+            }
+        }
         const int c = nd.first_child + f.next_child++;
         const QuadTree::Node& ch = nodes[c];
         if (ch.first_child < 0 && ch.m == 0.0f) continue;
@@ -673,10 +686,18 @@ size_t QuadTree::flatten_prepare(FlatPlan& plan) const
     return off;
 }
 
-void QuadTree::flatten_write(const FlatPlan& plan, BhNode* out) const
+void QuadTree::flatten_write(const FlatPlan& plan, BhNode* out, const std::function<void(size_t, size_t)>& chunk_done,
+                             size_t chunk_nodes) const
 {
     const int ni = (int)plan.items.size();
     std::atomic<int> next{0};
+    // items finish out of order; done[] lets the calling thread find the finished PREFIX of the array and hand it to
+    // chunk_done (the engine starts the host-to-device copy of that range while the rest is still being written)
+    std::unique_ptr<std::atomic<unsigned char>[]> done;
+    if (chunk_done) {
+        done.reset(new std::atomic<unsigned char>[(size_t)ni]);
+        for (int i = 0; i < ni; i++) done[(size_t)i].store(0, std::memory_order_relaxed);
+    }
     auto work = [&]() {
         for (;;) {
             const int i = next.fetch_add(1);
@@ -692,12 +713,32 @@ void QuadTree::flatten_write(const FlatPlan& plan, BhNode* out) const
             } else {
                 flatten_subtree_into(pools[it.piece], 0, out + it.offset, (int)it.offset);
             }
+            if (done) done[(size_t)i].store(1, std::memory_order_release);
         }
     };
     const int nt = std::max(1, std::min(host_threads(), ni));
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work);
-    work();
+    if (!chunk_done) {
+        for (int t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+        return;
+    }
+    for (int t = 0; t < std::max(1, nt - 1); t++) th.emplace_back(work);
+    int w = 0;            // items [0, w) are finished
+    size_t sent = 0;      // nodes [0, sent) were handed over
+    while (w < ni) {
+        if (!done[(size_t)w].load(std::memory_order_acquire)) {
+            std::this_thread::sleep_for(std::chrono::microseconds(50));   // not a worker: do not burn the CPU quota
+            continue;
+        }
+        while (w < ni && done[(size_t)w].load(std::memory_order_acquire)) w++;
+        const size_t upto = w < ni ? plan.items[(size_t)w].offset : plan.total;
+        if (upto - sent >= chunk_nodes || w == ni) {
+            if (upto > sent) chunk_done(sent, upto);
+            sent = upto;
+        }
+    }
     for (auto& t : th) t.join();
 }
 

@@ -4,6 +4,7 @@
 // Internal header; the public ABI is include/nbody_mi355x.h.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "kernels.h"
@@ -69,7 +70,10 @@ struct QuadTree {
         size_t total = 0;
     };
     size_t flatten_prepare(FlatPlan& plan) const;
-    void flatten_write(const FlatPlan& plan, BhNode* out) const;
+    // chunk_done (optional): called on the calling thread with [first, last) node ranges of `out` as soon as a
+    // prefix of at least chunk_nodes more nodes is complete (the ranges tile [0, total) in order)
+    void flatten_write(const FlatPlan& plan, BhNode* out, const std::function<void(size_t, size_t)>& chunk_done = {},
+                       size_t chunk_nodes = 262144) const;
 };
 
 }  // namespace nbx

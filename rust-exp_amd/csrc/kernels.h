@@ -61,6 +61,9 @@ hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel,
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
                           int mode, float2* force_out, hipStream_t stream, const unsigned* perm = nullptr);
 
+// planar (x, y) of posm[0..n) into device-visible pinned host arrays (input of the host quadtree build)
+hipError_t launch_split_xy(const float4* posm, int n, float* xs_host_pinned, float* ys_host_pinned, hipStream_t stream);
+
 hipError_t launch_bh_count(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
                            unsigned long long* totals, hipStream_t stream);
 
