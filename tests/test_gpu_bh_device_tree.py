@@ -165,3 +165,63 @@ def test_wave_uniform_walk_is_bit_identical_to_the_per_lane_walk(rx, ob, n, thet
         res.append((fx, fy, st["px"], st["vx"]))
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("case", ["identical", "collinear_x", "collinear_y", "two_clusters_far_apart", "three"])
+def test_device_tree_degenerate_inputs(rx, ob, case):
+    """Zero-extent boxes, 31-level chains and bodies that share a key: the scan-based build must stay finite, keep the
+    pre-order invariants (skip pointers nest, the root spans the array, root mass = total mass) and agree with
+    all-pairs where the approximation is exact (theta -> tiny)."""
+    rng = np.random.default_rng(11)
+    if case == "identical":
+        n = 300
+        x = np.full(n, 1.25, np.float32); y = np.full(n, -3.5, np.float32)
+    elif case == "collinear_x":
+        n = 2000
+        x = rng.uniform(-30, 30, n).astype(np.float32); y = np.full(n, 2.0, np.float32)
+    elif case == "collinear_y":
+        n = 2000
+        x = np.full(n, -7.0, np.float32); y = rng.uniform(-30, 30, n).astype(np.float32)
+    elif case == "two_clusters_far_apart":
+        n = 4000
+        x = np.concatenate([rng.normal(-40, 1e-3, n // 2), rng.normal(40, 1e-3, n // 2)]).astype(np.float32)
+        y = np.concatenate([rng.normal(0, 1e-3, n // 2), rng.normal(0, 1e-3, n // 2)]).astype(np.float32)
+    else:
+        n = 3
+        x = np.array([0.0, 1.0, 1.0], np.float32); y = np.array([0.0, 0.0, 1.0], np.float32)
+    m = rng.uniform(0.5, 2.0, n).astype(np.float32)
+    p = ob.particles(x, y, np.zeros(n), np.zeros(n), m)
+    e = engines(rx, p)
+    e.set_bh_tree("device")
+    dev = e.bh_flat_dump("device")
+    k = len(dev)
+    assert dev["skip"][0] == k
+    assert np.all(dev["skip"] > np.arange(k)) and np.all(dev["skip"] <= k)
+    inner = dev["interior"] == 1
+    # children start right after an interior node and every subtree ends inside its parent's span
+    assert np.all(dev["skip"][np.flatnonzero(inner) + 1] <= dev["skip"][inner])
+    assert abs(float(dev["m"][0]) - float(m.astype(np.float64).sum())) <= 1e-5 * float(m.sum())
+    assert np.array_equal(dev["q"][inner], dev["s"][inner] * dev["s"][inner]) and np.all(dev["q"][~inner] == -1.0)
+    bx, by, _ = e.forces(1e-3)
+    assert np.isfinite(bx).all() and np.isfinite(by).all()
+    # against the host (= reference) tree through the same traversal. Two reference quirks show up here and must be
+    # shared, not "fixed": coincident bodies sit in one leaf whose running-fold centre of mass (nbody.rs:315-318) lands
+    # an ulp off their position, so each feels a spurious m*M*ulp/EPS pull; and the opening test uses the x-extent
+    # only (nbody.rs:341), so a vertical line of bodies (s = 0 everywhere) accepts the root for everyone.
+    h = engines(rx, p)
+    hx, hy, _ = h.forces(1e-3)
+    scale = max(np.abs(hx).max(), np.abs(hy).max(), 1e-6)
+    # 1e-3: the host's centres of mass carry the reference's running-fold drift (up to 6e-4 relative), the device's are
+    # exact means -- e.g. the vertical line keeps x = -7 exactly on the device (zero x-force) but not on the host
+    assert np.abs(bx - hx).max() <= 1e-3 * scale and np.abs(by - hy).max() <= 1e-3 * scale
+    if case == "identical":
+        host = h.bh_flat_dump(False)
+        assert np.array_equal(host[-1:]["px"].view(np.uint32), dev[-1:]["px"].view(np.uint32))
+        assert np.array_equal(host[-1:]["m"].view(np.uint32), dev[-1:]["m"].view(np.uint32))
+    if case in ("collinear_x", "two_clusters_far_apart", "three"):
+        fx, fy, _ = e.forces(0.0)     # theta -> 0 opens everything: all-pairs up to summation order
+        scale = max(np.abs(fx).max(), np.abs(fy).max(), 1e-6)
+        assert np.abs(bx - fx).max() <= 1e-4 * scale and np.abs(by - fy).max() <= 1e-4 * scale
+    e.step_barnes_hut(0.5, 0.01, 1)
+    st = e.get_particles()
+    assert np.isfinite(st["px"]).all() and np.isfinite(st["vx"]).all()
