@@ -224,7 +224,7 @@ def main():
             "roofline": {"bound": "valu_fp32", "bound_contract_class": "mfma (dense fp32 peak: the f32 MFMA rate equals the fp32 vector rate, "
                                                                   "157.3 TFLOP/s; no MFMA is used)", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "kernel": {0: "k_force_tile", 1: "k_force_tile_pk", 2: "k_force_smem", 3: "k_force_tile_pk", 4: "k_force_tile_pkb", 5: "k_force_smem_pk", 16: "k_force_tile_pk_h"}.get(launch["variant"], "k_force"), "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_cnt,
+                         "kernel": {0: "k_force_tile", 1: "k_force_tile_pk", 2: "k_force_smem", 3: "k_force_tile_pk", 4: "k_force_tile_pkb", 5: "k_force_smem_pk", 16: "k_force_tile_pk_h", -1: "k_force_strict<1>", -2: "k_force_strict<2>", -4: "k_force_strict<4>"}.get(launch["variant"], "k_force"), "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_cnt,
                          "flops_per_interaction": flops_per_inter,
                          "interactions_per_launch": inter_per_launch,
                          "hbm_algorithmic_bytes_per_launch": 16.0 * n + 16.0 * (hi - lo) * launch["jsplit"],

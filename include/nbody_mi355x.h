@@ -241,7 +241,9 @@ int32_t nbx_bh_host_timing(nbx_engine *e, double *ms4, int32_t *steps, int32_t *
 /* Work of one Barnes-Hut evaluation on the current state: tree nodes visited and pair laws evaluated, summed
  * over this engine's slab (for roofline accounting; runs a counting traversal, no state change). */
 int32_t nbx_bh_work(nbx_engine *e, float theta, uint64_t *node_visits, uint64_t *pair_evals);
-/* launch geometry the last force launch used (for DESIGN/bench reporting); any pointer may be NULL */
+/* launch geometry the last force launch used (for DESIGN/bench reporting); any pointer may be NULL.
+ * Bit-exact kernel: jsplit = 1 (the source loop is never split), bodies_per_thread = 1 and
+ * variant = -C, C = 1, 2 or 4 adjacent lanes sharing one target (terms in parallel, sums in order). */
 int32_t nbx_last_launch(const nbx_engine *e, int32_t *grid, int32_t *block, int32_t *jsplit,
                         int32_t *bodies_per_thread, int32_t *dim, int32_t *variant);
 

@@ -249,8 +249,7 @@ int step_brute(nbx_engine* e, float dt)
         if (rc != NBX_OK) return rc;
         {
             ProfScope ps(e, NBX_K_FORCE);
-            HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream));
-            e->last = nbx::ForceLaunch{(slab + kTile - 1) / kTile, kTile, 1, 1, 2, -1};
+            HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream, &e->last));
         }
         {
             ProfScope ps(e, NBX_K_INTEGRATE);

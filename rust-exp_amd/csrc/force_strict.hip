@@ -7,9 +7,9 @@
 // (the matching integrator, v += (dt*F)/m ; p += dt*v_new, is k_integrate_f2 in bh_eval.hip)
 // IEEE-754 binary32 throughout: `/` is the correctly rounded divide (hipcc default
 // -fhip-fp32-correctly-rounded-divide-sqrt), no FMA contraction, f32 denormals kept (gfx950
-// default float_denorm_mode_32 = 3).  One thread per target body walks ALL sources in ascending
+// default float_denorm_mode_32 = 3).  Every target's running sums advance over ALL sources in ascending
 // order (no j-split, no multi-accumulator unrolling), so the summation order is the reference's.
-// Sources are staged through LDS in 256-body tiles exactly like the fast kernel.
+// Sources are staged through LDS in 256-body tiles like the fast LDS kernels.
 #include "kernels.h"
 
 namespace nbx {
@@ -25,16 +25,60 @@ __device__ __forceinline__ void ref_force(float px1, float py1, float m1, float 
     fy = __fmul_rn(f, dy);
 }
 
+// One thread per body leaves the chip idle at the reference's own scales (N = 10 000 gives 157 waves for 1024 SIMDs) and
+// the summation order forbids splitting the j loop.  What CAN be shared is the work per TERM: C adjacent lanes (a pair
+// or a quad) serve one target, lane c evaluating force(i, j) for the sources j = k + c of every group of C, each term
+// with exactly the reference's operations.  The running sums are then advanced in ascending j by ALL lanes of the
+// group (they stay identical copies), each add taking its term straight from the owning lane through a DPP quad
+// permute (v_add_f32_dpp: no extra instruction, no LDS).  Same terms, same order, same bits -- with C times the waves.
+// C = 4 up to 65 536 targets per GPU, 2 up to 131 072, 1 (plain one-thread-per-body) beyond.
+// fx += tx(lane 0 of the group); fx += tx(lane 1); ...  -- IEEE v_add_f32 with the term fetched through the DPP operand
+// path.  Written as one asm block because the compiler would otherwise pair fx/fy into v_pk_add_f32 (which has no DPP
+// form) behind eight v_mov_b32_dpp.  s_nop 1: a VGPR written by a VALU instruction needs two wait states before a DPP
+// read; the hazard recognizer does not look inside inline asm.
+#define NBX_DPP_ADD(QP)                                                              \
+    "v_add_f32_dpp %0, %2, %0 quad_perm:" QP " row_mask:0xf bank_mask:0xf\n\t"       \
+    "v_add_f32_dpp %1, %3, %1 quad_perm:" QP " row_mask:0xf bank_mask:0xf\n\t"
+
+template <int C>
+__device__ __forceinline__ void add_group_terms(float& fx, float& fy, const float tx, const float ty)
+{
+    if (C == 1) {
+        fx = __fadd_rn(fx, tx);                                         // nbody.rs:141
+        fy = __fadd_rn(fy, ty);                                         // :142
+    } else if (C == 2) {
+        asm("s_nop 1\n\t" NBX_DPP_ADD("[0,0,2,2]") NBX_DPP_ADD("[1,1,3,3]") : "+v"(fx), "+v"(fy) : "v"(tx), "v"(ty));
+    } else {
+        asm("s_nop 1\n\t" NBX_DPP_ADD("[0,0,0,0]") NBX_DPP_ADD("[1,1,1,1]") NBX_DPP_ADD("[2,2,2,2]") NBX_DPP_ADD("[3,3,3,3]")
+            : "+v"(fx), "+v"(fy) : "v"(tx), "v"(ty));
+    }
+}
+#undef NBX_DPP_ADD
+
+template <int C, bool kCheck>
+__device__ __forceinline__ void strict_group(const float4 sj, const int j, const int i, const int n, const float4 pi,
+                                             float& fx, float& fy)
+{
+    float tx, ty;
+    ref_force(pi.x, pi.y, pi.w, sj.x, sj.y, sj.w, tx, ty);              // nbody.rs:140
+    if (kCheck && (j == i || j >= n)) { tx = 0.0f; ty = 0.0f; }         // :136; +0 leaves a sum that started at +0 unchanged
+    add_group_terms<C>(fx, fy, tx, ty);                                 // ascending j
+}
+
+template <int C>
 __global__ __launch_bounds__(kTile) void k_force_strict(const float4* __restrict__ posm, const int n, const int lo,
                                                         const int n_targets, float2* __restrict__ force_out)
 {
+    constexpr int kTargets = kTile / C;            // targets per workgroup
     __shared__ float4 tile[2][kTile];
     const int tid = threadIdx.x;
-    const int it = blockIdx.x * kTile + tid;       // target index within the slab
+    const int c = tid % C;                         // which source of every group of C this lane evaluates
+    const int it = blockIdx.x * kTargets + tid / C;            // target index within the slab
     const int i = lo + (it < n_targets ? it : n_targets - 1);  // global body index (clamped)
     const float4 pi = posm[i];
+    const int wg_first = lo + blockIdx.x * kTargets;           // this workgroup's targets: [wg_first, wg_first + kTargets)
     float fx = 0.0f, fy = 0.0f;                    // nbody.rs:130
-    const int tiles = (n + kTile - 1) / kTile;
+    const int tiles = (n + kTile - 1) / kTile;     // posm is padded with zero-mass records up to a multiple of kTile
     float4 nxt = posm[tid];
     int buf = 0;
     for (int t = 0; t < tiles; t++) {
@@ -42,26 +86,38 @@ __global__ __launch_bounds__(kTile) void k_force_strict(const float4* __restrict
         __syncthreads();
         if (t + 1 < tiles) nxt = posm[(size_t)(t + 1) * kTile + tid];
         const int jbase = t * kTile;
-        const int cnt = (n - jbase) < kTile ? (n - jbase) : kTile;  // never touch the zero-mass padding
-        for (int k = 0; k < cnt; k++) {
-            if (jbase + k == i) continue;          // nbody.rs:136
-            const float4 sj = tile[buf][k];
-            float fx_add, fy_add;
-            ref_force(pi.x, pi.y, pi.w, sj.x, sj.y, sj.w, fx_add, fy_add);  // :140
-            fx = __fadd_rn(fx, fx_add);            // :141
-            fy = __fadd_rn(fy, fy_add);            // :142
+        // the index test and the end-of-array test are only compiled into the tiles that need them (uniform per workgroup)
+        if (jbase + kTile <= n && (jbase + kTile <= wg_first || jbase >= wg_first + kTargets)) {
+#pragma unroll 4
+            for (int k = 0; k < kTile; k += C) strict_group<C, false>(tile[buf][k + c], jbase + k + c, i, n, pi, fx, fy);
+        } else {
+#pragma unroll 2
+            for (int k = 0; k < kTile; k += C) strict_group<C, true>(tile[buf][k + c], jbase + k + c, i, n, pi, fx, fy);
         }
         buf ^= 1;
     }
-    if (it < n_targets) force_out[it] = make_float2(fx, fy);
+    if (c == 0 && it < n_targets) force_out[it] = make_float2(fx, fy);
 }
 
+// group size by targets per GPU (measured, profiles/r01_strict_coop_sweep.txt): 4 lanes per target up to 40 960
+// targets, 2 up to 98 304, one thread per body beyond
+int strict_group_size(int n_targets) { return n_targets <= 40960 ? 4 : (n_targets <= 98304 ? 2 : 1); }
+
 hipError_t launch_force_strict(const float4* posm, int n, int lo, int n_targets, float2* force_out,
-                               hipStream_t stream)
+                               hipStream_t stream, ForceLaunch* info)
 {
     if (n_targets <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_force_strict, dim3((n_targets + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, n, lo,
-                       n_targets, force_out);
+    const int c = strict_group_size(n_targets);
+    const int per_wg = kTile / c;
+    const dim3 grid((n_targets + per_wg - 1) / per_wg);
+    if (c == 4)
+        hipLaunchKernelGGL(k_force_strict<4>, grid, dim3(kTile), 0, stream, posm, n, lo, n_targets, force_out);
+    else if (c == 2)
+        hipLaunchKernelGGL(k_force_strict<2>, grid, dim3(kTile), 0, stream, posm, n, lo, n_targets, force_out);
+    else
+        hipLaunchKernelGGL(k_force_strict<1>, grid, dim3(kTile), 0, stream, posm, n, lo, n_targets, force_out);
+    // jsplit = 1: the source loop is never split; variant = -(lanes that share one target)
+    if (info) *info = ForceLaunch{(int)grid.x, kTile, 1, 1, 2, -c};
     return hipGetLastError();
 }
 

@@ -47,8 +47,9 @@ hipError_t launch_reduce_forces(const float4* posm, int lo, int n_targets, const
                                 int acc_stride, float4* out, hipStream_t stream);
 
 // strict (bit-exact) pair: one thread per body, ascending j, IEEE divide, no contraction. 2-D.
+// 1, 2 or 4 adjacent lanes share one target (terms in parallel, sums in order); info->variant = -(group size).
 hipError_t launch_force_strict(const float4* posm, int n, int lo, int n_targets, float2* force_out,
-                               hipStream_t stream);
+                               hipStream_t stream, ForceLaunch* info = nullptr);
 // kick-drift from a per-body force (v += (dt*F)/m, nbody.rs:155) or acceleration (is_accel: v += dt*a),
 // optional velocity kill box (nbody.rs:466-471).
 hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel, const float2* force, float dt,
