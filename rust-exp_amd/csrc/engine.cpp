@@ -325,13 +325,8 @@ int build_and_upload_tree(nbx_engine* e)
     if (rc != NBX_OK) return fail(rc, "quadtree build hit a reference assert (nbody.rs:267/:293/:304)");
     const auto t2 = clk::now();
     const bool big = e->tree.forest;
-    size_t count;
-    if (big) {
-        count = e->tree.flatten_prepare(e->plan);
-    } else {
-        e->tree.flatten(e->flat_small);
-        count = e->flat_small.size();
-    }
+    // upper bound of the flattened size before it is known exactly (the sequential tree is written in one pass)
+    size_t count = big ? e->tree.flatten_prepare(e->plan) : e->tree.nodes.size();
     if (count > e->h_nodes_cap) {
         if (e->h_nodes) HIP_TRY(hipHostFree(e->h_nodes));
         e->h_nodes = nullptr;
@@ -340,6 +335,7 @@ int build_and_upload_tree(nbx_engine* e)
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_nodes), sizeof(nbx::BhNode) * want, hipHostMallocDefault));
         e->h_nodes_cap = want;
     }
+    if (!big) count = e->tree.flatten_into(e->h_nodes);
     rc = grow(&e->d_nodes, &e->nodes_cap, std::max<size_t>(count, 1));
     if (rc != NBX_OK) return rc;
     hipError_t copy_err = hipSuccess;
@@ -351,7 +347,6 @@ int build_and_upload_tree(nbx_engine* e)
             if (ce != hipSuccess && copy_err == hipSuccess) copy_err = ce;
         });
     } else if (count) {
-        std::memcpy(e->h_nodes, e->flat_small.data(), sizeof(nbx::BhNode) * count);
         copy_err = hipMemcpyAsync(e->d_nodes, e->h_nodes, sizeof(nbx::BhNode) * count, hipMemcpyHostToDevice, e->stream);
     }
     e->n_flat = count;

@@ -560,7 +560,7 @@ static void flatten_subtree(const std::vector<QuadTree::Node>& nodes, int root, 
 
 // same walk, written straight into `out` (which must hold the subtree's live-node count); skips are absolute:
 // `base` = position of the subtree root in the final array
-static void flatten_subtree_into(const std::vector<QuadTree::Node>& nodes, int root, BhNode* out, int base)
+static int flatten_subtree_into(const std::vector<QuadTree::Node>& nodes, int root, BhNode* out, int base)
 {
     struct Frame { int node; int slot; int next_child; };
     Frame st[128];   // depth <= 52 (the build rejects deeper trees)
@@ -600,6 +600,15 @@ static void flatten_subtree_into(const std::vector<QuadTree::Node>& nodes, int r
         const int slot = emit(c);
         st[sp++] = Frame{c, slot, 0};
     }
+    return count;
+}
+
+size_t QuadTree::flatten_into(BhNode* out) const
+{
+    if (forest || nodes.empty()) return 0;
+    const Node& root = nodes[0];
+    if (root.first_child < 0 && root.m == 0.0f) return 0;   // empty tree
+    return (size_t)flatten_subtree_into(nodes, 0, out, 0);
 }
 
 void QuadTree::flatten(std::vector<BhNode>& out) const

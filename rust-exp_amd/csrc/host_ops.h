@@ -61,6 +61,9 @@ struct QuadTree {
     int dump_preorder(float* rows, int cap) const;
     // pre-order with empty exterior nodes dropped + skip pointers, for the GPU traversal (serial)
     void flatten(std::vector<BhNode>& out) const;
+    // the same for a tree built sequentially (forest == false), straight into a caller buffer that holds at least
+    // nodes.size() records (e.g. pinned memory); returns the number of records written
+    size_t flatten_into(BhNode* out) const;
     // the same array produced by host threads straight into a caller buffer (e.g. pinned memory):
     // prepare() returns the node count, write() fills out[0..count)
     struct FlatPlan {
