@@ -212,7 +212,12 @@ int32_t nbx_step_local(nbx_engine *e, float dt);
  * one process per GPU (the unmodified Haskell caller: set NB_GPUS=<n>|all and the six nb_* symbols use it).
  * Same slab sharding and the same single exchange per step as above, but the all-gather is issued by the
  * library itself through RCCL (ncclCommInitAll; librccl is dlopen'ed on first use). devices may be NULL
- * (0..count-1). Per-engine calls (options, profiling, forces) remain available through nbx_group_engine. */
+ * (0..count-1). Per-engine calls (options, profiling, forces) remain available through nbx_group_engine.
+ * Barnes-Hut steps build the quadtree once per step for the whole group (host build: engine 0's copy, node
+ * array sent to every device; device build: all devices concurrently).
+ * NBX_GROUP_EXCHANGE=copy (environment, read at nbx_group_create): replace the RCCL all-gather by
+ * event-ordered hipMemcpyPeerAsync pulls -- no communicator, no librccl, and a device may then be listed more
+ * than once (several engines sharing one GPU: how the group logic is tested on a single-GPU box). */
 typedef struct nbx_group nbx_group;
 int32_t nbx_group_create(nbx_group **out, const int32_t *devices, int32_t count);
 void nbx_group_destroy(nbx_group *g);

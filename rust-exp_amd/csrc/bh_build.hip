@@ -419,16 +419,16 @@ hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size
     return hipGetLastError();
 }
 
-// Builds the flattened tree for posm[0..n) into `out` (capacity node_cap records). Returns the node count in
-// *n_nodes_host (read back through the pinned host_counters; the function waits for the stream once, at its end) and
-// the sorted body order in *perm_dev (device pointer inside the workspace: body handled by thread t = perm[t]).
-// *status = 1 when the tree needs more than node_cap nodes (nothing usable was written).
-hipError_t device_tree_build(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
-                             int* host_counters /* pinned, >= 4 ints */, int* n_nodes_host, const unsigned** perm_dev,
-                             int* status, hipStream_t stream)
+// Builds the flattened tree for posm[0..n) into `out` (capacity node_cap records), in two halves so that a host
+// driving several devices can start every build before it waits for any of them:
+//   begin: enqueues everything on `stream`, including the copy of the node count into the pinned host_counters;
+//          *perm_dev = the sorted body order (device pointer inside the workspace: thread t handles body perm[t])
+//   end:   waits for the stream; *n_nodes_host = node count; *status = 1 when the tree needs more than node_cap
+//          nodes (nothing usable was written)
+hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
+                                   int* host_counters /* pinned, >= 4 ints */, const unsigned** perm_dev, hipStream_t stream)
 {
-    *status = 0;
-    *n_nodes_host = 0;
+    *perm_dev = nullptr;
     if (n <= 0) return hipSuccess;
     size_t sort_tmp = 0;
     if (device_tree_workspace_bytes(n, node_cap, &sort_tmp) > workspace_bytes) return hipErrorInvalidValue;
@@ -445,11 +445,19 @@ hipError_t device_tree_build(const float4* posm, int n, void* workspace, size_t 
     hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kTile), 0, stream, k.sb, k.keys1, k.box, k.pre, n, node_cap, out);
     e = hipMemcpyAsync(host_counters, k.counters, sizeof(int), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;
-    e = hipStreamSynchronize(stream);
+    return hipGetLastError();
+}
+
+hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status, hipStream_t stream)
+{
+    *status = 0;
+    *n_nodes_host = 0;
+    if (n <= 0) return hipSuccess;
+    const hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return e;
     if (host_counters[0] > node_cap) { *status = 1; return hipSuccess; }   // node pool exhausted (pathological input)
     *n_nodes_host = host_counters[0];
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 }  // namespace nbx

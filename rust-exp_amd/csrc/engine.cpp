@@ -280,13 +280,16 @@ int step_brute(nbx_engine* e, float dt)
     return NBX_OK;
 }
 
-// host tree (reference-faithful) -> flatten -> device
-int build_and_upload_tree(nbx_engine* e)
+// host tree (reference-faithful) -> flatten -> device.  `also` (single-process multi-GPU group): further engines that
+// hold the same bodies on other devices and receive the same node array, so the tree is built once per step, not once
+// per device.
+int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also, int n_also)
 {
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = clk::now();
     int rc = NBX_OK;
+    HIP_TRY(hipSetDevice(e->device));
     const float *bx = e->host.px.data(), *by = e->host.py.data();
     if (!e->host_pos_valid) {
         // the build needs (x, y) only (masses never change): the device writes them as planar arrays into pinned host
@@ -332,39 +335,54 @@ int build_and_upload_tree(nbx_engine* e)
         e->h_nodes = nullptr;
         e->h_nodes_cap = 0;
         const size_t want = std::max<size_t>(count + count / 4, 1024);
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_nodes), sizeof(nbx::BhNode) * want, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_nodes), sizeof(nbx::BhNode) * want, hipHostMallocPortable));   // read by every device of a group
         e->h_nodes_cap = want;
     }
     if (!big) count = e->tree.flatten_into(e->h_nodes);
-    rc = grow(&e->d_nodes, &e->nodes_cap, std::max<size_t>(count, 1));
-    if (rc != NBX_OK) return rc;
+    std::vector<nbx_engine*> dst{e};
+    for (int i = 0; i < n_also; i++) dst.push_back(also[i]);
+    for (nbx_engine* d : dst) {
+        HIP_TRY(hipSetDevice(d->device));
+        rc = grow(&d->d_nodes, &d->nodes_cap, std::max<size_t>(count, 1));
+        if (rc != NBX_OK) return rc;
+    }
     hipError_t copy_err = hipSuccess;
+    auto send = [&](size_t a, size_t b) {
+        for (nbx_engine* d : dst) {
+            hipError_t ce = dst.size() > 1 ? hipSetDevice(d->device) : hipSuccess;
+            if (ce == hipSuccess)
+                ce = hipMemcpyAsync(d->d_nodes + a, e->h_nodes + a, sizeof(nbx::BhNode) * (b - a), hipMemcpyHostToDevice, d->stream);
+            if (ce != hipSuccess && copy_err == hipSuccess) copy_err = ce;
+        }
+    };
     if (big) {
         // the host-to-device copy of every finished prefix of the array starts while the rest is still being written
-        e->tree.flatten_write(e->plan, e->h_nodes, [&](size_t a, size_t b) {
-            const hipError_t ce = hipMemcpyAsync(e->d_nodes + a, e->h_nodes + a, sizeof(nbx::BhNode) * (b - a),
-                                                 hipMemcpyHostToDevice, e->stream);
-            if (ce != hipSuccess && copy_err == hipSuccess) copy_err = ce;
-        });
+        e->tree.flatten_write(e->plan, e->h_nodes, send);
     } else if (count) {
-        copy_err = hipMemcpyAsync(e->d_nodes, e->h_nodes, sizeof(nbx::BhNode) * count, hipMemcpyHostToDevice, e->stream);
+        send(0, count);
     }
-    e->n_flat = count;
+    for (nbx_engine* d : dst) d->n_flat = count;
     const auto t3 = clk::now();
     HIP_TRY(copy_err);
-    if (count) HIP_TRY(hipStreamSynchronize(e->stream));  // the staging buffer is rewritten next step
+    if (count)
+        for (nbx_engine* d : dst) {   // the staging buffer is rewritten next step
+            HIP_TRY(hipSetDevice(d->device));
+            HIP_TRY(hipStreamSynchronize(d->stream));
+        }
+    HIP_TRY(hipSetDevice(e->device));
     const auto t4 = clk::now();
     e->host_ms[0] += ms(t0, t1); e->host_ms[1] += ms(t1, t2); e->host_ms[2] += ms(t2, t3); e->host_ms[3] += ms(t3, t4);
     e->host_steps++;
     return NBX_OK;
 }
 
-// quadtree on the device (bh_build.hip); falls back to the host build when the node pool overflows
-int build_tree_on_device(nbx_engine* e, bool* done)
+// quadtree on the device (bh_build.hip), in two halves so that a group can start every device's build before it waits
+// for any: begin enqueues the build, end waits for it. *done = false when the node pool overflowed (the caller falls
+// back to the host build).
+int build_tree_on_device_begin(nbx_engine* e)
 {
-    using clk = std::chrono::steady_clock;
-    *done = false;
-    const auto t0 = clk::now();
+    HIP_TRY(hipSetDevice(e->device));
+    e->tree_t0 = std::chrono::steady_clock::now();
     const int node_cap = 4 * e->n + 1024;
     size_t sort_tmp = 0;
     const size_t need = nbx::device_tree_workspace_bytes(e->n, node_cap, &sort_tmp);
@@ -376,21 +394,38 @@ int build_tree_on_device(nbx_engine* e, bool* done)
         e->tree_ws_bytes = need;
     }
     if (!e->h_counters) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_counters), 64, hipHostMallocDefault));
-    int rc = grow(&e->d_nodes, &e->nodes_cap, (size_t)node_cap);
+    const int rc = grow(&e->d_nodes, &e->nodes_cap, (size_t)node_cap);
     if (rc != NBX_OK) return rc;
+    HIP_TRY(nbx::device_tree_build_begin(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes, e->h_counters,
+                                         &e->d_perm, e->stream));
+    return NBX_OK;
+}
+
+int build_tree_on_device_end(nbx_engine* e, bool* done)
+{
+    *done = false;
+    HIP_TRY(hipSetDevice(e->device));
+    const int node_cap = 4 * e->n + 1024;
     int n_nodes = 0, status = 0;
-    HIP_TRY(nbx::device_tree_build(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes, e->h_counters,
-                                   &n_nodes, &e->d_perm, &status, e->stream));
+    HIP_TRY(nbx::device_tree_build_end(e->n, node_cap, e->h_counters, &n_nodes, &status, e->stream));
     if (status != 0) {
         e->bh_fallbacks++;
         e->d_perm = nullptr;
         return NBX_OK;   // caller takes the host path
     }
     e->n_flat = (size_t)n_nodes;
-    e->host_ms[1] += std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+    e->host_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - e->tree_t0).count();
     e->host_steps++;
     *done = true;
     return NBX_OK;
+}
+
+int build_tree_on_device(nbx_engine* e, bool* done)
+{
+    *done = false;
+    const int rc = build_tree_on_device_begin(e);
+    if (rc != NBX_OK) return rc;
+    return build_tree_on_device_end(e, done);
 }
 
 // Morton permutation of the bodies on the device (for the traversal of a host-built tree)
@@ -409,37 +444,20 @@ int spatial_order(nbx_engine* e)
     return NBX_OK;
 }
 
-int step_bh(nbx_engine* e, float theta, float dt)
+// traversal + kick-drift of this engine's slab against the node array it holds (e->d_nodes, e->n_flat)
+int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm)
 {
-    int rc = upload(e);
-    if (rc != NBX_OK) return rc;
+    HIP_TRY(hipSetDevice(e->device));
     const int slab = e->slab();
-    if (e->n == 0) return NBX_OK;
-    bool on_device = false;
-    if (e->bh_tree_device && e->force_mode == 0) {
-        rc = build_tree_on_device(e, &on_device);
-        if (rc != NBX_OK) return rc;
-    }
-    bool have_perm = on_device;
-    if (!on_device) {
-        rc = build_and_upload_tree(e);
-        if (rc != NBX_OK) return rc;
-        // host tree, fast walk, big system on one GPU: a Morton order of the bodies (0.4 ms at 1 M) makes the walk
-        // wave-coherent and lets it take the wave-uniform form (4.4 -> 1.2 ms). Results are unaffected.
-        if (e->force_mode == 0 && e->world == 1 && e->bh_wave && e->n >= 65536) {
-            rc = spatial_order(e);
-            if (rc != NBX_OK) return rc;
-            have_perm = e->d_perm != nullptr;
-        }
-    }
     if (slab == 0) return NBX_OK;
-    rc = grow(&e->d_f2, &e->f2_cap, (size_t)slab);
+    int rc = grow(&e->d_f2, &e->f2_cap, (size_t)slab);
     if (rc != NBX_OK) return rc;
+    const unsigned* perm = (have_perm && e->world == 1) ? e->d_perm : nullptr;
+    const bool wave = e->force_mode == 0 && perm && e->bh_wave;
     {
         ProfScope ps(e, NBX_K_BH_EVAL);
-        const unsigned* perm = (have_perm && e->world == 1) ? e->d_perm : nullptr;
-        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta,
-                                    (e->force_mode == 0 && perm && e->bh_wave) ? 2 : e->force_mode, e->d_f2, e->stream, perm));
+        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, wave ? 2 : e->force_mode, e->d_f2,
+                                    e->stream, perm));
     }
     {
         ProfScope ps(e, NBX_K_INTEGRATE);
@@ -455,7 +473,68 @@ int step_bh(nbx_engine* e, float theta, float dt)
     if (log_enabled())
         std::fprintf(stderr, "[nbx] step_barnes_hut dev=%d n=%d slab=[%d,%d) theta=%g dt=%g mode=%s tree=%s nodes=%zu walk=%s\n", e->device, e->n,
                      e->lo, e->hi, (double)theta, (double)dt, e->force_mode ? "strict" : "fast", on_device ? "device" : "host", e->n_flat,
-                     (have_perm && e->world == 1 && e->force_mode == 0 && e->bh_wave) ? "wave" : "lane");
+                     wave ? "wave" : "lane");
+    return NBX_OK;
+}
+
+int step_bh(nbx_engine* e, float theta, float dt)
+{
+    int rc = upload(e);
+    if (rc != NBX_OK) return rc;
+    if (e->n == 0) return NBX_OK;
+    bool on_device = false;
+    if (e->bh_tree_device && e->force_mode == 0) {
+        rc = build_tree_on_device(e, &on_device);
+        if (rc != NBX_OK) return rc;
+    }
+    bool have_perm = on_device;
+    if (!on_device) {
+        rc = build_and_upload_tree(e);
+        if (rc != NBX_OK) return rc;
+        // host tree, fast walk, big system on one GPU: a Morton order of the bodies (0.4 ms at 1 M) makes the walk
+        // wave-coherent and lets it take the wave-uniform form (4.4 -> 0.64 ms). Results are unaffected.
+        if (e->force_mode == 0 && e->world == 1 && e->bh_wave && e->n >= 65536) {
+            rc = spatial_order(e);
+            if (rc != NBX_OK) return rc;
+            have_perm = e->d_perm != nullptr;
+        }
+    }
+    return bh_eval_and_integrate(e, theta, dt, on_device, have_perm);
+}
+
+// One Barnes-Hut step of a single-process group: every engine holds the same bodies (positions replicated by the
+// per-step all-gather), so the quadtree is built ONCE -- on the host from engine 0's copy and sent to every device, or
+// on every device concurrently (all builds are enqueued before any is waited for) -- and each engine evaluates its slab.
+int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt)
+{
+    if (count == 1) return step_bh(eng[0], theta, dt);
+    for (int d = 0; d < count; d++) {
+        const int rc = upload(eng[d]);
+        if (rc != NBX_OK) return rc;
+    }
+    nbx_engine* e0 = eng[0];
+    if (e0->n == 0) return NBX_OK;
+    bool on_device = e0->bh_tree_device && e0->force_mode == 0;
+    if (on_device) {
+        for (int d = 0; d < count; d++) {
+            const int rc = build_tree_on_device_begin(eng[d]);
+            if (rc != NBX_OK) return rc;
+        }
+        for (int d = 0; d < count; d++) {
+            bool done = false;
+            const int rc = build_tree_on_device_end(eng[d], &done);
+            if (rc != NBX_OK) return rc;
+            if (!done) on_device = false;   // same bodies, same tree: if one pool overflows, all do
+        }
+    }
+    if (!on_device) {
+        const int rc = build_and_upload_tree(e0, eng + 1, count - 1);
+        if (rc != NBX_OK) return rc;
+    }
+    for (int d = 0; d < count; d++) {
+        const int rc = bh_eval_and_integrate(eng[d], theta, dt, on_device, false);
+        if (rc != NBX_OK) return rc;
+    }
     return NBX_OK;
 }
 

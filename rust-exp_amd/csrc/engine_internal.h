@@ -88,6 +88,7 @@ struct nbx_engine {
 
     std::vector<ProfRec> prof;
     nbx::ForceLaunch last{0, 0, 0, 0, 0, 0};
+    std::chrono::steady_clock::time_point tree_t0;   // start of the device tree build in flight
     double host_ms[4] = {0, 0, 0, 0};  // Barnes-Hut host phases: download, build, flatten, upload (cumulative)
     int host_steps = 0;
 
@@ -99,6 +100,9 @@ struct nbx_group {
     std::vector<int> devices;
     std::vector<ncclComm_t> comms;
     int exchanges = 0;
+    bool copy_exchange = false;             // NBX_GROUP_EXCHANGE=copy: peer copies + events instead of RCCL
+    std::vector<hipEvent_t> ev_ready;       // per engine: its slab is updated
+    std::vector<hipEvent_t> ev_copied;      // per engine: it has pulled every other slab
 };
 
 namespace nbxi {
@@ -155,8 +159,12 @@ int download_velocities(nbx_engine* e);
 void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* variant, int* bpt, int* jsplit, int* dim);
 int launch_forces_fast(nbx_engine* e);
 int step_brute(nbx_engine* e, float dt);
-int build_and_upload_tree(nbx_engine* e);
+int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also = nullptr, int n_also = 0);
+int build_tree_on_device_begin(nbx_engine* e);
+int build_tree_on_device_end(nbx_engine* e, bool* done);
 int build_tree_on_device(nbx_engine* e, bool* done);
+int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm);
+int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt);
 int spatial_order(nbx_engine* e);
 int step_bh(nbx_engine* e, float theta, float dt);
 void free_device(nbx_engine* e);

@@ -71,15 +71,66 @@ int group_comms(nbx_group* g)
     return NBX_OK;
 }
 
+// The same exchange without RCCL (NBX_GROUP_EXCHANGE=copy): every engine pulls every other engine's slab with
+// hipMemcpyPeerAsync on its own stream, ordered by events -- a slab is read only after its owner's kick-drift
+// (ev_ready), and nobody starts the next step before everyone has pulled from it (ev_copied).  Works with or
+// without peer access, needs no communicator, and lets several engines share one device (how the group logic is
+// tested on a single-GPU box).
+int group_exchange_copy(nbx_group* g)
+{
+    const int G = (int)g->eng.size();
+    if (g->ev_ready.empty()) {
+        g->ev_ready.resize(G);
+        g->ev_copied.resize(G);
+        for (int d = 0; d < G; d++) {
+            HIP_TRY(hipSetDevice(g->eng[d]->device));
+            HIP_TRY(hipEventCreateWithFlags(&g->ev_ready[d], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&g->ev_copied[d], hipEventDisableTiming));
+        }
+    }
+    for (int d = 0; d < G; d++) {
+        HIP_TRY(hipSetDevice(g->eng[d]->device));
+        HIP_TRY(hipEventRecord(g->ev_ready[d], g->eng[d]->stream));
+    }
+    for (int d = 0; d < G; d++) {
+        nbx_engine* dst = g->eng[d];
+        HIP_TRY(hipSetDevice(dst->device));
+        for (int s = 0; s < G; s++) {
+            if (s == d) continue;
+            nbx_engine* src = g->eng[s];
+            if (src->slab() == 0) continue;
+            HIP_TRY(hipStreamWaitEvent(dst->stream, g->ev_ready[s], 0));
+            HIP_TRY(hipMemcpyPeerAsync(dst->d_posm + src->lo, dst->device, src->d_posm + src->lo, src->device,
+                                       sizeof(float4) * (size_t)src->slab(), dst->stream));
+        }
+        HIP_TRY(hipEventRecord(g->ev_copied[d], dst->stream));
+    }
+    for (int d = 0; d < G; d++) {
+        HIP_TRY(hipSetDevice(g->eng[d]->device));
+        for (int s = 0; s < G; s++)
+            if (s != d) HIP_TRY(hipStreamWaitEvent(g->eng[d]->stream, g->ev_copied[s], 0));
+    }
+    return NBX_OK;
+}
+
 // one all-gather of the (x,y,z,m) slabs: in place, sendbuff = recvbuff + lo (per device), same stream as the kernels
 int group_exchange(nbx_group* g)
 {
     const int G = (int)g->eng.size();
+    const int n = g->eng[0]->n;
+    if (n == 0) return NBX_OK;
+    if (g->copy_exchange) {
+        if (G > 1) {
+            const int rc = group_exchange_copy(g);
+            if (rc != NBX_OK) return rc;
+        }
+        for (nbx_engine* e : g->eng) e->host_pos_valid = false;
+        g->exchanges++;
+        return NBX_OK;
+    }
     int rc = group_comms(g);
     if (rc != NBX_OK) return rc;
     RcclApi* api = rccl_api();
-    const int n = g->eng[0]->n;
-    if (n == 0) return NBX_OK;
     RCCL_TRY(api, api->GroupStart());
     if (n % G == 0) {
         for (int d = 0; d < G; d++) {
@@ -112,10 +163,11 @@ int32_t nbx_group_create(nbx_group** out, const int32_t* devices, int32_t count)
     const int present = nbx_device_count();
     nbx_group* g = new (std::nothrow) nbx_group();
     if (!g) return fail(NBX_ERR_ALLOC, "out of memory");
+    if (const char* x = std::getenv("NBX_GROUP_EXCHANGE")) g->copy_exchange = std::strcmp(x, "copy") == 0;
     for (int i = 0; i < count; i++) {
         const int dev = devices ? devices[i] : i;
-        for (int j = 0; j < i; j++)
-            if (g->devices[j] == dev) { nbx_group_destroy(g); return fail(NBX_ERR_INVALID, "device %d listed twice", dev); }
+        for (int j = 0; j < i; j++)   // RCCL wants one rank per device; the copy exchange does not care
+            if (g->devices[j] == dev && !g->copy_exchange) { nbx_group_destroy(g); return fail(NBX_ERR_INVALID, "device %d listed twice", dev); }
         if (present > 0 && (dev < 0 || dev >= present)) { nbx_group_destroy(g); return fail(NBX_ERR_NO_DEVICE, "no device %d (%d present)", dev, present); }
         nbx_engine* e = nullptr;
         if (nbx_create(&e, dev) != NBX_OK) { nbx_group_destroy(g); return NBX_ERR_ALLOC; }
@@ -136,6 +188,8 @@ void nbx_group_destroy(nbx_group* g)
     if (!g->comms.empty())
         if (RcclApi* api = rccl_api())
             for (ncclComm_t c : g->comms) (void)api->CommDestroy(c);
+    for (hipEvent_t ev : g->ev_ready) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : g->ev_copied) (void)hipEventDestroy(ev);
     for (nbx_engine* e : g->eng) nbx_destroy(e);
     delete g;
 }
@@ -201,10 +255,9 @@ int32_t nbx_group_step_barnes_hut(nbx_group* g, float theta, float dt, int32_t n
     if (!g) return fail(NBX_ERR_INVALID, "null group");
     if (theta == 0.0f) return nbx_group_step_brute_force(g, dt);   // nbody.rs:197-200
     if (nthreads <= 0) return fail(NBX_ERR_INVALID, "nthreads must be >= 1");
-    for (nbx_engine* e : g->eng) {   // tree replica per device; each evaluates its slab
-        const int rc = step_bh(e, theta, dt);
-        if (rc != NBX_OK) return rc;
-    }
+    // tree replica per device, built once per step and shared; each device evaluates its slab
+    const int rc = step_bh_group(g->eng.data(), (int)g->eng.size(), theta, dt);
+    if (rc != NBX_OK) return rc;
     return group_exchange(g);
 }
 

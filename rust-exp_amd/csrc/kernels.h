@@ -72,9 +72,10 @@ hipError_t launch_bh_count(const float4* posm, int lo, int n_targets, const BhNo
 size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes);
 hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size_t workspace_bytes, const unsigned** perm_dev,
                                 hipStream_t stream);
-hipError_t device_tree_build(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
-                             int* host_counters, int* n_nodes_host, const unsigned** perm_dev, int* status,
-                             hipStream_t stream);
+hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
+                                   int* host_counters, const unsigned** perm_dev, hipStream_t stream);
+hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status,
+                                 hipStream_t stream);
 
 // nb_draw on the device: counts (uint2 per pixel: body hits, tail hits) -> ABGR framebuffer
 hipError_t launch_draw(const float4* posm, const float4* vel, int n, int w, int h, float x1, float y1, float scalex,

@@ -164,6 +164,50 @@ def test_single_process_group_of_one_gpu_matches_plain_engine(rx, ob):
     assert_bit_equal(g.get_particles()["px"], r["px"])
 
 
+@pytest.mark.parametrize("G,n", [(2, 8192), (3, 4099), (4, 40000)])
+def test_single_process_group_of_several_engines_on_one_gpu(rx, ob, monkeypatch, G, n):
+    """The whole multi-engine group logic on the one GPU of the test box: NBX_GROUP_EXCHANGE=copy replaces the RCCL
+    all-gather by event-ordered peer copies and lets the engines share a device.  Slab split (ragged for 4099), the
+    per-step exchange, ONE host quadtree shared by all engines, concurrent device builds: bit-equal to the plain engine
+    in the bit-exact mode; in the fast mode Barnes-Hut is bit-equal too (same tree, same per-body walk) and brute force
+    agrees to the tolerance of a different launch shape."""
+    from rust_exp_amd.engine import NBX_OPT_BH_TREE
+
+    monkeypatch.setenv("NBX_GROUP_EXCHANGE", "copy")
+    p = ob.stable_orbits(n, 0.5, 30.0, 70 + G)
+    for mode, tree in (("strict", 0), ("fast", 0), ("fast", 1)):
+        g = rx.NBodyGroup([0] * G, mode=mode)
+        assert g.size() == G
+        g.set_option(NBX_OPT_BH_TREE, tree)
+        g.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+        e = rx.NBodyEngine(mode=mode)
+        e.set_option(NBX_OPT_BH_TREE, tree)
+        e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+        for _ in range(3):
+            g.step_barnes_hut(0.6, 0.01, 1); e.step_barnes_hut(0.6, 0.01, 1)
+        g.synchronize()
+        a, b = g.get_particles(), e.get_particles()
+        for k in ("px", "py", "vx", "vy"):
+            assert_bit_equal(a[k], b[k], f"G={G} {mode} tree={tree} BH {k}")
+        for _ in range(2):
+            g.step_brute_force(0.01); e.step_brute_force(0.01)
+        g.step_barnes_hut(0.0, 0.01, 1); e.step_barnes_hut(0.0, 0.01, 1)     # theta = 0 delegates (nbody.rs:197-200)
+        g.synchronize()
+        assert g.exchanges() == 6
+        a, b = g.get_particles(), e.get_particles()
+        for k in ("px", "py", "vx", "vy"):
+            if mode == "strict":
+                assert_bit_equal(a[k], b[k], f"G={G} strict brute {k}")
+            else:
+                assert np.abs(a[k] - b[k]).max() <= (1e-5 if k[0] == "p" else 2e-3), k
+        assert np.array_equal(g.draw(96, 96), e.draw(96, 96)) or mode == "fast"
+        g.close()
+    # without the copy exchange a device may appear only once (RCCL wants one rank per device)
+    monkeypatch.delenv("NBX_GROUP_EXCHANGE")
+    with pytest.raises(rx.NBodyError):
+        rx.NBodyGroup([0, 0])
+
+
 WORKER2 = r"""
 import os, sys, json
 sys.path.insert(0, os.environ["NBX_ROOT"])
