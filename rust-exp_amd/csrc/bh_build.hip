@@ -26,6 +26,7 @@
 #include <cstring>   // rocPRIM's texture_cache_iterator.hpp calls memset() without including it
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
 
 #include "kernels.h"
 
@@ -416,6 +417,45 @@ hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size
     const hipError_t e = sort_bodies(posm, n, k, sort_tmp, stream);
     if (e != hipSuccess) return e;
     *perm_dev = k.idx1;
+    return hipGetLastError();
+}
+
+// The sorted body order restricted to one slab of targets [lo, hi) (multi-GPU: every device walks the same tree for
+// its own slab): the entries of `perm` that fall in the slab, relative order kept, so that the slab's bodies are
+// still handed to consecutive lanes in Morton order and the wave-uniform walk applies.
+namespace {
+struct InSlab {
+    unsigned lo, hi;
+    __device__ bool operator()(const unsigned v) const { return v >= lo && v < hi; }
+};
+}  // namespace
+
+size_t device_slab_order_workspace_bytes(int n)
+{
+    size_t tmp = 0;
+    (void)rocprim::select(nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (size_t)n, InSlab{0u, 0u},
+                          (hipStream_t)0);
+    return ((tmp + 255) & ~(size_t)255) + (((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255) + 256;
+}
+
+hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* workspace, size_t workspace_bytes,
+                             const unsigned** slab_perm, hipStream_t stream)
+{
+    *slab_perm = nullptr;
+    if (n <= 0 || hi <= lo) return hipSuccess;
+    if (device_slab_order_workspace_bytes(n) > workspace_bytes) return hipErrorInvalidValue;
+    size_t tmp = 0;
+    (void)rocprim::select(nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (size_t)n, InSlab{0u, 0u},
+                          (hipStream_t)0);
+    char* w = static_cast<char*>(workspace);
+    void* sel_tmp = w;
+    w += (tmp + 255) & ~(size_t)255;
+    unsigned* out = reinterpret_cast<unsigned*>(w);
+    w += ((size_t)n * sizeof(unsigned) + 255) & ~(size_t)255;
+    unsigned* count = reinterpret_cast<unsigned*>(w);
+    const hipError_t e = rocprim::select(sel_tmp, tmp, perm, out, count, (size_t)n, InSlab{(unsigned)lo, (unsigned)hi}, stream);
+    if (e != hipSuccess) return e;
+    *slab_perm = out;
     return hipGetLastError();
 }
 

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict
     if (t >= n_targets) return;
     // perm (optional): a spatial (Morton) order of the bodies, so the 64 lanes of a wave walk nearly the same
     // nodes; it only changes which thread handles which body, never a result
-    const int it = perm ? (int)perm[t] : t;
+    const int it = perm ? (int)perm[t] - lo : t;
     const float4 pi = posm[lo + it];
     const float th2 = theta > 0.0f ? theta * theta : 0.0f;
     float ax = 0.0f, ay = 0.0f;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* 
     const int t = blockIdx.x * kWaveBlock + threadIdx.x;
     const bool valid = t < n_targets;
     if (__ballot(valid) == 0ull) return;
-    const int it = valid ? (perm ? (int)perm[t] : t) : 0;
+    const int it = valid ? (perm ? (int)perm[t] - lo : t) : 0;
     const float4 pi = posm[lo + it];
     const float th2 = theta > 0.0f ? theta * theta : 0.0f;
     float ax = 0.0f, ay = 0.0f;

@@ -444,6 +444,23 @@ int spatial_order(nbx_engine* e)
     return NBX_OK;
 }
 
+// world > 1: the Morton order of the bodies (e->d_perm, all n of them) restricted to this engine's slab
+int slab_order(nbx_engine* e)
+{
+    e->d_slab_perm = nullptr;
+    if (!e->d_perm || e->slab() == 0) return NBX_OK;
+    const size_t need = nbx::device_slab_order_workspace_bytes(e->n);
+    if (need > e->slab_ws_bytes) {
+        if (e->d_slab_ws) HIP_TRY(hipFree(e->d_slab_ws));
+        e->d_slab_ws = nullptr;
+        e->slab_ws_bytes = 0;
+        HIP_TRY(hipMalloc(&e->d_slab_ws, need));
+        e->slab_ws_bytes = need;
+    }
+    HIP_TRY(nbx::device_slab_order(e->d_perm, e->n, e->lo, e->hi, e->d_slab_ws, e->slab_ws_bytes, &e->d_slab_perm, e->stream));
+    return NBX_OK;
+}
+
 // traversal + kick-drift of this engine's slab against the node array it holds (e->d_nodes, e->n_flat)
 int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm)
 {
@@ -452,8 +469,17 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
     if (slab == 0) return NBX_OK;
     int rc = grow(&e->d_f2, &e->f2_cap, (size_t)slab);
     if (rc != NBX_OK) return rc;
-    const unsigned* perm = (have_perm && e->world == 1) ? e->d_perm : nullptr;
-    const bool wave = e->force_mode == 0 && perm && e->bh_wave;
+    const unsigned* perm = nullptr;
+    if (have_perm && e->force_mode == 0 && e->bh_wave) {
+        if (e->world == 1) {
+            perm = e->d_perm;
+        } else {   // several GPUs share the bodies: this engine's part of the Morton order
+            rc = slab_order(e);
+            if (rc != NBX_OK) return rc;
+            perm = e->d_slab_perm;
+        }
+    }
+    const bool wave = perm != nullptr;
     {
         ProfScope ps(e, NBX_K_BH_EVAL);
         HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, wave ? 2 : e->force_mode, e->d_f2,
@@ -493,7 +519,7 @@ int step_bh(nbx_engine* e, float theta, float dt)
         if (rc != NBX_OK) return rc;
         // host tree, fast walk, big system on one GPU: a Morton order of the bodies (0.4 ms at 1 M) makes the walk
         // wave-coherent and lets it take the wave-uniform form (4.4 -> 0.64 ms). Results are unaffected.
-        if (e->force_mode == 0 && e->world == 1 && e->bh_wave && e->n >= 65536) {
+        if (e->force_mode == 0 && e->bh_wave && e->n >= 65536) {
             rc = spatial_order(e);
             if (rc != NBX_OK) return rc;
             have_perm = e->d_perm != nullptr;
@@ -532,7 +558,15 @@ int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt)
         if (rc != NBX_OK) return rc;
     }
     for (int d = 0; d < count; d++) {
-        const int rc = bh_eval_and_integrate(eng[d], theta, dt, on_device, false);
+        nbx_engine* e = eng[d];
+        bool have_perm = on_device;
+        if (!on_device && e->force_mode == 0 && e->bh_wave && e->n >= 65536) {   // as in step_bh: Morton order for the walk
+            HIP_TRY(hipSetDevice(e->device));
+            const int rc = spatial_order(e);
+            if (rc != NBX_OK) return rc;
+            have_perm = e->d_perm != nullptr;
+        }
+        const int rc = bh_eval_and_integrate(e, theta, dt, on_device, have_perm);
         if (rc != NBX_OK) return rc;
     }
     return NBX_OK;
@@ -556,6 +590,7 @@ void free_device(nbx_engine* e)
     if (e->d_nodes) (void)hipFree(e->d_nodes);
     if (e->d_guard) (void)hipFree(e->d_guard);
     if (e->d_tree_ws) (void)hipFree(e->d_tree_ws);
+    if (e->d_slab_ws) (void)hipFree(e->d_slab_ws);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_fb) (void)hipFree(e->d_fb);

@@ -55,6 +55,9 @@ struct nbx_engine {
     size_t tree_ws_bytes = 0;
     int* h_counters = nullptr;     // pinned: per-level node counters of the device build
     const unsigned* d_perm = nullptr;   // spatial body order produced by the device build
+    const unsigned* d_slab_perm = nullptr;  // d_perm restricted to this engine's slab (world > 1)
+    void* d_slab_ws = nullptr;
+    size_t slab_ws_bytes = 0;
     int bh_tree_device = 0;
     int bh_wave = 1;               // wave-uniform traversal when a spatial body order is available
     int bh_fallbacks = 0;          // device builds that fell back to the host (node pool exhausted)
@@ -166,6 +169,7 @@ int build_tree_on_device(nbx_engine* e, bool* done);
 int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm);
 int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt);
 int spatial_order(nbx_engine* e);
+int slab_order(nbx_engine* e);
 int step_bh(nbx_engine* e, float theta, float dt);
 void free_device(nbx_engine* e);
 uint64_t entropy_seed();

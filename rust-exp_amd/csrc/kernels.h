@@ -58,7 +58,8 @@ hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel,
 // K3: Barnes-Hut traversal. mode 0 = fast (sequential pre-order accumulation, rcp),
 // mode 1 = strict (hierarchical summation order of nbody.rs:354-360 via an explicit frame stack,
 // IEEE sqrt/divide): bit-exact with the reference traversal.
-// perm (fast mode only, optional): thread t evaluates body perm[t] (spatial order => coherent waves)
+// perm (fast mode only, optional): thread t evaluates body perm[t] -- a GLOBAL body index inside the slab
+// [lo, lo + n_targets) -- instead of body lo + t (spatial order => coherent waves); force_out is indexed by body - lo
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
                           int mode, float2* force_out, hipStream_t stream, const unsigned* perm = nullptr);
 
@@ -72,6 +73,10 @@ hipError_t launch_bh_count(const float4* posm, int lo, int n_targets, const BhNo
 size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes);
 hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size_t workspace_bytes, const unsigned** perm_dev,
                                 hipStream_t stream);
+// perm restricted to the bodies of one slab [lo, hi), order kept (global body indices); *slab_perm points into workspace
+size_t device_slab_order_workspace_bytes(int n);
+hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* workspace, size_t workspace_bytes,
+                             const unsigned** slab_perm, hipStream_t stream);
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters, const unsigned** perm_dev, hipStream_t stream);
 hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status,

@@ -164,7 +164,7 @@ def test_single_process_group_of_one_gpu_matches_plain_engine(rx, ob):
     assert_bit_equal(g.get_particles()["px"], r["px"])
 
 
-@pytest.mark.parametrize("G,n", [(2, 8192), (3, 4099), (4, 40000)])
+@pytest.mark.parametrize("G,n", [(2, 8192), (3, 4099), (4, 40000), (2, 70001)])
 def test_single_process_group_of_several_engines_on_one_gpu(rx, ob, monkeypatch, G, n):
     """The whole multi-engine group logic on the one GPU of the test box: NBX_GROUP_EXCHANGE=copy replaces the RCCL
     all-gather by event-ordered peer copies and lets the engines share a device.  Slab split (ragged for 4099), the
