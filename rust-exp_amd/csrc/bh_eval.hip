@@ -114,22 +114,30 @@ __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* 
 __global__ __launch_bounds__(kTile) void k_bh_eval_strict(const float4* __restrict__ posm, const int lo,
                                                           const int n_targets, const BhNode* __restrict__ nodes,
                                                           const int n_nodes, const float theta,
-                                                          float2* __restrict__ out)
+                                                          float2* __restrict__ out, const unsigned* __restrict__ perm)
 {
-    const int it = blockIdx.x * kTile + threadIdx.x;
-    if (it >= n_targets) return;
+    const int t = blockIdx.x * kTile + threadIdx.x;
+    if (t >= n_targets) return;
+    // perm (optional): Morton order of the bodies -- neighbouring lanes walk nearly the same nodes (coherent loads,
+    // little divergence). It only decides which thread evaluates which body: every body's result is unchanged.
+    const int it = perm ? (int)perm[t] - lo : t;
     const float4 pi = posm[lo + it];
-    // frame stack: partial sums of the enclosing opened nodes and where each subtree ends
+    const float th_lo = theta - fabsf(theta) * 1.0e-5f, th_hi = theta + fabsf(theta) * 1.0e-5f;
+    // frame stack: partial sums of the enclosing opened nodes and where each subtree ends.  The end of the innermost
+    // open subtree lives in a register (cur_end); the stack keeps the outer ones, so a node visit touches the stack
+    // (scratch memory) only when a node is opened or a subtree finishes.
     float sfx[kMaxFrames], sfy[kMaxFrames];
     int send[kMaxFrames];
     int sp = 0;
+    int cur_end = -1;             // no open frame
     float fx = 0.0f, fy = 0.0f;   // running sum of the innermost open frame (nbody.rs:336-337)
     int i = 0;
     for (;;) {
-        while (sp > 0 && i == send[sp - 1]) {   // subtree finished: return (fx,fy) to the parent's sum
+        while (i == cur_end) {    // subtree finished: return (fx,fy) to the parent's sum
             sp--;
             fx = __fadd_rn(sfx[sp], fx);        // nbody.rs:358  fx += fx_add
             fy = __fadd_rn(sfy[sp], fy);
+            cur_end = send[sp];
         }
         if (i >= n_nodes) break;
         const float4 a = *reinterpret_cast<const float4*>(&nodes[i]);
@@ -137,19 +145,33 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_strict(const float4* __restri
         if (b.y) {
             const float dx = __fsub_rn(a.x, pi.x);                               // :342
             const float dy = __fsub_rn(a.y, pi.y);                               // :343
-            // sqrtf, NOT __fsqrt_rn: the latter lowers to the 1-ulp native v_sqrt_f32; sqrtf is correctly
-            // rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt) like Rust's f32::sqrt
-            const float d = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));        // :344
-            if (a.w / d < theta) {                                               // :345
-                // force(px,py,m, self.px,self.py,self.m)  :348
-                const float ddx = __fsub_rn(a.x, pi.x), ddy = __fsub_rn(a.y, pi.y);
-                const float dist_sq = __fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy));
+            const float dist_sq = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+            // The reference's test is fl(s / fl(sqrt(dist_sq))) < theta (:344-345), two correctly rounded operations:
+            // within 1.2e-7 of the real s/sqrt(dist_sq).  s * rsq(dist_sq) is within 1.8e-7 of it, so whenever that
+            // estimate is further than 1e-5 (relative) from theta, both land on the same side and the exact sqrt and
+            // divide (~30 instructions) can be skipped without changing a single decision.  NaN (d = 0 with s = 0)
+            // fails both comparisons and takes the exact path.
+            const float est = a.w * __builtin_amdgcn_rsqf(dist_sq);
+            bool accept;
+            if (est < th_lo) {
+                accept = true;
+            } else if (est > th_hi) {
+                accept = false;
+            } else {
+                // sqrtf, NOT __fsqrt_rn: the latter lowers to the 1-ulp native v_sqrt_f32; sqrtf is correctly
+                // rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt) like Rust's f32::sqrt
+                const float d = sqrtf(dist_sq);                                  // :344
+                accept = a.w / d < theta;                                        // :345
+            }
+            if (accept) {
+                // force(px,py,m, self.px,self.py,self.m)  :348  (same dx, dy, dist_sq as above: same operations)
                 const float f = __fmul_rn(pi.w, a.z) / __fadd_rn(dist_sq, kEps);
-                fx = __fadd_rn(fx, __fmul_rn(f, ddx));
-                fy = __fadd_rn(fy, __fmul_rn(f, ddy));
+                fx = __fadd_rn(fx, __fmul_rn(f, dx));
+                fy = __fadd_rn(fy, __fmul_rn(f, dy));
                 i = b.x;
             } else if (sp < kMaxFrames) {
-                sfx[sp] = fx; sfy[sp] = fy; send[sp] = b.x; sp++;               // open: children sum from 0
+                sfx[sp] = fx; sfy[sp] = fy; send[sp] = cur_end; sp++;           // open: children sum from 0
+                cur_end = b.x;
                 fx = 0.0f; fy = 0.0f;
                 i = i + 1;
             } else {
@@ -270,7 +292,7 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
     const dim3 grid((n_targets + kTile - 1) / kTile);
     if (mode == 1)
         hipLaunchKernelGGL(k_bh_eval_strict, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
-                           force_out);
+                           force_out, perm);
     else if (mode == 2 && perm)
         hipLaunchKernelGGL(k_bh_eval_fast_wave, dim3((n_targets + kWaveBlock - 1) / kWaveBlock), dim3(kWaveBlock), 0, stream,
                            posm, lo, n_targets, nodes, n_nodes, theta, force_out, perm);

@@ -470,7 +470,7 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
     int rc = grow(&e->d_f2, &e->f2_cap, (size_t)slab);
     if (rc != NBX_OK) return rc;
     const unsigned* perm = nullptr;
-    if (have_perm && e->force_mode == 0 && e->bh_wave) {
+    if (have_perm && e->bh_wave) {
         if (e->world == 1) {
             perm = e->d_perm;
         } else {   // several GPUs share the bodies: this engine's part of the Morton order
@@ -479,7 +479,7 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
             perm = e->d_slab_perm;
         }
     }
-    const bool wave = perm != nullptr;
+    const bool wave = perm != nullptr && e->force_mode == 0;   // the bit-exact kernel takes the order, not the shared walk
     {
         ProfScope ps(e, NBX_K_BH_EVAL);
         HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, wave ? 2 : e->force_mode, e->d_f2,
@@ -519,7 +519,7 @@ int step_bh(nbx_engine* e, float theta, float dt)
         if (rc != NBX_OK) return rc;
         // host tree, fast walk, big system on one GPU: a Morton order of the bodies (0.4 ms at 1 M) makes the walk
         // wave-coherent and lets it take the wave-uniform form (4.4 -> 0.64 ms). Results are unaffected.
-        if (e->force_mode == 0 && e->bh_wave && e->n >= 65536) {
+        if (e->bh_wave && e->n >= 65536) {
             rc = spatial_order(e);
             if (rc != NBX_OK) return rc;
             have_perm = e->d_perm != nullptr;
@@ -560,7 +560,7 @@ int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt)
     for (int d = 0; d < count; d++) {
         nbx_engine* e = eng[d];
         bool have_perm = on_device;
-        if (!on_device && e->force_mode == 0 && e->bh_wave && e->n >= 65536) {   // as in step_bh: Morton order for the walk
+        if (!on_device && e->bh_wave && e->n >= 65536) {   // as in step_bh: Morton order for the walk
             HIP_TRY(hipSetDevice(e->device));
             const int rc = spatial_order(e);
             if (rc != NBX_OK) return rc;
