@@ -77,6 +77,18 @@ def cpu_baseline(st, seconds):
     }
 
 
+def cpu_baseline_barnes_hut(st, theta, dt, threads, reps):
+    """The CPU-baseline leg of the Barnes-Hut measurements (tools/bench_bh.py): the oracle's nb_step_barnes_hut
+    (nbody.rs:186-480: serial tree build + `threads` traversal workers) timed on the host cores. Median ms per step."""
+    from oracle import binding as ob
+
+    p = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    ts, rc = [], 0
+    for _ in range(reps):
+        t0 = time.perf_counter(); rc = ob.step_barnes_hut(p, theta, dt, threads); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e3, rc
+
+
 def _claim_stdout():
     """RCCL (and other C libraries) print banners to the C stdout ("RCCL version : ..." at communicator
     creation, flushed at exit). The contract is ONE JSON line on stdout, so keep a private handle to the real

@@ -96,11 +96,10 @@ def main():
         "visits_per_second": wk["node_visits"] / (kms * 1e-3)}
 
     if not os.environ.get("BH_NO_CPU"):
-        from oracle import binding as ob
+        import bench   # the CPU-baseline legs live in bench.py (the only non-test code that may run the oracle)
 
-        p1 = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
-        t0 = time.perf_counter(); rc = ob.step_barnes_hut(p1, 0.5, 0.01, 16); t1 = time.perf_counter()
-        out["bh_1m_cpu_oracle_16threads"] = {"ms_per_step": (t1 - t0) * 1e3, "rc": rc,
+        ms1, rc = bench.cpu_baseline_barnes_hut(st, 0.5, 0.01, 16, 1)
+        out["bh_1m_cpu_oracle_16threads"] = {"ms_per_step": ms1, "rc": rc,
                                              "note": "oracle restatement of nbody.rs:186-480, serial tree build + 16 traversal threads (the caller's maximum, hs:94-97)"}
     # the reference's published scenario
     e2 = rx.NBodyEngine(mode="fast")
@@ -114,16 +113,14 @@ def main():
     med2, _ = timed(step2, 30)
     out["bh_10k_gpu"] = {"bodies": 10000, "theta": 0.85, "ms_per_step_median_of_30": med2 * 1e3}
     if not os.environ.get("BH_NO_CPU"):
-        from oracle import binding as ob
+        import bench
 
-        p = ob.particles(s0["px"], s0["py"], s0["vx"], s0["vy"], s0["m"])
-        ob.step_barnes_hut(p, 0.85, 0.01, 1)
-        med3, _ = timed(lambda: ob.step_barnes_hut(p, 0.85, 0.01, 1), 30)
-        out["bh_10k_cpu_oracle_1thread"] = {"ms_per_step_median_of_30": med3 * 1e3,
+        med3, _ = bench.cpu_baseline_barnes_hut(s0, 0.85, 0.01, 1, 31)
+        out["bh_10k_cpu_oracle_1thread"] = {"ms_per_step_median_of_30": med3,
                                             "reference_published_ms": 30.75, "note": "screenshot.png, unknown 2016 Mac"}
-        cores = os.cpu_count()
-        med4, _ = timed(lambda: ob.step_barnes_hut(p, 0.85, 0.01, min(cores, 16)), 30)
-        out["bh_10k_cpu_oracle_16threads"] = {"ms_per_step_median_of_30": med4 * 1e3, "threads": min(cores, 16)}
+        threads = min(bench.effective_cores(), 16)
+        med4, _ = bench.cpu_baseline_barnes_hut(s0, 0.85, 0.01, threads, 31)
+        out["bh_10k_cpu_oracle_16threads"] = {"ms_per_step_median_of_30": med4, "threads": threads}
     print(json.dumps(out))
 
 

@@ -10,14 +10,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import rust_exp_amd as rx  # noqa: E402
-from oracle import binding as ob  # noqa: E402
 
 out = {}
 for n, theta in ((10000, 0.85), (100000, 0.85), (1048576, 0.5)):
-    p = ob.stable_orbits(n, 0.5, 30.0, 5) if n <= 100000 else None
-    st = rx.plummer_sphere(n, dim=2) if p is None else {k: p[k] for k in ("px", "py", "vx", "vy", "m")}
     e = rx.NBodyEngine(mode="strict")
-    e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    if n <= 100000:
+        e.seed(5); e.stable_orbits(n, 0.5, 30.0)     # the reference's default scene (hs:42), seeded
+    else:
+        st = rx.plummer_sphere(n, dim=2)
+        e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
     e.step_barnes_hut(theta, 0.01, 1); e.synchronize()
     e.profile(True); e.profile_reset(); e.bh_host_timing()
     ts = []
