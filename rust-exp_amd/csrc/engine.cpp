@@ -13,7 +13,6 @@
 //   f2    float2[slab]         forces (strict / Barnes-Hut paths).
 //   nodes BhNode[n_nodes]      flattened quadtree, rebuilt on the host every Barnes-Hut step.
 #include <random>
-#include <thread>
 
 #include "engine_internal.h"
 
@@ -144,11 +143,7 @@ int download_positions(nbx_engine* e)
     };
     if (e->n >= 262144) {   // AoS -> SoA of the host mirror on a few threads (3 ms -> <1 ms at 1 M bodies)
         const int parts = 8;
-        std::vector<std::thread> th;
-        for (int p = 1; p < parts; p++)
-            th.emplace_back(unpack, (int)((long long)e->n * p / parts), (int)((long long)e->n * (p + 1) / parts));
-        unpack(0, e->n / parts);
-        for (auto& x : th) x.join();
+        nbx::parallel_for(parts, [&](int p) { unpack((int)((long long)e->n * p / parts), (int)((long long)e->n * (p + 1) / parts)); });
     } else {
         unpack(0, e->n);
     }
@@ -283,7 +278,7 @@ int step_brute(nbx_engine* e, float dt)
 // host tree (reference-faithful) -> flatten -> device.  `also` (single-process multi-GPU group): further engines that
 // hold the same bodies on other devices and receive the same node array, so the tree is built once per step, not once
 // per device.
-int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also, int n_also)
+int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also, int n_also, bool order_bodies)
 {
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -303,7 +298,14 @@ int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also, int n_also)
             e->h_xy_cap = want;
         }
         HIP_TRY(nbx::launch_split_xy(e->d_posm, e->n, e->h_xy, e->h_xy + e->h_xy_cap, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (!e->ev_xy) HIP_TRY(hipEventCreateWithFlags(&e->ev_xy, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(e->ev_xy, e->stream));
+        if (order_bodies) {   // GPU work that overlaps the host build
+            rc = spatial_order(e);
+            if (rc != NBX_OK) return rc;
+            order_bodies = false;
+        }
+        HIP_TRY(hipEventSynchronize(e->ev_xy));
         // into the (cacheable) host mirror: the build makes several scattered passes over the positions, which is
         // slow straight out of the pinned, device-visible allocation
         const float* sx = e->h_xy;
@@ -312,15 +314,18 @@ int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also, int n_also)
         float* dy = e->host.py.data();
         const size_t n = (size_t)e->n;
         if (n >= 262144) {
-            std::thread t1([&] { std::memcpy(dx + n / 2, sx + n / 2, sizeof(float) * (n - n / 2)); });
-            std::thread t2([&] { std::memcpy(dy, sy, sizeof(float) * (n / 2)); });
-            std::thread t3([&] { std::memcpy(dy + n / 2, sy + n / 2, sizeof(float) * (n - n / 2)); });
-            std::memcpy(dx, sx, sizeof(float) * (n / 2));
-            t1.join(); t2.join(); t3.join();
+            nbx::parallel_for(4, [&](int q) {
+                const size_t a = (q & 1) ? n / 2 : 0, b = (q & 1) ? n : n / 2;
+                std::memcpy((q < 2 ? dx : dy) + a, (q < 2 ? sx : sy) + a, sizeof(float) * (b - a));
+            });
         } else {
             std::memcpy(dx, sx, sizeof(float) * n);
             std::memcpy(dy, sy, sizeof(float) * n);
         }
+    }
+    if (order_bodies) {
+        rc = spatial_order(e);
+        if (rc != NBX_OK) return rc;
     }
     const auto t1 = clk::now();
     rc = e->tree.build(bx, by, e->host.m.data(), e->n);
@@ -515,15 +520,13 @@ int step_bh(nbx_engine* e, float theta, float dt)
     }
     bool have_perm = on_device;
     if (!on_device) {
-        rc = build_and_upload_tree(e);
+        // host tree, big system: a Morton order of the bodies (0.4 ms at 1 M) makes the walk wave-coherent and lets the
+        // fast mode take the wave-uniform form (4.4 -> 0.64 ms). Results are unaffected. The sort only reads the
+        // positions: it is enqueued right after the (x, y) download, so the GPU does it while the host builds the tree.
+        const bool want_order = e->bh_wave && e->n >= 65536;
+        rc = build_and_upload_tree(e, nullptr, 0, want_order);
         if (rc != NBX_OK) return rc;
-        // host tree, fast walk, big system on one GPU: a Morton order of the bodies (0.4 ms at 1 M) makes the walk
-        // wave-coherent and lets it take the wave-uniform form (4.4 -> 0.64 ms). Results are unaffected.
-        if (e->bh_wave && e->n >= 65536) {
-            rc = spatial_order(e);
-            if (rc != NBX_OK) return rc;
-            have_perm = e->d_perm != nullptr;
-        }
+        have_perm = want_order && e->d_perm != nullptr;
     }
     return bh_eval_and_integrate(e, theta, dt, on_device, have_perm);
 }
@@ -598,6 +601,7 @@ void free_device(nbx_engine* e)
     if (e->h_nodes) (void)hipHostFree(e->h_nodes);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->h_xy) (void)hipHostFree(e->h_xy);
+    if (e->ev_xy) (void)hipEventDestroy(e->ev_xy);
     if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
 }
 

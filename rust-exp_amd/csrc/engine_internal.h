@@ -88,6 +88,7 @@ struct nbx_engine {
     size_t h_stage_cap = 0;
     float* h_xy = nullptr;            // pinned, device-visible: planar x[cap], y[cap] for the host tree build
     size_t h_xy_cap = 0;
+    hipEvent_t ev_xy = nullptr;       // the planar (x, y) download has landed
 
     std::vector<ProfRec> prof;
     nbx::ForceLaunch last{0, 0, 0, 0, 0, 0};
@@ -162,7 +163,7 @@ int download_velocities(nbx_engine* e);
 void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* variant, int* bpt, int* jsplit, int* dim);
 int launch_forces_fast(nbx_engine* e);
 int step_brute(nbx_engine* e, float dt);
-int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also = nullptr, int n_also = 0);
+int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also = nullptr, int n_also = 0, bool order_bodies = false);
 int build_tree_on_device_begin(nbx_engine* e);
 int build_tree_on_device_end(nbx_engine* e, bool* done);
 int build_tree_on_device(nbx_engine* e, bool* done);

@@ -10,13 +10,116 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
+
+#include <unistd.h>
 
 #include "../../include/nbody_mi355x.h"
 
 namespace nbx {
+
+int host_threads()
+{
+    if (const char* env = std::getenv("NBX_HOST_THREADS")) {
+        const int t = std::atoi(env);
+        if (t >= 1) return t < 256 ? t : 256;
+    }
+    // Up to 32 threads even under a smaller cgroup CPU quota: the build is a ~15 ms burst and a CFS quota is a
+    // budget per 100 ms period, so the burst may use more CPUs than the long-run average allows (measured on a
+    // 16-CPU quota: 32 threads 6 ms for the subtree phase, 16 threads 11 ms).
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(hw ? hw : 1, 32);
+}
+
+// ---- persistent worker pool ------------------------------------------------------------------------------------------
+class WorkerPool {
+public:
+    static WorkerPool& instance()
+    {
+        static WorkerPool* pool = new WorkerPool();   // never destroyed: workers may outlive static destructors
+        return *pool;
+    }
+    void submit(TaskGroup* g, std::function<void()> fn)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        ensure_workers(lk);
+        g->pending_++;
+        queue_.push_back(Task{g, std::move(fn)});
+        lk.unlock();
+        cv_work_.notify_one();
+    }
+    void wait(TaskGroup* g)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        while (g->pending_ > 0) {
+            if (!queue_.empty()) {   // help: run any queued task (keeps the waiting core busy, cannot deadlock)
+                Task t = std::move(queue_.front());
+                queue_.pop_front();
+                lk.unlock();
+                t.fn();
+                lk.lock();
+                if (--t.group->pending_ == 0) cv_done_.notify_all();
+            } else {
+                cv_done_.wait(lk);
+            }
+        }
+    }
+
+private:
+    struct Task { TaskGroup* group; std::function<void()> fn; };
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::deque<Task> queue_;
+    int workers_ = 0;
+    pid_t pid_ = 0;
+
+    void ensure_workers(std::unique_lock<std::mutex>&)
+    {
+        const pid_t me = getpid();
+        if (pid_ != me) {   // first use, or a forked child (the parent's workers do not exist here)
+            pid_ = me;
+            workers_ = 0;
+        }
+        const int want = std::max(0, host_threads() - 1);
+        while (workers_ < want) {
+            std::thread([this] { worker(); }).detach();
+            workers_++;
+        }
+    }
+    void worker()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_work_.wait(lk, [this] { return !queue_.empty(); });
+            Task t = std::move(queue_.front());
+            queue_.pop_front();
+            lk.unlock();
+            t.fn();
+            lk.lock();
+            if (--t.group->pending_ == 0) cv_done_.notify_all();
+        }
+    }
+};
+
+void TaskGroup::run(std::function<void()> fn) { WorkerPool::instance().submit(this, std::move(fn)); }
+void TaskGroup::wait() { WorkerPool::instance().wait(this); }
+
+void parallel_for(int count, const std::function<void(int)>& fn)
+{
+    if (count <= 1) {
+        if (count == 1) fn(0);
+        return;
+    }
+    TaskGroup g;
+    for (int t = 1; t < count; t++) g.run([&fn, t] { fn(t); });
+    fn(0);
+    g.wait();
+}
 
 static constexpr float VP_WDH = 100.0f;   // nbody.rs:13
 static constexpr float VP_ORG_X = 0.0f;   // nbody.rs:14
@@ -279,18 +382,6 @@ struct Builder {
     }
 };
 
-int host_threads()
-{
-    if (const char* env = std::getenv("NBX_HOST_THREADS")) {
-        const int t = std::atoi(env);
-        if (t >= 1) return t < 256 ? t : 256;
-    }
-    // Up to 32 threads even under a smaller cgroup CPU quota: the build is a ~15 ms burst and a CFS quota is a
-    // budget per 100 ms period, so the burst may use more CPUs than the long-run average allows (measured on a
-    // 16-CPU quota: 32 threads 6 ms for the subtree phase, 16 threads 11 ms).
-    const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::min<unsigned>(hw ? hw : 1, 32);
-}
 
 }  // namespace
 
@@ -300,13 +391,35 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n)
     forest = false;
     n_buckets = 0;
     float x1 = 3.40282347e+38f, y1 = 3.40282347e+38f, x2 = -3.40282347e+38f, y2 = -3.40282347e+38f;  // :388-391
-    for (int i = 0; i < n; i++) {                                         // :392-398 strict < / >
-        x1 = px[i] < x1 ? px[i] : x1;
-        y1 = py[i] < y1 ? py[i] : y1;
-        x2 = px[i] > x2 ? px[i] : x2;
-        y2 = py[i] > y2 ? py[i] : y2;
-    }
     const int threads = host_threads();
+    auto minmax = [&](int a, int b, float* r) {                           // :392-398 strict < / >
+        float lx = r[0], ly = r[1], hx = r[2], hy = r[3];
+        for (int i = a; i < b; i++) {
+            lx = px[i] < lx ? px[i] : lx;
+            ly = py[i] < ly ? py[i] : ly;
+            hx = px[i] > hx ? px[i] : hx;
+            hy = py[i] > hy ? py[i] : hy;
+        }
+        r[0] = lx; r[1] = ly; r[2] = hx; r[3] = hy;
+    };
+    if (n >= 65536 && threads > 1) {   // min / max do not depend on the order: same box from any split
+        const int parts = std::min(threads, 16);
+        std::vector<float> part((size_t)parts * 16);   // one cache line per part
+        parallel_for(parts, [&](int t) {
+            float* r = &part[(size_t)t * 16];
+            r[0] = x1; r[1] = y1; r[2] = x2; r[3] = y2;
+            minmax((int)((long long)n * t / parts), (int)((long long)n * (t + 1) / parts), r);
+        });
+        for (int t = 0; t < parts; t++) {
+            const float* r = &part[(size_t)t * 16];
+            x1 = r[0] < x1 ? r[0] : x1; y1 = r[1] < y1 ? r[1] : y1;
+            x2 = r[2] > x2 ? r[2] : x2; y2 = r[3] > y2 ? r[3] : y2;
+        }
+    } else {
+        float r[4] = {x1, y1, x2, y2};
+        minmax(0, n, r);
+        x1 = r[0]; y1 = r[1]; x2 = r[2]; y2 = r[3];
+    }
     if (n < 32768 || threads < 2) {
         // sequential: exactly the reference's loop (nbody.rs:413-415, particle-index order)
         nodes.reserve((size_t)n * 3 + 8);
@@ -376,12 +489,41 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n)
             for (int c = 0; c < 4; c++) parent[top[k].first_child + c] = k;
     std::atomic<int> bad_mass{0};
     const int nt = std::max(1, threads);
-    auto run_threads = [&](int count, const std::function<void(int)>& fn) {
-        std::vector<std::thread> th;
-        for (int t = 1; t < count; t++) th.emplace_back(fn, t);
-        fn(0);
-        for (auto& t : th) t.join();
+    auto run_threads = [&](int count, const std::function<void(int)>& fn) { parallel_for(count, fn); };
+    // ancestors of every bucket root, per level (anc[b][l] = pass-through node at level l, or -1)
+    int max_level = 0;
+    for (int k = 0; k < ntop; k++) max_level = std::max<int>(max_level, level[k]);
+    std::vector<int> anc((size_t)nb * (size_t)(max_level + 1), -1);
+    for (int b2 = 0; b2 < nb; b2++)
+        for (int k = parent[root_of[b2]]; k >= 0; k = parent[k]) anc[(size_t)b2 * (max_level + 1) + level[k]] = k;
+    const int fold_levels = max_level;                                   // pass-through nodes live on levels 0..max_level-1
+    const int slices = std::max(1, std::min(4, nt / std::max(1, fold_levels)));
+    // (b) folds: one task per (level, slice of that level's nodes) adds the particles to that level's pass-through
+    // nodes in index order.  They run beside everything below and are only waited for at the very end.
+    auto fold = [&](int lvl, int slice) {
+        const size_t stride = (size_t)(max_level + 1);
+        // work on a private copy: 32-byte nodes of different levels share cache lines in `top`, and every fold
+        // thread writes its nodes a million times (false sharing cost 5x here)
+        std::vector<Node> mine(top.begin(), top.begin() + ntop);
+        for (int i = 0; i < rest; i++) {
+            const int k = anc[(size_t)pbucket[i] * stride + lvl];
+            if (k < 0 || (k % slices) != slice) continue;
+            add_mass(mine[k], px[warm + i], py[warm + i], m[warm + i]);   // interior: nbody.rs:236, index order
+        }
+        for (int k = 0; k < ntop; k++)
+            if (level[k] == lvl && bucket_of[k] < 0 && top[k].first_child >= 0 && (k % slices) == slice) {
+                top[k].px = mine[k].px; top[k].py = mine[k].py; top[k].m = mine[k].m;   // only what the fold changed
+            }
     };
+    // the root sees EVERY particle, a 1 M-long chain of dependent adds (~4 ms at 1 M bodies: the longest task of the
+    // build, the reference's own serial fold).  It needs no routing result, so it starts before anything else.
+    auto fold_root = [&]() {
+        Node mine = top[0];
+        for (int i = 0; i < rest; i++) add_mass(mine, px[warm + i], py[warm + i], m[warm + i]);
+        top[0].px = mine.px; top[0].py = mine.py; top[0].m = mine.m;
+    };
+    TaskGroup folds;   // declared after everything its tasks capture: its destructor waits for them on every exit path
+    if (fold_levels > 0) folds.run(fold_root);
     // (a) routing
     run_threads(nt, [&](int t) {
         const int lo = (int)((long long)rest * t / nt), hi = (int)((long long)rest * (t + 1) / nt);
@@ -395,38 +537,13 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n)
     });
     if (bad_mass.load()) return NBX_ERR_TREE;                              // nbody.rs:304
     const auto tpa = std::chrono::steady_clock::now();
-    // ancestors of every bucket root, per level (anc[b][l] = pass-through node at level l, or -1)
-    int max_level = 0;
-    for (int k = 0; k < ntop; k++) max_level = std::max<int>(max_level, level[k]);
-    std::vector<int> anc((size_t)nb * (size_t)(max_level + 1), -1);
-    for (int b2 = 0; b2 < nb; b2++)
-        for (int k = parent[root_of[b2]]; k >= 0; k = parent[k]) anc[(size_t)b2 * (max_level + 1) + level[k]] = k;
-    // (b) folds, one thread per (level, slice of that level's nodes); (c) counting sort -- run concurrently
-    auto tpb = tpa;
+    for (int lvl = 1; lvl < fold_levels; lvl++)
+        for (int sl = 0; sl < slices; sl++) folds.run([&fold, lvl, sl] { fold(lvl, sl); });
+    // (c) histogram + stable scatter of the particles into per-bucket queues (index order kept)
     std::vector<size_t> offset((size_t)nb + 1, 0);
     sorted.resize((size_t)rest);
     std::vector<std::vector<size_t>> hist(nt, std::vector<size_t>((size_t)nb, 0));
-    const int fold_levels = max_level;                                   // pass-through nodes live on levels 0..max_level-1
-    const int slices = std::max(1, std::min(4, nt / std::max(1, fold_levels)));
-    auto fold = [&](int lvl, int slice) {
-        const size_t stride = (size_t)(max_level + 1);
-        // work on a private copy: 32-byte nodes of different levels share cache lines in `top`, and every fold
-        // thread writes its nodes a million times (false sharing cost 5x here)
-        std::vector<Node> mine(top.begin(), top.begin() + ntop);
-        for (int i = 0; i < rest; i++) {
-            const int k = anc[(size_t)pbucket[i] * stride + lvl];
-            if (k < 0 || (lvl > 0 && (k % slices) != slice)) continue;
-            add_mass(mine[k], px[warm + i], py[warm + i], m[warm + i]);   // interior: nbody.rs:236, index order
-        }
-        for (int k = 0; k < ntop; k++)
-            if (level[k] == lvl && bucket_of[k] < 0 && top[k].first_child >= 0 && (lvl == 0 || (k % slices) == slice))
-                top[k] = mine[k];
-    };
     {
-        std::vector<std::thread> th;
-        for (int lvl = 0; lvl < fold_levels; lvl++)
-            for (int sl = 0; sl < (lvl == 0 ? 1 : slices); sl++) th.emplace_back(fold, lvl, sl);
-        // meanwhile: histogram + stable scatter of the particles into per-bucket queues (index order kept)
         run_threads(nt, [&](int t) {
             const int lo = (int)((long long)rest * t / nt), hi = (int)((long long)rest * (t + 1) / nt);
             for (int i = lo; i < hi; i++) hist[t][(size_t)pbucket[i]]++;
@@ -444,13 +561,12 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n)
                 sorted[hist[t][(size_t)b2]++] = Event{px[warm + i], py[warm + i], m[warm + i], (unsigned)level[root_of[b2]]};
             }
         });
-        tpb = std::chrono::steady_clock::now();
-        for (auto& t : th) t.join();
     }
     const auto tp2 = std::chrono::steady_clock::now();
 
     // Phase 2 (parallel over buckets): replay each queue on a private pool whose node 0 is the bucket root.
     if ((int)pools.size() < nb) pools.resize(nb);
+    pool_live.assign((size_t)nb, 0);
     std::vector<int> status(nb, NBX_OK);
     std::vector<int> order(nb);
     for (int b2 = 0; b2 < nb; b2++) order[b2] = b2;
@@ -474,8 +590,13 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n)
             }
             for (size_t i = offset[b2]; rc == NBX_OK && i < offset[b2 + 1]; i++) rc = lb.insert<false>(0, sorted[i]);  // ... then the rest
             status[b2] = rc;
+            size_t live = 0;   // what the flattened subtree will hold (empty exterior nodes are dropped); counted while hot
+            for (const Node& nd : pool) live += (nd.first_child >= 0 || nd.m != 0.0f) ? 1 : 0;
+            pool_live[(size_t)b2] = live;
         }
     });
+    const auto tp3a = std::chrono::steady_clock::now();
+    folds.wait();   // the pass-through nodes (touched by nobody else) are final now
     for (int b2 = 0; b2 < nb; b2++)
         if (status[b2] != NBX_OK) return status[b2];
     // The tree stays a forest: `nodes` = top levels, pools[b] = subtree of bucket b (local indices,
@@ -489,8 +610,8 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n)
         for (int b2 = 0; b2 < nb; b2++) big = std::max(big, qsize(b2));
         std::fprintf(stderr,
                      "[nbx] tree build n=%d threads=%d limit=%d buckets=%d (largest %zu): warm-up %.2f ms, route %.2f ms, scatter %.2f ms, "
-                     "folds (remaining) %.2f ms, subtrees %.2f ms\n",
-                     n, nt, limit, nb, big, ms(tp0, tp1), ms(tp1, tpa), ms(tpa, tpb), ms(tpb, tp2), ms(tp2, tp3));
+                     "subtrees %.2f ms, folds (remaining) %.2f ms\n",
+                     n, nt, limit, nb, big, ms(tp0, tp1), ms(tp1, tpa), ms(tpa, tp2), ms(tp2, tp3a), ms(tp3a, tp3));
     }
     return NBX_OK;
 }
@@ -664,28 +785,10 @@ size_t QuadTree::flatten_prepare(FlatPlan& plan) const
         const int item = add_item(c);
         st.push_back(Frame{c, item, 0});
     }
-    // parallel: live-node count of every referenced bucket (what its flattened piece will hold)
-    std::vector<int> jobs;
-    for (const auto& it : plan.items)
-        if (it.piece >= 0) jobs.push_back(it.piece);
+    // live-node count of every referenced bucket (what its flattened piece will hold): taken by the build
     plan.piece_size.assign((size_t)n_buckets, 0);
-    const int nj = (int)jobs.size();
-    std::atomic<int> next{0};
-    auto work = [&]() {
-        for (;;) {
-            const int j = next.fetch_add(1);
-            if (j >= nj) return;
-            const std::vector<Node>& pool = pools[jobs[j]];
-            size_t live = 0;
-            for (const Node& nd : pool) live += (nd.first_child >= 0 || nd.m != 0.0f) ? 1 : 0;
-            plan.piece_size[(size_t)jobs[j]] = live;
-        }
-    };
-    const int nt = std::max(1, std::min(host_threads(), nj));
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
+    for (const auto& it : plan.items)
+        if (it.piece >= 0) plan.piece_size[(size_t)it.piece] = pool_live[(size_t)it.piece];
     size_t off = 0;
     for (auto& it : plan.items) {
         it.offset = off;
@@ -726,14 +829,12 @@ void QuadTree::flatten_write(const FlatPlan& plan, BhNode* out, const std::funct
         }
     };
     const int nt = std::max(1, std::min(host_threads(), ni));
-    std::vector<std::thread> th;
     if (!chunk_done) {
-        for (int t = 1; t < nt; t++) th.emplace_back(work);
-        work();
-        for (auto& t : th) t.join();
+        parallel_for(nt, [&work](int) { work(); });
         return;
     }
-    for (int t = 0; t < std::max(1, nt - 1); t++) th.emplace_back(work);
+    TaskGroup writers;
+    for (int t = 0; t < std::max(1, nt - 1); t++) writers.run(work);
     int w = 0;            // items [0, w) are finished
     size_t sent = 0;      // nodes [0, sent) were handed over
     while (w < ni) {
@@ -748,7 +849,7 @@ void QuadTree::flatten_write(const FlatPlan& plan, BhNode* out, const std::funct
             sent = upto;
         }
     }
-    for (auto& t : th) t.join();
+    writers.wait();
 }
 
 }  // namespace nbx
