@@ -85,7 +85,7 @@ private:
             pid_ = me;
             workers_ = 0;
         }
-        const int want = std::max(0, host_threads() - 1);
+        const int want = std::max(1, host_threads() - 1);   // at least one: some callers hand all work to the pool
         while (workers_ < want) {
             std::thread([this] { worker(); }).detach();
             workers_++;
@@ -829,12 +829,13 @@ void QuadTree::flatten_write(const FlatPlan& plan, BhNode* out, const std::funct
         }
     };
     const int nt = std::max(1, std::min(host_threads(), ni));
-    if (!chunk_done) {
+    if (!chunk_done || nt == 1) {   // nt == 1: nobody to write while this thread watches the prefix
         parallel_for(nt, [&work](int) { work(); });
+        if (chunk_done && plan.total > 0) chunk_done(0, plan.total);
         return;
     }
     TaskGroup writers;
-    for (int t = 0; t < std::max(1, nt - 1); t++) writers.run(work);
+    for (int t = 0; t < nt - 1; t++) writers.run(work);
     int w = 0;            // items [0, w) are finished
     size_t sent = 0;      // nodes [0, sent) were handed over
     while (w < ni) {

@@ -100,3 +100,35 @@ def test_bh_large_n_force_error_vs_brute_sample(rx):
     num = np.hypot(bx - fx, by - fy)
     den = np.hypot(fx, fy) + 1e-12
     assert np.median(num / den) < 2e-2
+
+
+@pytest.mark.parametrize("threads", ["1", "2", "7"])
+def test_bh_big_host_tree_with_few_host_threads(rx, ob, threads):
+    """The pipelined flatten + upload (worker pool, prefix watcher) must not depend on how many workers exist:
+    NBX_HOST_THREADS = 1 leaves nobody but the caller. Bit-exact step on a system large enough for the threaded build."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import os, sys
+sys.path.insert(0, os.environ["NBX_ROOT"])
+import numpy as np
+import rust_exp_amd as rx
+from oracle import binding as ob
+p = ob.stable_orbits(70000, 0.5, 30.0, 9)
+e = rx.NBodyEngine(mode="strict")
+e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+for _ in range(2):
+    e.step_barnes_hut(0.7, 0.01, 1)
+q = p.copy()
+for _ in range(2):
+    assert ob.step_barnes_hut(q, 0.7, 0.01, 8) == 0
+st = e.get_particles()
+for k in ("px", "py", "vx", "vy"):
+    assert np.array_equal(st[k].view(np.uint32), q[k].view(np.uint32)), k
+print("OK")
+"""
+    env = dict(os.environ, NBX_HOST_THREADS=threads, NBX_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
