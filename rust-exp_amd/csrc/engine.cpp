@@ -121,32 +121,45 @@ int upload(nbx_engine* e)
     return NBX_OK;
 }
 
+// pinned staging buffer of at least `records` float4 (shared by the position and velocity downloads)
+static int ensure_stage(nbx_engine* e, size_t records)
+{
+    if (records <= e->h_stage_cap) return NBX_OK;
+    if (e->h_stage) HIP_TRY(hipHostFree(e->h_stage));
+    e->h_stage = nullptr;
+    e->h_stage_cap = 0;
+    const size_t want = std::max<size_t>(records, 256);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage), sizeof(float4) * want, hipHostMallocDefault));
+    e->h_stage_cap = want;
+    return NBX_OK;
+}
+
+// AoS staging -> SoA host mirror, on a few pool threads for big systems (3 ms -> <1 ms at 1 M bodies)
+template <typename F>
+static void unpack_records(int count, F&& one)
+{
+    if (count >= 262144) {
+        const int parts = 8;
+        nbx::parallel_for(parts, [&](int p) {
+            const int a = (int)((long long)count * p / parts), b = (int)((long long)count * (p + 1) / parts);
+            for (int i = a; i < b; i++) one(i);
+        });
+    } else {
+        for (int i = 0; i < count; i++) one(i);
+    }
+}
+
 int download_positions(nbx_engine* e)
 {
     if (e->host_pos_valid) return NBX_OK;
     int rc = ensure_device(e);
     if (rc != NBX_OK) return rc;
-    if ((size_t)e->n > e->h_stage_cap) {
-        if (e->h_stage) HIP_TRY(hipHostFree(e->h_stage));
-        e->h_stage = nullptr;
-        e->h_stage_cap = 0;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage), sizeof(float4) * (size_t)std::max(e->n, 256), hipHostMallocDefault));
-        e->h_stage_cap = (size_t)std::max(e->n, 256);
-    }
+    rc = ensure_stage(e, (size_t)e->n);
+    if (rc != NBX_OK) return rc;
     float4* tmp = e->h_stage;
     HIP_TRY(hipMemcpyAsync(tmp, e->d_posm, sizeof(float4) * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    auto unpack = [&](int a, int b) {
-        for (int i = a; i < b; i++) {
-            e->host.px[i] = tmp[i].x; e->host.py[i] = tmp[i].y; e->host.pz[i] = tmp[i].z;
-        }
-    };
-    if (e->n >= 262144) {   // AoS -> SoA of the host mirror on a few threads (3 ms -> <1 ms at 1 M bodies)
-        const int parts = 8;
-        nbx::parallel_for(parts, [&](int p) { unpack((int)((long long)e->n * p / parts), (int)((long long)e->n * (p + 1) / parts)); });
-    } else {
-        unpack(0, e->n);
-    }
+    unpack_records(e->n, [&](int i) { e->host.px[i] = tmp[i].x; e->host.py[i] = tmp[i].y; e->host.pz[i] = tmp[i].z; });
     e->host_pos_valid = true;
     return NBX_OK;
 }
@@ -158,12 +171,13 @@ int download_velocities(nbx_engine* e)
     if (rc != NBX_OK) return rc;
     const int slab = e->slab();
     if (slab > 0) {
-        std::vector<float4> tmp((size_t)slab);
-        HIP_TRY(hipMemcpyAsync(tmp.data(), e->d_vel, sizeof(float4) * (size_t)slab, hipMemcpyDeviceToHost, e->stream));
+        rc = ensure_stage(e, (size_t)slab);
+        if (rc != NBX_OK) return rc;
+        float4* tmp = e->h_stage;
+        HIP_TRY(hipMemcpyAsync(tmp, e->d_vel, sizeof(float4) * (size_t)slab, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
-        for (int i = 0; i < slab; i++) {
-            e->host.vx[e->lo + i] = tmp[i].x; e->host.vy[e->lo + i] = tmp[i].y; e->host.vz[e->lo + i] = tmp[i].z;
-        }
+        const int lo = e->lo;
+        unpack_records(slab, [&](int i) { e->host.vx[lo + i] = tmp[i].x; e->host.vy[lo + i] = tmp[i].y; e->host.vz[lo + i] = tmp[i].z; });
     }
     e->host_vel_valid = true;
     return NBX_OK;

@@ -232,6 +232,42 @@ void draw_particles(const float* px, const float* py, const float* vx, const flo
     const float scaley = (1.0f / (vy2 - vy1)) * (float)h;                    // :506
     const uint32_t col_body = pack_abgr(255, 215, 130, 0.3f);                // :520
     const uint32_t col_tail = pack_abgr(255, 215, 130, 0.25f);               // :521
+    const int threads = host_threads();
+    if (n >= 65536 && threads > 1) {
+        // A per-channel saturating add of non-negative colours is min(255, sum): the pixel only depends on HOW MANY
+        // bodies and tails hit it, not on their order.  So big systems are splatted by all host threads into hit
+        // counters (relaxed atomics) and resolved afterwards -- the same framebuffer, bit for bit.
+        const size_t npx = (size_t)w * (size_t)h;
+        std::vector<uint32_t> hits(2 * npx, 0u);                             // [0, npx): bodies, [npx, 2 npx): tails
+        const int parts = std::min(threads, 32);
+        parallel_for(parts, [&](int t) {
+            const int k0 = (int)((long long)n * t / parts), k1 = (int)((long long)n * (t + 1) / parts);
+            for (int k = k0; k < k1; k++) {
+                const int32_t xi = trunc_i32((px[k] - vx1) * scalex);        // :525, :536
+                const int32_t yi = trunc_i32((py[k] - vy1) * scaley);        // :526, :537
+                if (xi >= 0 && xi < w && yi >= 0 && yi < h)                  // :559
+                    __atomic_fetch_add(&hits[(size_t)xi + (size_t)yi * w], 1u, __ATOMIC_RELAXED);
+                const float angle = std::atan2(vy[k], vx[k]);                // :541
+                const int32_t oct = trunc_i32(8.0f * angle / (2.0f * PI_F32) + 8.0f) % 8;  // :542
+                const int32_t xt = xi - step[oct][0], yt = yi - step[oct][1];  // :553-554
+                if (xt >= 0 && xt < w && yt >= 0 && yt < h)
+                    __atomic_fetch_add(&hits[npx + (size_t)xt + (size_t)yt * w], 1u, __ATOMIC_RELAXED);
+            }
+        });
+        parallel_for(parts, [&](int t) {
+            const size_t p0 = npx * t / parts, p1 = npx * (t + 1) / parts;
+            for (size_t p = p0; p < p1; p++) {
+                const uint64_t nb = hits[p], nt = hits[npx + p];
+                if ((nb | nt) == 0) continue;
+                uint32_t out = 0;
+                for (int c = 0; c < 32; c += 8) {                            // :595-617 per channel, alpha byte included
+                    const uint64_t v = nb * ((col_body >> c) & 0xFFu) + nt * ((col_tail >> c) & 0xFFu);
+                    out |= (uint32_t)(v > 255 ? 255 : v) << c;
+                }
+                fb[p] = out;
+            }
+        });
+    } else
     for (int k = 0; k < n; k++) {
         const int32_t xi = trunc_i32((px[k] - vx1) * scalex);                // :525, :536
         const int32_t yi = trunc_i32((py[k] - vy1) * scaley);                // :526, :537

@@ -126,6 +126,19 @@ def test_product_draw_equals_oracle_draw(rx, ob, shape):
     assert np.array_equal(e.draw(w, h), ob.draw(d, w, h))
 
 
+@pytest.mark.parametrize("shape", [(512, 512), (101, 37)])
+def test_product_draw_of_a_big_system_uses_threads_and_equals_oracle_draw(rx, ob, shape):
+    """n >= 65536: all host threads splat into hit counters, resolved to min(255, hits * colour) per channel --
+    the saturating adds of nbody.rs:595-617 in any order. Heavy overlap (saturation) and out-of-view bodies included."""
+    w, h = shape
+    p = ob.stable_orbits(150000, 0.5, 30.0, 2)
+    p["px"][:2000] = 0.125; p["py"][:2000] = -0.25        # 2000 bodies on one pixel
+    p["px"][2000:2500] *= 4.0                              # out of the viewport
+    e = rx.NBodyEngine()
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    assert np.array_equal(e.draw(w, h), ob.draw(p, w, h))
+
+
 def test_product_draw_matches_golden(rx):
     g = golden("draw_n1024_orbits")
     e = rx.NBodyEngine()
