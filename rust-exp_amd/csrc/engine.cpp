@@ -84,6 +84,34 @@ int refresh_half_sources(nbx_engine* e, int first, int count)
     return NBX_OK;
 }
 
+// pinned staging buffer of at least `records` float4 (shared by the position and velocity downloads)
+static int ensure_stage(nbx_engine* e, size_t records)
+{
+    if (records <= e->h_stage_cap) return NBX_OK;
+    if (e->h_stage) HIP_TRY(hipHostFree(e->h_stage));
+    e->h_stage = nullptr;
+    e->h_stage_cap = 0;
+    const size_t want = std::max<size_t>(records, 256);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage), sizeof(float4) * want, hipHostMallocDefault));
+    e->h_stage_cap = want;
+    return NBX_OK;
+}
+
+// per-record conversion between the AoS staging buffer and the SoA host mirror, on a few pool threads for big systems
+template <typename F>
+static void unpack_records(int count, F&& one)
+{
+    if (count >= 262144) {
+        const int parts = 8;
+        nbx::parallel_for(parts, [&](int p) {
+            const int a = (int)((long long)count * p / parts), b = (int)((long long)count * (p + 1) / parts);
+            for (int i = a; i < b; i++) one(i);
+        });
+    } else {
+        for (int i = 0; i < count; i++) one(i);
+    }
+}
+
 int upload(nbx_engine* e)
 {
     int rc = ensure_device(e);
@@ -102,15 +130,19 @@ int upload(nbx_engine* e)
     const int slab = e->slab();
     rc = grow(&e->d_vel, &e->vel_cap, (size_t)std::max(slab, 1));
     if (rc != NBX_OK) return rc;
-    std::vector<float4> tmp((size_t)e->n_pad, make_float4(0.f, 0.f, 0.f, 0.f));
-    for (int i = 0; i < n; i++) tmp[i] = make_float4(e->host.px[i], e->host.py[i], e->host.pz[i], e->host.m[i]);
-    HIP_TRY(hipMemcpyAsync(e->d_posm, tmp.data(), sizeof(float4) * (size_t)e->n_pad, hipMemcpyHostToDevice, e->stream));
+    // pack SoA -> float4 records in the pinned staging buffer (threads for big systems), one copy per array
+    rc = ensure_stage(e, (size_t)e->n_pad);
+    if (rc != NBX_OK) return rc;
+    float4* tmp = e->h_stage;
+    unpack_records(e->n_pad, [&](int i) {
+        tmp[i] = i < n ? make_float4(e->host.px[i], e->host.py[i], e->host.pz[i], e->host.m[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    });
+    HIP_TRY(hipMemcpyAsync(e->d_posm, tmp, sizeof(float4) * (size_t)e->n_pad, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (slab > 0) {
-        std::vector<float4> tv((size_t)slab);
-        for (int i = 0; i < slab; i++)
-            tv[i] = make_float4(e->host.vx[e->lo + i], e->host.vy[e->lo + i], e->host.vz[e->lo + i], 0.f);
-        HIP_TRY(hipMemcpyAsync(e->d_vel, tv.data(), sizeof(float4) * (size_t)slab, hipMemcpyHostToDevice, e->stream));
+        const int lo = e->lo;
+        unpack_records(slab, [&](int i) { tmp[i] = make_float4(e->host.vx[lo + i], e->host.vy[lo + i], e->host.vz[lo + i], 0.f); });
+        HIP_TRY(hipMemcpyAsync(e->d_vel, tmp, sizeof(float4) * (size_t)slab, hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
     e->dev_valid = true;
@@ -119,34 +151,6 @@ int upload(nbx_engine* e)
         if (rc != NBX_OK) return rc;
     }
     return NBX_OK;
-}
-
-// pinned staging buffer of at least `records` float4 (shared by the position and velocity downloads)
-static int ensure_stage(nbx_engine* e, size_t records)
-{
-    if (records <= e->h_stage_cap) return NBX_OK;
-    if (e->h_stage) HIP_TRY(hipHostFree(e->h_stage));
-    e->h_stage = nullptr;
-    e->h_stage_cap = 0;
-    const size_t want = std::max<size_t>(records, 256);
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_stage), sizeof(float4) * want, hipHostMallocDefault));
-    e->h_stage_cap = want;
-    return NBX_OK;
-}
-
-// AoS staging -> SoA host mirror, on a few pool threads for big systems (3 ms -> <1 ms at 1 M bodies)
-template <typename F>
-static void unpack_records(int count, F&& one)
-{
-    if (count >= 262144) {
-        const int parts = 8;
-        nbx::parallel_for(parts, [&](int p) {
-            const int a = (int)((long long)count * p / parts), b = (int)((long long)count * (p + 1) / parts);
-            for (int i = a; i < b; i++) one(i);
-        });
-    } else {
-        for (int i = 0; i < count; i++) one(i);
-    }
 }
 
 int download_positions(nbx_engine* e)
