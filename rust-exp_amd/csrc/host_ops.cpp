@@ -484,7 +484,7 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n)
     //   phase 2 (parallel over buckets): replay each queue on a private pool (node 0 = the bucket root).
     const bool timing = std::getenv("NBX_TIMING") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
-    const int limit = n >= 262144 ? 6 : (n >= 65536 ? 5 : 4);
+    const int limit = n >= 262144 ? 7 : (n >= 65536 ? 5 : 4);   // 7: ~3000 buckets at 1 M bodies, largest ~7000 bodies
     const int warm = std::min(n, 8192);
     std::vector<Node>& top = nodes;
     std::vector<uint8_t> level;
