@@ -346,7 +346,7 @@ int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also, int n_also, bo
         if (rc != NBX_OK) return rc;
     }
     const auto t1 = clk::now();
-    rc = e->tree.build(bx, by, e->host.m.data(), e->n);
+    rc = e->tree.build(bx, by, e->host.m.data(), e->n, /*preflatten=*/true);
     if (rc == NBX_ERR_TREE_DEPTH) return fail(rc, "quadtree depth > 50 (the reference panics here, nbody.rs:230-232)");
     if (rc != NBX_OK) return fail(rc, "quadtree build hit a reference assert (nbody.rs:267/:293/:304)");
     const auto t2 = clk::now();

@@ -421,10 +421,13 @@ struct Builder {
 
 }  // namespace
 
-int QuadTree::build(const float* px, const float* py, const float* m, int n)
+static int flatten_subtree_into(const std::vector<QuadTree::Node>& nodes, int root, BhNode* out, int base);
+
+int QuadTree::build(const float* px, const float* py, const float* m, int n, bool preflatten)
 {
     nodes.clear();
     forest = false;
+    preflattened = false;
     n_buckets = 0;
     float x1 = 3.40282347e+38f, y1 = 3.40282347e+38f, x2 = -3.40282347e+38f, y2 = -3.40282347e+38f;  // :388-391
     const int threads = host_threads();
@@ -603,6 +606,7 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n)
     // Phase 2 (parallel over buckets): replay each queue on a private pool whose node 0 is the bucket root.
     if ((int)pools.size() < nb) pools.resize(nb);
     pool_live.assign((size_t)nb, 0);
+    if (preflatten && (int)flat_pools.size() < nb) flat_pools.resize(nb);
     std::vector<int> status(nb, NBX_OK);
     std::vector<int> order(nb);
     for (int b2 = 0; b2 < nb; b2++) order[b2] = b2;
@@ -629,6 +633,11 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n)
             size_t live = 0;   // what the flattened subtree will hold (empty exterior nodes are dropped); counted while hot
             for (const Node& nd : pool) live += (nd.first_child >= 0 || nd.m != 0.0f) ? 1 : 0;
             pool_live[(size_t)b2] = live;
+            if (preflatten && rc == NBX_OK) {
+                std::vector<BhNode>& fp = flat_pools[(size_t)b2];
+                fp.resize(live);
+                if (live) flatten_subtree_into(pool, 0, fp.data(), 0);
+            }
         }
     });
     const auto tp3a = std::chrono::steady_clock::now();
@@ -638,6 +647,7 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n)
     // The tree stays a forest: `nodes` = top levels, pools[b] = subtree of bucket b (local indices,
     // node 0 = the bucket root, which supersedes nodes[root_of[b]]).  Traversals below understand both.
     forest = true;
+    preflattened = preflatten;
     n_buckets = nb;
     if (timing) {
         const auto tp3 = std::chrono::steady_clock::now();
@@ -858,6 +868,15 @@ void QuadTree::flatten_write(const FlatPlan& plan, BhNode* out, const std::funct
                 b.interior = nd.first_child >= 0 ? 1 : 0; b.q = bh_node_q(b.s, b.interior != 0); b.pad1 = 0;
                 b.skip = (int)(it.end_item < ni ? plan.items[it.end_item].offset : plan.total);
                 out[it.offset] = b;
+            } else if (preflattened) {
+                const std::vector<BhNode>& src = flat_pools[(size_t)it.piece];
+                BhNode* dst = out + it.offset;
+                const int base = (int)it.offset;
+                for (size_t j = 0; j < src.size(); j++) {
+                    BhNode b = src[j];
+                    b.skip += base;
+                    dst[j] = b;
+                }
             } else {
                 flatten_subtree_into(pools[it.piece], 0, out + it.offset, (int)it.offset);
             }

@@ -71,12 +71,16 @@ struct QuadTree {
     std::vector<int> root_of;                   // bucket id -> top node
     std::vector<std::vector<Node>> pools;       // capacity reused from step to step
     std::vector<size_t> pool_live;              // per pool: nodes that survive flattening (non-empty)
+    std::vector<std::vector<BhNode>> flat_pools; // per pool: its flattened form with pool-local skips (preflatten)
+    bool preflattened = false;
     std::vector<std::vector<Event>> queues;     // per-bucket insert queues of the last build (reused)
     std::vector<int> pbucket;                   // scratch of the threaded build (reused)
     std::vector<Event> sorted;                  // scratch: particles grouped by bucket, index order kept
     size_t node_count() const;
     // status: 0 ok, else the NBX_ERR_* code standing in for the reference panic
-    int build(const float* px, const float* py, const float* m, int n);
+    // preflatten: the threaded build also flattens every bucket subtree right after replaying it (while it is hot in
+    // the cache) into flat_pools; flatten_write then only copies the pieces into place and rebases their skip pointers
+    int build(const float* px, const float* py, const float* m, int n, bool preflatten = false);
     // pre-order, all nodes (including empty exteriors), rows of 8 floats (see nbx_bh_tree_dump)
     int dump_preorder(float* rows, int cap) const;
     // pre-order with empty exterior nodes dropped + skip pointers, for the GPU traversal (serial)
