@@ -459,7 +459,7 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n, boo
         minmax(0, n, r);
         x1 = r[0]; y1 = r[1]; x2 = r[2]; y2 = r[3];
     }
-    if (n < 32768 || threads < 2) {
+    if (n < 4096 || threads < 2) {
         // sequential: exactly the reference's loop (nbody.rs:413-415, particle-index order)
         nodes.reserve((size_t)n * 3 + 8);
         nodes.push_back(Node{x1, y1, x2, y2, 0.0f, 0.0f, 0.0f, -1});      // :410
@@ -487,8 +487,10 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n, boo
     //   phase 2 (parallel over buckets): replay each queue on a private pool (node 0 = the bucket root).
     const bool timing = std::getenv("NBX_TIMING") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
-    const int limit = n >= 262144 ? 7 : (n >= 65536 ? 5 : 4);   // 7: ~3000 buckets at 1 M bodies, largest ~7000 bodies
-    const int warm = std::min(n, 8192);
+    // bucket level, sequential warm-up and worker count by size (measured on the target host, profiles/README.md):
+    // small systems want few workers (waking 31 threads for 10 000 bodies costs more than it buys) and a short warm-up
+    const int limit = n >= 262144 ? 7 : (n >= 65536 ? 5 : (n >= 16384 ? 5 : 4));   // 7: ~3000 buckets at 1 M bodies
+    const int warm = std::min(n, n >= 32768 ? 8192 : (n >= 16384 ? 2048 : 1024));
     std::vector<Node>& top = nodes;
     std::vector<uint8_t> level;
     bucket_of.clear();
@@ -527,7 +529,7 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n, boo
         if (top[k].first_child >= 0 && bucket_of[k] < 0)
             for (int c = 0; c < 4; c++) parent[top[k].first_child + c] = k;
     std::atomic<int> bad_mass{0};
-    const int nt = std::max(1, threads);
+    const int nt = std::max(1, n >= 32768 ? threads : std::min(threads, n >= 16384 ? 8 : 4));
     auto run_threads = [&](int count, const std::function<void(int)>& fn) { parallel_for(count, fn); };
     // ancestors of every bucket root, per level (anc[b][l] = pass-through node at level l, or -1)
     int max_level = 0;
@@ -883,7 +885,8 @@ void QuadTree::flatten_write(const FlatPlan& plan, BhNode* out, const std::funct
             if (done) done[(size_t)i].store(1, std::memory_order_release);
         }
     };
-    const int nt = std::max(1, std::min(host_threads(), ni));
+    int nt = std::max(1, std::min(host_threads(), ni));
+    if (plan.total < 262144) nt = std::min(nt, plan.total < 65536 ? 2 : 4);   // small trees: waking the whole pool costs more than the copy
     if (!chunk_done || nt == 1) {   // nt == 1: nobody to write while this thread watches the prefix
         parallel_for(nt, [&work](int) { work(); });
         if (chunk_done && plan.total > 0) chunk_done(0, plan.total);
