@@ -396,3 +396,37 @@ def test_group_host_side_without_device(rx):
         assert ei.value.code == rx.NBX_ERR_NO_DEVICE
     with pytest.raises(rx.NBodyError):
         rx.NBodyGroup([0, 0])                 # the same device twice
+
+
+def test_host_worker_pool_serves_concurrent_builds(rx, ob):
+    """Several engines building big trees at the same time from different caller threads (ctypes drops the GIL): the
+    shared worker pool must neither deadlock nor mix results -- every dump equals the single-threaded one."""
+    import threading
+
+    ps = [ob.stable_orbits(40000 + 1000 * k, 0.5, 30.0, 100 + k) for k in range(4)]
+    want = []
+    for p in ps:
+        e = rx.NBodyEngine()
+        e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+        want.append(e.bh_flat_dump(False))
+    got = [None] * len(ps)
+    errs = []
+
+    def work(k):
+        try:
+            e = rx.NBodyEngine()
+            e.set_particles(ps[k]["px"], ps[k]["py"], ps[k]["vx"], ps[k]["vy"], ps[k]["m"])
+            for _ in range(4):
+                got[k] = e.bh_flat_dump(True)
+        except Exception as ex:   # noqa: BLE001
+            errs.append(ex)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(ps))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+        assert not t.is_alive(), "worker pool deadlock"
+    assert not errs, errs
+    for k in range(len(ps)):
+        assert np.array_equal(got[k], want[k])
