@@ -37,6 +37,9 @@ extern "C" {
 /* single-process multi-GPU group, see nbx_group_*), NB_SEED (u64,                               */
 /* default: OS entropy, as the reference's thread_rng), NB_FORCE_MODE=fast|strict,                */
 /* NB_DRAW=host|device, NB_BH_TREE=host|device.                                                  */
+/* Both levels: NBX_HOST_THREADS (workers of the host quadtree build / flatten / draw; default   */
+/* min(hardware threads, 32)), NBX_GROUP_EXCHANGE=copy (see nbx_group_*), NBX_LOG=1 (one stderr   */
+/* line per step), NBX_TIMING=1 (host tree-build phases).                                         */
 
 /* replaces nbody.rs:34-37   pub extern fn nb_num_particles() -> i32 */
 int32_t nb_num_particles(void);
