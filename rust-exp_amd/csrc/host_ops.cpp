@@ -36,6 +36,15 @@ int host_threads()
     return (int)std::min<unsigned>(hw ? hw : 1, 32);
 }
 
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
 // ---- persistent worker pool ------------------------------------------------------------------------------------------
 class WorkerPool {
 public:
@@ -50,6 +59,7 @@ public:
         ensure_workers(lk);
         g->pending_++;
         queue_.push_back(Task{g, std::move(fn)});
+        queued_.fetch_add(1, std::memory_order_relaxed);
         lk.unlock();
         cv_work_.notify_one();
     }
@@ -60,6 +70,7 @@ public:
             if (!queue_.empty()) {   // help: run any queued task (keeps the waiting core busy, cannot deadlock)
                 Task t = std::move(queue_.front());
                 queue_.pop_front();
+                queued_.fetch_sub(1, std::memory_order_relaxed);
                 lk.unlock();
                 t.fn();
                 lk.lock();
@@ -75,6 +86,7 @@ private:
     std::mutex m_;
     std::condition_variable cv_work_, cv_done_;
     std::deque<Task> queue_;
+    std::atomic<int> queued_{0};          // queue_.size(), readable without the lock
     int workers_ = 0;
     pid_t pid_ = 0;
 
@@ -95,9 +107,15 @@ private:
     {
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
+            if (queue_.empty()) {   // parallel regions come in bursts: look again for a few microseconds before sleeping
+                lk.unlock();
+                for (int spin = 0; spin < 4000 && queued_.load(std::memory_order_relaxed) == 0; spin++) cpu_relax();
+                lk.lock();
+            }
             cv_work_.wait(lk, [this] { return !queue_.empty(); });
             Task t = std::move(queue_.front());
             queue_.pop_front();
+            queued_.fetch_sub(1, std::memory_order_relaxed);
             lk.unlock();
             t.fn();
             lk.lock();
