@@ -75,14 +75,19 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict
 // (At least one lane is active at every visited node: lanes that open a node stay active at i+1, and when nobody
 // opens, the active lanes all resume at skip = the next i.)
 // One wave per workgroup: walks differ in length (dense core vs outskirts).
+// BPW = bodies per wave.  A small system is latency-bound with most SIMDs idle (10 000 bodies are 157 full waves for
+// 1024 SIMDs): giving each wave only 8..32 consecutive (Morton-ordered) bodies multiplies the number of walks in
+// flight AND shortens each of them, since the union of what 8 neighbours need is smaller than what 64 need.  The
+// unused lanes never take part (resume index = "never"); per-body results do not depend on BPW.
 constexpr int kWaveBlock = 64;
+template <int BPW>
 __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* __restrict__ posm, const int lo,
                                                                   const int n_targets, const BhNode* __restrict__ nodes,
                                                                   const int n_nodes, const float theta,
                                                                   float2* __restrict__ out, const unsigned* __restrict__ perm)
 {
-    const int t = blockIdx.x * kWaveBlock + threadIdx.x;
-    const bool valid = t < n_targets;
+    const int t = blockIdx.x * BPW + threadIdx.x;
+    const bool valid = (int)threadIdx.x < BPW && t < n_targets;
     if (__ballot(valid) == 0ull) return;
     const int it = valid ? (perm ? (int)perm[t] - lo : t) : 0;
     const float4 pi = posm[lo + it];
@@ -293,9 +298,19 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
     if (mode == 1)
         hipLaunchKernelGGL(k_bh_eval_strict, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
                            force_out, perm);
-    else if (mode == 2 && perm)
-        hipLaunchKernelGGL(k_bh_eval_fast_wave, dim3((n_targets + kWaveBlock - 1) / kWaveBlock), dim3(kWaveBlock), 0, stream,
-                           posm, lo, n_targets, nodes, n_nodes, theta, force_out, perm);
+    else if (mode == 2 && perm) {
+        // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 8 and 64 bodies each
+        int bpw = 64;
+        while (bpw > 8 && (n_targets + bpw - 1) / bpw < 4096) bpw >>= 1;
+        const dim3 g((n_targets + bpw - 1) / bpw);
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, g, dim3(kWaveBlock), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta, force_out, perm);
+        };
+        if (bpw == 64) go(k_bh_eval_fast_wave<64>);
+        else if (bpw == 32) go(k_bh_eval_fast_wave<32>);
+        else if (bpw == 16) go(k_bh_eval_fast_wave<16>);
+        else go(k_bh_eval_fast_wave<8>);
+    }
     else
         hipLaunchKernelGGL(k_bh_eval_fast, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
                            force_out, perm);
