@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict
                                                         const int n_nodes, const float theta,
                                                         float2* __restrict__ out, const unsigned* __restrict__ perm)
 {
-    const int t = blockIdx.x * kTile + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;   // 64 threads per workgroup for small systems, kTile otherwise
     if (t >= n_targets) return;
     // perm (optional): a spatial (Morton) order of the bodies, so the 64 lanes of a wave walk nearly the same
     // nodes; it only changes which thread handles which body, never a result
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_strict(const float4* __restri
                                                           const int n_nodes, const float theta,
                                                           float2* __restrict__ out, const unsigned* __restrict__ perm)
 {
-    const int t = blockIdx.x * kTile + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;   // 64 threads per workgroup for small systems, kTile otherwise
     if (t >= n_targets) return;
     // perm (optional): Morton order of the bodies -- neighbouring lanes walk nearly the same nodes (coherent loads,
     // little divergence). It only decides which thread evaluates which body: every body's result is unchanged.
@@ -294,9 +294,11 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
                           int mode, float2* force_out, hipStream_t stream, const unsigned* perm)
 {
     if (n_targets <= 0) return hipSuccess;
-    const dim3 grid((n_targets + kTile - 1) / kTile);
+    // per-lane walks: one wave per workgroup while the system is too small to fill the chip (spreads the waves over the CUs)
+    const int block = n_targets <= 65536 ? 64 : kTile;
+    const dim3 grid((n_targets + block - 1) / block);
     if (mode == 1)
-        hipLaunchKernelGGL(k_bh_eval_strict, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
+        hipLaunchKernelGGL(k_bh_eval_strict, grid, dim3(block), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
                            force_out, perm);
     else if (mode == 2 && perm) {
         // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 8 and 64 bodies each
@@ -312,7 +314,7 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
         else go(k_bh_eval_fast_wave<8>);
     }
     else
-        hipLaunchKernelGGL(k_bh_eval_fast, grid, dim3(kTile), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
+        hipLaunchKernelGGL(k_bh_eval_fast, grid, dim3(block), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
                            force_out, perm);
     return hipGetLastError();
 }
