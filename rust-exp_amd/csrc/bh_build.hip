@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
                                                 const unsigned* __restrict__ box, const Prefix pre, const int n,
                                                 const int node_cap, BhNode* __restrict__ out)
 {
-    const int a = blockIdx.x * kTile + threadIdx.x;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;   // 64 threads per workgroup for small systems, kTile otherwise
     if (a >= n) return;
     const int first = pre.base[a];
     const int count = pre.base[a + 1] - first;
@@ -482,7 +482,8 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, k.sb, k.keys1, n, k.block_sums);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kTile), 0, stream, k.block_sums, sb);
     hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, k.sb, k.keys1, n, k.block_sums, k.pre, k.counters);
-    hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kTile), 0, stream, k.sb, k.keys1, k.box, k.pre, n, node_cap, out);
+    const int eb = n <= 65536 ? 64 : kTile;   // spread a small system's few waves over the CUs
+    hipLaunchKernelGGL(k_emit, dim3((n + eb - 1) / eb), dim3(eb), 0, stream, k.sb, k.keys1, k.box, k.pre, n, node_cap, out);
     e = hipMemcpyAsync(host_counters, k.counters, sizeof(int), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
