@@ -399,6 +399,9 @@ int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also, int n_also, bo
     return NBX_OK;
 }
 
+// node slots are 32-bit and a body can own up to 32 nodes: beyond this size the host build is used
+static constexpr int kDeviceTreeMaxBodies = 1 << 25;
+
 // quadtree on the device (bh_build.hip), in two halves so that a group can start every device's build before it waits
 // for any: begin enqueues the build, end waits for it. *done = false when the node pool overflowed (the caller falls
 // back to the host build).
@@ -446,6 +449,7 @@ int build_tree_on_device_end(nbx_engine* e, bool* done)
 int build_tree_on_device(nbx_engine* e, bool* done)
 {
     *done = false;
+    if (e->n > kDeviceTreeMaxBodies) return NBX_OK;   // caller takes the host path
     const int rc = build_tree_on_device_begin(e);
     if (rc != NBX_OK) return rc;
     return build_tree_on_device_end(e, done);
@@ -561,7 +565,7 @@ int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt)
     }
     nbx_engine* e0 = eng[0];
     if (e0->n == 0) return NBX_OK;
-    bool on_device = e0->bh_tree_device && e0->force_mode == 0;
+    bool on_device = e0->bh_tree_device && e0->force_mode == 0 && e0->n <= kDeviceTreeMaxBodies;
     if (on_device) {
         for (int d = 0; d < count; d++) {
             const int rc = build_tree_on_device_begin(eng[d]);
