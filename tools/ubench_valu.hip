@@ -66,6 +66,9 @@ __global__ __launch_bounds__(256) void k_mix(float* out, int iters, float seed, 
     float ax[4] = {0, 0, 0, 0}, ay[4] = {0, 0, 0, 0}, az[4] = {0, 0, 0, 0};
     v2f pax[4], pay[4], paz[4];
     for (int k = 0; k < 4; k++) pax[k] = pay[k] = paz[k] = v2f{0.f, 0.f};
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f macc[4][2];
+    for (int k = 0; k < 4; k++) macc[k][0] = macc[k][1] = v4f{0.f, 0.f, 0.f, 0.f};
     const v2f pxi = {xi, xi + 1.f}, pyi = {yi, yi + 1.f}, pzi = {zi, zi + 1.f};
     const v2f eps2 = {1e-4f, 1e-4f};
     float sx = seed * 3.f, sy = seed * 5.f, sz = seed * 7.f, sm = 1.0f;
@@ -106,6 +109,14 @@ __global__ __launch_bounds__(256) void k_mix(float* out, int iters, float seed, 
                     : "v"(pxi), "v"(pyi), "v"(pzi), "v"(sxy), "v"(szm), "v"(eps2));
                 inv = v2f{__builtin_amdgcn_rcpf(r2.x), __builtin_amdgcn_rcpf(r2.y)};
                 asm volatile("v_pk_mul_f32 %0, %1, %0 op_sel:[1,0] op_sel_hi:[1,1]" : "+v"(inv) : "v"(szm));
+                if (KIND == 22) {
+                    // accumulation on the matrix pipe: rank-1 updates acc[4 comps] += a[comp] * s[target], one MFMA per
+                    // half of the packed pair; a = the source's (x-c, y-c, z-c, 1)[lane % 4] (one v_mov stands in for it)
+                    float aval;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(aval) : "v"(sx));
+                    macc[k][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(aval, inv.x, macc[k][0], 0, 0, 0);
+                    macc[k][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(aval, inv.y, macc[k][1], 0, 0, 0);
+                } else
                 asm volatile(
                     "v_pk_fma_f32 %0, %3, %4, %0\n\t"
                     "v_pk_fma_f32 %1, %3, %5, %1\n\t"
@@ -118,6 +129,8 @@ __global__ __launch_bounds__(256) void k_mix(float* out, int iters, float seed, 
     const long long t1 = __builtin_readcyclecounter();
     float s = 0.f;
     for (int k = 0; k < 4; k++) s += ax[k] + ay[k] + az[k] + pax[k].x + pax[k].y + pay[k].x + pay[k].y + paz[k].x + paz[k].y;
+    for (int k = 0; k < 4; k++)
+        for (int h = 0; h < 2; h++) s += macc[k][h].x + macc[k][h].y + macc[k][h].z + macc[k][h].w;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
@@ -185,6 +198,9 @@ int main()
             cus, w, (long long)iters * 4 * 11, (double)iters * 4);
     for (int w : {1, 2, 4, 8})
         run("K1 mix packed (12 VALU/2 inter)", [&](int b, float* o, long long* c) { hipLaunchKernelGGL(k_mix<21>, dim3(b), dim3(256), 0, 0, o, iters, 1.5f, c); },
+            cus, w, (long long)iters * 4 * 12, (double)iters * 4 * 2);
+    for (int w : {1, 2, 4, 8})
+        run("K1 mix packed + 2 MFMA 4x4x1 (10 VALU + 2 MFMA / 2 inter)", [&](int b, float* o, long long* c) { hipLaunchKernelGGL(k_mix<22>, dim3(b), dim3(256), 0, 0, o, iters, 1.5f, c); },
             cus, w, (long long)iters * 4 * 12, (double)iters * 4 * 2);
     return 0;
 }
