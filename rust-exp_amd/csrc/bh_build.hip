@@ -420,6 +420,116 @@ hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size
     return hipGetLastError();
 }
 
+// ---- help for the HOST quadtree build: routing + stable scatter on the device ------------------------------------------
+//
+// The threaded host build (host_ops.cpp) inserts the first `warm` bodies sequentially, freezes the top levels, and then
+// needs every remaining body's bucket (the top-tree leaf it falls into, found by the reference's own quadrant test,
+// nbody.rs:322-331) and the bodies grouped by bucket in index order.  Both are data-parallel, the positions already
+// live here, and the host has better things to do with its 10 ms: the device descends the (uploaded, few-thousand-node)
+// top tree per body, sorts (bucket, index) pairs with a STABLE radix sort on the bucket bits only -- so index order
+// survives inside every bucket -- and writes the insert events and the bucket offsets straight into pinned host memory.
+struct TopNodeDev {
+    float x1, y1, x2, y2;
+    int32_t first_child;   // children first_child .. +3 in the order [UL, UR, LL, LR]
+    int32_t bucket;        // >= 0: this node is a bucket root; -1: pass-through
+};
+
+__global__ __launch_bounds__(kTile) void k_route(const float4* __restrict__ posm, const int warm, const int rest,
+                                                 const TopNodeDev* __restrict__ top, unsigned* __restrict__ keys,
+                                                 unsigned* __restrict__ idx, int* __restrict__ pbucket_host)
+{
+    const int i = blockIdx.x * kTile + threadIdx.x;
+    if (i >= rest) return;
+    const float4 p = posm[warm + i];
+    int k = 0;
+    TopNodeDev nd = top[0];
+    while (nd.bucket < 0) {
+        const float cx = __fmul_rn(__fadd_rn(nd.x1, nd.x2), 0.5f);   // quadrant_from_point, unfused like the host
+        const float cy = __fmul_rn(__fadd_rn(nd.y1, nd.y2), 0.5f);
+        k = nd.first_child + (p.y < cy ? 2 : 0) + (p.x < cx ? 0 : 1);
+        nd = top[k];
+    }
+    keys[i] = (unsigned)nd.bucket;
+    idx[i] = (unsigned)i;
+    pbucket_host[i] = nd.bucket;
+}
+
+struct HostEvent { float x, y, m; unsigned depth; };   // == QuadTree::Event
+
+__global__ __launch_bounds__(kTile) void k_gather_events(const float4* __restrict__ posm, const int warm, const int rest,
+                                                         const unsigned* __restrict__ keys_sorted,
+                                                         const unsigned* __restrict__ idx_sorted,
+                                                         const int* __restrict__ bucket_depth, HostEvent* __restrict__ events_host)
+{
+    const int p = blockIdx.x * kTile + threadIdx.x;
+    if (p >= rest) return;
+    const float4 b = posm[warm + (int)idx_sorted[p]];
+    events_host[p] = HostEvent{b.x, b.y, b.w, (unsigned)bucket_depth[keys_sorted[p]]};
+}
+
+// offset[b] = first sorted position whose bucket is >= b (b = 0 .. nb); one thread per bucket
+__global__ __launch_bounds__(kTile) void k_bucket_offsets(const unsigned* __restrict__ keys_sorted, const int rest, const int nb,
+                                                          unsigned long long* __restrict__ offset_host)
+{
+    const int b = blockIdx.x * kTile + threadIdx.x;
+    if (b > nb) return;
+    int lo = 0, hi = rest;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys_sorted[mid] < (unsigned)b) lo = mid + 1; else hi = mid;
+    }
+    offset_host[b] = (unsigned long long)lo;
+}
+
+size_t device_route_workspace_bytes(int rest, int ntop, int nb)
+{
+    size_t tmp = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
+                                    (size_t)rest, 0, 32, (hipStream_t)0);
+    size_t bytes = 0;
+    auto add = [&](size_t b) { bytes += (b + 255) & ~(size_t)255; };
+    add(sizeof(unsigned) * (size_t)rest * 4);     // keys in/out, idx in/out
+    add(tmp);
+    add(sizeof(TopNodeDev) * (size_t)ntop);
+    add(sizeof(int) * (size_t)nb);
+    return bytes;
+}
+
+// top_host: ntop records of 6 x 4 bytes (x1, y1, x2, y2, first_child, bucket) ; all *_host outputs are pinned, device-visible
+hipError_t device_route_and_scatter(const float4* posm, int warm, int rest, const void* top_host, int ntop,
+                                    const int* bucket_depth_host, int nb, void* workspace, size_t workspace_bytes,
+                                    int* pbucket_host, void* events_host, unsigned long long* offset_host, hipStream_t stream)
+{
+    if (rest <= 0) return hipSuccess;
+    if (device_route_workspace_bytes(rest, ntop, nb) > workspace_bytes) return hipErrorInvalidValue;
+    size_t tmp = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
+                                    (size_t)rest, 0, 32, (hipStream_t)0);
+    char* w = static_cast<char*>(workspace);
+    auto take = [&](size_t b) { char* p = w; w += (b + 255) & ~(size_t)255; return p; };
+    unsigned* keys0 = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * (size_t)rest * 4));
+    unsigned* keys1 = keys0 + rest;
+    unsigned* idx0 = keys1 + rest;
+    unsigned* idx1 = idx0 + rest;
+    void* sort_tmp = take(tmp);
+    TopNodeDev* top = reinterpret_cast<TopNodeDev*>(take(sizeof(TopNodeDev) * (size_t)ntop));
+    int* depth = reinterpret_cast<int*>(take(sizeof(int) * (size_t)nb));
+    hipError_t e = hipMemcpyAsync(top, top_host, sizeof(TopNodeDev) * (size_t)ntop, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(depth, bucket_depth_host, sizeof(int) * (size_t)nb, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    const int blocks = (rest + kTile - 1) / kTile;
+    hipLaunchKernelGGL(k_route, dim3(blocks), dim3(kTile), 0, stream, posm, warm, rest, top, keys0, idx0, pbucket_host);
+    int bits = 1;
+    while ((1 << bits) < nb) bits++;
+    e = rocprim::radix_sort_pairs(sort_tmp, tmp, keys0, keys1, idx0, idx1, (size_t)rest, 0, bits, stream);   // stable
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gather_events, dim3(blocks), dim3(kTile), 0, stream, posm, warm, rest, keys1, idx1, depth,
+                       reinterpret_cast<HostEvent*>(events_host));
+    hipLaunchKernelGGL(k_bucket_offsets, dim3((nb + 1 + kTile - 1) / kTile), dim3(kTile), 0, stream, keys1, rest, nb, offset_host);
+    return hipGetLastError();
+}
+
 // The sorted body order restricted to one slab of targets [lo, hi) (multi-GPU: every device walks the same tree for
 // its own slab): the entries of `perm` that fall in the slab, relative order kept, so that the slab's bodies are
 // still handed to consecutive lanes in Morton order and the wave-uniform walk applies.

@@ -346,7 +346,52 @@ int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also, int n_also, bo
         if (rc != NBX_OK) return rc;
     }
     const auto t1 = clk::now();
-    rc = e->tree.build(bx, by, e->host.m.data(), e->n, /*preflatten=*/true);
+    // big systems: the routing of the bodies to the top tree's buckets and their stable scatter run on the device
+    // (bh_build.hip) while the host threads fold; any device-side problem just leaves both to the host
+    nbx::QuadTree::RouteFn route = [e](const nbx::QuadTree::TopView& v, int warm, int rest, int* pbucket,
+                                       nbx::QuadTree::Event* sorted, size_t* offset) -> bool {
+        struct TopRec { float x1, y1, x2, y2; int32_t first_child, bucket; };
+        static_assert(sizeof(TopRec) == 24 && sizeof(nbx::QuadTree::Event) == 16, "layout shared with bh_build.hip");
+        std::vector<TopRec> top((size_t)v.ntop);
+        for (int k = 0; k < v.ntop; k++)
+            top[(size_t)k] = TopRec{v.top[k].x1, v.top[k].y1, v.top[k].x2, v.top[k].y2, v.top[k].first_child, v.bucket_of[k]};
+        const size_t need_ws = nbx::device_route_workspace_bytes(rest, v.ntop, v.nb);
+        if (need_ws > e->route_ws_bytes) {
+            if (e->d_route_ws && hipFree(e->d_route_ws) != hipSuccess) return false;
+            e->d_route_ws = nullptr;
+            e->route_ws_bytes = 0;
+            if (hipMalloc(&e->d_route_ws, need_ws + need_ws / 8) != hipSuccess) return false;
+            e->route_ws_bytes = need_ws + need_ws / 8;
+        }
+        const size_t ev_bytes = ((size_t)rest * 16 + 255) & ~(size_t)255, pb_bytes = ((size_t)rest * 4 + 255) & ~(size_t)255;
+        const size_t need_host = ev_bytes + pb_bytes + ((size_t)v.nb + 1) * 8;
+        if (need_host > e->h_route_bytes) {
+            if (e->h_route && hipHostFree(e->h_route) != hipSuccess) return false;
+            e->h_route = nullptr;
+            e->h_route_bytes = 0;
+            if (hipHostMalloc(reinterpret_cast<void**>(&e->h_route), need_host + need_host / 8, hipHostMallocDefault) != hipSuccess) return false;
+            e->h_route_bytes = need_host + need_host / 8;
+        }
+        char* ev_host = e->h_route;
+        int* pb_host = reinterpret_cast<int*>(e->h_route + ev_bytes);
+        unsigned long long* off_host = reinterpret_cast<unsigned long long*>(e->h_route + ev_bytes + pb_bytes);
+        if (nbx::device_route_and_scatter(e->d_posm, warm, rest, top.data(), v.ntop, v.bucket_depth, v.nb, e->d_route_ws,
+                                          e->route_ws_bytes, pb_host, ev_host, off_host, e->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+        // out of the pinned allocation into the build's own (cacheable) arrays
+        nbx::parallel_for(8, [&](int t) {
+            const size_t a = (size_t)rest * t / 8, b = (size_t)rest * (t + 1) / 8;
+            std::memcpy(sorted + a, ev_host + a * 16, (b - a) * 16);
+            std::memcpy(pbucket + a, pb_host + a, (b - a) * 4);
+        });
+        for (int b = 0; b <= v.nb; b++) offset[b] = (size_t)off_host[b];
+        return true;
+    };
+    const bool device_routes = e->dev_valid && e->n >= 262144;
+    rc = e->tree.build(bx, by, e->host.m.data(), e->n, /*preflatten=*/true, device_routes ? &route : nullptr);
     if (rc == NBX_ERR_TREE_DEPTH) return fail(rc, "quadtree depth > 50 (the reference panics here, nbody.rs:230-232)");
     if (rc != NBX_OK) return fail(rc, "quadtree build hit a reference assert (nbody.rs:267/:293/:304)");
     const auto t2 = clk::now();
@@ -624,6 +669,8 @@ void free_device(nbx_engine* e)
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->h_xy) (void)hipHostFree(e->h_xy);
     if (e->ev_xy) (void)hipEventDestroy(e->ev_xy);
+    if (e->d_route_ws) (void)hipFree(e->d_route_ws);
+    if (e->h_route) (void)hipHostFree(e->h_route);
     if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
 }
 

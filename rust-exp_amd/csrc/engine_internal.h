@@ -89,6 +89,10 @@ struct nbx_engine {
     float* h_xy = nullptr;            // pinned, device-visible: planar x[cap], y[cap] for the host tree build
     size_t h_xy_cap = 0;
     hipEvent_t ev_xy = nullptr;       // the planar (x, y) download has landed
+    void* d_route_ws = nullptr;       // device workspace of the routing + scatter help for the host build
+    size_t route_ws_bytes = 0;
+    char* h_route = nullptr;          // pinned, device-visible: insert events | bucket per body | bucket offsets
+    size_t h_route_bytes = 0;
 
     std::vector<ProfRec> prof;
     nbx::ForceLaunch last{0, 0, 0, 0, 0, 0};

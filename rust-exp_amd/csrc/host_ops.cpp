@@ -441,7 +441,7 @@ struct Builder {
 
 static int flatten_subtree_into(const std::vector<QuadTree::Node>& nodes, int root, BhNode* out, int base);
 
-int QuadTree::build(const float* px, const float* py, const float* m, int n, bool preflatten)
+int QuadTree::build(const float* px, const float* py, const float* m, int n, bool preflatten, const RouteFn* route)
 {
     nodes.clear();
     forest = false;
@@ -578,31 +578,45 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n, boo
     // build, the reference's own serial fold).  It needs no routing result, so it starts before anything else.
     auto fold_root = [&]() {
         Node mine = top[0];
-        for (int i = 0; i < rest; i++) add_mass(mine, px[warm + i], py[warm + i], m[warm + i]);
+        for (int i = 0; i < rest; i++)
+            if (!add_mass(mine, px[warm + i], py[warm + i], m[warm + i])) bad_mass.store(1);   // nbody.rs:304
         top[0].px = mine.px; top[0].py = mine.py; top[0].m = mine.m;
     };
     TaskGroup folds;   // declared after everything its tasks capture: its destructor waits for them on every exit path
     if (fold_levels > 0) folds.run(fold_root);
-    // (a) routing
-    run_threads(nt, [&](int t) {
-        const int lo = (int)((long long)rest * t / nt), hi = (int)((long long)rest * (t + 1) / nt);
-        for (int i = lo; i < hi; i++) {
-            const float qx = px[warm + i], qy = py[warm + i];
-            if (!(m[warm + i] > 0.0f)) bad_mass.store(1);
-            int k = 0;
-            while (bucket_of[k] < 0) k = top[k].first_child + quadrant(top[k], qx, qy);
-            pbucket[i] = bucket_of[k];
-        }
-    });
-    if (bad_mass.load()) return NBX_ERR_TREE;                              // nbody.rs:304
-    const auto tpa = std::chrono::steady_clock::now();
-    for (int lvl = 1; lvl < fold_levels; lvl++)
-        for (int sl = 0; sl < slices; sl++) folds.run([&fold, lvl, sl] { fold(lvl, sl); });
-    // (c) histogram + stable scatter of the particles into per-bucket queues (index order kept)
     std::vector<size_t> offset((size_t)nb + 1, 0);
     sorted.resize((size_t)rest);
-    std::vector<std::vector<size_t>> hist(nt, std::vector<size_t>((size_t)nb, 0));
-    {
+    bool routed = false;
+    if (route && *route) {   // phases (a) and (c) elsewhere (the engine does them on the GPU)
+        std::vector<int> bucket_depth((size_t)nb);
+        for (int b2 = 0; b2 < nb; b2++) bucket_depth[(size_t)b2] = level[root_of[b2]];
+        const TopView view{top.data(), bucket_of.data(), ntop, bucket_depth.data(), nb};
+        routed = (*route)(view, warm, rest, pbucket.data(), sorted.data(), offset.data());
+        if (routed && fold_levels == 0)   // nobody else looks at the masses then
+            for (int i = 0; i < rest; i++)
+                if (!(m[warm + i] > 0.0f)) bad_mass.store(1);
+    }
+    auto tpa = std::chrono::steady_clock::now();
+    if (!routed) {
+        // (a) routing
+        run_threads(nt, [&](int t) {
+            const int lo = (int)((long long)rest * t / nt), hi = (int)((long long)rest * (t + 1) / nt);
+            for (int i = lo; i < hi; i++) {
+                const float qx = px[warm + i], qy = py[warm + i];
+                if (!(m[warm + i] > 0.0f)) bad_mass.store(1);
+                int k = 0;
+                while (bucket_of[k] < 0) k = top[k].first_child + quadrant(top[k], qx, qy);
+                pbucket[i] = bucket_of[k];
+            }
+        });
+        if (bad_mass.load()) return NBX_ERR_TREE;                              // nbody.rs:304
+        tpa = std::chrono::steady_clock::now();
+    }
+    for (int lvl = 1; lvl < fold_levels; lvl++)
+        for (int sl = 0; sl < slices; sl++) folds.run([&fold, lvl, sl] { fold(lvl, sl); });
+    if (!routed) {
+        // (c) histogram + stable scatter of the particles into per-bucket queues (index order kept)
+        std::vector<std::vector<size_t>> hist(nt, std::vector<size_t>((size_t)nb, 0));
         run_threads(nt, [&](int t) {
             const int lo = (int)((long long)rest * t / nt), hi = (int)((long long)rest * (t + 1) / nt);
             for (int i = lo; i < hi; i++) hist[t][(size_t)pbucket[i]]++;
@@ -662,6 +676,7 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n, boo
     });
     const auto tp3a = std::chrono::steady_clock::now();
     folds.wait();   // the pass-through nodes (touched by nobody else) are final now
+    if (bad_mass.load()) return NBX_ERR_TREE;                                  // nbody.rs:304
     for (int b2 = 0; b2 < nb; b2++)
         if (status[b2] != NBX_OK) return status[b2];
     // The tree stays a forest: `nodes` = top levels, pools[b] = subtree of bucket b (local indices,

@@ -80,7 +80,20 @@ struct QuadTree {
     // status: 0 ok, else the NBX_ERR_* code standing in for the reference panic
     // preflatten: the threaded build also flattens every bucket subtree right after replaying it (while it is hot in
     // the cache) into flat_pools; flatten_write then only copies the pieces into place and rebases their skip pointers
-    int build(const float* px, const float* py, const float* m, int n, bool preflatten = false);
+    // route (optional): an external implementation of phase 1a/1c of the threaded build -- given the frozen top
+    // levels it must fill, for the bodies warm .. n-1, pbucket[i - warm] = bucket of body i, `sorted` = their insert
+    // events grouped by bucket with the index order kept inside every bucket (depth = level of the bucket root), and
+    // offset[b] .. offset[b+1] = bucket b's range in `sorted`.  Returns false to make the build do it itself.
+    // (The engine routes and scatters on the GPU, where the positions already are: bh_build.hip.)
+    struct TopView {
+        const Node* top;            // nodes of the top levels; top[k].first_child >= 0 for pass-through nodes
+        const int* bucket_of;       // per top node: bucket id, or -1 for a pass-through node
+        int ntop;
+        const int* bucket_depth;    // per bucket: level of its root (the depth its inserts start at)
+        int nb;
+    };
+    using RouteFn = std::function<bool(const TopView& view, int warm, int rest, int* pbucket, Event* sorted, size_t* offset)>;
+    int build(const float* px, const float* py, const float* m, int n, bool preflatten = false, const RouteFn* route = nullptr);
     // pre-order, all nodes (including empty exteriors), rows of 8 floats (see nbx_bh_tree_dump)
     int dump_preorder(float* rows, int cap) const;
     // pre-order with empty exterior nodes dropped + skip pointers, for the GPU traversal (serial)

@@ -73,6 +73,13 @@ hipError_t launch_bh_count(const float4* posm, int lo, int n_targets, const BhNo
 size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes);
 hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size_t workspace_bytes, const unsigned** perm_dev,
                                 hipStream_t stream);
+// Routing + stable scatter for the host quadtree build (see bh_build.hip): top_host = ntop records of (x1, y1, x2, y2,
+// first_child, bucket); pbucket_host / events_host / offset_host are pinned, device-visible host arrays of rest ints,
+// rest 16-byte insert events and nb + 1 64-bit offsets.  Enqueues on `stream`; the caller waits.
+size_t device_route_workspace_bytes(int rest, int ntop, int nb);
+hipError_t device_route_and_scatter(const float4* posm, int warm, int rest, const void* top_host, int ntop,
+                                    const int* bucket_depth_host, int nb, void* workspace, size_t workspace_bytes,
+                                    int* pbucket_host, void* events_host, unsigned long long* offset_host, hipStream_t stream);
 // perm restricted to the bodies of one slab [lo, hi), order kept (global body indices); *slab_perm points into workspace
 size_t device_slab_order_workspace_bytes(int n);
 hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* workspace, size_t workspace_bytes,

@@ -30,7 +30,7 @@ def test_bh_strict_matches_golden_bitwise(rx, name):
 
 
 @pytest.mark.parametrize("n,seed,theta", [(2, 1, 0.5), (10000, 2, 0.85), (10000, 3, 0.3), (30000, 4, 0.95),
-                                          (100000, 6, 0.5), (150001, 7, 0.7)])
+                                          (100000, 6, 0.5), (150001, 7, 0.7), (300001, 8, 0.6), (300000, 9, 0.85)])   # >= 262144: device-side routing + scatter
 def test_bh_strict_matches_oracle_bitwise(rx, ob, n, seed, theta):
     p = ob.stable_orbits(n, 0.5, 30.0, seed) if seed % 2 == 0 else ob.random_disk(n, seed)
     e = rx.NBodyEngine(mode="strict")

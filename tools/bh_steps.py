@@ -15,7 +15,10 @@ st = rx.plummer_sphere(n, dim=2)
 e = rx.NBodyEngine(mode="fast")
 e.set_bh_tree(tree)
 e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+import time
+e.step_barnes_hut(0.5, 0.01, 1); e.synchronize(); e.bh_host_timing()     # warm-up (allocations)
+ts = []
 for _ in range(steps):
-    e.step_barnes_hut(0.5, 0.01, 1)
-e.synchronize()
-print("ok", e.bh_host_timing())
+    t0 = time.perf_counter(); e.step_barnes_hut(0.5, 0.01, 1); e.synchronize(); ts.append(time.perf_counter() - t0)
+ts.sort()
+print("ok median_ms %.3f min_ms %.3f" % (ts[len(ts) // 2] * 1e3, ts[0] * 1e3), e.bh_host_timing())
