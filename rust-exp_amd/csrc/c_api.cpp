@@ -263,7 +263,13 @@ int32_t nbx_forces(nbx_engine* e, float theta, int32_t cap, float* fx, float* fy
     bool is_accel = false;
     if (theta == 0.0f) {
         ProfScope ps(e, NBX_K_FORCE);
-        HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream));
+        unsigned* guard = nullptr;
+        if (nbx::strict_fastdiv_ok(e->mass_min, e->mass_max)) {
+            rc = grow(&e->d_guard, &e->guard_cap, 1);
+            if (rc != NBX_OK) return rc;
+            guard = e->d_guard;
+        }
+        HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream, nullptr, guard));
     } else {
         bool on_device = false;
         if (e->bh_tree_device && e->force_mode == 0) {

@@ -262,7 +262,13 @@ int step_brute(nbx_engine* e, float dt)
         if (rc != NBX_OK) return rc;
         {
             ProfScope ps(e, NBX_K_FORCE);
-            HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream, &e->last));
+            unsigned* guard = nullptr;   // the short exact division needs the mass range here and max|coordinate| on the device
+            if (nbx::strict_fastdiv_ok(e->mass_min, e->mass_max)) {
+                rc = grow(&e->d_guard, &e->guard_cap, 1);
+                if (rc != NBX_OK) return rc;
+                guard = e->d_guard;
+            }
+            HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream, &e->last, guard));
         }
         {
             ProfScope ps(e, NBX_K_INTEGRATE);
@@ -689,6 +695,13 @@ void after_host_state_change(nbx_engine* e)
     e->any_z = false;
     for (int i = 0; i < e->n && !e->any_z; i++)
         if (e->host.pz[i] != 0.0f || e->host.vz[i] != 0.0f) e->any_z = true;
+    e->mass_min = e->n ? e->host.m[0] : 0.0f;
+    e->mass_max = e->mass_min;
+    for (int i = 1; i < e->n; i++) {
+        const float m = e->host.m[i];
+        if (!(m >= e->mass_min)) e->mass_min = m;   // a NaN mass ends up in mass_min and fails every range test
+        if (m > e->mass_max) e->mass_max = m;
+    }
 }
 
 

@@ -74,6 +74,7 @@ struct nbx_engine {
     // options
     int force_mode = 0, jsplit = 0, bpt = 0, dim_opt = 0, profile = 0, variant = -1;
     bool any_z = false;
+    float mass_min = 0.0f, mass_max = 0.0f;   // over the current bodies (masses never change during a run)
 
     nbx::Rng rng{0};
     bool seeded = false;

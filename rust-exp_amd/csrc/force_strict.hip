@@ -14,13 +14,34 @@
 
 namespace nbx {
 
+// Correctly rounded a / b.  FASTDIV = false: the compiler's IEEE expansion (v_div_scale x2, v_rcp, five fma/mul,
+// v_div_fmas, v_div_fixup).  FASTDIV = true: the arithmetic core of that same expansion -- reciprocal refined once, quotient
+// refined twice -- without the three range-handling instructions.  The two agree bit for bit whenever v_div_scale has
+// nothing to scale and v_div_fixup nothing to fix: both operands normal, numerator above 2^-103, exponent difference
+// inside (-126, 96).  The kernel takes this path only when the launch has PROVEN that for every pair (mass range known
+// on the host, max|coordinate| reduced on the device just before the launch; see strict_fastdiv_ok).
+template <bool FASTDIV>
+__device__ __forceinline__ float ieee_div(const float a, const float b)
+{
+    if (!FASTDIV) return a / b;
+    float y = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, y, 1.0f);
+    y = __builtin_fmaf(e0, y, y);
+    float q = a * y;
+    const float r0 = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r0, y, q);
+    const float r1 = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r1, y, q);
+}
+
+template <bool FASTDIV>
 __device__ __forceinline__ void ref_force(float px1, float py1, float m1, float px2, float py2, float m2,
                                           float& fx, float& fy)
 {
     const float dx = __fsub_rn(px2, px1);                                // nbody.rs:174
     const float dy = __fsub_rn(py2, py1);                                // :175
     const float dist_sq = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));  // :176
-    const float f = __fmul_rn(m1, m2) / __fadd_rn(dist_sq, kEps);        // :180
+    const float f = ieee_div<FASTDIV>(__fmul_rn(m1, m2), __fadd_rn(dist_sq, kEps));   // :180
     fx = __fmul_rn(f, dx);                                               // :183
     fy = __fmul_rn(f, dy);
 }
@@ -55,19 +76,23 @@ __device__ __forceinline__ void add_group_terms(float& fx, float& fy, const floa
 }
 #undef NBX_DPP_ADD
 
-template <int C, bool kCheck>
+template <int C, bool kCheck, bool FASTDIV>
 __device__ __forceinline__ void strict_group(const float4 sj, const int j, const int i, const int n, const float4 pi,
                                              float& fx, float& fy)
 {
     float tx, ty;
-    ref_force(pi.x, pi.y, pi.w, sj.x, sj.y, sj.w, tx, ty);              // nbody.rs:140
+    ref_force<FASTDIV>(pi.x, pi.y, pi.w, sj.x, sj.y, sj.w, tx, ty);     // nbody.rs:140
     if (kCheck && (j == i || j >= n)) { tx = 0.0f; ty = 0.0f; }         // :136; +0 leaves a sum that started at +0 unchanged
     add_group_terms<C>(fx, fy, tx, ty);                                 // ascending j
 }
 
-template <int C>
-__global__ __launch_bounds__(kTile) void k_force_strict(const float4* __restrict__ posm, const int n, const int lo,
-                                                        const int n_targets, float2* __restrict__ force_out)
+// |coordinate| bound under which the short division is exact for every pair (with the mass bounds of strict_fastdiv_ok):
+// d^2 + EPS <= 8 * 1e5^2 + EPS < 1e11
+constexpr unsigned kFastDivCoordBits = 0x47C35000u;   // 1.0e5f
+
+template <int C, bool FASTDIV>
+__device__ __forceinline__ void strict_sweep(const float4* __restrict__ posm, const int n, const int lo, const int n_targets,
+                                             float2* __restrict__ force_out)
 {
     constexpr int kTargets = kTile / C;            // targets per workgroup
     __shared__ float4 tile[2][kTile];
@@ -89,33 +114,56 @@ __global__ __launch_bounds__(kTile) void k_force_strict(const float4* __restrict
         // the index test and the end-of-array test are only compiled into the tiles that need them (uniform per workgroup)
         if (jbase + kTile <= n && (jbase + kTile <= wg_first || jbase >= wg_first + kTargets)) {
 #pragma unroll 4
-            for (int k = 0; k < kTile; k += C) strict_group<C, false>(tile[buf][k + c], jbase + k + c, i, n, pi, fx, fy);
+            for (int k = 0; k < kTile; k += C)
+                strict_group<C, false, FASTDIV>(tile[buf][k + c], jbase + k + c, i, n, pi, fx, fy);
         } else {
 #pragma unroll 2
-            for (int k = 0; k < kTile; k += C) strict_group<C, true>(tile[buf][k + c], jbase + k + c, i, n, pi, fx, fy);
+            for (int k = 0; k < kTile; k += C)
+                strict_group<C, true, FASTDIV>(tile[buf][k + c], jbase + k + c, i, n, pi, fx, fy);
         }
         buf ^= 1;
     }
     if (c == 0 && it < n_targets) force_out[it] = make_float2(fx, fy);
 }
 
+// guard: device word with max|coordinate| of the sources as float bits (k_max_coord, same stream), or null = always the
+// compiler's IEEE division.  The choice is uniform for the whole launch.
+template <int C>
+__global__ __launch_bounds__(kTile) void k_force_strict(const float4* __restrict__ posm, const int n, const int lo,
+                                                        const int n_targets, float2* __restrict__ force_out,
+                                                        const unsigned* __restrict__ guard)
+{
+    if (guard && guard[0] <= kFastDivCoordBits)
+        strict_sweep<C, true>(posm, n, lo, n_targets, force_out);
+    else
+        strict_sweep<C, false>(posm, n, lo, n_targets, force_out);
+}
+
 // group size by targets per GPU (measured, profiles/r01_strict_coop_sweep.txt): 4 lanes per target up to 40 960
 // targets, 2 up to 98 304, one thread per body beyond
 int strict_group_size(int n_targets) { return n_targets <= 40960 ? 4 : (n_targets <= 98304 ? 2 : 1); }
 
+// Masses for which m_i * m_j is a normal float in [1e-20, 1e20] for every pair; together with |coordinates| <= 1e5
+// (checked on the device) no pair's division needs the scaling / fix-up steps of the IEEE expansion.
+bool strict_fastdiv_ok(float mass_min, float mass_max) { return mass_min >= 1.0e-10f && mass_max <= 1.0e10f; }
+
 hipError_t launch_force_strict(const float4* posm, int n, int lo, int n_targets, float2* force_out,
-                               hipStream_t stream, ForceLaunch* info)
+                               hipStream_t stream, ForceLaunch* info, unsigned* guard)
 {
     if (n_targets <= 0) return hipSuccess;
+    if (guard) {   // refresh max|coordinate| of the current sources (padding records are zeros)
+        const hipError_t e = launch_max_coord(posm, ((n + kTile - 1) / kTile) * kTile, guard, stream);
+        if (e != hipSuccess) return e;
+    }
     const int c = strict_group_size(n_targets);
     const int per_wg = kTile / c;
     const dim3 grid((n_targets + per_wg - 1) / per_wg);
     if (c == 4)
-        hipLaunchKernelGGL(k_force_strict<4>, grid, dim3(kTile), 0, stream, posm, n, lo, n_targets, force_out);
+        hipLaunchKernelGGL(k_force_strict<4>, grid, dim3(kTile), 0, stream, posm, n, lo, n_targets, force_out, guard);
     else if (c == 2)
-        hipLaunchKernelGGL(k_force_strict<2>, grid, dim3(kTile), 0, stream, posm, n, lo, n_targets, force_out);
+        hipLaunchKernelGGL(k_force_strict<2>, grid, dim3(kTile), 0, stream, posm, n, lo, n_targets, force_out, guard);
     else
-        hipLaunchKernelGGL(k_force_strict<1>, grid, dim3(kTile), 0, stream, posm, n, lo, n_targets, force_out);
+        hipLaunchKernelGGL(k_force_strict<1>, grid, dim3(kTile), 0, stream, posm, n, lo, n_targets, force_out, guard);
     // jsplit = 1: the source loop is never split; variant = -(lanes that share one target)
     if (info) *info = ForceLaunch{(int)grid.x, kTile, 1, 1, 2, -c};
     return hipGetLastError();

@@ -284,6 +284,16 @@ __global__ __launch_bounds__(kTile) void k_max_coord(const float4* __restrict__ 
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+hipError_t launch_max_coord(const float4* posm, int n_records, unsigned* guard, hipStream_t stream)
+{
+    const hipError_t e = hipMemsetAsync(guard, 0, sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
+    if (n_records <= 0) return hipSuccess;
+    const int blocks = (n_records + kTile - 1) / kTile;
+    hipLaunchKernelGGL(k_max_coord, dim3(blocks < 256 ? blocks : 256), dim3(kTile), 0, stream, posm, n_records, guard);
+    return hipGetLastError();
+}
+
 template <int P, int DIM, int UNROLL>
 __global__ __launch_bounds__(kTile) void k_force_tile_pk(const float4* __restrict__ posm, const int lo,
                                                          const int n_targets, const int tiles_total,
@@ -489,10 +499,8 @@ static hipError_t launch_variant(int variant, dim3 grid, hipStream_t stream, con
                            n_targets, tiles_total, jsplit, acc_partial, acc_stride);
     else if (variant == 4 && (B % 2) == 0 && guard) {
         // refresh max|coord| of the source array this launch will read, on the same stream
-        hipError_t e = hipMemsetAsync(guard, 0, sizeof(unsigned), stream);
+        const hipError_t e = launch_max_coord(posm, tiles_total * kTile, guard, stream);
         if (e != hipSuccess) return e;
-        const int mblocks = tiles_total < 256 ? tiles_total : 256;
-        hipLaunchKernelGGL(k_max_coord, dim3(mblocks), dim3(kTile), 0, stream, posm, tiles_total * kTile, guard);
         hipLaunchKernelGGL((k_force_tile_pkb<(B >= 2 ? B / 2 : 1), DIM, 8, true>), grid, dim3(kTile), 0, stream, posm,
                            lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride, guard);
         hipLaunchKernelGGL((k_force_tile_pkb<(B >= 2 ? B / 2 : 1), DIM, 8, false>), grid, dim3(kTile), 0, stream, posm,

@@ -48,8 +48,14 @@ hipError_t launch_reduce_forces(const float4* posm, int lo, int n_targets, const
 
 // strict (bit-exact) pair: one thread per body, ascending j, IEEE divide, no contraction. 2-D.
 // 1, 2 or 4 adjacent lanes share one target (terms in parallel, sums in order); info->variant = -(group size).
+// guard (optional device word): when given, max|coordinate| of the sources is reduced into it first and the kernel takes
+// the short correctly-rounded division whenever that maximum is <= 1e5 -- the caller passes it only if
+// strict_fastdiv_ok(min mass, max mass); null = always the compiler's IEEE division. Results are identical either way.
 hipError_t launch_force_strict(const float4* posm, int n, int lo, int n_targets, float2* force_out,
-                               hipStream_t stream, ForceLaunch* info = nullptr);
+                               hipStream_t stream, ForceLaunch* info = nullptr, unsigned* guard = nullptr);
+bool strict_fastdiv_ok(float mass_min, float mass_max);
+// *guard = float bits of max(|x|, |y|, |z|) over posm[0..n_records) (NaN counts as +inf)
+hipError_t launch_max_coord(const float4* posm, int n_records, unsigned* guard, hipStream_t stream);
 // kick-drift from a per-body force (v += (dt*F)/m, nbody.rs:155) or acceleration (is_accel: v += dt*a),
 // optional velocity kill box (nbody.rs:466-471).
 hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel, const float2* force, float dt,

@@ -288,3 +288,45 @@ def test_profile_records_kernel_time(rx, ob):
     assert cnt == 4 and ms > 0
     ms2, cnt2 = e.profile_read(rx.NBX_K_INTEGRATE)
     assert cnt2 == 4 and ms2 > 0 and ms2 < ms
+
+
+@pytest.mark.parametrize("case", ["edge_of_fast_range", "tiny_masses", "huge_masses", "far_coordinates", "zero_mass", "mixed_16k"])
+def test_strict_division_paths_are_bit_exact(rx, ob, case):
+    """The bit-exact kernel divides with the short exact sequence only when the launch has proven that no pair needs the
+    scaling / fix-up steps of the IEEE expansion (masses in [1e-10, 1e10], |coordinates| <= 1e5), and with the
+    compiler's full expansion otherwise. Both must equal the oracle bit for bit: at the edge of the fast range (mass
+    products 1e-20 .. 1e20, separations up to 2.8e5) and on every side of it."""
+    rng = np.random.default_rng(31)
+    n = 16384 if case == "mixed_16k" else 3000
+    x = rng.uniform(-40, 40, n).astype(np.float32)
+    y = rng.uniform(-40, 40, n).astype(np.float32)
+    m = rng.uniform(0.5, 2.0, n).astype(np.float32)
+    if case in ("edge_of_fast_range", "mixed_16k"):
+        m[: n // 3] = 1e-10
+        m[n // 3: 2 * n // 3] = 1e10
+        x[::7] = rng.uniform(-1e5, 1e5, len(x[::7])).astype(np.float32)
+        y[::11] = rng.uniform(-1e5, 1e5, len(y[::11])).astype(np.float32)
+        x[5] = 1e5; y[5] = -1e5; x[6] = -1e5; y[6] = 1e5          # the largest separation the guard admits
+        x[7] = x[8]; y[7] = np.nextafter(y[8], np.float32(1e9))    # and the smallest: one ulp apart
+    elif case == "tiny_masses":
+        m[::3] = 1e-15; m[1::3] = 3e-38
+    elif case == "huge_masses":
+        m[::3] = 1e12; m[1::3] = 1e18
+    elif case == "far_coordinates":
+        x[::5] *= 1e4; y[::9] *= 1e5
+    else:
+        m[::4] = 0.0
+    p = ob.particles(x, y, rng.normal(0, 1, n), rng.normal(0, 1, n), m)
+    e = rx.NBodyEngine(mode="strict")
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    fx, fy, _ = e.forces(0.0)
+    wx, wy = ob.brute_forces(p, 0, n)
+    assert_bit_equal(fx, wx, case + " fx"); assert_bit_equal(fy, wy, case + " fy")
+    q = p.copy()
+    for _ in range(2):
+        e.step_brute_force(DT)
+        ob.step_brute_force(q, DT)
+    st = e.get_particles()
+    with np.errstate(invalid="ignore"):
+        for k in ("px", "py", "vx", "vy"):
+            assert np.array_equal(st[k].view(np.uint32), q[k].view(np.uint32)), f"{case} {k}"
