@@ -557,13 +557,15 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n, boo
         for (int k = parent[root_of[b2]]; k >= 0; k = parent[k]) anc[(size_t)b2 * (max_level + 1) + level[k]] = k;
     const int fold_levels = max_level;                                   // pass-through nodes live on levels 0..max_level-1
     const int slices = std::max(1, std::min(4, nt / std::max(1, fold_levels)));
+    const std::vector<Node> top0(top.begin(), top.begin() + ntop);   // the top levels as the warm-up left them
     // (b) folds: one task per (level, slice of that level's nodes) adds the particles to that level's pass-through
     // nodes in index order.  They run beside everything below and are only waited for at the very end.
     auto fold = [&](int lvl, int slice) {
         const size_t stride = (size_t)(max_level + 1);
         // work on a private copy: 32-byte nodes of different levels share cache lines in `top`, and every fold
-        // thread writes its nodes a million times (false sharing cost 5x here)
-        std::vector<Node> mine(top.begin(), top.begin() + ntop);
+        // thread writes its nodes a million times (false sharing cost 5x here).  The copy comes from a snapshot taken
+        // before any fold started, so no task ever reads what another one is writing back.
+        std::vector<Node> mine(top0);
         for (int i = 0; i < rest; i++) {
             const int k = anc[(size_t)pbucket[i] * stride + lvl];
             if (k < 0 || (k % slices) != slice) continue;
@@ -577,7 +579,7 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n, boo
     // the root sees EVERY particle, a 1 M-long chain of dependent adds (~4 ms at 1 M bodies: the longest task of the
     // build, the reference's own serial fold).  It needs no routing result, so it starts before anything else.
     auto fold_root = [&]() {
-        Node mine = top[0];
+        Node mine = top0[0];
         for (int i = 0; i < rest; i++)
             if (!add_mass(mine, px[warm + i], py[warm + i], m[warm + i])) bad_mass.store(1);   // nbody.rs:304
         top[0].px = mine.px; top[0].py = mine.py; top[0].m = mine.m;

@@ -1,0 +1,31 @@
+// Host-side sanitizer harness: threaded quadtree build (+ pre-flatten), pipelined flatten, threaded draw, straight on
+// nbx::QuadTree / nbx::draw_particles (no device).  Built and run by tests/test_host_sanitizers.py with
+// -fsanitize=thread and -fsanitize=address,undefined.
+#include <cstdio>
+#include <random>
+#include <vector>
+#include "host_ops.h"
+int main()
+{
+    const int n = 120000;
+    std::mt19937 rng(5);
+    std::normal_distribution<float> g(0.f, 8.f);
+    std::uniform_real_distribution<float> um(0.5f, 2.f);
+    std::vector<float> px(n), py(n), vx(n), vy(n), m(n);
+    for (int i = 0; i < n; i++) { px[i] = g(rng); py[i] = g(rng); vx[i] = g(rng); vy[i] = g(rng); m[i] = um(rng); }
+    nbx::QuadTree t;
+    for (int rep = 0; rep < 3; rep++) {
+        int rc = t.build(px.data(), py.data(), m.data(), n, true);
+        nbx::QuadTree::FlatPlan plan;
+        size_t cnt = t.flatten_prepare(plan);
+        std::vector<nbx::BhNode> out(cnt);
+        size_t sent = 0;
+        t.flatten_write(plan, out.data(), [&](size_t a, size_t b) { sent += b - a; });
+        std::printf("rc=%d nodes=%zu sent=%zu skip0=%d\n", rc, cnt, sent, out[0].skip);
+    }
+    std::vector<uint32_t> fb(512 * 512);
+    nbx::draw_particles(px.data(), py.data(), vx.data(), vy.data(), n, 512, 512, fb.data());
+    size_t lit = 0; for (auto v : fb) lit += v != 0;
+    std::printf("lit=%zu\n", lit);
+    return 0;
+}
