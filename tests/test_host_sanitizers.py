@@ -29,4 +29,4 @@ def test_host_code_is_sanitizer_clean(tmp_path, san, threads):
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
     assert "Sanitizer" not in out and "runtime error" not in out, out[-3000:]
-    assert out.count("rc=0") == 3 and "lit=" in out
+    assert out.count("rc=0") == 5 and "lit=" in out

@@ -3,6 +3,7 @@
 // -fsanitize=thread and -fsanitize=address,undefined.
 #include <cstdio>
 #include <random>
+#include <thread>
 #include <vector>
 #include "host_ops.h"
 int main()
@@ -22,6 +23,19 @@ int main()
         size_t sent = 0;
         t.flatten_write(plan, out.data(), [&](size_t a, size_t b) { sent += b - a; });
         std::printf("rc=%d nodes=%zu sent=%zu skip0=%d\n", rc, cnt, sent, out[0].skip);
+    }
+    {   // two callers at once: both use the one worker pool
+        auto caller = [&](int seed) {
+            std::vector<float> qx(px), qy(py);
+            for (int i = 0; i < n; i += 3) { qx[i] += 0.001f * seed; qy[i] -= 0.002f * seed; }
+            nbx::QuadTree u;
+            const int rc = u.build(qx.data(), qy.data(), m.data(), n, true);
+            std::vector<nbx::BhNode> flat;
+            u.flatten(flat);
+            std::printf("caller %d rc=%d flat=%zu\n", seed, rc, flat.size());
+        };
+        std::thread a(caller, 1), b(caller, 2);
+        a.join(); b.join();
     }
     std::vector<uint32_t> fb(512 * 512);
     nbx::draw_particles(px.data(), py.data(), vx.data(), vy.data(), n, 512, 512, fb.data());
