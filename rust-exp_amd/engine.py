@@ -320,6 +320,9 @@ class NBodyEngine:
     def set_mode(self, mode):
         self.set_option(NBX_OPT_FORCE_MODE, {"fast": 0, "strict": 1}[mode])
 
+    def get_option(self, opt):
+        return int(self._L.nbx_get_option(self._h, opt))
+
     def set_launch(self, jsplit=0, bodies_per_thread=0, dim=0, variant=-1):
         self.set_option(NBX_OPT_JSPLIT, jsplit)
         self.set_option(NBX_OPT_BODIES_PER_THREAD, bodies_per_thread)

@@ -330,3 +330,29 @@ def test_strict_division_paths_are_bit_exact(rx, ob, case):
     with np.errstate(invalid="ignore"):
         for k in ("px", "py", "vx", "vy"):
             assert np.array_equal(st[k].view(np.uint32), q[k].view(np.uint32)), f"{case} {k}"
+
+
+def test_mode_switch_on_a_live_engine_and_half_source_size(rx, ob):
+    """NBX_OPT_FORCE_MODE may change between steps of one engine: each step then equals the same step of an engine
+    that was in that mode all along (fast within tolerance, strict bit for bit); the fp16 source copy reports
+    8 bytes per padded body."""
+    p = ob.stable_orbits(5000, 0.5, 30.0, 12)
+    e = rx.NBodyEngine(mode="fast")
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    e.set_mode("strict")
+    e.step_brute_force(DT)
+    q = p.copy(); ob.step_brute_force(q, DT)
+    st = e.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        assert_bit_equal(st[k], q[k], k)
+    e.set_mode("fast")
+    e.step_brute_force(DT)
+    ob.step_brute_force(q, DT)
+    st = e.get_particles()
+    assert np.abs(st["px"] - q["px"]).max() <= 1e-5 * max(1.0, np.abs(q["px"]).max())
+    assert np.abs(st["vx"] - q["vx"]).max() <= 2e-3
+    e.set_source_precision(16)
+    e.step_brute_force(DT)
+    assert e.half_sources_bytes() == ((5000 + 255) // 256) * 256 * 8
+    from rust_exp_amd.engine import NBX_OPT_FORCE_MODE, NBX_OPT_SOURCE_PRECISION
+    assert e.get_option(NBX_OPT_FORCE_MODE) == 0 and e.get_option(NBX_OPT_SOURCE_PRECISION) == 16
