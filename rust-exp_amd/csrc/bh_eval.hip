@@ -196,6 +196,90 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_strict(const float4* __restri
     out[it] = make_float2(fx, fy);
 }
 
+// Wave-uniform form of the bit-exact walk (bodies in Morton order): the 64 lanes share one walk like
+// k_bh_eval_fast_wave -- scalar node loads, uniform control flow, lanes parked on subtrees they accepted -- and keep the
+// reference's hierarchical sums.  The frames become WAVE frames: when any lane opens a node the wave pushes one frame
+// (its end index lives in lane d of a register, read back with v_readlane), and exactly the lanes that opened it save
+// their running sums at depth d (bit d of `mine`); when the walk reaches the frame's end those lanes fold the child sum
+// back, parent + children, like nbody.rs:358.  The per-lane arrays are indexed by the uniform depth, so the scratch
+// accesses are coalesced.  Every lane performs the same decisions and the same additions in the same order as in
+// k_bh_eval_strict: same bits.
+template <int BPW>
+__global__ __launch_bounds__(kWaveBlock) void k_bh_eval_strict_wave(const float4* __restrict__ posm, const int lo,
+                                                                    const int n_targets, const BhNode* __restrict__ nodes,
+                                                                    const int n_nodes, const float theta,
+                                                                    float2* __restrict__ out, const unsigned* __restrict__ perm)
+{
+    const int t = blockIdx.x * BPW + threadIdx.x;
+    const bool valid = (int)threadIdx.x < BPW && t < n_targets;
+    if (__ballot(valid) == 0ull) return;
+    const int it = valid ? (perm ? (int)perm[t] - lo : t) : 0;
+    const float4 pi = posm[lo + it];
+    const float th_lo = theta - fabsf(theta) * 1.0e-5f, th_hi = theta + fabsf(theta) * 1.0e-5f;
+    float sfx[kMaxFrames], sfy[kMaxFrames];   // this lane's saved sums, by wave frame depth
+    unsigned long long mine = 0ull;           // bit d: this lane opened wave frame d
+    int ends = 0;                             // lane d holds the end index of wave frame d
+    int d = 0;                                // wave frames open (uniform)
+    int cur_end = -1;                         // end of the innermost wave frame (uniform)
+    float fx = 0.0f, fy = 0.0f;
+    int r = valid ? 0 : 0x7FFFFFFF;           // resume index: the lane takes part in node i iff r <= i
+    int i = 0;                                // wave-uniform
+    for (;;) {
+        while (i == cur_end) {                // the wave leaves a subtree: its openers return the child sum to the parent's
+            d--;
+            if ((mine >> d) & 1ull) {
+                fx = __fadd_rn(sfx[d], fx);   // nbody.rs:358  fx += fx_add
+                fy = __fadd_rn(sfy[d], fy);
+                mine &= ~(1ull << d);
+            }
+            cur_end = d > 0 ? __builtin_amdgcn_readlane(ends, d - 1) : -1;
+        }
+        if (i >= n_nodes) break;
+        typedef float f8 __attribute__((ext_vector_type(8)));
+        const f8 rec = *reinterpret_cast<const f8*>(&nodes[(unsigned)__builtin_amdgcn_readfirstlane(i)]);
+        const float nx = rec[0], ny = rec[1], nm = rec[2], ns = rec[3];
+        const int skip = __float_as_int(rec[4]);
+        const bool interior = __float_as_int(rec[5]) != 0;
+        const bool active = r <= i;
+        const float dx = __fsub_rn(nx, pi.x);                                    // :342 / :174
+        const float dy = __fsub_rn(ny, pi.y);
+        const float dist_sq = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+        bool take;                                                               // evaluate force(body, node) now
+        if (interior) {
+            const float est = ns * __builtin_amdgcn_rsqf(dist_sq);               // see k_bh_eval_strict
+            bool accept = est < th_lo;
+            if (active && !accept && !(est > th_hi)) {                           // near the boundary (or NaN): exact test
+                const float dd = sqrtf(dist_sq);                                 // :344
+                accept = ns / dd < theta;                                        // :345
+            }
+            take = active && accept;
+        } else {
+            take = active && !(nx == pi.x && ny == pi.y);                        // :365
+        }
+        if (take) {
+            const float f = __fmul_rn(pi.w, nm) / __fadd_rn(dist_sq, kEps);      // :180
+            fx = __fadd_rn(fx, __fmul_rn(f, dx));
+            fy = __fadd_rn(fy, __fmul_rn(f, dy));
+        }
+        const bool open = interior && active && !take;
+        if (active && !open) r = skip;                                           // leaf, accepted node: done with this subtree
+        if (__ballot(open) != 0ull && d < kMaxFrames) {
+            if (open) {                                                          // children sum from 0 (:336-337)
+                sfx[d] = fx; sfy[d] = fy;
+                fx = 0.0f; fy = 0.0f;
+                mine |= 1ull << d;
+            }
+            if ((int)threadIdx.x == d) ends = skip;                              // lane d keeps frame d's end
+            cur_end = skip;
+            d++;
+            i = i + 1;
+        } else {
+            i = skip;
+        }
+    }
+    if (valid) out[it] = make_float2(fx, fy);
+}
+
 // Kick-drift from a per-body force (divide by m, nbody.rs:453-454) or acceleration (is_accel),
 // optional velocity kill (nbody.rs:466-471).
 __global__ __launch_bounds__(kTile) void k_integrate_f2(float4* __restrict__ posm, const int lo, const int n_targets,
@@ -297,7 +381,18 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
     // per-lane walks: one wave per workgroup while the system is too small to fill the chip (spreads the waves over the CUs)
     const int block = n_targets <= 65536 ? 64 : kTile;
     const dim3 grid((n_targets + block - 1) / block);
-    if (mode == 1)
+    if (mode == 3 && perm) {
+        int bpw = 64;
+        while (bpw > 8 && (n_targets + bpw - 1) / bpw < 4096) bpw >>= 1;
+        const dim3 g((n_targets + bpw - 1) / bpw);
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, g, dim3(kWaveBlock), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta, force_out, perm);
+        };
+        if (bpw == 64) go(k_bh_eval_strict_wave<64>);
+        else if (bpw == 32) go(k_bh_eval_strict_wave<32>);
+        else if (bpw == 16) go(k_bh_eval_strict_wave<16>);
+        else go(k_bh_eval_strict_wave<8>);
+    } else if (mode == 1 || mode == 3)
         hipLaunchKernelGGL(k_bh_eval_strict, grid, dim3(block), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
                            force_out, perm);
     else if (mode == 2 && perm) {

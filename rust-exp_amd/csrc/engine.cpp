@@ -557,10 +557,11 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
             perm = e->d_slab_perm;
         }
     }
-    const bool wave = perm != nullptr && e->force_mode == 0;   // the bit-exact kernel takes the order, not the shared walk
+    const bool wave = perm != nullptr;   // shared walk per wave, in both modes (same results as the per-lane walks)
     {
         ProfScope ps(e, NBX_K_BH_EVAL);
-        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, wave ? 2 : e->force_mode, e->d_f2,
+        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta,
+                                    wave ? (e->force_mode == 0 ? 2 : 3) : e->force_mode, e->d_f2,
                                     e->stream, perm));
     }
     {

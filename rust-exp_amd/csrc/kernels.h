@@ -63,7 +63,8 @@ hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel,
 
 // K3: Barnes-Hut traversal. mode 0 = fast (sequential pre-order accumulation, rcp),
 // mode 1 = strict (hierarchical summation order of nbody.rs:354-360 via an explicit frame stack,
-// IEEE sqrt/divide): bit-exact with the reference traversal.
+// IEEE sqrt/divide): bit-exact with the reference traversal.  mode 2 / 3 = the wave-uniform forms of 0 / 1
+// (need perm: bodies in a spatial order); same results as 0 / 1.
 // perm (optional): thread t evaluates body perm[t] -- a GLOBAL body index inside the slab
 // [lo, lo + n_targets) -- instead of body lo + t (spatial order => coherent waves); force_out is indexed by body - lo
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,

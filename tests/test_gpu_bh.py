@@ -132,3 +132,24 @@ print("OK")
     env = dict(os.environ, NBX_HOST_THREADS=threads, NBX_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("n,theta", [(70000, 0.5), (131072, 0.85)])
+def test_bh_strict_wave_walk_equals_per_lane_walk_and_oracle(rx, ob, n, theta):
+    """Bit-exact mode, n >= 65536: the wave-uniform walk with wave frames (NBX_OPT_BH_WAVE = 1, the default) and the
+    per-lane walk with its private frame stack produce the same bits, and both are the oracle's."""
+    from rust_exp_amd.engine import NBX_OPT_BH_WAVE
+
+    p = ob.stable_orbits(n, 0.5, 30.0, 17)
+    q = p.copy()
+    for _ in range(2):
+        assert ob.step_barnes_hut(q, theta, DT, 8) == 0
+    for wave in (1, 0):
+        e = rx.NBodyEngine(mode="strict")
+        e.set_option(NBX_OPT_BH_WAVE, wave)
+        e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+        for _ in range(2):
+            e.step_barnes_hut(theta, DT, 1)
+        st = e.get_particles()
+        for k in ("px", "py", "vx", "vy"):
+            assert_bit_equal(st[k], q[k], f"wave={wave} {k}")
