@@ -26,14 +26,35 @@ namespace nbx {
 
 constexpr int kMaxFrames = 56;
 
-// The fast kernels test the opening criterion without the square root and without a node-type branch:
+// The fast kernels decide "take or open" without the square root and without a node-type branch:
 //     take = q < theta^2 * d^2,   q = s*s (interior)  or  -1 (leaf)            (BhNode::q, set when the tree is flattened)
 // interior: s/d < theta <=> s*s < theta^2 d^2 for s, d >= 0 (d = 0 -> open, as in the reference where s/0 = +inf; a
-// non-positive theta accepts nothing).  Same truth table away from the rounding boundary; a body whose s/d sits within
-// ~1e-7 of theta may open one node more or less than the reference -- well inside the fast mode's tolerance class (the
-// bit-exact kernel keeps sqrt and divide).  leaf: always taken; the reference's self-skip (position bit-equal,
+// non-positive theta accepts nothing).  leaf: always taken; the reference's self-skip (position bit-equal,
 // nbody.rs:365) needs no test here because a coincident leaf contributes m * 0 / (0 + EPS) = exactly 0.
+// Decisions within 1e-5 of the boundary are re-made with the reference's own arithmetic (take_node), so the fast walks
+// open exactly the nodes the reference opens; they differ from it by rcp-vs-divide, FMA and summation order only.
 // A node that is not taken adds an exact zero (scale 0), so both walks below produce identical bits.
+
+// take (accept an interior node / evaluate a leaf) or open?  q < theta^2 d^2 decides everything outside a 1e-5-wide band
+// around the boundary; inside the band (or with NaNs) the reference's own test runs -- unfused d^2, correctly rounded
+// sqrt and divide (nbody.rs:341-345) -- so every decision is the one the reference makes.  The band is far wider than
+// the rounding of either form (a few 1e-7), so the cheap comparison can never contradict the exact one outside it.
+// the reference's test, kept out of line: it runs for a few decisions per million and must not cost the walk registers
+__device__ __attribute__((noinline)) bool take_node_exact(const float s, const float dx, const float dy, const float theta)
+{
+    const float dist_sq = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));         // :344
+    return s / sqrtf(dist_sq) < theta;                                             // :345
+}
+
+__device__ __forceinline__ bool take_node(const float q, const float s, const float d2, const float dx, const float dy,
+                                          const float th2_lo, const float th2_hi, const float theta)
+{
+    bool take = q < th2_lo * d2;
+    const bool below_hi = q <= th2_hi * d2;
+    if (__builtin_expect(below_hi && !take, 0))                                    // in the band: a few decisions per million
+        take = take_node_exact(s, dx, dy, theta);
+    return take;                                                                   // (NaN d^2: not taken, like s/NaN < theta)
+}
 
 __global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict__ posm, const int lo,
                                                         const int n_targets, const BhNode* __restrict__ nodes,
@@ -47,6 +68,7 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict
     const int it = perm ? (int)perm[t] - lo : t;
     const float4 pi = posm[lo + it];
     const float th2 = theta > 0.0f ? theta * theta : 0.0f;
+    const float th2_lo = th2 * (1.0f - 1.0e-5f), th2_hi = th2 * (1.0f + 1.0e-5f);
     float ax = 0.0f, ay = 0.0f;
     int i = 0;
     while (i < n_nodes) {
@@ -57,7 +79,7 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict
         const float dx = a.x - pi.x;
         const float dy = a.y - pi.y;
         const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-        const bool take = q < th2 * d2;
+        const bool take = take_node(q, a.w, d2, dx, dy, th2_lo, th2_hi, theta);
         const float s = take ? a.z * __builtin_amdgcn_rcpf(d2 + kEps) : 0.0f;
         ax = __builtin_fmaf(s, dx, ax);
         ay = __builtin_fmaf(s, dy, ay);
@@ -92,6 +114,7 @@ __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* 
     const int it = valid ? (perm ? (int)perm[t] - lo : t) : 0;
     const float4 pi = posm[lo + it];
     const float th2 = theta > 0.0f ? theta * theta : 0.0f;
+    const float th2_lo = th2 * (1.0f - 1.0e-5f), th2_hi = th2 * (1.0f + 1.0e-5f);
     float ax = 0.0f, ay = 0.0f;
     int r = valid ? 0 : 0x7FFFFFFF;   // resume index: the lane takes part in node i iff r <= i
     int i = 0;                        // wave-uniform
@@ -105,7 +128,7 @@ __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* 
         const float dx = nx - pi.x;
         const float dy = ny - pi.y;
         const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-        const bool take = (r <= i) && (q < th2 * d2);   // parked lanes (r > i) take nothing
+        const bool take = (r <= i) && take_node(q, rec[3], d2, dx, dy, th2_lo, th2_hi, theta);   // parked lanes take nothing
         const float s = take ? nm * __builtin_amdgcn_rcpf(d2 + kEps) : 0.0f;
         ax = __builtin_fmaf(s, dx, ax);
         ay = __builtin_fmaf(s, dy, ay);
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(kTile) void k_bh_count(const float4* __restrict__ p
             const float4 c = *reinterpret_cast<const float4*>(&nodes[i].skip);
             const float dx = a.x - pi.x, dy = a.y - pi.y;
             const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-            const bool take = c.z < th2 * d2;
+            const bool take = take_node(c.z, a.w, d2, dx, dy, th2 * (1.0f - 1.0e-5f), th2 * (1.0f + 1.0e-5f), theta);
             visits++;
             pairs += take ? 1u : 0u;
             i = take ? __float_as_int(c.x) : i + 1;

@@ -548,7 +548,7 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
     int rc = grow(&e->d_f2, &e->f2_cap, (size_t)slab);
     if (rc != NBX_OK) return rc;
     const unsigned* perm = nullptr;
-    if (have_perm && e->bh_wave) {
+    if (have_perm) {   // a Morton order helps the per-lane walks too (NBX_OPT_BH_WAVE = 0 only turns the shared walk off)
         if (e->world == 1) {
             perm = e->d_perm;
         } else {   // several GPUs share the bodies: this engine's part of the Morton order
@@ -557,7 +557,7 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
             perm = e->d_slab_perm;
         }
     }
-    const bool wave = perm != nullptr;   // shared walk per wave, in both modes (same results as the per-lane walks)
+    const bool wave = perm != nullptr && e->bh_wave;   // shared walk per wave, in both modes (same results as the per-lane walks)
     {
         ProfScope ps(e, NBX_K_BH_EVAL);
         HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta,

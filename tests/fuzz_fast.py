@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Fuzz campaign of the FAST mode, run by hand on a GPU box (pytest does not collect it):
+    python tests/fuzz_fast.py [first_seed] [count]
+Random sizes / scales / mass ranges / clumps as in fuzz_strict.py. Per case: everything finite; fast all-pairs forces
+within 5e-5 max|F| sqrt(N)/64 of the bit-exact kernel's; fast Barnes-Hut (host tree) within 1e-4 max|F| of the bit-exact walk;
+device-built tree vs host tree through the same walk: median relative difference <= 1e-4 (sub-EPS pairs differ by
+design, hence the median)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rust_exp_amd as rx  # noqa: E402
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    bad = 0
+    t0 = time.time()
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(seed)
+        n = int(rng.choice([2, 3, 17, 255, 256, 257, 1000, 4097, 9000, 20000, 70000, 150000]))
+        scale = float(rng.choice([1e-2, 1.0, 30.0, 3e3]))
+        x = (rng.normal(0, 1, n) * scale).astype(np.float32)
+        y = (rng.normal(0, 1, n) * scale).astype(np.float32)
+        if rng.random() < 0.5 and n > 50:
+            k = n // 5
+            x[:k] = x[k:2 * k] + (rng.normal(0, 1e-3, k) * scale).astype(np.float32)
+            y[:k] = y[k:2 * k] + (rng.normal(0, 1e-3, k) * scale).astype(np.float32)
+        mk = rng.choice(["unit", "wide"])
+        m = {"unit": rng.uniform(0.5, 2.0, n), "wide": 10.0 ** rng.uniform(-3, 3, n)}[mk].astype(np.float32)
+        vx = rng.normal(0, 1, n).astype(np.float32); vy = rng.normal(0, 1, n).astype(np.float32)
+        theta = float(rng.choice([0.3, 0.5, 0.85]))
+        why = []
+        try:
+            def eng(mode, tree=0):
+                e = rx.NBodyEngine(mode=mode)
+                e.set_bh_tree("device" if tree else "host")
+                e.set_particles(x, y, vx, vy, m)
+                return e
+            fs, ff = eng("strict"), eng("fast")
+            sx, sy, _ = fs.forces(0.0)
+            fx, fy, _ = ff.forces(0.0)
+            sc = max(np.abs(sx).max(), np.abs(sy).max(), 1e-30)
+            if not (np.isfinite(fx).all() and np.isfinite(fy).all()):
+                why.append("brute not finite")
+            elif max(np.abs(fx - sx).max(), np.abs(fy - sy).max()) > 5e-5 * sc * max(1.0, np.sqrt(n) / 64):   # summation-order class, grows with sqrt(N); wide mass ranges sit near it
+                why.append("brute tol %.2e" % (max(np.abs(fx - sx).max(), np.abs(fy - sy).max()) / sc))
+            try:
+                bsx, bsy, _ = fs.forces(theta)
+                tree_ok = True
+            except rx.NBodyError:
+                tree_ok = False
+            if tree_ok:
+                bfx, bfy, _ = ff.forces(theta)
+                bsc = max(np.abs(bsx).max(), np.abs(bsy).max(), 1e-30)
+                if not np.isfinite(bfx).all():
+                    why.append("bh not finite")
+                elif max(np.abs(bfx - bsx).max(), np.abs(bfy - bsy).max()) > 1e-4 * bsc:
+                    why.append("bh tol %.2e" % (max(np.abs(bfx - bsx).max(), np.abs(bfy - bsy).max()) / bsc))
+                fd = eng("fast", 1)
+                dx_, dy_, _ = fd.forces(theta)
+                rel = np.hypot(dx_ - bfx, dy_ - bfy) / (np.hypot(bfx, bfy) + 1e-30)
+                if not np.isfinite(dx_).all():
+                    why.append("device tree not finite")
+                elif np.median(rel) > 1e-4:
+                    why.append("device tree median %.2e" % np.median(rel))
+                for e in (ff, fd):
+                    e.step_barnes_hut(theta, 0.01, 1); e.step_brute_force(0.01)
+                    st = e.get_particles()
+                    if not (np.isfinite(st["px"]).all() and np.isfinite(st["vx"]).all()):
+                        why.append("state not finite")
+        except Exception as ex:   # noqa: BLE001
+            why.append("exception " + repr(ex))
+        if why:
+            bad += 1
+            print("FAIL seed", seed, "n", n, "scale", scale, "masses", mk, "theta", theta, why)
+    print("fuzz fast: %d cases, %d failures, %.1f s" % (count, bad, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
