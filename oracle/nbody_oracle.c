@@ -9,9 +9,10 @@
  * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path
  *  and cannot be compiled here (Rust 2016-era crate; no rustc/cargo in the
  * image), so this restatement cannot be checked against reference OUTPUT.  It is pinned instead
- * by (1) two independent restatements written from the Rust source in another language --
- * oracle/nbody_numpy.py (brute-force step) and oracle/nbody_bh_py.py (Barnes-Hut step) -- that
- * must agree with this file bit for bit (tests/test_oracle_golden.py, tests/test_oracle_bh_py.py),
+ * by (1) independent restatements written from the Rust source in another language --
+ * oracle/nbody_numpy.py (brute-force step), oracle/nbody_bh_py.py (Barnes-Hut step) and
+ * oracle/nbody_draw_py.py (nb_draw) -- that must agree with this file bit for bit
+ * (tests/test_oracle_golden.py, tests/test_oracle_bh_py.py),
  * (2) known-answer tests implied by the source semantics (tests/test_oracle_kat.py),
  * (3) an fp64 arbiter.  Golden vectors under tests/golden/ are produced by THIS file.
  *

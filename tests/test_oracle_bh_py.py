@@ -42,3 +42,19 @@ def test_both_refuse_what_the_reference_panics_on(ob):
     a = {k: p[k].astype(np.float32).copy() for k in ("px", "py", "vx", "vy", "m")}
     with pytest.raises(bhpy.TreePanic):
         bhpy.step_barnes_hut(a["px"], a["py"], a["vx"], a["vy"], a["m"], 0.5, 0.01)
+
+
+@pytest.mark.parametrize("shape", [(64, 48), (101, 37), (200, 200)])
+def test_c_oracle_draw_equals_python_restatement(ob, shape):
+    """nb_draw (nbody.rs:482-617): the C oracle against oracle/nbody_draw_py.py, pixel for pixel -- aspect handling,
+    truncating casts, octant tails, saturation under heavy overlap, out-of-view bodies, the magenta cross."""
+    from oracle import nbody_draw_py as drawpy
+
+    w, h = shape
+    p = ob.stable_orbits(2500, 0.5, 30.0, 21)
+    p["px"][:300] = 0.125; p["py"][:300] = -0.25      # 300 bodies on one pixel: saturation
+    p["px"][300:330] *= 5.0                            # outside the viewport
+    p["vx"][330:340] = 0.0; p["vy"][330:340] = 0.0     # atan2(0, 0)
+    want = drawpy.draw(p["px"], p["py"], p["vx"], p["vy"], w, h)
+    got = np.asarray(ob.draw(p, w, h)).reshape(h, w)
+    assert np.array_equal(got, want)
