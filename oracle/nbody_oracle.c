@@ -10,9 +10,10 @@
  *  and cannot be compiled here (Rust 2016-era crate; no rustc/cargo in the
  * image), so this restatement cannot be checked against reference OUTPUT.  It is pinned instead
  * by (1) independent restatements written from the Rust source in another language --
- * oracle/nbody_numpy.py (brute-force step), oracle/nbody_bh_py.py (Barnes-Hut step) and
- * oracle/nbody_draw_py.py (nb_draw) -- that must agree with this file bit for bit
- * (tests/test_oracle_golden.py, tests/test_oracle_bh_py.py),
+ * oracle/nbody_numpy.py (brute-force step), oracle/nbody_bh_py.py (Barnes-Hut step),
+ * oracle/nbody_draw_py.py (nb_draw) and oracle/nbody_presets_py.py (presets) -- that must agree
+ * with this file bit for bit
+ * (tests/test_oracle_golden.py, tests/test_oracle_restatements.py),
  * (2) known-answer tests implied by the source semantics (tests/test_oracle_kat.py),
  * (3) an fp64 arbiter.  Golden vectors under tests/golden/ are produced by THIS file.
  *

@@ -58,3 +58,16 @@ def test_c_oracle_draw_equals_python_restatement(ob, shape):
     want = drawpy.draw(p["px"], p["py"], p["vx"], p["vy"], w, h)
     got = np.asarray(ob.draw(p, w, h)).reshape(h, w)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n,seed", [(1, 3), (2, 4), (500, 5), (3000, 0xDEADBEEFCAFEF00D)])
+def test_c_oracle_presets_equal_python_restatement(ob, n, seed):
+    """nb_random_disk / nb_stable_orbits (nbody.rs:39-104): f32 construction from the bit stream, Range sampling, draw
+    order and arithmetic -- the C oracle against oracle/nbody_presets_py.py, bit for bit."""
+    from oracle import nbody_presets_py as prepy
+
+    for got, want in ((ob.random_disk(n, seed), prepy.random_disk(n, seed)),
+                      (ob.stable_orbits(n, 0.5, 30.0, seed), prepy.stable_orbits(n, 0.5, 30.0, seed))):
+        assert len(got) == len(want)
+        for j, k in enumerate(("px", "py", "vx", "vy", "m")):
+            assert np.array_equal(got[k].view(np.uint32), want[:, j].view(np.uint32)), k
