@@ -2,19 +2,34 @@
 """bench.py -- body-pair interactions/s of the brute-force N-body step (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One "step" = one nb_step_brute_force (rs-src/nbody.rs:106-162): all-pairs force + kick-drift over
 the whole synthetic system.  Workload: N = 262 144-body Plummer sphere (3-D float4 kernel,
 17 algorithmic flops / interaction), the configuration the metric is quoted on; it fits one GPU.
-With N GPUs the SAME system is sharded as slabs of targets (strong scaling) with one all-gather of
-(x,y,z,m) per step.  Inputs are resident in HBM before the timed region.
-Prints ONE JSON line on rank 0.
+With N GPUs the SAME system is sharded as slabs of targets (strong scaling, the reference's own
+thread split nbody.rs:426-428) with one all-gather of (x,y,z,m) per step.  Inputs are resident in
+HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+Three hosts drive the same library (`--host`, default auto):
+  single  one engine on one GPU (N = 1)
+  group   ONE process, N GPUs: the library's own multi-GPU group (nbx_group_*: one engine per device,
+          ncclCommInitAll + one in-place ncclAllGather per step issued by the library; no torch).
+          This is what a plain `python bench.py --gpus N` runs for N > 1.
+  torch   one process per GPU under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+          (WORLD_SIZE is set): torch.distributed (backend nccl = RCCL) does the all-gather on torch-owned memory.
+
+`--workload bh`: one step = nb_step_barnes_hut(theta, dt) (nbody.rs:186-480) on N bodies (BASELINE config #4:
+--n 1048576 --theta 0.5): ms/step split host build / flatten / upload / eval, CPU oracle step beside it.
 """
 import argparse
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -24,6 +39,10 @@ sys.path.insert(0, ROOT)
 
 FLOPS_PER_INTERACTION = 17   # 3 sub, 3 mul + 2 add, 1 add eps, 1 mul, 1 div, 3 mul, 3 add
 DT = 0.01                    # RustNBodyExperiment.hs:45
+
+KERNEL_NAMES = {0: "k_force_tile", 1: "k_force_tile_pk", 2: "k_force_smem", 3: "k_force_tile_pk", 4: "k_force_tile_pkb",
+                5: "k_force_smem_pk", 6: "k_force_smem_pkw", 7: "k_force_smem_pk1m", 16: "k_force_tile_pk_h",
+                -1: "k_force_strict<1>", -2: "k_force_strict<2>", -4: "k_force_strict<4>"}
 
 
 def effective_cores():
@@ -78,7 +97,7 @@ def cpu_baseline(st, seconds):
 
 
 def cpu_baseline_barnes_hut(st, theta, dt, threads, reps):
-    """The CPU-baseline leg of the Barnes-Hut measurements (tools/bench_bh.py): the oracle's nb_step_barnes_hut
+    """The CPU-baseline leg of the Barnes-Hut measurements: the oracle's nb_step_barnes_hut
     (nbody.rs:186-480: serial tree build + `threads` traversal workers) timed on the host cores. Median ms per step."""
     from oracle import binding as ob
 
@@ -99,15 +118,99 @@ def _claim_stdout():
     return real
 
 
-def main():
-    real_stdout = _claim_stdout()
-    # multi-process GPU work on this stack needs dmabuf IPC (exported by the driver; harmless to restate)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+class PowerSampler:
+    """Board power from the amdgpu hwmon node (power1_average / power1_input, microwatts), sampled on a thread while
+    the timed loop runs. None when the node is not readable."""
+
+    def __init__(self, device=0, period=0.01):
+        self.paths = []
+        for card in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            for name in ("power1_average", "power1_input"):
+                p = os.path.join(card, name)
+                if os.path.exists(p):
+                    self.paths.append(p)
+                    break
+        self.path = self.paths[device] if device < len(self.paths) else None
+        self.period = period
+        self.samples = []
+        self._stop = threading.Event()
+        self._t = None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append((time.perf_counter(), int(open(self.path).read()) * 1e-6))
+            except (OSError, ValueError):
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.path:
+            self._t = threading.Thread(target=self._run, daemon=True)
+            self._t.start()
+
+    def stop(self):
+        if self._t:
+            self._stop.set()
+            self._t.join()
+
+    def summary(self, t0, t1, interactions):
+        w = [p for (t, p) in self.samples if t0 <= t <= t1]
+        if not w:
+            return None
+        avg = float(np.mean(w))
+        return {"avg_w": avg, "max_w": float(np.max(w)), "samples": len(w), "source": self.path,
+                "joules_per_interaction": avg * (t1 - t0) / interactions if interactions else None}
+
+
+def measure_traffic(argv_tail, kernel_substr, timeout=240):
+    """HBM bytes per launch of the dominant kernel, measured NOW on this box with rocprofv3 PMC counters exactly as
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes
+    (TCC slots), unit KiB, FETCH_SIZE doubled on gfx950 (it reports 1/2 of the bytes of 16-B/lane coalesced reads),
+    WRITE_SIZE as reported. Each pass re-runs this script as a short child (--traffic-child). Returns (dict | None)."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    import csv
+
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="nbx_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--traffic-child"] + argv_tail
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+            if r.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            out[counter] = float(np.mean(vals))
+            out[counter + "_launches"] = len(vals)
+        read_b = 2.0 * out["FETCH_SIZE"] * 1024.0
+        write_b = out["WRITE_SIZE"] * 1024.0
+        return {"bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_bytes": write_b,
+                "launches_sampled": out["FETCH_SIZE_launches"],
+                "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) on a 3-step child run of this "
+                       "command, this box, this run; KiB -> B, FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM)"}
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=262144)
+    ap.add_argument("--n", type=int, default=0, help="bodies (default 262144; 1048576 for --workload bh)")
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--mode", default="fast")
     ap.add_argument("--jsplit", type=int, default=0)
@@ -115,149 +218,385 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="plummer", choices=["plummer", "two_galaxies"])
+    ap.add_argument("--workload", default="plummer", choices=["plummer", "two_galaxies", "bh"])
+    ap.add_argument("--theta", type=float, default=0.5, help="--workload bh: opening angle")
+    ap.add_argument("--bh-tree", default="default", choices=["default", "host", "device"])
     ap.add_argument("--source-bits", type=int, default=32, choices=[16, 32],
                     help="16 = fp16 source copy / fp32 accumulators (BASELINE config #5)")
-    ap.add_argument("--torch-path", action="store_true",
-                    help="use the multi-GPU code path (torch-owned buffer + torch stream) even on one GPU")
-    args = ap.parse_args()
+    ap.add_argument("--host", default="auto", choices=["auto", "single", "group", "torch"])
+    ap.add_argument("--torch-path", action="store_true", help="same as --host torch (kept for round-1 command lines)")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="single GPU: run only rank 0's slab of an N-way shard (per-GPU shape of an N-GPU run; not the metric)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC passes (roofline.traffic = null)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
 
-    import rust_exp_amd as rx
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    n = args.n
-    st = rx.plummer_sphere(n, dim=args.dim) if args.workload == "plummer" else rx.two_galaxies(n)
+def make_state(args, rx):
+    if args.workload == "bh":
+        return rx.plummer_sphere(args.n, dim=2)   # the reference (and its quadtree) is 2-D
+    if args.workload == "plummer":
+        return rx.plummer_sphere(args.n, dim=args.dim)
+    return rx.two_galaxies(args.n)
 
-    if world == 1 and not args.torch_path:
-        eng = rx.NBodyEngine(device=0, mode=args.mode)
-        eng.set_source_precision(args.source_bits)
-        eng.set_launch(jsplit=args.jsplit, bodies_per_thread=args.bpt, variant=args.variant)
-        eng.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
 
-        def step():
-            eng.step_brute_force(DT)
+class SingleHost:
+    """One engine on one GPU."""
+    kind = "single"
 
-        def sync():
-            eng.synchronize()
+    def __init__(self, args, rx, st, device=0):
+        self.rx, self.world, self.rank = rx, 1, 0
+        e = rx.NBodyEngine(device=device, mode=args.mode)
+        e.set_source_precision(args.source_bits)
+        e.set_launch(jsplit=args.jsplit, bodies_per_thread=args.bpt, variant=args.variant)
+        if args.bh_tree != "default":
+            e.set_bh_tree(args.bh_tree)
+        if args.shard_of > 1:
+            e.set_shard(0, args.shard_of)
+        e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
+        self.eng = e
+        self.engines = [e]
+        self.local_only = args.shard_of > 1
 
-        def barrier():
-            pass
+    def prepare(self):
+        self.eng.forces(0.0)   # uploads the state, sizes the work buffers; no state change
 
-        engine = eng
-    else:
+    def step_brute(self):
+        if self.local_only:
+            self.eng.step_local(DT)
+        else:
+            self.eng.step_brute_force(DT)
+
+    def step_bh(self, theta):
+        self.eng.step_barnes_hut(theta, DT, 1)
+
+    def sync(self):
+        self.eng.synchronize()
+
+    def barrier(self):
+        pass
+
+    def reduce_max(self, x):
+        return x
+
+    def close(self):
+        pass
+
+
+class GroupHost:
+    """ONE process, G GPUs: the library's own group (nbx_group_*). RCCL is issued by the library; no torch anywhere."""
+    kind = "group"
+
+    def __init__(self, args, rx, st):
+        self.rx, self.world, self.rank = rx, args.gpus, 0
+        have = rx.device_count()
+        if have < args.gpus and os.environ.get("NBX_GROUP_EXCHANGE") != "copy":
+            sys.exit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible (set NBX_GROUP_EXCHANGE=copy to let "
+                     f"the engines of the group share devices: control-flow check only, not a measurement)")
+        devices = [i % max(have, 1) for i in range(args.gpus)]
+        g = rx.NBodyGroup(devices, mode=args.mode)
+        g.set_source_precision(args.source_bits)
+        from rust_exp_amd.engine import NBX_OPT_BH_TREE, NBX_OPT_BODIES_PER_THREAD, NBX_OPT_JSPLIT, NBX_OPT_KERNEL_VARIANT
+
+        g.set_option(NBX_OPT_JSPLIT, args.jsplit)
+        g.set_option(NBX_OPT_BODIES_PER_THREAD, args.bpt)
+        g.set_option(NBX_OPT_KERNEL_VARIANT, args.variant)
+        if args.bh_tree != "default":
+            g.set_option(NBX_OPT_BH_TREE, {"host": 0, "device": 1}[args.bh_tree])
+        g.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
+        self.group = g
+        self.engines = [g.engine(i) for i in range(g.size())]
+        self.eng = self.engines[0]
+        self.devices = devices
+
+    def prepare(self):
+        for e in self.engines:
+            e.forces(0.0)
+        # communicator set-up (ncclCommInitAll) outside the timed region: a zero-length step gathers the unchanged positions
+        self.group.step_brute_force(0.0)
+        self.group.synchronize()
+
+    def step_brute(self):
+        self.group.step_brute_force(DT)
+
+    def step_bh(self, theta):
+        self.group.step_barnes_hut(theta, DT, 1)
+
+    def sync(self):
+        self.group.synchronize()
+
+    def barrier(self):
+        pass
+
+    def reduce_max(self, x):
+        return x
+
+    def close(self):
+        self.group.close()
+
+
+class TorchHost:
+    """One process per GPU (torch.distributed.run); torch.distributed's nccl backend (= RCCL) moves the slabs."""
+    kind = "torch"
+
+    def __init__(self, args, rx, st):
         import torch
         import torch.distributed as dist
 
+        self.torch, self.dist, self.rx = torch, dist, rx
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # one rank per GPU. (NBX_DIST_BACKEND=gloo lets several ranks share one GPU: the builder's only way to
         # run this multi-rank path on a single-GPU box; the driver's launch uses the default, nccl = RCCL.)
         backend = os.environ.get("NBX_DIST_BACKEND", "nccl")
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
-        if world > 1:
+        self.local_rank = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
             if backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
             else:
                 dist.init_process_group(backend)
-        slab = rx.sharded.TorchSlabEngine(local_rank, mode=args.mode, source_half=args.source_bits == 16)
+        slab = rx.sharded.TorchSlabEngine(self.local_rank, mode=args.mode, source_half=args.source_bits == 16)
         slab.eng.set_launch(jsplit=args.jsplit, bodies_per_thread=args.bpt, variant=args.variant)
-        sim = rx.ShardedNBody(slab)
-        sim.set_particles(st)
+        if args.bh_tree != "default":
+            slab.eng.set_bh_tree(args.bh_tree)
+        self.sim = rx.ShardedNBody(slab)
+        self.sim.set_particles(st)
+        self.eng = slab.eng
+        self.engines = [slab.eng]
 
-        def step():
-            sim.step_brute_force(DT)
+    def prepare(self):
+        self.eng.forces(0.0)
+        if self.world > 1:
+            self.sim._exchange()   # communicator set-up outside the timed region (re-gathers the initial positions: a no-op on the data)
 
-        def sync():
-            torch.cuda.synchronize()
+    def step_brute(self):
+        self.sim.step_brute_force(DT)
 
-        def barrier():
-            if world > 1:
-                dist.barrier()
+    def step_bh(self, theta):
+        self.sim.step_barnes_hut(theta, DT, 1)
 
-        engine = slab.eng
+    def sync(self):
+        self.torch.cuda.synchronize()
 
-    # inputs resident in HBM and every buffer allocated before anything is timed, whatever --warmup says: a force-only
-    # evaluation (no state change) uploads the state and sizes the work buffers; the W warm-up steps follow
-    engine.forces(0.0)
-    if world > 1:
-        sim._exchange()   # communicator set-up outside the timed region too (re-gathers the initial positions: a no-op on the data)
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def reduce_max(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_floats(self, xs):
+        """list of floats of every rank, on every rank"""
+        if self.world == 1:
+            return [xs]
+        t = self.torch.tensor(xs, dtype=self.torch.float64, device="cuda")
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [o.tolist() for o in out]
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def main():
+    real_stdout = _claim_stdout()
+    # multi-process GPU work on this stack needs dmabuf IPC (exported by the driver; harmless to restate)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    args = parse_args()
+    if args.n <= 0:
+        args.n = 1048576 if args.workload == "bh" else 262144
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    host_kind = args.host
+    if args.torch_path:
+        host_kind = "torch"
+    if host_kind == "auto":
+        host_kind = "torch" if env_world > 1 else ("group" if args.gpus > 1 else "single")
+    if host_kind == "torch" and env_world != args.gpus and not (env_world == 1 and args.gpus == 1):
+        sys.exit(f"bench.py --host torch: WORLD_SIZE={env_world} but --gpus {args.gpus} (launch with torch.distributed.run, "
+                 f"or drop --host torch to use the single-process group)")
+    if host_kind == "single" and args.gpus != 1:
+        sys.exit("--host single is one GPU")
+
+    if host_kind == "torch":
+        import torch  # noqa: F401  (before the HIP library: both then share torch's HIP runtime, see sharded.py)
+    import rust_exp_amd as rx
+
+    n = args.n
+    st = make_state(args, rx)
+    host = {"single": SingleHost, "group": GroupHost, "torch": TorchHost}[host_kind](args, rx, st)
+    world, rank = host.world, host.rank
+    is_bh = args.workload == "bh"
+
+    def step():
+        if is_bh:
+            host.step_bh(args.theta)
+        else:
+            host.step_brute()
+
+    # inputs resident in HBM, every buffer allocated and the communicator created before anything is timed, whatever
+    # --warmup says; the W warm-up steps follow
+    host.prepare()
+    if args.traffic_child:
+        for _ in range(3):
+            step()
+        host.sync()
+        host.close()
+        return
     for _ in range(args.warmup):
         step()
-    sync()
-    engine.profile(True)
-    engine.profile_reset()
-    barrier(); sync()
+    host.sync()
+    for e in host.engines:
+        e.profile(True)      # creates its events now, outside the timed region
+        e.profile_reset()
+        e.bh_host_timing()
+    power = PowerSampler(device=0) if rank == 0 else None
+    if power:
+        power.start()
+    host.barrier(); host.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    sync(); barrier()
-    elapsed = time.perf_counter() - t0
-    k_ms, k_cnt = engine.profile_read(rx.NBX_K_FORCE)
-    i_ms, _ = engine.profile_read(rx.NBX_K_INTEGRATE)
-    engine.profile(False)
-    if world > 1:
-        import torch
-        import torch.distributed as dist
+    host.sync(); host.barrier()
+    t1 = time.perf_counter()
+    elapsed = host.reduce_max(t1 - t0)
+    if power:
+        power.stop()
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # per-engine kernel times (HIP events on each engine's own stream, inside the timed region)
+    per = []
+    for e in host.engines:
+        k_ms, k_cnt = e.profile_read(rx.NBX_K_FORCE)
+        i_ms, i_cnt = e.profile_read(rx.NBX_K_INTEGRATE)
+        b_ms, b_cnt = e.profile_read(rx.NBX_K_BH_EVAL)
+        x_ms, x_cnt = e.profile_read(rx.NBX_K_EXCHANGE)
+        lo, hi = e.slab()
+        per.append({"slab": [lo, hi], "force_ms": k_ms / max(k_cnt, 1), "force_launches": k_cnt,
+                    "integrate_ms": i_ms / max(i_cnt, 1), "bh_eval_ms": b_ms / max(b_cnt, 1), "bh_eval_launches": b_cnt,
+                    "exchange_us": 1e3 * x_ms / max(x_cnt, 1), "exchanges": x_cnt})
+        e.profile(False)
+    if host_kind == "torch" and world > 1:
+        rows = host.gather_floats([per[0]["slab"][0], per[0]["slab"][1], per[0]["force_ms"], per[0]["force_launches"],
+                                   per[0]["integrate_ms"], per[0]["bh_eval_ms"], per[0]["bh_eval_launches"]])
+        per = [{"slab": [int(r[0]), int(r[1])], "force_ms": r[2], "force_launches": int(r[3]), "integrate_ms": r[4],
+                "bh_eval_ms": r[5], "bh_eval_launches": int(r[6]), "exchange_us": None, "exchanges": 0} for r in rows]
+        per[0]["exchange_us"] = None   # torch's collective runs on ProcessGroupNCCL's own stream: see ms_per_step minus kernels
 
     if rank == 0:
-        info = rx.device_info(local_rank)
-        interactions_per_step = float(n) * float(n - 1)
-        value = interactions_per_step * args.steps / elapsed
-        lo, hi = engine.slab()
+        info = rx.device_info(getattr(host, "local_rank", 0))
+        engine = host.eng
         launch = engine.last_launch()
-        # dominant kernel: K1 force tiles. Algorithmic work of ONE launch on this rank:
-        inter_per_launch = float(hi - lo) * float(n - 1)
-        flops_per_inter = FLOPS_PER_INTERACTION if launch["dim"] == 3 else 12
-        k_avg_s = (k_ms / max(k_cnt, 1)) * 1e-3
-        achieved = inter_per_launch * flops_per_inter / k_avg_s / 1e12
         peak = info["peak_fp32_flops"] / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile) and world == 1 and n == 262144:
-            try:
-                traffic = json.load(open(tfile)).get("k_force_tile_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "body-pair interactions/s at N=262144 (brute-force O(N^2) step)" if n == 262144
-                      else f"body-pair interactions/s at N={n} (brute-force O(N^2) step)",
-            "value": value, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32" if args.source_bits == 32 else "f32 (fp16 source copy)", "data": "synthetic",
-            "config": {"workload": f"{'plummer_sphere' if args.workload == 'plummer' else 'two_galaxies'}_N{n}_brute_force_dim{launch['dim']}_dt{DT}"
-                                   + ("_fp16sources" if args.source_bits == 16 else ""),
-                       "bodies": n, "seed": "0x5EED0001", "force_mode": args.mode,
-                       "sharding": f"slab x{world}, one all-gather of (x,y,z,m) per step" if world > 1 else "single GPU",
-                       "launch": launch},
-            "roofline": {"bound": "valu_fp32", "bound_contract_class": "mfma (dense fp32 peak: the f32 MFMA rate equals the fp32 vector rate, "
-                                                                  "157.3 TFLOP/s; no MFMA is used)", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "kernel": {0: "k_force_tile", 1: "k_force_tile_pk", 2: "k_force_smem", 3: "k_force_tile_pk", 4: "k_force_tile_pkb", 5: "k_force_smem_pk", 16: "k_force_tile_pk_h", -1: "k_force_strict<1>", -2: "k_force_strict<2>", -4: "k_force_strict<4>"}.get(launch["variant"], "k_force"), "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_cnt,
-                         "flops_per_interaction": flops_per_inter,
-                         "interactions_per_launch": inter_per_launch,
-                         "hbm_algorithmic_bytes_per_launch": 16.0 * n + 16.0 * (hi - lo) * launch["jsplit"],
-                         "note": "VALU-bound path (arithmetic intensity ~1e5 flop/B): peak = CUs*clock*256 flop/clk "
-                                 "(fp32 vector FMA roofline, = the f32 MFMA rate); HBM is not the bound"},
-            "integrate_kernel_avg_ms": i_ms / max(k_cnt, 1),
-            "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],
-            "clock_khz": info["clock_khz"],
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(st, args.cpu_seconds)
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {"n_gpus": world if host_kind != "single" else 1, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "data": "synthetic"}
+        sharding = ("single GPU" if world == 1 else
+                    f"slab x{world} (reference split nbody.rs:426-428), one all-gather of "
+                    f"{'half4' if args.source_bits == 16 and not is_bh else 'float4'} (x,y,z,m) per step; host = "
+                    + ("one process, library-issued RCCL (nbx_group_*)" if host_kind == "group" else "one process per GPU, torch.distributed nccl"))
+        if not is_bh:
+            interactions_per_step = float(n) * float(n - 1)
+            if args.shard_of > 1:
+                lo, hi = engine.slab()
+                interactions_per_step = float(hi - lo) * float(n - 1)
+            value = interactions_per_step * args.steps / elapsed
+            flops_per_inter = FLOPS_PER_INTERACTION if launch["dim"] == 3 else 12
+            # dominant kernel: K1. Roofline from the SLOWEST rank's launches (the step waits for it).
+            worst = max(per, key=lambda r: r["force_ms"])
+            inter_per_launch = float(worst["slab"][1] - worst["slab"][0]) * float(n - 1)
+            k_avg_s = worst["force_ms"] * 1e-3
+            achieved = inter_per_launch * flops_per_inter / k_avg_s / 1e12
+            slab_rows = worst["slab"][1] - worst["slab"][0]
+            # algorithmic HBM bytes of one K1 launch (SURVEY 8(d): ~16 B x N sources read once + 16 B per target read);
+            # the per-split partial-acceleration slabs K1 writes for K2 are NOT algorithmic: they show up in `traffic`
+            algorithmic = 16.0 * n + 16.0 * slab_rows
+            traffic, traffic_info = None, None
+            if world == 1 and not args.no_traffic:
+                tail = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
+                traffic_info = measure_traffic(tail + ["--no-cpu-baseline", "--no-traffic"], "k_force")
+                if traffic_info:
+                    traffic = traffic_info["bytes_per_launch"]
+            out.update({
+                "metric": f"body-pair interactions/s at N={n} (brute-force O(N^2) step)",
+                "value": value, "unit": "interactions/s",
+                "dtype": "f32" if args.source_bits == 32 else "f32 (fp16 source copy)",
+                "config": {"workload": f"{'plummer_sphere' if args.workload == 'plummer' else 'two_galaxies'}_N{n}_brute_force_dim{launch['dim']}_dt{DT}"
+                                       + ("_fp16sources" if args.source_bits == 16 else "")
+                                       + (f"_rank0_of_{args.shard_of}_slab_only" if args.shard_of > 1 else ""),
+                           "bodies": n, "seed": "0x5EED0001", "force_mode": args.mode, "host": host_kind,
+                           "sharding": sharding, "launch": launch},
+                "roofline": {"bound": "valu_fp32",
+                             "bound_contract_class": "mfma (dense fp32 peak: the f32 MFMA rate equals the fp32 vector rate, "
+                                                     "157.3 TFLOP/s; no MFMA is used)",
+                             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                             "traffic": traffic, "traffic_measurement": traffic_info,
+                             "kernel": KERNEL_NAMES.get(launch["variant"], "k_force"),
+                             "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": worst["force_launches"],
+                             "flops_per_interaction": flops_per_inter, "interactions_per_launch": inter_per_launch,
+                             "hbm_algorithmic_bytes_per_launch": algorithmic,
+                             "partial_slab_bytes_written_per_launch": 16.0 * slab_rows * launch.get("acc_slabs", launch["jsplit"]),
+                             "note": "VALU-bound path (arithmetic intensity ~1e5 flop/B): peak = CUs*clock*256 flop/clk "
+                                     "(fp32 vector FMA roofline, = the f32 MFMA rate); HBM is not the bound. With several GPUs: the "
+                                     "slowest rank's kernel (its slab x all sources per launch)"},
+                "integrate_kernel_avg_ms": per[0]["integrate_ms"],
+            })
+        else:
+            value = float(n) * args.steps / elapsed
+            ht = engine.bh_host_timing()
+            wk = engine.bh_work(args.theta)
+            ev_s = max(per[0]["bh_eval_ms"], 1e-9) * 1e-3
+            lane_ops_per_visit = 8.4   # 4 VALU lane-ops for the opening test + 6 for the pair law on the ~74 % of visits that take the node
+            valu_peak = info["compute_units"] * 4 * info["clock_khz"] * 1e3 * 32.0   # lane-ops/s: 32 lanes per cycle per SIMD
+            visits_per_s = wk["node_visits"] / ev_s
+            out.update({
+                "metric": f"bodies/s through nb_step_barnes_hut (theta={args.theta}) at N={n}",
+                "value": value, "unit": "body-steps/s", "dtype": "f32",
+                "config": {"workload": f"plummer_disk_projection_N{n}_barnes_hut_theta{args.theta}_dt{DT}", "bodies": n,
+                           "seed": "0x5EED0001", "force_mode": args.mode, "host": host_kind, "sharding": sharding,
+                           "tree": {0: "host (reference-faithful insertion build)", 1: "device (bh_build.hip)"}[engine.get_option(rx.engine.NBX_OPT_BH_TREE)]},
+                "ms_split": {"bh_eval_kernel": per[0]["bh_eval_ms"], "integrate_kernel": per[0]["integrate_ms"],
+                             "host_download": ht["download_ms"], "tree_build": ht["build_ms"], "flatten": ht["flatten_ms"],
+                             "upload_wait": ht["upload_ms"], "tree_nodes": ht["nodes"]},
+                "roofline": {"bound": "valu_issue", "bound_contract_class": "neither hbm nor mfma: a serial per-wave tree walk, bounded by "
+                             "instruction issue (DESIGN.md K3)", "kernel": "k_bh_eval_*",
+                             "achieved": visits_per_s * lane_ops_per_visit / 1e12, "peak": valu_peak / 1e12, "unit": "T lane-op/s",
+                             "frac": visits_per_s * lane_ops_per_visit / valu_peak,
+                             "node_visits_per_body": wk["node_visits"] / n, "pair_evals_per_body": wk["pair_evals"] / n,
+                             "kernel_avg_ms": per[0]["bh_eval_ms"],
+                             "hbm_algorithmic_bytes_per_launch": 32.0 * ht["nodes"] + 24.0 * n,
+                             "hbm_frac_of_8TBps": (32.0 * ht["nodes"] + 24.0 * n) / ev_s / 8e12, "traffic": None},
+            })
+        if world > 1 or host_kind != "single":
+            out["per_gpu"] = per
+            if host_kind == "group":
+                out["all_gather_us_per_step"] = float(np.mean([r["exchange_us"] for r in per]))
+        out.update({"device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],
+                    "clock_khz": info["clock_khz"]})
+        if power:
+            inter = (float(n) * float(n - 1) * args.steps) if not is_bh else 0
+            ps = power.summary(t0, t1, inter)
+            if ps:
+                out["power"] = ps
+        if not args.no_cpu_baseline and world == 1 and args.shard_of <= 1:
+            if is_bh:
+                cores = min(effective_cores(), 16)
+                ms1, rc = cpu_baseline_barnes_hut(st, args.theta, DT, cores, 3 if n > 200000 else 15)
+                out["cpu_baseline"] = {"value": n / (ms1 * 1e-3), "unit": "body-steps/s", "cores": cores, "kind": "port",
+                                       "ms_per_step": ms1, "rc": rc,
+                                       "sample": f"oracle nb_step_barnes_hut on the same {n} bodies: serial tree build + {cores} traversal "
+                                                 f"threads (the caller's maximum is 16, hs:94-97), median of {3 if n > 200000 else 15} steps"}
+            else:
+                out["cpu_baseline"] = cpu_baseline(st, args.cpu_seconds)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.destroy_process_group()
+    host.close()
 
 
 if __name__ == "__main__":

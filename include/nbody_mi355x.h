@@ -110,6 +110,9 @@ enum nbx_option {
     NBX_OPT_BH_WAVE = 9,           /* 1 (default): with the device-built tree, walk the tree once per WAVE (node
                                     * records through the scalar cache, lanes park on accepted subtrees); 0: one
                                     * independent walk per lane. Bit-identical results either way */
+    NBX_OPT_BH_FALLBACKS = 10,     /* read only (nbx_get_option): device tree builds that ran out of node pool and were
+                                    * redone on the host since the engine was created */
+    NBX_OPT_BH_LAST_TREE = 11,     /* read only: where the tree of the last Barnes-Hut evaluation was built: 0 host, 1 device */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };
@@ -118,7 +121,9 @@ enum nbx_kernel_id {
     NBX_K_FORCE = 0,     /* all-pairs force tile kernel (fast or strict) */
     NBX_K_INTEGRATE = 1, /* partial-sum reduce + kick-drift */
     NBX_K_BH_EVAL = 2,   /* Barnes-Hut traversal + kick-drift + velocity-kill */
-    NBX_K_COUNT = 3
+    NBX_K_EXCHANGE = 3,  /* nbx_group_*: the per-step all-gather as seen from this engine's stream (includes the wait
+                          * for the slowest peer) */
+    NBX_K_COUNT = 4
 };
 
 typedef struct nbx_device_info {
@@ -218,6 +223,10 @@ int32_t nbx_step_local(nbx_engine *e, float dt);
  * (0..count-1). Per-engine calls (options, profiling, forces) remain available through nbx_group_engine.
  * Barnes-Hut steps build the quadtree once per step for the whole group (host build: engine 0's copy, node
  * array sent to every device; device build: all devices concurrently).
+ * fp16 sources (NBX_OPT_SOURCE_PRECISION = 16 on every engine, fast mode): the per-step all-gather moves the half4
+ * source copy instead (ncclFloat16, half the bytes; BASELINE config #5). The fp32 positions of the other slabs are then
+ * re-gathered lazily, when a group call needs them (get_particles, draw, a Barnes-Hut or bit-exact step); per-engine
+ * calls through nbx_group_engine see them only after such a call.
  * NBX_GROUP_EXCHANGE=copy (environment, read at nbx_group_create): replace the RCCL all-gather by
  * event-ordered hipMemcpyPeerAsync pulls -- no communicator, no librccl, and a device may then be listed more
  * than once (several engines sharing one GPU: how the group logic is tested on a single-GPU box). */

@@ -21,6 +21,7 @@ from .engine import (  # noqa: F401
     NBX_ERR_TREE,
     NBX_ERR_TREE_DEPTH,
     NBX_K_BH_EVAL,
+    NBX_K_EXCHANGE,
     NBX_K_FORCE,
     NBX_K_INTEGRATE,
     NBodyEngine,

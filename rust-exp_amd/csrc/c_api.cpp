@@ -76,6 +76,14 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
             return NBX_OK;
         case NBX_OPT_PROFILE:
             e->profile = value ? 1 : 0;
+            if (e->profile && e->dev_ready && e->ev_free.size() < 64) {   // events exist before anything is timed
+                HIP_TRY(hipSetDevice(e->device));
+                while (e->ev_free.size() < 64) {
+                    hipEvent_t ev = nullptr;
+                    HIP_TRY(hipEventCreate(&ev));
+                    e->ev_free.push_back(ev);
+                }
+            }
             return NBX_OK;
         case NBX_OPT_KERNEL_VARIANT:
             e->variant = (int)value;
@@ -118,6 +126,8 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_DRAW_DEVICE: return e->draw_device;
         case NBX_OPT_BH_TREE: return e->bh_tree_device;
         case NBX_OPT_BH_WAVE: return e->bh_wave;
+        case NBX_OPT_BH_FALLBACKS: return e->bh_fallbacks;
+        case NBX_OPT_BH_LAST_TREE: return e->bh_last_tree_device;
         default: return NBX_ERR_INVALID;
     }
 }
@@ -280,6 +290,7 @@ int32_t nbx_forces(nbx_engine* e, float theta, int32_t cap, float* fx, float* fy
             rc = build_and_upload_tree(e);
             if (rc != NBX_OK) return rc;
         }
+        e->bh_last_tree_device = on_device ? 1 : 0;
         ProfScope ps(e, NBX_K_BH_EVAL);
         const unsigned* perm = (on_device && e->world == 1) ? e->d_perm : nullptr;
         HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta,
@@ -506,34 +517,22 @@ int32_t nbx_profile_reset(nbx_engine* e)
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
     if (e->dev_ready) {
         HIP_TRY(hipSetDevice(e->device));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        prof_fold(e, true);
     }
-    for (auto& r : e->prof) {
-        (void)hipEventDestroy(r.start);
-        (void)hipEventDestroy(r.stop);
-    }
-    e->prof.clear();
+    for (int k = 0; k < NBX_K_COUNT; k++) { e->prof_ms[k] = 0.0; e->prof_n[k] = 0; }
     return NBX_OK;
 }
 
 int32_t nbx_profile_read(nbx_engine* e, int32_t kernel_id, double* total_ms, int32_t* launches)
 {
     if (!e || kernel_id < 0 || kernel_id >= NBX_K_COUNT) return fail(NBX_ERR_INVALID, "bad kernel id");
-    double total = 0.0;
-    int count = 0;
     if (e->dev_ready) {
         HIP_TRY(hipSetDevice(e->device));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        for (auto& r : e->prof) {
-            if (r.kernel != kernel_id) continue;
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
-            total += ms;
-            count++;
-        }
+        prof_fold(e, true);
+        if (!e->prof.empty()) return fail(NBX_ERR_HIP, "profiling events could not be read");
     }
-    if (total_ms) *total_ms = total;
-    if (launches) *launches = count;
+    if (total_ms) *total_ms = e->prof_ms[kernel_id];
+    if (launches) *launches = e->prof_n[kernel_id];
     return NBX_OK;
 }
 

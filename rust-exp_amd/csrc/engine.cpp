@@ -557,6 +557,7 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
             perm = e->d_slab_perm;
         }
     }
+    e->bh_last_tree_device = on_device ? 1 : 0;
     const bool wave = perm != nullptr && e->bh_wave;   // shared walk per wave, in both modes (same results as the per-lane walks)
     {
         ProfScope ps(e, NBX_K_BH_EVAL);
@@ -659,6 +660,8 @@ void free_device(nbx_engine* e)
         (void)hipEventDestroy(r.stop);
     }
     e->prof.clear();
+    for (hipEvent_t ev : e->ev_free) (void)hipEventDestroy(ev);
+    e->ev_free.clear();
     if (e->d_posm && !e->posm_external) (void)hipFree(e->d_posm);
     if (e->d_vel) (void)hipFree(e->d_vel);
     if (e->d_acc) (void)hipFree(e->d_acc);

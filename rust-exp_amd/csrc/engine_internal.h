@@ -60,6 +60,7 @@ struct nbx_engine {
     size_t slab_ws_bytes = 0;
     int bh_tree_device = 0;
     int bh_wave = 1;               // wave-uniform traversal when a spatial body order is available
+    int bh_last_tree_device = 0;   // where the last evaluated tree was built
     int bh_fallbacks = 0;          // device builds that fell back to the host (node pool exhausted)
     void* d_counts = nullptr;      // device draw: uint2 hit counters per pixel
     size_t counts_cap = 0;         // pixels
@@ -95,7 +96,10 @@ struct nbx_engine {
     char* h_route = nullptr;          // pinned, device-visible: insert events | bucket per body | bucket offsets
     size_t h_route_bytes = 0;
 
-    std::vector<ProfRec> prof;
+    std::vector<ProfRec> prof;              // event pairs still in flight (profiling on)
+    std::vector<hipEvent_t> ev_free;        // recycled events: a long profiled run creates no new ones
+    double prof_ms[NBX_K_COUNT] = {};       // folded totals per kernel id since the last reset
+    int prof_n[NBX_K_COUNT] = {};
     nbx::ForceLaunch last{0, 0, 0, 0, 0, 0};
     std::chrono::steady_clock::time_point tree_t0;   // start of the device tree build in flight
     double host_ms[4] = {0, 0, 0, 0};  // Barnes-Hut host phases: download, build, flatten, upload (cumulative)
@@ -109,6 +113,7 @@ struct nbx_group {
     std::vector<int> devices;
     std::vector<ncclComm_t> comms;
     int exchanges = 0;
+    bool fp32_stale = false;                // only the fp16 source copy was exchanged: fp32 positions of other slabs are old
     bool copy_exchange = false;             // NBX_GROUP_EXCHANGE=copy: peer copies + events instead of RCCL
     std::vector<hipEvent_t> ev_ready;       // per engine: its slab is updated
     std::vector<hipEvent_t> ev_copied;      // per engine: it has pulled every other slab
@@ -141,21 +146,58 @@ int grow(T** ptr, size_t* cap, size_t need)
     return NBX_OK;
 }
 
+// Finished event pairs -> per-kernel totals; their events go back to the free list.  wait = false folds only the pairs
+// that have already completed (no synchronisation inside a step).
+inline void prof_fold(nbx_engine* e, bool wait)
+{
+    size_t k = 0;
+    for (; k < e->prof.size(); k++) {
+        ProfRec& r = e->prof[k];
+        if (wait) {
+            if (hipEventSynchronize(r.stop) != hipSuccess) break;
+        } else if (hipEventQuery(r.stop) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess && r.kernel >= 0 && r.kernel < NBX_K_COUNT) {
+            e->prof_ms[r.kernel] += ms;
+            e->prof_n[r.kernel]++;
+        }
+        e->ev_free.push_back(r.start);
+        e->ev_free.push_back(r.stop);
+    }
+    e->prof.erase(e->prof.begin(), e->prof.begin() + (long)k);
+}
+
+inline bool prof_event(nbx_engine* e, hipEvent_t* ev)
+{
+    if (!e->ev_free.empty()) {
+        *ev = e->ev_free.back();
+        e->ev_free.pop_back();
+        return true;
+    }
+    return hipEventCreate(ev) == hipSuccess;
+}
+
+// HIP event pair on the engine's stream around a launch (NBX_OPT_PROFILE). The caller has made e->device current.
 struct ProfScope {
     nbx_engine* e;
-    int idx = -1;
+    hipEvent_t stop = nullptr;
     ProfScope(nbx_engine* eng, int kernel) : e(eng)
     {
         if (!e->profile) return;
+        if (e->prof.size() >= 256) prof_fold(e, false);
         ProfRec r{kernel, nullptr, nullptr};
-        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+        if (!prof_event(e, &r.start)) return;
+        if (!prof_event(e, &r.stop)) { e->ev_free.push_back(r.start); return; }
         (void)hipEventRecord(r.start, e->stream);
         e->prof.push_back(r);
-        idx = (int)e->prof.size() - 1;
+        stop = r.stop;
     }
     ~ProfScope()
     {
-        if (idx >= 0) (void)hipEventRecord(e->prof[idx].stop, e->stream);
+        if (stop) (void)hipEventRecord(stop, e->stream);
     }
 };
 

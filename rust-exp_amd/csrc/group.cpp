@@ -1,6 +1,8 @@
 // group.cpp -- single-process multi-GPU group (nbx_group_*), RCCL resolved with dlopen.
 #include <dlfcn.h>
 
+#include <memory>
+
 #include "engine_internal.h"
 
 using namespace nbxi;
@@ -76,9 +78,10 @@ int group_comms(nbx_group* g)
 // (ev_ready), and nobody starts the next step before everyone has pulled from it (ev_copied).  Works with or
 // without peer access, needs no communicator, and lets several engines share one device (how the group logic is
 // tested on a single-GPU box).
-int group_exchange_copy(nbx_group* g)
+int group_exchange_copy(nbx_group* g, bool half)
 {
     const int G = (int)g->eng.size();
+    const size_t rec = half ? 8 : sizeof(float4);   // half4 source copy or float4 (x,y,z,m)
     if (g->ev_ready.empty()) {
         g->ev_ready.resize(G);
         g->ev_copied.resize(G);
@@ -92,16 +95,19 @@ int group_exchange_copy(nbx_group* g)
         HIP_TRY(hipSetDevice(g->eng[d]->device));
         HIP_TRY(hipEventRecord(g->ev_ready[d], g->eng[d]->stream));
     }
+    std::vector<std::unique_ptr<ProfScope>> scopes;   // per engine: start after its own kernels, stop when it may go on
     for (int d = 0; d < G; d++) {
         nbx_engine* dst = g->eng[d];
         HIP_TRY(hipSetDevice(dst->device));
+        scopes.emplace_back(new ProfScope(dst, NBX_K_EXCHANGE));
         for (int s = 0; s < G; s++) {
             if (s == d) continue;
             nbx_engine* src = g->eng[s];
             if (src->slab() == 0) continue;
             HIP_TRY(hipStreamWaitEvent(dst->stream, g->ev_ready[s], 0));
-            HIP_TRY(hipMemcpyPeerAsync(dst->d_posm + src->lo, dst->device, src->d_posm + src->lo, src->device,
-                                       sizeof(float4) * (size_t)src->slab(), dst->stream));
+            char* to = (half ? static_cast<char*>(dst->d_posh) : reinterpret_cast<char*>(dst->d_posm)) + rec * (size_t)src->lo;
+            const char* from = (half ? static_cast<const char*>(src->d_posh) : reinterpret_cast<const char*>(src->d_posm)) + rec * (size_t)src->lo;
+            HIP_TRY(hipMemcpyPeerAsync(to, dst->device, from, src->device, rec * (size_t)src->slab(), dst->stream));
         }
         HIP_TRY(hipEventRecord(g->ev_copied[d], dst->stream));
     }
@@ -109,33 +115,42 @@ int group_exchange_copy(nbx_group* g)
         HIP_TRY(hipSetDevice(g->eng[d]->device));
         for (int s = 0; s < G; s++)
             if (s != d) HIP_TRY(hipStreamWaitEvent(g->eng[d]->stream, g->ev_copied[s], 0));
+        scopes[(size_t)d].reset();   // stop event on d's stream, with d's device current
     }
     return NBX_OK;
 }
 
-// one all-gather of the (x,y,z,m) slabs: in place, sendbuff = recvbuff + lo (per device), same stream as the kernels
-int group_exchange(nbx_group* g)
+// one all-gather of the slabs of ONE array, in place (sendbuff = recvbuff + lo), on the same streams as the kernels:
+// half = false: the float4 (x,y,z,m) array; half = true: the half4 source copy (ncclFloat16, half the bytes on the wire --
+// SURVEY.md 8(e), BASELINE config #5)
+int group_exchange_array(nbx_group* g, bool half)
 {
     const int G = (int)g->eng.size();
     const int n = g->eng[0]->n;
-    if (n == 0) return NBX_OK;
     if (g->copy_exchange) {
         if (G > 1) {
-            const int rc = group_exchange_copy(g);
+            const int rc = group_exchange_copy(g, half);
             if (rc != NBX_OK) return rc;
         }
-        for (nbx_engine* e : g->eng) e->host_pos_valid = false;
         g->exchanges++;
         return NBX_OK;
     }
     int rc = group_comms(g);
     if (rc != NBX_OK) return rc;
     RcclApi* api = rccl_api();
+    const ncclDataType_t ty = half ? ncclFloat16 : ncclFloat32;
+    const size_t rec = half ? 8 : sizeof(float4);
+    auto base = [&](nbx_engine* e) { return half ? static_cast<char*>(e->d_posh) : reinterpret_cast<char*>(e->d_posm); };
+    std::vector<std::unique_ptr<ProfScope>> scopes;
+    for (nbx_engine* e : g->eng) {
+        HIP_TRY(hipSetDevice(e->device));
+        scopes.emplace_back(new ProfScope(e, NBX_K_EXCHANGE));
+    }
     RCCL_TRY(api, api->GroupStart());
     if (n % G == 0) {
         for (int d = 0; d < G; d++) {
             nbx_engine* e = g->eng[d];
-            RCCL_TRY(api, api->AllGather(e->d_posm + e->lo, e->d_posm, (size_t)e->slab() * 4, ncclFloat32, g->comms[d], e->stream));
+            RCCL_TRY(api, api->AllGather(base(e) + rec * (size_t)e->lo, base(e), (size_t)e->slab() * 4, ty, g->comms[d], e->stream));
         }
     } else {   // ragged last slab (reference split): one broadcast per owner
         for (int r = 0; r < G; r++) {
@@ -143,13 +158,63 @@ int group_exchange(nbx_group* g)
             if (cnt == 0) continue;
             for (int d = 0; d < G; d++) {
                 nbx_engine* e = g->eng[d];
-                RCCL_TRY(api, api->Broadcast(e->d_posm + lo, e->d_posm + lo, (size_t)cnt * 4, ncclFloat32, r, g->comms[d], e->stream));
+                RCCL_TRY(api, api->Broadcast(base(e) + rec * (size_t)lo, base(e) + rec * (size_t)lo, (size_t)cnt * 4, ty, r, g->comms[d], e->stream));
             }
         }
     }
     RCCL_TRY(api, api->GroupEnd());
-    for (nbx_engine* e : g->eng) e->host_pos_valid = false;
+    for (size_t d = 0; d < g->eng.size(); d++) {
+        HIP_TRY(hipSetDevice(g->eng[d]->device));
+        scopes[d].reset();
+    }
     g->exchanges++;
+    return NBX_OK;
+}
+
+// every engine runs the packed fp16-source sweep: the half4 copy is then the ONLY array the next all-pairs step reads
+// from other slabs, so it is the array that travels
+bool group_wants_half_exchange(const nbx_group* g)
+{
+    for (const nbx_engine* e : g->eng)
+        if (!(e->source_half && e->force_mode == 0)) return false;
+    return true;
+}
+
+// bring the fp32 (x,y,z,m) array of every engine up to date after steps that exchanged only the fp16 copy
+int group_replicate_fp32(nbx_group* g)
+{
+    if (!g->fp32_stale) return NBX_OK;
+    const int rc = group_exchange_array(g, false);
+    if (rc != NBX_OK) return rc;
+    g->fp32_stale = false;
+    return NBX_OK;
+}
+
+// The per-step exchange. fp32 sources: one all-gather of (x,y,z,m). fp16 sources on every engine: one all-gather of the
+// half4 copy instead (each engine refreshed its own slab's slot in step_brute); the fp32 positions of the other slabs go
+// stale and are re-gathered only when somebody needs them (get, draw, Barnes-Hut, a bit-exact step).  Mixed settings
+// (some engines fp16): fp32 travels and those engines re-pack the slabs they received.
+int group_exchange(nbx_group* g, bool allow_half)
+{
+    const int n = g->eng[0]->n;
+    if (n == 0) return NBX_OK;
+    int rc;
+    if (allow_half && group_wants_half_exchange(g)) {
+        rc = group_exchange_array(g, true);
+        if (rc != NBX_OK) return rc;
+        g->fp32_stale = g->eng.size() > 1;
+    } else {
+        g->fp32_stale = false;   // everything is about to be current
+        rc = group_exchange_array(g, false);
+        if (rc != NBX_OK) return rc;
+        for (nbx_engine* e : g->eng)
+            if (e->source_half && g->eng.size() > 1) {   // stream-ordered after the gather on e's stream
+                HIP_TRY(hipSetDevice(e->device));
+                rc = refresh_half_sources(e, 0, e->n_pad);
+                if (rc != NBX_OK) return rc;
+            }
+    }
+    for (nbx_engine* e : g->eng) e->host_pos_valid = false;
     return NBX_OK;
 }
 
@@ -217,6 +282,7 @@ int32_t nbx_group_set_particles3(nbx_group* g, int32_t n, const float* px, const
         const int rc = nbx_set_particles3(e, n, px, py, pz, vx, vy, vz, m);
         if (rc != NBX_OK) return rc;
     }
+    g->fp32_stale = false;
     return NBX_OK;
 }
 
@@ -226,7 +292,9 @@ int32_t nbx_group_get_particles3(nbx_group* g, int32_t cap, float* px, float* py
     if (!g) return fail(NBX_ERR_INVALID, "null group");
     nbx_engine* e0 = g->eng[0];
     if (cap < e0->n) return fail(NBX_ERR_INVALID, "capacity %d < particle count %d", cap, e0->n);
-    int rc = nbx_get_particles3(e0, cap, px, py, pz, vx, vy, vz, m);   // positions are replicated after the all-gather
+    int rc = group_replicate_fp32(g);
+    if (rc != NBX_OK) return rc;
+    rc = nbx_get_particles3(e0, cap, px, py, pz, vx, vy, vz, m);   // positions are replicated after the all-gather
     if (rc < 0) return rc;
     for (size_t d = 1; d < g->eng.size(); d++) {                        // velocities live on their owner
         nbx_engine* e = g->eng[d];
@@ -243,11 +311,15 @@ int32_t nbx_group_get_particles3(nbx_group* g, int32_t cap, float* px, float* py
 int32_t nbx_group_step_brute_force(nbx_group* g, float dt)
 {
     if (!g) return fail(NBX_ERR_INVALID, "null group");
+    if (g->fp32_stale && !group_wants_half_exchange(g)) {   // e.g. a bit-exact step after fp16-source steps: it reads fp32 sources
+        const int rc = group_replicate_fp32(g);
+        if (rc != NBX_OK) return rc;
+    }
     for (nbx_engine* e : g->eng) {   // asynchronous: every device works on its slab concurrently
         const int rc = step_brute(e, dt);
         if (rc != NBX_OK) return rc;
     }
-    return group_exchange(g);
+    return group_exchange(g, true);
 }
 
 int32_t nbx_group_step_barnes_hut(nbx_group* g, float theta, float dt, int32_t nthreads)
@@ -256,9 +328,11 @@ int32_t nbx_group_step_barnes_hut(nbx_group* g, float theta, float dt, int32_t n
     if (theta == 0.0f) return nbx_group_step_brute_force(g, dt);   // nbody.rs:197-200
     if (nthreads <= 0) return fail(NBX_ERR_INVALID, "nthreads must be >= 1");
     // tree replica per device, built once per step and shared; each device evaluates its slab
-    const int rc = step_bh_group(g->eng.data(), (int)g->eng.size(), theta, dt);
+    int rc = group_replicate_fp32(g);   // the tree is built from, and the walk reads, fp32 positions
     if (rc != NBX_OK) return rc;
-    return group_exchange(g);
+    rc = step_bh_group(g->eng.data(), (int)g->eng.size(), theta, dt);
+    if (rc != NBX_OK) return rc;
+    return group_exchange(g, false);
 }
 
 int32_t nbx_group_synchronize(nbx_group* g)

@@ -34,10 +34,13 @@ NBX_OPT_SOURCE_PRECISION = 6
 NBX_OPT_DRAW_DEVICE = 7
 NBX_OPT_BH_TREE = 8
 NBX_OPT_BH_WAVE = 9
+NBX_OPT_BH_FALLBACKS = 10
+NBX_OPT_BH_LAST_TREE = 11
 
 NBX_K_FORCE = 0
 NBX_K_INTEGRATE = 1
 NBX_K_BH_EVAL = 2
+NBX_K_EXCHANGE = 3
 
 
 class NBodyError(RuntimeError):
@@ -294,11 +297,23 @@ class NBodyEngine:
         h = C.c_void_p()
         _check(self._L.nbx_create(C.byref(h), device))
         self._h = h
+        self._owned = True
         self.set_mode(mode)
+
+    @classmethod
+    def _borrow(cls, handle, keepalive):
+        """View of an engine owned by somebody else (a group member, nbx_group_engine): never destroyed from here."""
+        self = cls.__new__(cls)
+        self._L = lib()
+        self._h = C.c_void_p(handle)
+        self._owned = False
+        self._keepalive = keepalive
+        return self
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.nbx_destroy(self._h)
+            if getattr(self, "_owned", True):
+                self._L.nbx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -500,6 +515,16 @@ class NBodyGroup:
 
     def size(self):
         return _check(self._L.nbx_group_size(self._h))
+
+    def engine(self, i):
+        """Member engine i (per-engine options, profiling, slab, forces)."""
+        h = self._L.nbx_group_engine(self._h, i)
+        if not h:
+            raise IndexError(i)
+        return NBodyEngine._borrow(h, self)
+
+    def set_source_precision(self, bits):
+        self.set_option(NBX_OPT_SOURCE_PRECISION, bits)
 
     def set_option(self, opt, value):
         _check(self._L.nbx_group_set_option(self._h, opt, int(value)))

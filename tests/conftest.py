@@ -62,3 +62,21 @@ def assert_bit_equal(a, b, what=""):
 
 def particles_from(ob, d, prefix="in_"):
     return ob.particles(d[prefix + "px"], d[prefix + "py"], d[prefix + "vx"], d[prefix + "vy"], d["in_m"])
+
+
+def fast_tolerances(ob, p, dt, steps=1, amax=None, n=None):
+    """The stated fp32 tolerance of the fast mode against the CPU-f32 oracle, computed from the case:
+        1 step:   max|dp| <= 1e-5,  max|dv| <= 1e-5 * max|a| * dt * max(1, sqrt(N)/64)
+        k steps:  max|dp| <= 1e-5 * k,  max|dv| <= 2.5 * k * (1-step bound)
+    (k = 10 gives the survey's 1e-4 / 5e-3 on its 4 096-body case where max|a| ~ 2e3).  max|a| comes from the
+    oracle's own all-pairs forces on the initial state `p` (a = F/m, nbody.rs:140-142,:155); sizes where that takes
+    minutes pass `amax` (and `n`) measured another way and say how."""
+    if amax is None:
+        n = len(p)
+        fx, fy = ob.brute_forces(p, nthreads=8)
+        m = np.asarray(p["m"], np.float64)
+        amax = float(np.max(np.hypot(fx / m, fy / m))) if n else 0.0
+    v1 = 1e-5 * amax * dt * max(1.0, np.sqrt(n) / 64.0)
+    if steps <= 1:
+        return 1e-5, v1
+    return 1e-5 * steps, 2.5 * steps * v1

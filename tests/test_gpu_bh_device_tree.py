@@ -123,28 +123,36 @@ def test_strict_mode_ignores_the_device_tree(rx, ob):
 
 
 def test_device_tree_node_pool_overflow_falls_back_to_host_build(rx, ob):
-    """Thousands of pairs 1e-6 apart force ~20-level chains (> 4 nodes per body): the device build reports pool
-    exhaustion and the step silently takes the reference-faithful host build (which EPS-merges the pairs)."""
+    """Thousands of pairs 2e-4 apart (farther than EPS in x, so nobody merges them: nbody.rs:249) force ~18-level chains,
+    more than the 4 nodes per body the device pool holds: the device build reports pool exhaustion and the evaluation takes
+    the reference-faithful host build instead. Which build ran is ASSERTED (NBX_OPT_BH_FALLBACKS / NBX_OPT_BH_LAST_TREE),
+    and the result is then the host-tree result bit for bit."""
+    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+
     rng = np.random.default_rng(8)
     x = rng.uniform(-20, 20, 4000).astype(np.float32)
     y = rng.uniform(-20, 20, 4000).astype(np.float32)
-    x2 = np.concatenate([x, x + np.float32(1e-6) * np.maximum(np.abs(x), 1)])
+    x2 = np.concatenate([x, x + np.float32(2e-4)])
     y2 = np.concatenate([y, y])
+    assert np.all(np.abs(x2[4000:] - x2[:4000]) >= 1.5e-4)
     n = len(x2)
     p = ob.particles(x2, y2, np.zeros(n), np.zeros(n), np.ones(n))
     a = rx.NBodyEngine(); a.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     b = rx.NBodyEngine(); b.set_bh_tree("device"); b.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     fx, fy, _ = a.forces(0.5)
+    assert a.get_option(NBX_OPT_BH_LAST_TREE) == 0 and a.get_option(NBX_OPT_BH_FALLBACKS) == 0
     gx, gy, _ = b.forces(0.5)
-    assert np.isfinite(gx).all()
-    dev = b.bh_host_timing()
-    if dev["nodes"] == a.bh_host_timing()["nodes"] or True:
-        # whichever build ran, the result must agree with the host-tree result to traversal tolerance
-        scale = max(np.abs(fx).max(), np.abs(fy).max())
-        rel = np.hypot(gx - fx, gy - fy) / scale
-        assert np.median(rel) <= 1e-5
+    assert b.get_option(NBX_OPT_BH_FALLBACKS) == 1 and b.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    assert b.bh_host_timing()["nodes"] == a.bh_host_timing()["nodes"] > 4 * n
+    assert np.array_equal(gx.view(np.uint32), fx.view(np.uint32)) and np.array_equal(gy.view(np.uint32), fy.view(np.uint32))
     b.step_barnes_hut(0.5, 0.01, 1)
+    assert b.get_option(NBX_OPT_BH_FALLBACKS) == 2
     assert np.isfinite(b.get_particles()["px"]).all()
+    # a well-separated system of the same size stays on the device
+    q = ob.random_disk(n, 5)
+    b.set_particles(q["px"], q["py"], q["vx"], q["vy"], q["m"])
+    b.forces(0.5)
+    assert b.get_option(NBX_OPT_BH_LAST_TREE) == 1 and b.get_option(NBX_OPT_BH_FALLBACKS) == 2
 
 
 @pytest.mark.parametrize("n,theta", [(1, 0.5), (70, 0.5), (5000, 0.3), (100000, 0.85)])

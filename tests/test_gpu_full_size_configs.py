@@ -9,6 +9,8 @@
 import numpy as np
 import pytest
 
+from conftest import fast_tolerances
+
 pytestmark = pytest.mark.gpu
 
 
@@ -40,6 +42,12 @@ def test_config3_262144_eight_slabs_stitch_to_the_unsharded_step(rx):
     st = rx.plummer_sphere(n)
     ref = rx.NBodyEngine()
     ref.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
+    # tolerance from the data; at this size max|a| comes from the engine's own force evaluation (the oracle
+    # needs minutes for 6.9e10 pairs) -- it only scales the bound. Two fast results are compared, each within the bound
+    # of the oracle: hence the factor 2.
+    fx, fy, fz = ref.forces()
+    amax = float(np.max(np.sqrt(fx.astype(np.float64) ** 2 + fy.astype(np.float64) ** 2 + fz.astype(np.float64) ** 2) / st["m"]))
+    ptol, vtol = fast_tolerances(None, None, 0.01, 1, amax=amax, n=n)
     ref.step_brute_force(0.01)
     want = ref.get_particles()
     for r in (0, 3, 7):      # first, middle, last slab (each is 32 768 targets x 262 144 sources)
@@ -51,9 +59,9 @@ def test_config3_262144_eight_slabs_stitch_to_the_unsharded_step(rx):
         assert (lo, hi) == (r * 32768, (r + 1) * 32768)
         got = e.get_particles()
         for k in ("px", "py", "pz"):
-            assert np.abs(got[k][lo:hi] - want[k][lo:hi]).max() <= 1e-5, (r, k)
+            assert np.abs(got[k][lo:hi] - want[k][lo:hi]).max() <= 2 * ptol, (r, k)
         for k in ("vx", "vy", "vz"):
-            assert np.abs(got[k][lo:hi] - want[k][lo:hi]).max() <= 2e-3, (r, k)
+            assert np.abs(got[k][lo:hi] - want[k][lo:hi]).max() <= 2 * vtol, (r, k, vtol)
         ll = e.last_launch()
         assert ll["grid"] >= 2048 and ll["dim"] == 3      # the j-split keeps the chip full with 32 768 targets
 

@@ -5,6 +5,8 @@ of quantising source coordinates to 11 bits: median relative acceleration error 
 import numpy as np
 import pytest
 
+from conftest import fast_tolerances
+
 pytestmark = pytest.mark.gpu
 
 
@@ -59,7 +61,7 @@ def test_half_sources_accuracy_class_vs_fp32(rx):
     assert np.array_equal(pb["m"], st["m"])
 
 
-def test_half_sources_sharded_slabs_stitch(rx):
+def test_half_sources_sharded_slabs_stitch(rx, ob):
     """Every rank's nbx_step_local in fp16-source mode (own slab fp32, sources = fp16 copy of all bodies)
     reproduces the unsharded fp16-source step to fp32 rounding."""
     n, world = 16384, 8
@@ -69,6 +71,9 @@ def test_half_sources_sharded_slabs_stitch(rx):
     ref.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
     ref.step_brute_force(0.01)
     want = ref.get_particles()
+    # both sides sweep the SAME fp16-rounded sources in fp32: they differ by launch shape only, i.e. by twice the fast
+    # mode's bound for this case (from the oracle's max|a| on this state)
+    ptol, vtol = fast_tolerances(ob, ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"]), 0.01, 1)
     for r in range(world):
         e = rx.NBodyEngine()
         e.set_source_precision(16)
@@ -77,8 +82,8 @@ def test_half_sources_sharded_slabs_stitch(rx):
         e.step_local(0.01)
         lo, hi = e.slab()
         got = e.get_particles()
-        assert np.abs(got["px"][lo:hi] - want["px"][lo:hi]).max() <= 1e-5
-        assert np.abs(got["vx"][lo:hi] - want["vx"][lo:hi]).max() <= 2e-3
+        assert np.abs(got["px"][lo:hi] - want["px"][lo:hi]).max() <= 2 * ptol
+        assert np.abs(got["vx"][lo:hi] - want["vx"][lo:hi]).max() <= 2 * vtol, vtol
 
 
 def test_switching_precision_on_a_live_engine(rx):

@@ -8,7 +8,7 @@ import socket
 import numpy as np
 import pytest
 
-from conftest import assert_bit_equal
+from conftest import assert_bit_equal, fast_tolerances
 
 pytestmark = pytest.mark.gpu
 
@@ -131,8 +131,9 @@ def test_slab_kernels_of_all_ranks_stitch_to_the_single_gpu_step(rx, ob, world, 
             for k in news:
                 assert_bit_equal(news[k], q[k], k)
         else:
-            assert np.abs(news["px"] - q["px"]).max() <= 1e-5
-            assert np.abs(news["vx"] - q["vx"]).max() <= 2e-4
+            ptol, vtol = fast_tolerances(ob, p, 0.01, 1)
+            assert np.abs(news["px"] - q["px"]).max() <= ptol
+            assert np.abs(news["vx"] - q["vx"]).max() <= vtol, vtol
 
 
 def test_single_process_group_of_one_gpu_matches_plain_engine(rx, ob):
@@ -195,11 +196,13 @@ def test_single_process_group_of_several_engines_on_one_gpu(rx, ob, monkeypatch,
         g.synchronize()
         assert g.exchanges() == 6
         a, b = g.get_particles(), e.get_particles()
+        # two fast results (different launch shapes), each within the stated bound of the oracle (SURVEY 8(d), 3 brute steps)
+        ptol, vtol = fast_tolerances(ob, p, 0.01, 3)
         for k in ("px", "py", "vx", "vy"):
             if mode == "strict":
                 assert_bit_equal(a[k], b[k], f"G={G} strict brute {k}")
             else:
-                assert np.abs(a[k] - b[k]).max() <= (1e-5 if k[0] == "p" else 2e-3), k
+                assert np.abs(a[k] - b[k]).max() <= 2 * (ptol if k[0] == "p" else vtol), (k, vtol)
         assert np.array_equal(g.draw(96, 96), e.draw(96, 96)) or mode == "fast"
         g.close()
     # without the copy exchange a device may appear only once (RCCL wants one rank per device)
@@ -239,7 +242,7 @@ if rank == 0:
     want = ref.get_particles()
     for k in ("px", "py", "pz", "vx", "vy", "vz"):
         err = float(np.abs(np.asarray(full[k]) - want[k]).max())
-        if err > (1e-5 if k[0] == "p" else 2e-3):
+        if err > 2 * float(os.environ["NBX_PTOL" if k[0] == "p" else "NBX_VTOL"]):   # two fast results, same launch shape
             bad.append((k, err))
 dist.barrier()
 dist.destroy_process_group()
@@ -249,7 +252,7 @@ if rank == 0:
 
 
 @pytest.mark.parametrize("world,n", [(2, 16384), (3, 10000)])
-def test_two_and_three_ranks_share_the_gpu_over_gloo(rx, world, n):
+def test_two_and_three_ranks_share_the_gpu_over_gloo(rx, ob, world, n):
     """The real multi-process path (TorchSlabEngine on torch-owned device memory, slab kernels of several ranks,
     one all-gather per step, velocity gather) with world size > 1: the ranks share the single test GPU and
     exchange over gloo (RCCL refuses two ranks on one device). Even (2 x 8192) and ragged (3 ranks) slabs."""
@@ -261,9 +264,11 @@ def test_two_and_three_ranks_share_the_gpu_over_gloo(rx, world, n):
 
     port = _free_port()
     procs = []
+    st = rx.plummer_sphere(n)      # SURVEY 8(d) bound for 3 steps of this case, from the oracle's max|a| (x, y of the 3-D state:
+    ptol, vtol = fast_tolerances(ob, ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"]), 0.01, 3)   # scale only)
     for r in range(world):
         env = dict(os.environ, NBX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r),
-                   WORLD_SIZE=str(world), NBX_N=str(n))
+                   WORLD_SIZE=str(world), NBX_N=str(n), NBX_PTOL=repr(ptol), NBX_VTOL=repr(vtol))
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER2], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
