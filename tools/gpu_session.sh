@@ -1,0 +1,61 @@
+#!/bin/bash
+# One parametrised GPU session (replaces the round-1 gpu_session*.sh scratch scripts).  Run through gpurun from the repo root:
+#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh smoke tests bench prof pmc power'
+# Every stage writes under gpurun_out/<TAG>_* (TAG env, default r02); copy what is to be judged into profiles/.
+#   smoke   __graft_entry__.smoke()
+#   tests   pytest -m gpu (TESTS env narrows the selection, e.g. TESTS='tests/test_gpu_group.py')
+#   bench   bench.py default line (N=1) + --gpus 2 through the group host (copy exchange when the box has one GPU)
+#   bh      bench.py --workload bh (host tree, device tree)
+#   prof    rocprofv3 --kernel-trace --stats of the bench command
+#   pmc     six rocprofv3 --pmc passes of the bench command (summarise locally with tools/pmc_summary.py TAG)
+#   power   tools/power_probe.py: board power during a >= 6 s K1 loop
+#   shapes  launch-shape sweeps (sweep_shapes.py, shard-of-8 shape)
+#   ubench  instruction-issue microbenchmarks
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+TAG="${TAG:-r02}"
+O=gpurun_out
+mkdir -p $O
+export TMPDIR=/tmp
+for stage in "$@"; do
+  echo "== $stage $(date +%T)"
+  case "$stage" in
+    smoke) timeout 600 python __graft_entry__.py smoke > $O/${TAG}_smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/${TAG}_smoke.log ;;
+    tests) timeout ${TEST_TIMEOUT:-3000} python -m pytest ${TESTS:-tests} -m gpu -q -x > $O/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/${TAG}_pytest_gpu.log; tail -5 $O/${TAG}_pytest_gpu.log ;;
+    bench)
+      timeout 900 python bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err; echo "bench rc=$?"; cat $O/${TAG}_bench_n1.json
+      if [ "$(python -c 'import rust_exp_amd as r; print(r.device_count())' 2>/dev/null)" -ge 2 ]; then
+        timeout 900 python bench.py --gpus 2 > $O/${TAG}_bench_group2.json 2> $O/${TAG}_bench_group2.err
+      else
+        NBX_GROUP_EXCHANGE=copy timeout 900 python bench.py --gpus 2 --no-cpu-baseline > $O/${TAG}_bench_group2_one_gpu_copy.json 2> $O/${TAG}_bench_group2.err
+      fi
+      echo "group bench rc=$?" ;;
+    bh)
+      timeout 900 python bench.py --workload bh > $O/${TAG}_bench_bh_default.json 2> $O/${TAG}_bench_bh_default.err; echo "bh rc=$?"; cat $O/${TAG}_bench_bh_default.json
+      timeout 900 python bench.py --workload bh --bh-tree host --no-cpu-baseline > $O/${TAG}_bench_bh_host.json 2> $O/${TAG}_bench_bh_host.err
+      timeout 900 python bench.py --workload bh --bh-tree device --no-cpu-baseline > $O/${TAG}_bench_bh_device.json 2> $O/${TAG}_bench_bh_device.err ;;
+    prof)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/${TAG}_prof -o p --output-format csv -- python $OLDPWD/bench.py --no-cpu-baseline --no-traffic > $OLDPWD/$O/${TAG}_prof_bench.json 2> $OLDPWD/$O/${TAG}_prof.err)
+      find $O/${TAG}_prof -name '*kernel_stats.csv' -exec cp {} $O/${TAG}_bench_kernel_stats.csv \; ; head -5 $O/${TAG}_bench_kernel_stats.csv ;;
+    pmc)
+      i=0
+      for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE GRBM_COUNT" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+        name=$(echo fetch write sq1 sq2 grbm tcc | cut -d' ' -f$((i+1))); i=$((i+1))
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp -d $OLDPWD/$O/pmc_$name -o p --output-format csv -- python $OLDPWD/bench.py --no-cpu-baseline --no-traffic --steps 5 --warmup 1 > /dev/null 2> $OLDPWD/$O/pmc_$name.err)
+        f=$(find $O/pmc_$name -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp "$f" $O/pmc_$name/p_counter_collection.csv
+      done ;;
+    power)
+      timeout 300 python tools/power_probe.py 6 > $O/${TAG}_power_k1.json 2> $O/${TAG}_power_k1.err; echo "power rc=$?"; cut -c1-1500 $O/${TAG}_power_k1.json
+      timeout 300 python tools/power_probe.py 6 --variant 4 > $O/${TAG}_power_k1_variant4.json 2>> $O/${TAG}_power_k1.err
+      timeout 300 python tools/power_probe.py 6 --variant 1 > $O/${TAG}_power_k1_variant1.json 2>> $O/${TAG}_power_k1.err
+      ls /sys/class/drm/card*/device/hwmon/hwmon*/ > $O/${TAG}_hwmon_ls.txt 2>&1
+      rocm-smi --showpower --showclocks --showmaxpower > $O/${TAG}_rocm_smi.txt 2>&1 ;;
+    shapes)
+      timeout 1200 python tools/sweep_shapes.py > $O/${TAG}_shapes.log 2>&1
+      for v in 5 ; do for s in 0 32 64 128; do
+        timeout 300 python bench.py --shard-of 8 --variant $v --jsplit $s --no-cpu-baseline --no-traffic >> $O/${TAG}_shard_of_8.jsonl 2>> $O/${TAG}_shard.err
+      done; done ;;
+    ubench) tools/ubench_valu > $O/${TAG}_ubench_valu.txt 2>&1; tools/ubench_banks > $O/${TAG}_ubench_banks.txt 2>&1 ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
+echo "== done $(date +%T)"
