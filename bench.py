@@ -29,7 +29,6 @@ import shutil
 import subprocess
 import sys
 import tempfile
-import threading
 import time
 
 import numpy as np
@@ -41,7 +40,7 @@ FLOPS_PER_INTERACTION = 17   # 3 sub, 3 mul + 2 add, 1 add eps, 
 DT = 0.01                    # RustNBodyExperiment.hs:45
 
 KERNEL_NAMES = {0: "k_force_tile", 1: "k_force_tile_pk", 2: "k_force_smem", 3: "k_force_tile_pk", 4: "k_force_tile_pkb",
-                5: "k_force_smem_pk", 6: "k_force_smem_pkw", 7: "k_force_smem_pk1m", 16: "k_force_tile_pk_h",
+                5: "k_force_smem_pk", 6: "k_force_smem_pkw<unit_mass=0>", 7: "k_force_smem_pkw<unit_mass=1>", 16: "k_force_tile_pk_h",
                 -1: "k_force_strict<1>", -2: "k_force_strict<2>", -4: "k_force_strict<4>"}
 
 
@@ -116,51 +115,6 @@ def _claim_stdout():
     real = os.dup(1)
     os.dup2(2, 1)
     return real
-
-
-class PowerSampler:
-    """Board power from the amdgpu hwmon node (power1_average / power1_input, microwatts), sampled on a thread while
-    the timed loop runs. None when the node is not readable."""
-
-    def __init__(self, device=0, period=0.01):
-        self.paths = []
-        for card in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
-            for name in ("power1_average", "power1_input"):
-                p = os.path.join(card, name)
-                if os.path.exists(p):
-                    self.paths.append(p)
-                    break
-        self.path = self.paths[device] if device < len(self.paths) else None
-        self.period = period
-        self.samples = []
-        self._stop = threading.Event()
-        self._t = None
-
-    def _run(self):
-        while not self._stop.is_set():
-            try:
-                self.samples.append((time.perf_counter(), int(open(self.path).read()) * 1e-6))
-            except (OSError, ValueError):
-                pass
-            self._stop.wait(self.period)
-
-    def start(self):
-        if self.path:
-            self._t = threading.Thread(target=self._run, daemon=True)
-            self._t.start()
-
-    def stop(self):
-        if self._t:
-            self._stop.set()
-            self._t.join()
-
-    def summary(self, t0, t1, interactions):
-        w = [p for (t, p) in self.samples if t0 <= t <= t1]
-        if not w:
-            return None
-        avg = float(np.mean(w))
-        return {"avg_w": avg, "max_w": float(np.max(w)), "samples": len(w), "source": self.path,
-                "joules_per_interaction": avg * (t1 - t0) / interactions if interactions else None}
 
 
 def measure_traffic(argv_tail, kernel_substr, timeout=240):
@@ -457,9 +411,6 @@ def main():
         e.profile(True)      # creates its events now, outside the timed region
         e.profile_reset()
         e.bh_host_timing()
-    power = PowerSampler(device=0) if rank == 0 else None
-    if power:
-        power.start()
     host.barrier(); host.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -467,8 +418,6 @@ def main():
     host.sync(); host.barrier()
     t1 = time.perf_counter()
     elapsed = host.reduce_max(t1 - t0)
-    if power:
-        power.stop()
 
     # per-engine kernel times (HIP events on each engine's own stream, inside the timed region)
     per = []
@@ -580,11 +529,6 @@ def main():
                 out["all_gather_us_per_step"] = float(np.mean([r["exchange_us"] for r in per]))
         out.update({"device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],
                     "clock_khz": info["clock_khz"]})
-        if power:
-            inter = (float(n) * float(n - 1) * args.steps) if not is_bh else 0
-            ps = power.summary(t0, t1, inter)
-            if ps:
-                out["power"] = ps
         if not args.no_cpu_baseline and world == 1 and args.shard_of <= 1:
             if is_bh:
                 cores = min(effective_cores(), 16)

@@ -12,6 +12,8 @@
 //   acc   float4[S][stride]    per-source-split partial accelerations of the fast kernel.
 //   f2    float2[slab]         forces (strict / Barnes-Hut paths).
 //   nodes BhNode[n_nodes]      flattened quadtree, rebuilt on the host every Barnes-Hut step.
+#include <cmath>
+#include <limits>
 #include <random>
 
 #include "engine_internal.h"
@@ -199,19 +201,22 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
     *dim = e->dim_opt ? e->dim_opt : (e->any_z ? 3 : 2);
     int v = e->variant;
     if (v < 0) v = (tiles_total * kTile >= 32768) ? 5 : 1;
+    if (v == 7 && !(e->n > 0 && e->mass_min == e->mass_max && e->mass_min > 0.0f)) v = 6;   // unit-mass sweep needs equal masses
     *variant = v;
-    int b = e->bpt ? e->bpt : (n_targets >= 32768 ? 4 : 2);
+    const bool wave_split = v == 6 || v == 7;   // 256 targets per workgroup, 4 source quarters per workgroup
+    int b = wave_split ? 4 : (e->bpt ? e->bpt : (n_targets >= 32768 ? 4 : 2));
     if (b != 1 && b != 2 && b != 4) b = 2;
     *bpt = b;
     int s = e->jsplit;
     if (s <= 0) {
-        const int iblocks = (n_targets + kTile * b - 1) / (kTile * b);
+        const int per_wg = wave_split ? kTile : kTile * b;
+        const int iblocks = (n_targets + per_wg - 1) / per_wg;
         // 64 workgroups per CU only where targets are scarce (sharded shapes: tail effect); 32 otherwise --
         // same speed at N = 262144 on one GPU and half the partial-slab traffic
-        const int want = e->cu_count * ((v == 5 && n_targets < 131072) ? 64 : 32);
+        const int want = e->cu_count * (((v == 5 || wave_split) && n_targets < 131072) ? 64 : 32);
         s = 1;
         while (iblocks * s < want && s < 64) s *= 2;
-        s = std::min(s, std::max(1, tiles_total / 2));
+        s = std::min(s, std::max(1, tiles_total / (wave_split ? 4 : 2)));
     }
     s = std::max(1, std::min(s, tiles_total));
     *jsplit = s;
@@ -234,6 +239,12 @@ int launch_forces_fast(nbx_engine* e)
         ProfScope ps(e, NBX_K_FORCE);
         HIP_TRY(nbx::launch_force_tile_half(e->d_posm, e->d_posh, e->lo, slab, tiles_total, jsplit, bpt, dim, e->d_acc,
                                             stride, e->stream, &e->last));
+        return NBX_OK;
+    }
+    if (variant == 6 || variant == 7) {
+        ProfScope ps(e, NBX_K_FORCE);
+        HIP_TRY(nbx::launch_force_wave_split(e->d_posm, e->lo, slab, tiles_total, e->n, jsplit, dim, variant == 7, e->mass_min,
+                                             e->d_acc, stride, e->stream, &e->last));
         return NBX_OK;
     }
     {
@@ -699,13 +710,19 @@ void after_host_state_change(nbx_engine* e)
     e->any_z = false;
     for (int i = 0; i < e->n && !e->any_z; i++)
         if (e->host.pz[i] != 0.0f || e->host.vz[i] != 0.0f) e->any_z = true;
-    e->mass_min = e->n ? e->host.m[0] : 0.0f;
-    e->mass_max = e->mass_min;
-    for (int i = 1; i < e->n; i++) {
+    // mass range of the current bodies; ONE NaN or infinite mass anywhere poisons the range for good (sticky: a running
+    // min/max would overwrite it with the next finite mass) so that every range test -- strict_fastdiv_ok -- fails
+    bool bad = false;
+    float lo = e->n ? e->host.m[0] : 0.0f, hi = lo;
+    for (int i = 0; i < e->n; i++) {
         const float m = e->host.m[i];
-        if (!(m >= e->mass_min)) e->mass_min = m;   // a NaN mass ends up in mass_min and fails every range test
-        if (m > e->mass_max) e->mass_max = m;
+        if (!(m == m) || std::isinf(m)) bad = true;
+        if (m < lo) lo = m;
+        if (m > hi) hi = m;
     }
+    const float nan = std::numeric_limits<float>::quiet_NaN();
+    e->mass_min = bad ? nan : lo;
+    e->mass_max = bad ? nan : hi;
 }
 
 

@@ -410,6 +410,88 @@ __global__ __launch_bounds__(kTile) void k_force_smem_pk(const float4* __restric
     }
 }
 
+// variants 6 / 7: variant 5's sweep with the FOUR WAVES of a workgroup sharing one block of 256 targets (64 lanes x 2 packed
+// pairs) and each taking a quarter of the workgroup's source range; the four partial sums meet in LDS once, at the end, and
+// are added in wave order (fixed => bit-reproducible).  Same instruction stream per wave, same number of workgroups for a
+// given total split, but only a quarter of the partial-acceleration slabs ever reach HBM (N = 262 144: 8 slabs = 34 MB
+// per launch instead of 32 = 134 MB) and K2 adds 8 terms per body instead of 32.
+// UNIT_MASS (variant 7): every body has the SAME mass (known on the host: min == max) -> a_i = m * sum_j d / (|d|^2 + eps):
+// the per-interaction v_pk_mul (m_j * inv) leaves the loop -- 9 packed ops + 2 rcp per 2 interactions instead of 10 + 2 --
+// and the common mass multiplies the finished sums.  Sources are then weightless, so the zero-mass padding records cannot be
+// swept: the source loop ends at the true body count.
+template <int DIM, int UNROLL, bool UNIT_MASS>
+__global__ __launch_bounds__(kTile) void k_force_smem_pkw(const float4* __restrict__ posm, const int lo,
+                                                          const int n_targets, const int tiles_total, const int n_sources,
+                                                          const int jsplit, float4* __restrict__ acc_partial,
+                                                          const int acc_stride, const float unit_mass)
+{
+    constexpr int P = 2;
+    __shared__ float red[4][3][kTile];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x % jsplit;
+    const int iblk = blockIdx.x / jsplit;
+    const int j0 = (int)(((unsigned)tiles_total * (unsigned)split) / (unsigned)jsplit) * kTile;
+    const int j1 = (int)(((unsigned)tiles_total * (unsigned)(split + 1)) / (unsigned)jsplit) * kTile;
+    const int quarter = (j1 - j0) >> 2;             // whole tiles per workgroup: a multiple of 64
+    const int ja = j0 + quarter * wave;
+    int jb = ja + quarter;
+    if (UNIT_MASS) jb = jb < n_sources ? jb : n_sources;
+    v2f xi[P], yi[P], zi[P], ax[P], ay[P], az[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        int ia = iblk * kTile + (2 * p) * 64 + lane;
+        int ib = ia + 64;
+        ia = ia < n_targets ? ia : n_targets - 1;
+        ib = ib < n_targets ? ib : n_targets - 1;
+        const float4 pa = posm[lo + ia];
+        const float4 pb = posm[lo + ib];
+        xi[p] = v2f{pa.x, pb.x}; yi[p] = v2f{pa.y, pb.y}; zi[p] = v2f{pa.z, pb.z};
+        ax[p] = v2f{0.f, 0.f}; ay[p] = v2f{0.f, 0.f}; az[p] = v2f{0.f, 0.f};
+    }
+#pragma unroll UNROLL
+    for (int j = ja; j < jb; j++) {
+        const float4 s = posm[j];
+        const v2f sx = {s.x, s.x}, sy = {s.y, s.y}, sz = {s.z, s.z}, sm = {s.w, s.w};
+        const v2f eps = {kEps, kEps};
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const v2f dx = sx - xi[p];
+            const v2f dy = sy - yi[p];
+            v2f r2 = __builtin_elementwise_fma(dx, dx, eps);
+            r2 = __builtin_elementwise_fma(dy, dy, r2);
+            v2f dz = {0.f, 0.f};
+            if (DIM == 3) {
+                dz = sz - zi[p];
+                r2 = __builtin_elementwise_fma(dz, dz, r2);
+            }
+            v2f sc;
+            sc.x = __builtin_amdgcn_rcpf(r2.x);
+            sc.y = __builtin_amdgcn_rcpf(r2.y);
+            if (!UNIT_MASS) sc = sm * sc;
+            ax[p] = __builtin_elementwise_fma(sc, dx, ax[p]);
+            ay[p] = __builtin_elementwise_fma(sc, dy, ay[p]);
+            if (DIM == 3) az[p] = __builtin_elementwise_fma(sc, dz, az[p]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {   // body b of lane l is target b * 64 + l of the block: conflict-free rows
+        red[wave][0][(2 * p) * 64 + lane] = ax[p].x; red[wave][0][(2 * p + 1) * 64 + lane] = ax[p].y;
+        red[wave][1][(2 * p) * 64 + lane] = ay[p].x; red[wave][1][(2 * p + 1) * 64 + lane] = ay[p].y;
+        red[wave][2][(2 * p) * 64 + lane] = az[p].x; red[wave][2][(2 * p + 1) * 64 + lane] = az[p].y;
+    }
+    __syncthreads();
+    const int it = iblk * kTile + tid;
+    if (it < n_targets) {
+        float a0 = red[0][0][tid], a1 = red[0][1][tid], a2 = red[0][2][tid];
+#pragma unroll
+        for (int w = 1; w < 4; w++) { a0 += red[w][0][tid]; a1 += red[w][1][tid]; a2 += red[w][2][tid]; }
+        if (UNIT_MASS) { a0 *= unit_mass; a1 *= unit_mass; a2 *= unit_mass; }
+        acc_partial[(size_t)split * acc_stride + it] = make_float4(a0, a1, a2, 0.0f);
+    }
+}
+
 // variant 2: no LDS. The source index is wave-uniform, so the compiler fetches sources through
 // the scalar cache (s_load_dwordx4..x16 into SGPRs) and feeds them to the VALU as scalar operands.
 template <int B, int DIM, int UNROLL>
@@ -520,6 +602,26 @@ static hipError_t launch_variant(int variant, dim3 grid, hipStream_t stream, con
     else
         hipLaunchKernelGGL((k_force_tile<B, DIM, 16>), grid, dim3(kTile), 0, stream, posm, lo, n_targets,
                            tiles_total, jsplit, acc_partial, acc_stride);
+    return hipGetLastError();
+}
+
+// variants 6 / 7: one workgroup = 256 targets x 4 source quarters; `jsplit` partial slabs
+hipError_t launch_force_wave_split(const float4* posm, int lo, int n_targets, int tiles_total, int n_sources, int jsplit, int dim,
+                                   bool unit_mass, float mass, float4* acc_partial, int acc_stride, hipStream_t stream,
+                                   ForceLaunch* info)
+{
+    if (n_targets <= 0 || tiles_total <= 0) return hipSuccess;
+    if (jsplit < 1) jsplit = 1;
+    if (jsplit > tiles_total) jsplit = tiles_total;
+    const int iblocks = (n_targets + kTile - 1) / kTile;
+    const dim3 grid((unsigned)(iblocks * jsplit));
+    if (info) *info = ForceLaunch{(int)grid.x, kTile, jsplit, 4, dim, unit_mass ? 7 : 6};
+#define NBX_WS(DD, UM) \
+    hipLaunchKernelGGL((k_force_smem_pkw<DD, 8, UM>), grid, dim3(kTile), 0, stream, posm, lo, n_targets, tiles_total, n_sources, \
+                       jsplit, acc_partial, acc_stride, mass)
+    if (dim == 3) { if (unit_mass) NBX_WS(3, true); else NBX_WS(3, false); }
+    else          { if (unit_mass) NBX_WS(2, true); else NBX_WS(2, false); }
+#undef NBX_WS
     return hipGetLastError();
 }
 

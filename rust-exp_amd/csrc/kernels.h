@@ -31,6 +31,13 @@ hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tile
                              int dim, int variant, float4* acc_partial, int acc_stride, unsigned* guard,
                              hipStream_t stream, ForceLaunch* info);
 
+// K1, variants 6 / 7 (k_force_smem_pkw): the four waves of a workgroup share 256 targets and split the workgroup's source
+// range; partial sums meet in LDS, so only `jsplit` slabs are written for 4 * jsplit source ranges. unit_mass: every body
+// has mass `mass` (the per-interaction multiply leaves the loop); n_sources = true body count (no padding swept).
+hipError_t launch_force_wave_split(const float4* posm, int lo, int n_targets, int tiles_total, int n_sources, int jsplit, int dim,
+                                   bool unit_mass, float mass, float4* acc_partial, int acc_stride, hipStream_t stream,
+                                   ForceLaunch* info);
+
 // K4: the packed sweep with sources read from a half4 (x,y,z,m) copy (8 B/body), targets fp32.
 hipError_t launch_force_tile_half(const float4* posm, const void* posh, int lo, int n_targets, int tiles_total,
                                   int jsplit, int bpt, int dim, float4* acc_partial, int acc_stride, hipStream_t stream,

@@ -136,6 +136,61 @@ def test_fast_accelerations_all_launch_shapes(rx, ob, variant, bpt, jsplit):
     assert rel_err(gx, ofx) <= 1e-5 and rel_err(gy, ofy) <= 1e-5 and not gz.any()
 
 
+@pytest.mark.parametrize("n", [1, 63, 256, 4096 + 37, 20000])
+@pytest.mark.parametrize("jsplit", [0, 1, 3, 8])
+def test_wave_split_variants_6_and_7(rx, ob, n, jsplit):
+    """k_force_smem_pkw: the four waves of a workgroup share 256 targets and split the source range; partial sums meet in
+    LDS in wave order. Variant 6 = general masses; variant 7 = unit-mass sweep (a = m * sum d/(r^2+eps), no per-pair
+    multiply), selected only when every mass is equal -- otherwise the request silently runs variant 6.  The unit-mass
+    sweep ends at the true body count (padding records would otherwise attract)."""
+    p = ob.random_disk(n, 19)
+    ofx, ofy = ob.brute_forces(p, nthreads=8)
+    scale = max(np.abs(ofx).max(), np.abs(ofy).max(), 1e-30)
+    e = rx.NBodyEngine(mode="fast")
+    for variant, dim in ((6, 2), (6, 3), (7, 2)):
+        load(e, p)
+        e.set_launch(jsplit=jsplit, dim=dim, variant=variant)
+        fx, fy, fz = e.forces()
+        ll = e.last_launch()
+        assert ll["variant"] == 6 and ll["dim"] == dim and ll["bodies_per_thread"] == 4     # random masses: 7 -> 6
+        assert (jsplit == 0 or ll["jsplit"] == min(jsplit, (n + 255) // 256)) and ll["grid"] == ll["jsplit"] * ((n + 255) // 256)
+        assert np.abs(fx - ofx).max() <= 1e-5 * scale and np.abs(fy - ofy).max() <= 1e-5 * scale and not fz.any()
+    # equal masses: the unit-mass sweep really runs, for 2-D and 3-D, and a full step matches the oracle
+    q = p.copy()
+    q["m"][:] = np.float32(0.37)
+    ofx, ofy = ob.brute_forces(q, nthreads=8)
+    scale = max(np.abs(ofx).max(), np.abs(ofy).max(), 1e-30)
+    for dim in (2, 3):
+        load(e, q)
+        e.set_launch(jsplit=jsplit, dim=dim, variant=7)
+        fx, fy, _ = e.forces()
+        assert e.last_launch()["variant"] == 7
+        assert np.abs(fx - ofx).max() <= 1e-5 * scale and np.abs(fy - ofy).max() <= 1e-5 * scale, (n, dim)
+    ptol, vtol = fast_tolerances(ob, q, DT, 1) if n > 1 else (1e-5, 1e-30)
+    e.step_brute_force(DT)
+    r = q.copy(); ob.step_brute_force(r, DT, nthreads=8)
+    st = e.get_particles()
+    assert np.abs(st["px"] - r["px"]).max() <= ptol and np.abs(st["vx"] - r["vx"]).max() <= vtol + 1e-30
+
+
+def test_unit_mass_sweep_in_3d_against_fp64(rx):
+    """Variant 7 on a real 3-D equal-mass system (the bench workload's shape) against an fp64 sum on a sample of targets."""
+    st = rx.plummer_sphere(8192)
+    e = rx.NBodyEngine()
+    e.set_launch(variant=7)
+    e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
+    fx, fy, fz = e.forces()
+    assert e.last_launch() == dict(e.last_launch(), variant=7, dim=3)
+    P = np.stack([st["px"], st["py"], st["pz"]], 1).astype(np.float64)
+    m = st["m"].astype(np.float64)
+    idx = np.arange(0, 8192, 61)
+    d = P[None, :, :] - P[idx, None, :]
+    w = m[None, :] / ((d * d).sum(2) + 1e-4 * (1 + 0 * m[None, :]))   # EPS = 1e-4 (f32 0.0001 differs in the 9th digit)
+    F = (w[:, :, None] * d).sum(1) * m[idx, None]
+    got = np.stack([fx, fy, fz], 1)[idx]
+    assert np.abs(got - F).max() <= 1e-5 * np.abs(F).max()
+
+
 @pytest.mark.parametrize("scale,expect_batched", [(1.0, True), (200.0, True), (1000.0, False), (1.0e6, False)])
 def test_batched_reciprocal_guard(rx, ob, scale, expect_batched):
     """Variant 4 multiplies four softened squared distances before its single v_rcp_f32: safe only while

@@ -268,7 +268,7 @@ def test_two_and_three_ranks_share_the_gpu_over_gloo(rx, ob, world, n):
     ptol, vtol = fast_tolerances(ob, ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"]), 0.01, 3)   # scale only)
     for r in range(world):
         env = dict(os.environ, NBX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r),
-                   WORLD_SIZE=str(world), NBX_N=str(n), NBX_PTOL=repr(ptol), NBX_VTOL=repr(vtol))
+                   WORLD_SIZE=str(world), NBX_N=str(n), NBX_PTOL=repr(float(ptol)), NBX_VTOL=repr(float(vtol)))
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER2], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]

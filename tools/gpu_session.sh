@@ -10,6 +10,7 @@
 #   pmc     six rocprofv3 --pmc passes of the bench command (summarise locally with tools/pmc_summary.py TAG)
 #   power   tools/power_probe.py: board power during a >= 6 s K1 loop
 #   shapes  launch-shape sweeps (sweep_shapes.py, shard-of-8 shape)
+#   k1ab    K1 kernel variants 5/6/7 A/B (bench lines + board power)
 #   ubench  instruction-issue microbenchmarks
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG="${TAG:-r02}"
@@ -54,6 +55,22 @@ for stage in "$@"; do
       for v in 5 ; do for s in 0 32 64 128; do
         timeout 300 python bench.py --shard-of 8 --variant $v --jsplit $s --no-cpu-baseline --no-traffic >> $O/${TAG}_shard_of_8.jsonl 2>> $O/${TAG}_shard.err
       done; done ;;
+    k1ab)   # K1 variants A/B: bench line + board power per variant, at the headline size, config #2's size and the 8-way shard shape
+      for v in 5 6 7; do
+        timeout 300 python bench.py --variant $v --no-cpu-baseline --no-traffic >> $O/${TAG}_k1ab_n262144.jsonl 2>> $O/${TAG}_k1ab.err
+        timeout 300 python bench.py --variant $v --n 65536 --no-cpu-baseline --no-traffic >> $O/${TAG}_k1ab_n65536.jsonl 2>> $O/${TAG}_k1ab.err
+        timeout 300 python bench.py --variant $v --shard-of 8 --no-cpu-baseline --no-traffic >> $O/${TAG}_k1ab_shard_of_8.jsonl 2>> $O/${TAG}_k1ab.err
+        timeout 300 python tools/power_probe.py 6 --variant $v > $O/${TAG}_power_k1_variant$v.json 2>> $O/${TAG}_k1ab.err
+      done
+      python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/*_k1ab_*.jsonl")):
+    for ln in open(f):
+        d=json.loads(ln); print(f.split("/")[-1], d["config"]["launch"], "%.3e"%d["value"], "frac %.4f"%d["roofline"]["frac"], "k_ms %.3f"%d["roofline"]["kernel_avg_ms"], "step %.3f"%d["ms_per_step"])
+for f in sorted(glob.glob("gpurun_out/*_power_k1_variant*.json")):
+    d=json.load(open(f)); r=d.get("rocm-smi",{}); print(f.split("/")[-1], "%.3e"%d["interactions_per_s"], r.get("avg_w"), r.get("joules_per_interaction"))
+PY
+      ;;
     ubench) tools/ubench_valu > $O/${TAG}_ubench_valu.txt 2>&1; tools/ubench_banks > $O/${TAG}_ubench_banks.txt 2>&1 ;;
     *) echo "unknown stage $stage" ;;
   esac
