@@ -102,8 +102,10 @@ enum nbx_option {
                                     *  0 = compiler-scheduled LDS tiles, 2 = scalar-cache scalar math,
                                     *  3 = 1 with 4-source LDS batches            (all A/B'd in DESIGN.md 6) */
     NBX_OPT_DRAW_DEVICE = 7,       /* 1: nbx_draw/nb_draw splat on the GPU (count + resolve kernels, one w*h*4 B
-                                    * download) instead of downloading the state; body pixels identical, a tail may
-                                    * move one octant when v is within ~1e-6 rad of a multiple of 45 deg. Default 0 */
+                                    * download) instead of downloading the state. Pixel-identical to the host draw: the
+                                    * few tails whose octant sits within 1e-5 of a step of the reference's f32 expression
+                                    * (diagonal or near-diagonal velocities) are decided by the host's own atan2f.
+                                    * Default: 0 below 65 536 bodies, 1 from there on (NB_DRAW / this option override) */
     NBX_OPT_BH_TREE = 8,           /* Barnes-Hut tree: 0 = built on the host exactly like the reference (default;
                                     * required by strict mode), 1 = built on the device (same node set; interior
                                     * centres of mass folded per child, no EPS merge: own tolerance class) */
@@ -113,6 +115,7 @@ enum nbx_option {
     NBX_OPT_BH_FALLBACKS = 10,     /* read only (nbx_get_option): device tree builds that ran out of node pool and were
                                     * redone on the host since the engine was created */
     NBX_OPT_BH_LAST_TREE = 11,     /* read only: where the tree of the last Barnes-Hut evaluation was built: 0 host, 1 device */
+    NBX_OPT_DRAW_AMBIGUOUS = 12,   /* read only: tails the last device draw left to the host; -1 = the last draw ran on the host */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };

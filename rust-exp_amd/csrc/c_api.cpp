@@ -89,7 +89,7 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
             e->variant = (int)value;
             return NBX_OK;
         case NBX_OPT_DRAW_DEVICE:
-            e->draw_device = value ? 1 : 0;
+            e->draw_device = value < 0 ? -1 : (value ? 1 : 0);   // -1 = by size (default)
             return NBX_OK;
         case NBX_OPT_BH_WAVE:
             e->bh_wave = value ? 1 : 0;
@@ -128,6 +128,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_BH_WAVE: return e->bh_wave;
         case NBX_OPT_BH_FALLBACKS: return e->bh_fallbacks;
         case NBX_OPT_BH_LAST_TREE: return e->bh_last_tree_device;
+        case NBX_OPT_DRAW_AMBIGUOUS: return e->draw_ambiguous;
         default: return NBX_ERR_INVALID;
     }
 }
@@ -328,16 +329,37 @@ static int draw_on_device(nbx_engine* e, int32_t w, int32_t h, uint32_t* fb)
     const float x1 = 0.0f - 100.0f / 2.0f, y1 = (0.0f - 100.0f / 2.0f) * aspect;
     const float x2 = 0.0f + 100.0f / 2.0f, y2 = (0.0f + 100.0f / 2.0f) * aspect;
     const float scalex = (1.0f / (x2 - x1)) * (float)w, scaley = (1.0f / (y2 - y1)) * (float)h;
-    HIP_TRY(nbx::launch_draw(e->d_posm, e->d_vel, e->n, w, h, x1, y1, scalex, scaley, e->d_counts, e->d_fb, e->stream));
+    // list of the particles whose tail octant the device leaves to the host (draw.hip): a counter + up to n records
+    const size_t amb_need = 16 + sizeof(nbx::DrawAmbiguous) * (size_t)std::max(e->n, 1);
+    if (amb_need > e->amb_bytes) {
+        if (e->d_amb) HIP_TRY(hipFree(e->d_amb));
+        e->d_amb = nullptr;
+        e->amb_bytes = 0;
+        HIP_TRY(hipMalloc(&e->d_amb, amb_need + amb_need / 8));
+        e->amb_bytes = amb_need + amb_need / 8;
+    }
+    unsigned* d_cnt = static_cast<unsigned*>(e->d_amb);
+    nbx::DrawAmbiguous* d_rec = reinterpret_cast<nbx::DrawAmbiguous*>(static_cast<char*>(e->d_amb) + 16);
+    HIP_TRY(nbx::launch_draw(e->d_posm, e->d_vel, e->n, w, h, x1, y1, scalex, scaley, e->d_counts, e->d_fb, d_cnt, d_rec, e->stream));
+    unsigned n_amb = 0;
     HIP_TRY(hipMemcpyAsync(fb, e->d_fb, px * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(&n_amb, d_cnt, sizeof n_amb, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    e->draw_ambiguous = (int)n_amb;
+    if (n_amb) {
+        std::vector<nbx::DrawAmbiguous> rec(n_amb);
+        HIP_TRY(hipMemcpy(rec.data(), d_rec, sizeof(nbx::DrawAmbiguous) * n_amb, hipMemcpyDeviceToHost));
+        for (const nbx::DrawAmbiguous& r : rec) nbx::draw_add_tail(fb, w, h, r.xi, r.yi, r.vx, r.vy);
+    }
     return NBX_OK;
 }
 
 int32_t nbx_draw(nbx_engine* e, int32_t w, int32_t h, uint32_t* fb)
 {
     if (!e || !fb || w <= 0 || h <= 0) return fail(NBX_ERR_INVALID, "bad draw arguments");
-    if (e->draw_device) {
+    // -1 (default): on the device once the state lives there and a frame would otherwise download >= 65 536 x 32 B
+    const bool on_device = e->draw_device == 1 || (e->draw_device < 0 && e->dev_valid && e->world == 1 && e->n >= 65536);
+    if (on_device) {
         if (e->world != 1) return fail(NBX_ERR_STATE, "device draw needs the whole state on one GPU");
         return draw_on_device(e, w, h, fb);
     }
@@ -346,6 +368,7 @@ int32_t nbx_draw(nbx_engine* e, int32_t w, int32_t h, uint32_t* fb)
     rc = download_velocities(e);
     if (rc != NBX_OK) return rc;
     nbx::draw_particles(e->host.px.data(), e->host.py.data(), e->host.vx.data(), e->host.vy.data(), e->n, w, h, fb);
+    e->draw_ambiguous = -1;   // host draw
     return NBX_OK;
 }
 

@@ -9,11 +9,17 @@
 // resolve pass turns counts into colours.  Pixel coordinates use the reference's f32 expression
 // ((p - origin) * scale, truncated toward zero, `as i32` saturating / NaN -> 0 = v_cvt_i32_f32).
 //
-// Tolerance class: body pixels are bit-identical to the host path.  The tail octant is
-// ((8*atan2(vy,vx)/(2*pi) + 8) as i32) % 8; the device atan2f may differ from the host libm by an ulp, so a
-// tail can land in the neighbouring octant when the velocity direction is within ~1e-6 rad of a multiple of
-// 45 degrees (exact multiples, incl. v = 0, agree).  The default nb_draw therefore stays on the host;
-// the device path is opt-in (NBX_OPT_DRAW_DEVICE / NB_DRAW=device).
+// BIT-EXACT with the host path / the reference, tails included.  The tail octant is
+// ((8*atan2(vy,vx)/(2*pi) + 8) as i32) % 8 evaluated in f32 with the platform libm's atan2f (nbody.rs:541-542), a step
+// function of the velocity whose steps sit wherever that f32 expression happens to cross an integer.  The device decides
+// the octant from a double-precision evaluation of the same expression (same f32 constants) whenever that value is
+// farther than 1e-5 from an integer -- the f32 evaluation (libm error <= 1 ulp of the angle, one rounding in the
+// divide, one in the add: <= 1.1e-6 in total) then lands on the same side -- and handles the exact cases every libm
+// agrees on (vy = +-0: angle +-0 or +-pi; vx = +-0: +-pi/2, where 8a/2pi is exactly an integer) itself.  Everything
+// else -- diagonal velocities, directions within 1e-5/1.27 rad of a multiple of 45 degrees -- is AMBIGUOUS: the particle's
+// pixel and velocity go to a short list and the HOST evaluates the reference expression with its own atan2f for those few
+// and adds their tail hits to the downloaded framebuffer (a saturating add of one more non-negative term commutes with
+// the resolve).  The same pattern as the Barnes-Hut opening test: cheap decision + exact fallback in a narrow band.
 #include "kernels.h"
 
 namespace nbx {
@@ -21,7 +27,8 @@ namespace nbx {
 __global__ __launch_bounds__(kTile) void k_draw_count(const float4* __restrict__ posm, const float4* __restrict__ vel,
                                                       const int n, const int w, const int h, const float x1,
                                                       const float y1, const float scalex, const float scaley,
-                                                      uint2* __restrict__ counts)
+                                                      uint2* __restrict__ counts, unsigned* __restrict__ amb_count,
+                                                      DrawAmbiguous* __restrict__ amb)
 {
     const int k = blockIdx.x * kTile + threadIdx.x;
     if (k >= n) return;
@@ -30,8 +37,24 @@ __global__ __launch_bounds__(kTile) void k_draw_count(const float4* __restrict__
     const int xi = (int)__fmul_rn(__fsub_rn(p.x, x1), scalex);   // nbody.rs:525, :536
     const int yi = (int)__fmul_rn(__fsub_rn(p.y, y1), scaley);   // nbody.rs:526, :537
     if (xi >= 0 && xi < w && yi >= 0 && yi < h) atomicAdd(&counts[xi + yi * w].x, 1u);   // :559-565
-    const float angle = atan2f(v.y, v.x);                                                 // :541
-    const int oct = (int)(8.0f * angle / (2.0f * 3.14159274f) + 8.0f) % 8;                // :542
+    int oct = 0;                                                                           // NaN angle: `as i32` gives 0
+    if (v.x == v.x && v.y == v.y) {
+        if (v.y == 0.0f) {
+            oct = (__float_as_uint(v.x) >> 31) ? 4 : 0;       // atan2f(+-0, x): +-0 for x = +0 or x > 0, +-pi for x = -0 or x < 0
+        } else if (v.x == 0.0f) {
+            oct = v.y > 0.0f ? 2 : 6;                         // +-pi/2: 8 * (pi_f/2) / (2 pi_f) = 2 exactly
+        } else {
+            const double a = atan2((double)v.y, (double)v.x);
+            const double t = 8.0 * a / (2.0 * (double)3.14159274f) + 8.0;                 // :541-542 with the f32 constants
+            const double fl = floor(t);
+            if (t - fl < 1e-5 || fl + 1.0 - t < 1e-5) {       // too close to a step of the f32 expression: the host decides
+                const unsigned slot = atomicAdd(amb_count, 1u);
+                amb[slot] = DrawAmbiguous{xi, yi, v.x, v.y};  // capacity n: cannot overflow
+                return;
+            }
+            oct = (int)fl % 8;
+        }
+    }
     const int dxs[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     const int dys[8] = {0, 1, 1, 1, 0, -1, -1, -1};
     const int xt = xi - dxs[oct], yt = yi - dys[oct];                                     // :553-554
@@ -63,13 +86,15 @@ __global__ __launch_bounds__(kTile) void k_draw_resolve(const uint2* __restrict_
 }
 
 hipError_t launch_draw(const float4* posm, const float4* vel, int n, int w, int h, float x1, float y1, float scalex,
-                       float scaley, void* counts, unsigned* fb, hipStream_t stream)
+                       float scaley, void* counts, unsigned* fb, unsigned* amb_count, DrawAmbiguous* amb, hipStream_t stream)
 {
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(uint2) * (size_t)w * (size_t)h, stream);
     if (e != hipSuccess) return e;
+    e = hipMemsetAsync(amb_count, 0, sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
     if (n > 0)
         hipLaunchKernelGGL(k_draw_count, dim3((n + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, vel, n, w, h, x1, y1,
-                           scalex, scaley, static_cast<uint2*>(counts));
+                           scalex, scaley, static_cast<uint2*>(counts), amb_count, amb);
     hipLaunchKernelGGL(k_draw_resolve, dim3((w * h + kTile - 1) / kTile), dim3(kTile), 0, stream,
                        static_cast<const uint2*>(counts), w, h, fb);
     return hipGetLastError();

@@ -216,7 +216,9 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
         const int want = e->cu_count * (((v == 5 || wave_split) && n_targets < 131072) ? 64 : 32);
         s = 1;
         while (iblocks * s < want && s < 64) s *= 2;
-        s = std::min(s, std::max(1, tiles_total / (wave_split ? 4 : 2)));
+        // every workgroup keeps >= 2 tiles of sources; a wave-split workgroup >= 16 (4 per wave: a wave's sweep must
+        // outweigh its prologue + LDS reduction; profiles/r02_k1_wave_split_sweep.txt)
+        s = std::min(s, std::max(1, tiles_total / (wave_split ? 16 : 2)));
     }
     s = std::max(1, std::min(s, tiles_total));
     *jsplit = s;
@@ -685,6 +687,7 @@ void free_device(nbx_engine* e)
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_fb) (void)hipFree(e->d_fb);
+    if (e->d_amb) (void)hipFree(e->d_amb);
     if (e->d_posh && !e->posh_external) (void)hipFree(e->d_posh);
     if (e->h_nodes) (void)hipHostFree(e->h_nodes);
     if (e->h_stage) (void)hipHostFree(e->h_stage);

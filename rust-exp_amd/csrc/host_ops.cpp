@@ -311,6 +311,21 @@ void draw_particles(const float* px, const float* py, const float* vx, const flo
     }
 }
 
+void draw_add_tail(uint32_t* fb, int32_t w, int32_t h, int32_t xi, int32_t yi, float vx, float vy)
+{
+    static const int8_t step[8][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+    const float angle = std::atan2(vy, vx);                                       // nbody.rs:541
+    const int32_t oct = trunc_i32(8.0f * angle / (2.0f * PI_F32) + 8.0f) % 8;     // :542
+    const int32_t xt = xi - step[oct][0], yt = yi - step[oct][1];                 // :553-554
+    if (xt < 0 || xt >= w || yt < 0 || yt >= h) return;                           // :559
+    if (w >= 3 && h >= 3) {                                                       // :571-577 overwrite these afterwards
+        const int32_t cx = w / 2, cy = h / 2;
+        if ((yt == cy && (xt == cx || xt == cx + 1 || xt == cx - 1)) || (xt == cx && (yt == cy + 1 || yt == cy - 1))) return;
+    }
+    uint32_t& px = fb[(size_t)xt + (size_t)yt * (size_t)w];
+    px = sat_add_abgr(px, pack_abgr(255, 215, 130, 0.25f));                       // :521
+}
+
 // ---- quadtree --------------------------------------------------------------------------------
 //
 // The reference inserts recursively into a Box-linked tree (nbody.rs:226-284). Here the same

@@ -52,6 +52,11 @@ void preset_stable_orbits(HostState& st, int n, float rmin, float rmax, Rng& rng
 // nbody.rs:482-617; fb is w*h ABGR words, cleared here
 void draw_particles(const float* px, const float* py, const float* vx, const float* vy, int n, int32_t w,
                     int32_t h, uint32_t* fb);
+// One particle's TAIL (nbody.rs:541-565) added to an already drawn framebuffer: octant from the reference's f32 expression
+// with this host's atan2f, bounds check, per-channel saturating add; the five centre-cross pixels stay magenta (the
+// reference writes them last). Used by the device draw for the few particles whose octant it leaves to the host.
+void draw_add_tail(uint32_t* fb, int32_t w, int32_t h, int32_t xi, int32_t yi, float vx, float vy);
+
 
 // Quadtree with index-linked nodes. Node k's children (if any) are first_child[k] .. +3 in the
 // reference's order [UL, UR, LL, LR] (nbody.rs:295-300).

@@ -103,8 +103,14 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
 hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status,
                                  hipStream_t stream);
 
-// nb_draw on the device: counts (uint2 per pixel: body hits, tail hits) -> ABGR framebuffer
+// nb_draw on the device: counts (uint2 per pixel: body hits, tail hits) -> ABGR framebuffer. Particles whose tail octant
+// cannot be decided safely on the device (see draw.hip) are appended to amb[0..*amb_count) (capacity n) with their body
+// pixel and velocity; their body hit is counted, their tail is the host's to add.
+struct DrawAmbiguous {
+    int32_t xi, yi;
+    float vx, vy;
+};
 hipError_t launch_draw(const float4* posm, const float4* vel, int n, int w, int h, float x1, float y1, float scalex,
-                       float scaley, void* counts, unsigned* fb, hipStream_t stream);
+                       float scaley, void* counts, unsigned* fb, unsigned* amb_count, DrawAmbiguous* amb, hipStream_t stream);
 
 }  // namespace nbx

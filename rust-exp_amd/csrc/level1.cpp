@@ -31,6 +31,7 @@ static void apply_env(nbx_engine* e)
     if (tree && std::strcmp(tree, "device") == 0) e->bh_tree_device = 1;
     const char* draw = std::getenv("NB_DRAW");
     if (draw && std::strcmp(draw, "device") == 0) e->draw_device = 1;
+    if (draw && std::strcmp(draw, "host") == 0) e->draw_device = 0;
 }
 
 static nbx_engine* global_engine()   // engine 0 of the group when NB_GPUS > 1

@@ -36,6 +36,7 @@ NBX_OPT_BH_TREE = 8
 NBX_OPT_BH_WAVE = 9
 NBX_OPT_BH_FALLBACKS = 10
 NBX_OPT_BH_LAST_TREE = 11
+NBX_OPT_DRAW_AMBIGUOUS = 12
 
 NBX_K_FORCE = 0
 NBX_K_INTEGRATE = 1
@@ -407,7 +408,8 @@ class NBodyEngine:
         self.set_option(NBX_OPT_BH_TREE, {"host": 0, "device": 1}[where])
 
     def set_draw_device(self, on=True):
-        self.set_option(NBX_OPT_DRAW_DEVICE, 1 if on else 0)
+        """True / False force the device / host draw; None = by size (the default)."""
+        self.set_option(NBX_OPT_DRAW_DEVICE, -1 if on is None else (1 if on else 0))
 
     def draw(self, w, h):
         fb = np.zeros(w * h, np.uint32)

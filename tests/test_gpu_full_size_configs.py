@@ -84,6 +84,36 @@ def test_config4_barnes_hut_1m_theta_half_force_error(rx, tree):
     assert np.isfinite(p["px"]).all() and np.abs(p["px"]).max() < 60
 
 
+def test_config4_barnes_hut_1m_theta_half_against_the_oracle(rx, ob):
+    """BASELINE config #4 at its FULL size pinned to the oracle directly (the oracle does a 1 M-body
+    Barnes-Hut step in ~1 s on the host cores): the bit-exact mode's step (threaded host build with device-side routing,
+    wave-uniform strict walk) equals orc_step_barnes_hut (nbody.rs:186-480) bit for bit on all 1 048 576 bodies; the fast
+    mode's forces (host tree, the default) are within 2e-5 * max|F| of orc_bh_forces (nbody.rs:333-377)."""
+    n, theta, dt = 1048576, 0.5, 0.01
+    st = rx.plummer_sphere(n, dim=2)
+    p = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    rc, ofx, ofy = ob.bh_forces(p, theta, nthreads=16)
+    assert rc == 0
+    f = rx.NBodyEngine(mode="fast")
+    f.set_bh_tree("host")
+    f.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    fx, fy, _ = f.forces(theta)
+    scale = max(np.abs(ofx).max(), np.abs(ofy).max())
+    assert np.abs(fx - ofx).max() <= 2e-5 * scale and np.abs(fy - ofy).max() <= 2e-5 * scale
+    e = rx.NBodyEngine(mode="strict")
+    e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    sx, sy, _ = e.forces(theta)
+    assert np.array_equal(sx.view(np.uint32), ofx.view(np.uint32)) and np.array_equal(sy.view(np.uint32), ofy.view(np.uint32))
+    q = p.copy()
+    for _ in range(2):
+        e.step_barnes_hut(theta, dt, 1)
+        assert ob.step_barnes_hut(q, theta, dt, 16) == 0
+    got = e.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        bad = np.nonzero(got[k].view(np.uint32) != q[k].view(np.uint32))[0]
+        assert bad.size == 0, (k, bad.size, bad[:5])
+
+
 def test_config5_two_galaxies_524288_fp16_sources(rx):
     n = 524288
     st = rx.two_galaxies(n)

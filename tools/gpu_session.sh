@@ -71,6 +71,19 @@ for f in sorted(glob.glob("gpurun_out/*_power_k1_variant*.json")):
     d=json.load(open(f)); r=d.get("rocm-smi",{}); print(f.split("/")[-1], "%.3e"%d["interactions_per_s"], r.get("avg_w"), r.get("joules_per_interaction"))
 PY
       ;;
+    k1sweep)   # source-split sweep of the wave-split kernels at the three shapes that matter
+      for v in 6 7; do
+        for sp in 2 4 8 16 32; do timeout 300 python bench.py --variant $v --jsplit $sp --no-cpu-baseline --no-traffic >> $O/${TAG}_k1sweep_n262144.jsonl 2>> $O/${TAG}_k1sweep.err; done
+        for sp in 2 4 8 16 32 64; do timeout 300 python bench.py --variant $v --jsplit $sp --n 65536 --no-cpu-baseline --no-traffic >> $O/${TAG}_k1sweep_n65536.jsonl 2>> $O/${TAG}_k1sweep.err; done
+        for sp in 8 16 32 64 128; do timeout 300 python bench.py --variant $v --jsplit $sp --shard-of 8 --no-cpu-baseline --no-traffic >> $O/${TAG}_k1sweep_shard_of_8.jsonl 2>> $O/${TAG}_k1sweep.err; done
+      done
+      python - <<'PY' | tee gpurun_out/${TAG}_k1_wave_split_sweep.txt
+import json,glob
+for f in sorted(glob.glob("gpurun_out/*_k1sweep_*.jsonl")):
+    for ln in open(f):
+        d=json.loads(ln); print(f.split("/")[-1], d["config"]["launch"], "%.3e"%d["value"], "frac %.4f"%d["roofline"]["frac"], "k_ms %.3f"%d["roofline"]["kernel_avg_ms"], "step %.3f"%d["ms_per_step"])
+PY
+      ;;
     ubench) tools/ubench_valu > $O/${TAG}_ubench_valu.txt 2>&1; tools/ubench_banks > $O/${TAG}_ubench_banks.txt 2>&1 ;;
     *) echo "unknown stage $stage" ;;
   esac
