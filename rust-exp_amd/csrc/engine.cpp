@@ -192,15 +192,17 @@ int download_velocities(nbx_engine* e)
 
 void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* variant, int* bpt, int* jsplit, int* dim)
 {
-    // Defaults from the measured launch-shape sweeps (profiles/r01_shapes_sweep*.txt):
-    //  * kernel: scalar-cache sources + packed math (variant 5) once the source array has >= 32768 bodies
-    //    (no LDS traffic -> +2.4 % clock under the power cap, +3.5 % throughput); LDS tiles (variant 1) below.
-    //  * register blocking 4 (two packed pairs) when a GPU owns >= 32768 targets, else 2.
-    //  * source split S = smallest power of two giving >= 32 workgroups per CU (64 for variant 5 with < 131072
-    //    targets per GPU), capped at 64 and at half the tile count.
+    // Defaults from the measured launch-shape sweeps (profiles/r01_shapes_sweep*.txt, profiles/r02_k1_wave_split_sweep.txt):
+    //  * kernel, >= 32768 sources: the wave-split scalar-cache sweep -- variant 7 (unit-mass: 9 packed ops + 2 rcp per two
+    //    interactions) when every body has the same mass, else variant 6 (10 + 2); LDS tiles (variant 1) below that size.
+    //  * variants 6 / 7: 256 targets per workgroup, S = smallest power of two giving >= 64 workgroups per CU, at most 64 and
+    //    at least 4 source tiles per workgroup (one per wave).  N = 262144: S = 16 (67 MB of partial slabs per launch;
+    //    variant 5 wrote 134 MB), 32768 targets x 262144 sources (8-way shard): S = 64.
+    //  * other variants: register blocking 4 (two packed pairs) when a GPU owns >= 32768 targets, else 2; S = smallest power
+    //    of two giving >= 32 workgroups per CU (64 for variant 5 with < 131072 targets), capped at 64 and half the tiles.
     *dim = e->dim_opt ? e->dim_opt : (e->any_z ? 3 : 2);
     int v = e->variant;
-    if (v < 0) v = (tiles_total * kTile >= 32768) ? 5 : 1;
+    if (v < 0) v = (tiles_total * kTile >= 32768) ? 7 : 1;
     if (v == 7 && !(e->n > 0 && e->mass_min == e->mass_max && e->mass_min > 0.0f)) v = 6;   // unit-mass sweep needs equal masses
     *variant = v;
     const bool wave_split = v == 6 || v == 7;   // 256 targets per workgroup, 4 source quarters per workgroup
@@ -213,12 +215,11 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
         const int iblocks = (n_targets + per_wg - 1) / per_wg;
         // 64 workgroups per CU only where targets are scarce (sharded shapes: tail effect); 32 otherwise --
         // same speed at N = 262144 on one GPU and half the partial-slab traffic
-        const int want = e->cu_count * (((v == 5 || wave_split) && n_targets < 131072) ? 64 : 32);
+        const int want = e->cu_count * ((wave_split || (v == 5 && n_targets < 131072)) ? 64 : 32);
         s = 1;
         while (iblocks * s < want && s < 64) s *= 2;
-        // every workgroup keeps >= 2 tiles of sources; a wave-split workgroup >= 16 (4 per wave: a wave's sweep must
-        // outweigh its prologue + LDS reduction; profiles/r02_k1_wave_split_sweep.txt)
-        s = std::min(s, std::max(1, tiles_total / (wave_split ? 16 : 2)));
+        // every workgroup keeps >= 2 tiles of sources; a wave-split workgroup >= 4 (one per wave)
+        s = std::min(s, std::max(1, tiles_total / (wave_split ? 4 : 2)));
     }
     s = std::max(1, std::min(s, tiles_total));
     *jsplit = s;
