@@ -510,7 +510,7 @@ def main():
                 "value": value, "unit": "body-steps/s", "dtype": "f32",
                 "config": {"workload": f"plummer_disk_projection_N{n}_barnes_hut_theta{args.theta}_dt{DT}", "bodies": n,
                            "seed": "0x5EED0001", "force_mode": args.mode, "host": host_kind, "sharding": sharding,
-                           "tree": {0: "host (reference-faithful insertion build)", 1: "device (bh_build.hip)"}[engine.get_option(rx.engine.NBX_OPT_BH_TREE)]},
+                           "tree": {0: "host (reference-faithful insertion build)", 1: "device (bh_build.hip)"}[engine.get_option(rx.engine.NBX_OPT_BH_LAST_TREE)]},
                 "ms_split": {"bh_eval_kernel": per[0]["bh_eval_ms"], "integrate_kernel": per[0]["integrate_ms"],
                              "host_download": ht["download_ms"], "tree_build": ht["build_ms"], "flatten": ht["flatten_ms"],
                              "upload_wait": ht["upload_ms"], "tree_nodes": ht["nodes"]},

@@ -36,7 +36,7 @@ extern "C" {
 /* Environment knobs read once at first use: NB_DEVICE (ordinal, default 0), NB_GPUS (n | all:   */
 /* single-process multi-GPU group, see nbx_group_*), NB_SEED (u64,                               */
 /* default: OS entropy, as the reference's thread_rng), NB_FORCE_MODE=fast|strict,                */
-/* NB_DRAW=host|device, NB_BH_TREE=host|device.                                                  */
+/* NB_DRAW=host|device, NB_BH_TREE=host|device (both default: by size).                           */
 /* Both levels: NBX_HOST_THREADS (workers of the host quadtree build / flatten / draw; default   */
 /* min(hardware threads, 32)), NBX_GROUP_EXCHANGE=copy (see nbx_group_*), NBX_LOG=1 (one stderr   */
 /* line per step), NBX_TIMING=1 (host tree-build phases).                                         */
@@ -111,9 +111,11 @@ enum nbx_option {
                                     * few tails whose octant sits within 1e-5 of a step of the reference's f32 expression
                                     * (diagonal or near-diagonal velocities) are decided by the host's own atan2f.
                                     * Default: 0 below 65 536 bodies, 1 from there on (NB_DRAW / this option override) */
-    NBX_OPT_BH_TREE = 8,           /* Barnes-Hut tree: 0 = built on the host exactly like the reference (default;
-                                    * required by strict mode), 1 = built on the device (same node set; interior
-                                    * centres of mass folded per child, no EPS merge: own tolerance class) */
+    NBX_OPT_BH_TREE = 8,           /* Barnes-Hut tree: 0 = built on the host exactly like the reference (always used by
+                                    * the bit-exact mode), 1 = built on the device (bh_build.hip: same node set and leaf
+                                    * records incl. the reference's EPS merge of close pairs; interior centres of mass are
+                                    * roundings of the exact mean instead of the reference's running f32 fold: own tolerance
+                                    * class), -1 (default) = device in the fast mode from 4096 bodies on, else host */
     NBX_OPT_BH_WAVE = 9,           /* 1 (default): with the device-built tree, walk the tree once per WAVE (node
                                     * records through the scalar cache, lanes park on accepted subtrees); 0: one
                                     * independent walk per lane. Bit-identical results either way */

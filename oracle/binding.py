@@ -65,6 +65,8 @@ def lib():
         L.orc_step_barnes_hut.restype = C.c_int
         L.orc_bh_forces.argtypes = [vp, C.c_int, C.c_float, C.c_int, vp, vp]
         L.orc_bh_forces.restype = C.c_int
+        L.orc_bh_forces_exact.argtypes = [vp, C.c_int, C.c_float, C.c_int, vp, vp]
+        L.orc_bh_forces_exact.restype = C.c_int
         L.orc_bh_tree_stats.argtypes = [vp, C.c_int] + [C.POINTER(C.c_int)] * 3 + [f32p] * 3
         L.orc_bh_tree_stats.restype = C.c_int
         L.orc_bh_tree_dump.argtypes = [vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
@@ -142,6 +144,15 @@ def bh_forces(p, theta, nthreads=1):
     fx = np.zeros(len(p), np.float32)
     fy = np.zeros(len(p), np.float32)
     rc = lib().orc_bh_forces(_ptr(p), len(p), theta, nthreads, _ptr(fx), _ptr(fy))
+    return rc, fx, fy
+
+
+def bh_forces_exact(p, theta, nthreads=1):
+    """fp64 arbiter (not in the reference): the reference's tree and opening law with exact node masses / centres and fp64
+    arithmetic throughout (nbody_oracle.c, orc_bh_forces_exact)."""
+    fx = np.zeros(len(p), np.float64)
+    fy = np.zeros(len(p), np.float64)
+    rc = lib().orc_bh_forces_exact(_ptr(p), len(p), theta, nthreads, _ptr(fx), _ptr(fy))
     return rc, fx, fy
 
 

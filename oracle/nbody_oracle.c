@@ -186,6 +186,8 @@ typedef struct orc_node {
     float x1, y1, x2, y2;
     float px, py, m;
     struct orc_node *children; /* NULL or block of 4 */
+    double em, emx, emy;       /* NOT in the reference: exact (fp64) mass and first moments, filled by exact_sums() for the
+                                * arbiter below; never read by the restatement of the reference's own code */
 } orc_node;
 
 static void node_new(orc_node *nd, float x1, float y1, float x2, float y2) /* :216-222 */
@@ -374,6 +376,87 @@ int orc_step_barnes_hut(orc_particle *p, int n, float theta, float dt, int nthre
 int orc_bh_forces(const orc_particle *p, int n, float theta, int nthreads, float *fx, float *fy)
 {
     return bh_run((orc_particle *)p, n, theta, 0.0f, nthreads, fx, fy);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fp64 ARBITER for Barnes-Hut (not in the reference; SURVEY.md 8(d) asks for an fp64 arbiter).   */
+/* The reference's own tree (same insertion, same merges, same boxes) and its own opening law     */
+/* s/d < theta and pair law, but with every interior node's mass and centre taken as the EXACT    */
+/* sum / weighted mean of its leaves (fp64) instead of the f32 running fold of nbody.rs:303-320,  */
+/* and all arithmetic of the traversal in fp64.  Whoever is closer to this -- the f32 restatement */
+/* or a GPU build with exactly rounded centres -- is closer to what the algorithm means.          */
+static void exact_sums(orc_node *nd)
+{
+    if (!nd->children) {
+        nd->em = (double)nd->m; nd->emx = (double)nd->m * (double)nd->px; nd->emy = (double)nd->m * (double)nd->py;
+        return;
+    }
+    nd->em = nd->emx = nd->emy = 0.0;
+    for (int i = 0; i < 4; i++) {
+        exact_sums(&nd->children[i]);
+        nd->em += nd->children[i].em; nd->emx += nd->children[i].emx; nd->emy += nd->children[i].emy;
+    }
+}
+
+static void force_f64(double px1, double py1, double m1, double px2, double py2, double m2, double *fx, double *fy)
+{
+    double dx = px2 - px1, dy = py2 - py1;
+    double f = m1 * m2 / (dx * dx + dy * dy + (double)EPS);
+    *fx = f * dx; *fy = f * dy;
+}
+
+static void node_force_exact(const orc_node *nd, float px, float py, float m, double theta, double *ofx, double *ofy)
+{
+    double fx = 0.0, fy = 0.0;
+    if (nd->children) {
+        double s = (double)(nd->x2 - nd->x1);                       /* the f32 box width, as :341 */
+        double cx = nd->emx / nd->em, cy = nd->emy / nd->em;
+        double dx = cx - (double)px, dy = cy - (double)py;
+        double d = sqrt(dx * dx + dy * dy);
+        if (s / d < theta) {
+            force_f64(px, py, m, cx, cy, nd->em, &fx, &fy);
+        } else {
+            for (int i = 0; i < 4; i++) {
+                double ax, ay;
+                node_force_exact(&nd->children[i], px, py, m, theta, &ax, &ay);
+                fx += ax; fy += ay;
+            }
+        }
+    } else if (!(nd->px == px && nd->py == py) && nd->m != 0.0f) {  /* :365, :368 */
+        force_f64(px, py, m, nd->px, nd->py, nd->m, &fx, &fy);
+    }
+    *ofx = fx; *ofy = fy;
+}
+
+typedef struct { const orc_particle *p; const orc_node *tree; int lo, hi; double theta; double *fx, *fy; } arb_job;
+
+static void *arb_worker(void *arg)
+{
+    arb_job *j = (arb_job *)arg;
+    for (int i = j->lo; i < j->hi; i++)
+        node_force_exact(j->tree, j->p[i].px, j->p[i].py, j->p[i].m, j->theta, &j->fx[i], &j->fy[i]);
+    return NULL;
+}
+
+int orc_bh_forces_exact(const orc_particle *p, int n, float theta, int nthreads, double *fx, double *fy)
+{
+    if (nthreads <= 0) return ORC_PANIC_NTHREADS;
+    orc_node root;
+    int rc = build_tree(p, n, &root);
+    if (rc != ORC_OK) { node_free(&root); return rc; }
+    if (n > 0) exact_sums(&root);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    arb_job *jobs = (arb_job *)malloc(sizeof(arb_job) * (size_t)nthreads);
+    if (!th || !jobs) { free(th); free(jobs); node_free(&root); return ORC_PANIC_ALLOC; }
+    int range = n / nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t] = (arb_job){p, &root, range * t, (t == nthreads - 1) ? n : range * (t + 1), (double)theta, fx, fy};
+        pthread_create(&th[t], NULL, arb_worker, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(th); free(jobs);
+    node_free(&root);
+    return ORC_OK;
 }
 
 /* Tree statistics for tests: node count, leaf count, max depth */

@@ -17,12 +17,20 @@
 //      f32 per node); node sizes by replaying the first body's path with the reference's f32 midpoints
 //
 // Same node set, same s = x2-x1 per node (box replayed with the same f32 arithmetic), same leaf records as the
-// host build + flatten.  What differs (its own tolerance class): interior centres of
-// mass are the f32 rounding of the exact weighted mean instead of the reference's particle-by-particle f32 running
-// fold (nbody.rs:303-320, which drifts by up to ~6e-4 relative at 100 k bodies), bodies
-// closer than EPS are NOT merged (nbody.rs:249-260 merges them in arrival order; here they get their own
-// leaves a few levels deeper), bodies identical down to level 31 share one leaf, and there is no depth-50
-// panic.  Hence: fast mode only; the bit-exact mode keeps the host build.
+// host build + flatten, INCLUDING the reference's EPS merge for pairs (nbody.rs:249-260): two bodies closer than EPS in both
+// axes become one leaf (mass sum, centre folded in arrival order) exactly when the reference would have merged them --
+// i.e. when the later arrival finds the earlier one still alone in a leaf that contains both, which depends on which OTHER
+// bodies arrived before (step 3b below replays that condition from the sorted keys and the body indices).
+// What still differs (its own tolerance class):
+//   * interior centres of mass are the f32 rounding of the exact weighted mean instead of the reference's
+//     particle-by-particle f32 running fold (nbody.rs:303-320, which drifts by up to ~6e-4 relative at 100 k bodies);
+//   * a merged pair's leaf sits on the path of its FIRST-arrived member, the reference's on the path of the blob's centre
+//     (different only when a third body shares the pair's last common cell, <= EPS-sized);
+//   * clusters of three or more bodies within EPS: the reference folds arrivals into one blob while each stays within EPS
+//     of the blob's current centre; here only the first two of a run of mutually-close sorted neighbours merge (bodies whose
+//     62-bit keys are identical -- the same level-31 cell, 4.7e-8 of the box -- always share one leaf, any number of them);
+//   * no depth-50 panic (nbody.rs:230-232): keys stop at level 31.
+// Hence: fast mode only; the bit-exact mode keeps the host build.
 #include <cstring>   // rocPRIM's texture_cache_iterator.hpp calls memset() without including it
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -131,16 +139,95 @@ __device__ __forceinline__ ScanItem scan_add(const ScanItem& a, const ScanItem& 
 constexpr int kScanPerThread = 4;
 constexpr int kScanBlock = kTile * kScanPerThread;
 
-// sorted body j: record (x, y, z, m) gathered into sb, and the number of tree nodes that start at j
+// first index > j whose key differs from keys[j] (n if none): bodies with identical (merged) keys form one leaf
+__device__ __forceinline__ int run_end(const unsigned long long* __restrict__ keys, const int j, const int n)
+{
+    const unsigned long long k = keys[j];
+    int lo = j, step = 1;                   // keys[lo] == k
+    while (lo + step < n && keys[lo + step] == k) { lo += step; step <<= 1; }
+    int hi = lo + step < n ? lo + step : n; // first known mismatch (n = past the end)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] == k) lo = mid; else hi = mid;
+    }
+    return hi;
+}
+
+// number of tree nodes that start at sorted body j.  Bodies with identical keys (the same level-31 cell, or an EPS-merged
+// pair after k_merge_keys) are ONE leaf: only the first of them starts nodes, and its leaf sits one level below the depth
+// it shares with its nearest DIFFERENT neighbours -- exactly where the reference leaves a merged blob (nbody.rs:249-260).
 __device__ __forceinline__ int nodes_starting_at(const unsigned long long* __restrict__ keys, const int j, const int n)
 {
     const unsigned long long k = keys[j];
     const int cl = j == 0 ? -1 : common_digits(keys[j - 1], k);
     if (j > 0 && cl >= kLevels) return 0;
-    const int cr = j == n - 1 ? -1 : common_digits(k, keys[j + 1]);
+    const int e = run_end(keys, j, n);
+    const int cr = e == n ? -1 : common_digits(k, keys[e]);
     int leaf = 1 + (cl > cr ? cl : cr);
     if (leaf > kLevels) leaf = kLevels;
     return leaf - cl;
+}
+
+// ---- 3b. the reference's EPS merge, for pairs ----------------------------------------------------------------------------
+// nbody.rs:249-260: a body B arriving at a non-empty exterior node merges into it when the node's content A is closer than
+// EPS in both axes.  B arrives at A's leaf iff that leaf -- one level below the deepest cell A shares with any body inserted
+// BEFORE B -- still contains B, i.e. iff no earlier body C shares at least as many leading digits with A as B does:
+//     merge(A, B)  <=>  |dx| < EPS and |dy| < EPS  and  there is no C with idx(C) < idx(B), C != A, common(A, C) >= common(A, B)
+// (A = the earlier of the two).  Candidates for C are contiguous around the pair in the sorted order (everything sharing
+// >= common(A, B) digits with A), so the test is a short outward scan from the pair.  link[j] = 1: sorted bodies j-1 and j merge.
+constexpr int kMergeScanCap = 4096;   // per side; undecided after that many neighbours -> merge (needs an early, crowded pair)
+
+__global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
+                                                       const unsigned* __restrict__ idx, const int n,
+                                                       unsigned char* __restrict__ link)
+{
+    const int j = blockIdx.x * kTile + threadIdx.x;
+    if (j >= n) return;
+    unsigned char out = 0;
+    if (j > 0) {
+        const float4 a = sb[j - 1], b = sb[j];
+        const bool close = fabsf(__fsub_rn(a.x, b.x)) < kEps && fabsf(__fsub_rn(a.y, b.y)) < kEps;   // nbody.rs:249
+        const int c = common_digits(keys[j - 1], keys[j]);
+        if (c >= kLevels) {
+            out = 1;                                   // same level-31 cell: they meet in every leaf on the way down
+        } else if (close) {
+            const unsigned ia = idx[j - 1], ib = idx[j];
+            const unsigned second = ia > ib ? ia : ib;
+            const unsigned long long kf = ia < ib ? keys[j - 1] : keys[j];   // the earlier arrival's path
+            bool earlier_rival = false;
+            for (int x = j - 2, t = 0; x >= 0 && t < kMergeScanCap && !earlier_rival; x--, t++) {
+                if (common_digits(kf, keys[x]) < c) break;
+                earlier_rival = idx[x] < second;
+            }
+            for (int x = j + 1, t = 0; x < n && t < kMergeScanCap && !earlier_rival; x++, t++) {
+                if (common_digits(kf, keys[x]) < c) break;
+                earlier_rival = idx[x] < second;
+            }
+            out = earlier_rival ? 0 : 1;
+        }
+    }
+    link[j] = out;
+}
+
+// Pairs only: of a run of linked neighbours the first two merge (link'[j] = link[j] && !link'[j-1] would need a scan; the
+// local rule link[j] && !link[j-1] keeps every merge disjoint and deterministic).  Both members of a merged pair take the key
+// of the one that arrived first; the array stays sorted (the new key lies between the pair's two old keys).  Bodies that
+// already had identical keys are left alone (they share a leaf anyway).
+__global__ __launch_bounds__(kTile) void k_merge_keys(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
+                                                      const unsigned char* __restrict__ link, const int n,
+                                                      unsigned long long* __restrict__ out, int* __restrict__ crowded)
+{
+    const int j = blockIdx.x * kTile + threadIdx.x;
+    if (j >= n) return;
+    // third and later members of a run of mutually-close bodies (not counting bodies of one level-31 cell, which share a leaf
+    // exactly like the reference's): where the reference would have grown a blob of three or more, this build only pairs
+    if (j > 1 && link[j] && link[j - 1] && keys[j] != keys[j - 1]) atomicAdd(crowded, 1);
+    const bool follows = j > 0 && link[j] && !link[j - 1];                 // merges with j-1
+    const bool leads = j + 1 < n && link[j + 1] && !link[j];               // j+1 merges with j
+    unsigned long long k = keys[j];
+    if (follows) k = idx[j - 1] < idx[j] ? keys[j - 1] : keys[j];
+    else if (leads) k = idx[j] < idx[j + 1] ? keys[j] : keys[j + 1];
+    out[j] = k;
 }
 
 __global__ __launch_bounds__(kTile) void k_gather(const float4* __restrict__ posm, const unsigned* __restrict__ idx,
@@ -278,8 +365,8 @@ __device__ __forceinline__ int group_end(const unsigned long long* __restrict__ 
 
 // one thread per sorted body a: writes all nodes that start at a (pre-order slots base[a] ...)
 __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
-                                                const unsigned* __restrict__ box, const Prefix pre, const int n,
-                                                const int node_cap, BhNode* __restrict__ out)
+                                                const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const Prefix pre,
+                                                const int n, const int node_cap, BhNode* __restrict__ out)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;   // 64 threads per workgroup for small systems, kTile otherwise
     if (a >= n) return;
@@ -299,13 +386,21 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
         out[first + (l - top)].s = __fsub_rn(x2, x1);   // nbody.rs:341
         if (l < leaf) descend(x1, y1, x2, y2, p.x, p.y);
     }
-    // the leaf: this body, or the bodies whose keys agree with it down to level 31
-    int b = group_end(keys, ka, a + 1, n, leaf);
+    // the leaf: this body, or the bodies that share its key (same level-31 cell / EPS-merged pair), folded in ARRIVAL order
+    // like the reference's add_mass (nbody.rs:303-320).  Equal keys come out of the stable sort in index order already; a
+    // merged pair (two bodies whose keys were made equal afterwards) may need swapping.
+    int b = run_end(keys, a, n);
     {
         float px = p.x, py = p.y, m = p.w;
-        for (int j = a + 1; j < b; j++) {
-            const float4 q = sb[j];
-            fold_mass(px, py, m, q.x, q.y, q.w);
+        if (b - a == 2 && idx[a + 1] < idx[a]) {
+            const float4 q = sb[a + 1];
+            px = q.x; py = q.y; m = q.w;
+            fold_mass(px, py, m, p.x, p.y, p.w);
+        } else {
+            for (int j = a + 1; j < b; j++) {
+                const float4 q = sb[j];
+                fold_mass(px, py, m, q.x, q.y, q.w);
+            }
         }
         BhNode* o = &out[first + count - 1];
         o->px = px; o->py = py; o->m = m;
@@ -357,6 +452,7 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     add(sizeof(double) * ((size_t)n + 1) * 3);         // prefix sums m, m*x, m*y
     add(sizeof(int) * ((size_t)n + 1));                // pre-order base
     add(sizeof(ScanItem) * (nb + 1));                  // block sums
+    add((size_t)n);                                    // EPS-merge links
     add(256);                                          // counters + box
     return bytes;
 }
@@ -369,6 +465,7 @@ struct Workspace {
     float4* sb;
     Prefix pre;
     ScanItem* block_sums;
+    unsigned char* link;
     int* counters;   // [0] node count; [4..7] box (as unsigned)
     unsigned* box;
 };
@@ -388,6 +485,7 @@ Workspace carve(void* workspace, int n, size_t sort_tmp)
     k.pre.m = d; k.pre.mx = d + (size_t)n + 1; k.pre.my = d + 2 * ((size_t)n + 1);
     k.pre.base = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)n + 1)));
     k.block_sums = reinterpret_cast<ScanItem*>(take(sizeof(ScanItem) * (nb + 1)));
+    k.link = reinterpret_cast<unsigned char*>(take((size_t)n));
     k.counters = reinterpret_cast<int*>(take(256));
     k.box = reinterpret_cast<unsigned*>(k.counters + 4);
     return k;
@@ -574,7 +672,8 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 //   begin: enqueues everything on `stream`, including the copy of the node count into the pinned host_counters;
 //          *perm_dev = the sorted body order (device pointer inside the workspace: thread t handles body perm[t])
 //   end:   waits for the stream; *n_nodes_host = node count; *status = 1 when the tree needs more than node_cap
-//          nodes (nothing usable was written)
+//          nodes (nothing usable was written), 2 when more than max(16, n/2000) bodies sit in clusters of >= 3 within EPS
+//          (the caller should build on the host: the reference's multi-body merges are not reproduced here)
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters /* pinned, >= 4 ints */, const unsigned** perm_dev, hipStream_t stream)
 {
@@ -589,12 +688,19 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     const int nb = (n + kTile - 1) / kTile;
     const int sb = (n + kScanBlock - 1) / kScanBlock;
     hipLaunchKernelGGL(k_gather, dim3(nb), dim3(kTile), 0, stream, posm, k.idx1, n, k.sb);
-    hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, k.sb, k.keys1, n, k.block_sums);
+    // EPS merge (pairs): links from the sorted keys + arrival order, then both members of a pair share one key (keys0 is free
+    // again after the sort); everything below works on the merged keys
+    hipLaunchKernelGGL(k_merge_links, dim3(nb), dim3(kTile), 0, stream, k.sb, k.keys1, k.idx1, n, k.link);
+    hipError_t me = hipMemsetAsync(k.counters, 0, 4 * sizeof(int), stream);
+    if (me != hipSuccess) return me;
+    hipLaunchKernelGGL(k_merge_keys, dim3(nb), dim3(kTile), 0, stream, k.keys1, k.idx1, k.link, n, k.keys0, k.counters + 1);
+    const unsigned long long* mk = k.keys0;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, k.sb, mk, n, k.block_sums);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kTile), 0, stream, k.block_sums, sb);
-    hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, k.sb, k.keys1, n, k.block_sums, k.pre, k.counters);
+    hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, k.sb, mk, n, k.block_sums, k.pre, k.counters);
     const int eb = n <= 65536 ? 64 : kTile;   // spread a small system's few waves over the CUs
-    hipLaunchKernelGGL(k_emit, dim3((n + eb - 1) / eb), dim3(eb), 0, stream, k.sb, k.keys1, k.box, k.pre, n, node_cap, out);
-    e = hipMemcpyAsync(host_counters, k.counters, sizeof(int), hipMemcpyDeviceToHost, stream);
+    hipLaunchKernelGGL(k_emit, dim3((n + eb - 1) / eb), dim3(eb), 0, stream, k.sb, mk, k.idx1, k.box, k.pre, n, node_cap, out);
+    e = hipMemcpyAsync(host_counters, k.counters, 2 * sizeof(int), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
@@ -607,6 +713,9 @@ hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, 
     const hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return e;
     if (host_counters[0] > node_cap) { *status = 1; return hipSuccess; }   // node pool exhausted (pathological input)
+    // Many bodies in clusters of three or more within EPS: the reference grows multi-body blobs there (nbody.rs:249-260) that
+    // the pairs-only merge does not reproduce -- leave such systems to the reference-faithful host build.
+    if (host_counters[1] > (n / 2000 > 16 ? n / 2000 : 16)) { *status = 2; return hipSuccess; }
     *n_nodes_host = host_counters[0];
     return hipSuccess;
 }

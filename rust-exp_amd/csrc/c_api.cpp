@@ -96,7 +96,7 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
             return NBX_OK;
         case NBX_OPT_BH_TREE:
             if (value != 0 && value != 1) return fail(NBX_ERR_INVALID, "bh tree must be 0 (host) or 1 (device)");
-            e->bh_tree_device = (int)value;
+            e->bh_tree_device = value < 0 ? -1 : (value ? 1 : 0);   // -1 = by mode and size (default)
             return NBX_OK;
         case NBX_OPT_SOURCE_PRECISION:
             if (value != 16 && value != 32) return fail(NBX_ERR_INVALID, "source precision must be 16 or 32");
@@ -283,7 +283,7 @@ int32_t nbx_forces(nbx_engine* e, float theta, int32_t cap, float* fx, float* fy
         HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream, nullptr, guard));
     } else {
         bool on_device = false;
-        if (e->bh_tree_device && e->force_mode == 0) {
+        if (e->use_device_tree()) {
             rc = build_tree_on_device(e, &on_device);
             if (rc != NBX_OK) return rc;
         }
@@ -565,7 +565,7 @@ int32_t nbx_bh_work(nbx_engine* e, float theta, uint64_t* node_visits, uint64_t*
     int rc = upload(e);
     if (rc != NBX_OK) return rc;
     bool on_device = false;
-    if (e->bh_tree_device && e->force_mode == 0) {
+    if (e->use_device_tree()) {
         rc = build_tree_on_device(e, &on_device);
         if (rc != NBX_OK) return rc;
     }

@@ -603,7 +603,7 @@ int step_bh(nbx_engine* e, float theta, float dt)
     if (rc != NBX_OK) return rc;
     if (e->n == 0) return NBX_OK;
     bool on_device = false;
-    if (e->bh_tree_device && e->force_mode == 0) {
+    if (e->use_device_tree()) {
         rc = build_tree_on_device(e, &on_device);
         if (rc != NBX_OK) return rc;
     }
@@ -632,7 +632,7 @@ int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt)
     }
     nbx_engine* e0 = eng[0];
     if (e0->n == 0) return NBX_OK;
-    bool on_device = e0->bh_tree_device && e0->force_mode == 0 && e0->n <= kDeviceTreeMaxBodies;
+    bool on_device = e0->use_device_tree() && e0->n <= kDeviceTreeMaxBodies;
     if (on_device) {
         for (int d = 0; d < count; d++) {
             const int rc = build_tree_on_device_begin(eng[d]);

@@ -29,6 +29,7 @@ static void apply_env(nbx_engine* e)
     if (mode && std::strcmp(mode, "strict") == 0) e->force_mode = 1;
     const char* tree = std::getenv("NB_BH_TREE");
     if (tree && std::strcmp(tree, "device") == 0) e->bh_tree_device = 1;
+    if (tree && std::strcmp(tree, "host") == 0) e->bh_tree_device = 0;
     const char* draw = std::getenv("NB_DRAW");
     if (draw && std::strcmp(draw, "device") == 0) e->draw_device = 1;
     if (draw && std::strcmp(draw, "host") == 0) e->draw_device = 0;

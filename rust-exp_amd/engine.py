@@ -404,8 +404,9 @@ class NBodyEngine:
         return fx, fy, fz
 
     def set_bh_tree(self, where):
-        """'host' (reference-faithful, default) or 'device' (bh_build.hip)."""
-        self.set_option(NBX_OPT_BH_TREE, {"host": 0, "device": 1}[where])
+        """'host' (reference-faithful insertion build), 'device' (bh_build.hip) or 'auto' (default: device in the fast
+        mode from 4096 bodies on)."""
+        self.set_option(NBX_OPT_BH_TREE, {"host": 0, "device": 1, "auto": -1}[where])
 
     def set_draw_device(self, on=True):
         """True / False force the device / host draw; None = by size (the default)."""

@@ -69,12 +69,16 @@ def test_random_barnes_hut_strict_bitwise(rx, ob, seed):
         assert_bit_equal(st[k], q[k], f"seed {seed} {k}")
     # fast traversal on the host tree and on the device tree: close to the oracle's forces
     rc, ofx, ofy = ob.bh_forces(p, theta)
+    rc, ex, ey = ob.bh_forces_exact(p, theta)            # fp64 arbiter: how far the reference's own f32 node folds are off
     scale = max(np.abs(ofx).max(), np.abs(ofy).max(), 1e-30)
+    drift = max(np.abs(ofx - ex).max(), np.abs(ofy - ey).max())
     for where in ("host", "device"):
         f = rx.NBodyEngine(mode="fast")
         f.set_bh_tree(where)
         f.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
         fx, fy, _ = f.forces(theta)
         assert np.isfinite(fx).all()
-        tol = 5e-5 if where == "host" else 5e-2     # device tree: no EPS merge -> clump members differ
-        assert np.abs(fx - ofx).max() <= tol * scale and np.abs(fy - ofy).max() <= tol * scale, (seed, where)
+        # host tree: the walk's own fp32 rounding. device tree (exact node sums; crowded systems fall back to the host
+        # build): that plus the reference's drift; a handful of bodies in clusters of >= 3 within EPS may remain un-merged
+        tol = 5e-5 * scale if where == "host" else 5e-5 * scale + drift + 1e-3 * scale
+        assert np.abs(fx - ofx).max() <= tol and np.abs(fy - ofy).max() <= tol, (seed, where)
