@@ -174,59 +174,75 @@ __device__ __forceinline__ int nodes_starting_at(const unsigned long long* __res
 // BEFORE B -- still contains B, i.e. iff no earlier body C shares at least as many leading digits with A as B does:
 //     merge(A, B)  <=>  |dx| < EPS and |dy| < EPS  and  there is no C with idx(C) < idx(B), C != A, common(A, C) >= common(A, B)
 // (A = the earlier of the two).  Candidates for C are contiguous around the pair in the sorted order (everything sharing
-// >= common(A, B) digits with A), so the test is a short outward scan from the pair.  link[j] = 1: sorted bodies j-1 and j merge.
+// >= common(A, B) digits with A), so the test is a short outward scan from the pair.
+// The unit of all this is an ENTITY: a maximal run of bodies with identical keys (one level-31 cell: they always end up in one
+// leaf, in index order thanks to the stable sort) -- usually a single body.  close[j] = 1 marks a boundary j between two
+// different entities (the one ending at j-1 and the one starting at j) that the reference merges.
 constexpr int kMergeScanCap = 4096;   // per side; undecided after that many neighbours -> merge (needs an early, crowded pair)
+constexpr int kRunCap = 4096;         // longest identical-key run walked back to its start (longer: treated as starting there)
+
+__device__ __forceinline__ int run_start(const unsigned long long* __restrict__ keys, const int j)
+{
+    const unsigned long long k = keys[j];
+    int r = j;
+    for (int t = 0; r > 0 && t < kRunCap && keys[r - 1] == k; t++) r--;
+    return r;
+}
 
 __global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
                                                        const unsigned* __restrict__ idx, const int n,
-                                                       unsigned char* __restrict__ link)
+                                                       unsigned char* __restrict__ close)
 {
     const int j = blockIdx.x * kTile + threadIdx.x;
     if (j >= n) return;
     unsigned char out = 0;
-    if (j > 0) {
-        const float4 a = sb[j - 1], b = sb[j];
-        const bool close = fabsf(__fsub_rn(a.x, b.x)) < kEps && fabsf(__fsub_rn(a.y, b.y)) < kEps;   // nbody.rs:249
-        const int c = common_digits(keys[j - 1], keys[j]);
-        if (c >= kLevels) {
-            out = 1;                                   // same level-31 cell: they meet in every leaf on the way down
-        } else if (close) {
-            const unsigned ia = idx[j - 1], ib = idx[j];
+    if (j > 0 && keys[j - 1] != keys[j]) {
+        // the entity's position is its first arrival's (later arrivals of the same cell are < 5e-8 of the box away)
+        const int r = run_start(keys, j - 1);
+        const float4 a = sb[r], b = sb[j];
+        if (fabsf(__fsub_rn(a.x, b.x)) < kEps && fabsf(__fsub_rn(a.y, b.y)) < kEps) {   // nbody.rs:249
+            const int c = common_digits(keys[j - 1], keys[j]);
+            const unsigned ia = idx[r], ib = idx[j];           // first arrival of either entity (stable sort: run start)
             const unsigned second = ia > ib ? ia : ib;
-            const unsigned long long kf = ia < ib ? keys[j - 1] : keys[j];   // the earlier arrival's path
+            const unsigned long long kf = ia < ib ? keys[j - 1] : keys[j];   // the earlier entity's path
             bool earlier_rival = false;
-            for (int x = j - 2, t = 0; x >= 0 && t < kMergeScanCap && !earlier_rival; x--, t++) {
+            for (int x = r - 1, t = 0; x >= 0 && t < kMergeScanCap && !earlier_rival; x--, t++) {
                 if (common_digits(kf, keys[x]) < c) break;
                 earlier_rival = idx[x] < second;
             }
+            const unsigned long long kj = keys[j];
             for (int x = j + 1, t = 0; x < n && t < kMergeScanCap && !earlier_rival; x++, t++) {
+                if (keys[x] == kj) continue;                   // the right entity's own later arrivals
                 if (common_digits(kf, keys[x]) < c) break;
                 earlier_rival = idx[x] < second;
             }
             out = earlier_rival ? 0 : 1;
         }
     }
-    link[j] = out;
+    close[j] = out;
 }
 
-// Pairs only: of a run of linked neighbours the first two merge (link'[j] = link[j] && !link'[j-1] would need a scan; the
-// local rule link[j] && !link[j-1] keeps every merge disjoint and deterministic).  Both members of a merged pair take the key
-// of the one that arrived first; the array stays sorted (the new key lies between the pair's two old keys).  Bodies that
-// already had identical keys are left alone (they share a leaf anyway).
+// Pairs of entities only: of a chain of close boundaries every other one is dropped by the local rule "a boundary merges iff
+// the boundary at the start of its left entity does not" (deterministic, no scan, merges stay disjoint).  All members of a
+// merged pair of entities take the key of the entity that arrived first; the array stays sorted (the new key lies between the
+// old ones).  Bodies left behind by the rule -- third and later entities of a chain, where the reference would have grown a
+// bigger blob -- are counted in *crowded.
 __global__ __launch_bounds__(kTile) void k_merge_keys(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
-                                                      const unsigned char* __restrict__ link, const int n,
+                                                      const unsigned char* __restrict__ close, const int n,
                                                       unsigned long long* __restrict__ out, int* __restrict__ crowded)
 {
     const int j = blockIdx.x * kTile + threadIdx.x;
     if (j >= n) return;
-    // third and later members of a run of mutually-close bodies (not counting bodies of one level-31 cell, which share a leaf
-    // exactly like the reference's): where the reference would have grown a blob of three or more, this build only pairs
-    if (j > 1 && link[j] && link[j - 1] && keys[j] != keys[j - 1]) atomicAdd(crowded, 1);
-    const bool follows = j > 0 && link[j] && !link[j - 1];                 // merges with j-1
-    const bool leads = j + 1 < n && link[j + 1] && !link[j];               // j+1 merges with j
+    const int r = run_start(keys, j);             // this body's entity is [r, e)
+    const int e = run_end(keys, j, n);
     unsigned long long k = keys[j];
-    if (follows) k = idx[j - 1] < idx[j] ? keys[j - 1] : keys[j];
-    else if (leads) k = idx[j] < idx[j + 1] ? keys[j] : keys[j + 1];
+    if (r > 0 && close[r]) {
+        const int rl = run_start(keys, r - 1);    // left neighbour entity [rl, r)
+        if (!(rl > 0 && close[rl])) k = idx[rl] < idx[r] ? keys[rl] : keys[r];   // merges with it
+        else atomicAdd(crowded, 1);               // its left neighbour is already taken
+    } else if (e < n && close[e]) {
+        k = idx[r] < idx[e] ? keys[r] : keys[e];  // the entity starting at e merges with this one (close[r] is 0 here)
+    }
     out[j] = k;
 }
 
@@ -386,21 +402,21 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
         out[first + (l - top)].s = __fsub_rn(x2, x1);   // nbody.rs:341
         if (l < leaf) descend(x1, y1, x2, y2, p.x, p.y);
     }
-    // the leaf: this body, or the bodies that share its key (same level-31 cell / EPS-merged pair), folded in ARRIVAL order
-    // like the reference's add_mass (nbody.rs:303-320).  Equal keys come out of the stable sort in index order already; a
-    // merged pair (two bodies whose keys were made equal afterwards) may need swapping.
+    // the leaf: this body, or the bodies that share its key (same level-31 cell / EPS-merged pair of entities), folded in
+    // ARRIVAL order like the reference's add_mass (nbody.rs:303-320).  Equal keys come out of the stable sort in index order;
+    // a merged pair of entities is two such ascending segments back to back: fold them as a two-way merge by index.
     int b = run_end(keys, a, n);
     {
-        float px = p.x, py = p.y, m = p.w;
-        if (b - a == 2 && idx[a + 1] < idx[a]) {
-            const float4 q = sb[a + 1];
-            px = q.x; py = q.y; m = q.w;
-            fold_mass(px, py, m, p.x, p.y, p.w);
-        } else {
-            for (int j = a + 1; j < b; j++) {
-                const float4 q = sb[j];
-                fold_mass(px, py, m, q.x, q.y, q.w);
-            }
+        int split = b;                              // start of the second ascending segment, if any
+        for (int j = a + 1; j < b; j++)
+            if (idx[j] < idx[j - 1]) { split = j; break; }
+        int u = a, v = split;
+        float px = 0.0f, py = 0.0f, m = 0.0f;
+        while (u < split || v < b) {
+            const bool take_u = v >= b || (u < split && idx[u] < idx[v]);
+            const float4 q = sb[take_u ? u : v];
+            if (take_u) u++; else v++;
+            fold_mass(px, py, m, q.x, q.y, q.w);    // the first one is copied exactly (m == 0 branch)
         }
         BhNode* o = &out[first + count - 1];
         o->px = px; o->py = py; o->m = m;
