@@ -59,8 +59,8 @@ void nb_step_brute_force(float dt);
  * theta == 0.0 delegates to brute force (nbody.rs:197-200).  Otherwise: quadtree built on the
  * host exactly as the reference builds it, force evaluation + integration + velocity-kill on
  * the GPU.  `nthreads` (CPU worker count in the reference, nbody.rs:424-428) is accepted and
- * ignored by the GPU evaluation; nthreads <= 0 (a division by zero panic in the reference) is a
- * no-op here. */
+ * ignored by the GPU evaluation; nthreads <= 0 updates no particle, as in the reference (its workers are
+ * `(0..nthreads).map(..)`: an empty iterator; the tree build and its asserts still run). */
 void nb_step_barnes_hut(float theta, float dt, int32_t nthreads);
 
 /* replaces nbody.rs:482-583 pub extern fn nb_draw(w: i32, h: i32, fb: *mut u32)

@@ -48,7 +48,10 @@ enum {
     ORC_PANIC_SAME_POS = -2,   /* nbody.rs:267 */
     ORC_PANIC_SUBDIVIDE = -3,  /* nbody.rs:293 */
     ORC_PANIC_MASS = -4,       /* nbody.rs:304 */
-    ORC_PANIC_NTHREADS = -5,   /* nbody.rs:426 (integer division by zero) */
+    ORC_PANIC_NTHREADS = -5,   /* NOT a reference panic: returned by the helpers of this file that need >= 1 worker
+                                * (orc_brute_forces_mt, orc_bh_forces*). nb_step_barnes_hut with nthreads <= 0 does not panic:
+                                * the division `len / nthreads` sits inside the (0..nthreads).map closure, nbody.rs:424-428,
+                                * which never runs -- see orc_step_barnes_hut */
     ORC_PANIC_ALLOC = -6
 };
 
@@ -369,6 +372,15 @@ static int bh_run(orc_particle *p, int n, float theta, float dt, int nthreads, f
 int orc_step_barnes_hut(orc_particle *p, int n, float theta, float dt, int nthreads)
 {
     if (theta == 0.0f) return orc_step_brute_force(p, n, dt);  /* :197-200 exact compare */
+    if (nthreads <= 0) {
+        /* :424 `(0..nthreads).map(|i| {...})` is an empty iterator: no worker is spawned, the closure holding the
+         * division by nthreads (:426) never runs, no particle is touched.  The tree IS built first (:380-417), so its
+         * asserts can still fire. */
+        orc_node root;
+        int rc = build_tree(p, n, &root);
+        node_free(&root);
+        return rc;
+    }
     return bh_run(p, n, theta, dt, nthreads, NULL, NULL);
 }
 

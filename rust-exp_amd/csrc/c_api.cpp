@@ -1,4 +1,6 @@
 // c_api.cpp -- level 2 of the C ABI (include/nbody_mi355x.h): the handle-based nbx_* entry points.
+#include <new>
+
 #include "engine_internal.h"
 
 using namespace nbxi;
@@ -153,7 +155,11 @@ int32_t nbx_random_disk(nbx_engine* e, int32_t n)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
     ensure_seed(e);
-    nbx::preset_random_disk(e->host, n, e->rng);
+    try {   // nothing may unwind across the C ABI
+        nbx::preset_random_disk(e->host, n, e->rng);
+    } catch (const std::bad_alloc&) {
+        return fail(NBX_ERR_ALLOC, "out of memory for %d particles", (int)n);
+    }
     after_host_state_change(e);
     return NBX_OK;
 }
@@ -162,7 +168,11 @@ int32_t nbx_stable_orbits(nbx_engine* e, int32_t n, float rmin, float rmax)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
     ensure_seed(e);
-    nbx::preset_stable_orbits(e->host, n, rmin, rmax, e->rng);
+    try {
+        nbx::preset_stable_orbits(e->host, n, rmin, rmax, e->rng);
+    } catch (const std::bad_alloc&) {
+        return fail(NBX_ERR_ALLOC, "out of memory for %d particles", (int)n);
+    }
     after_host_state_change(e);
     return NBX_OK;
 }
@@ -174,7 +184,11 @@ int32_t nbx_set_particles3(nbx_engine* e, int32_t n, const float* px, const floa
 {
     if (!e || n < 0) return fail(NBX_ERR_INVALID, "bad engine or n");
     if (n > 0 && (!px || !py || !vx || !vy || !m)) return fail(NBX_ERR_INVALID, "null input array");
-    e->host.resize(n);
+    try {
+        e->host.resize(n);
+    } catch (const std::bad_alloc&) {
+        return fail(NBX_ERR_ALLOC, "out of memory for %d particles", (int)n);
+    }
     for (int i = 0; i < n; i++) {
         e->host.px[i] = px[i]; e->host.py[i] = py[i]; e->host.pz[i] = pz ? pz[i] : 0.0f;
         e->host.vx[i] = vx[i]; e->host.vy[i] = vy[i]; e->host.vz[i] = vz ? vz[i] : 0.0f;
@@ -225,7 +239,9 @@ int32_t nbx_step_barnes_hut(nbx_engine* e, float theta, float dt, int32_t nthrea
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
     if (theta == 0.0f) return step_brute(e, dt);  // nbody.rs:197-200 (exact compare, before anything else)
-    if (nthreads <= 0) return fail(NBX_ERR_INVALID, "nthreads must be >= 1 (the reference divides by it, nbody.rs:426)");
+    // the reference spawns no worker and updates nobody for nthreads <= 0 (the division by it sits inside the closure of an
+    // empty iterator, nbody.rs:424-428); level 2 reports the argument instead of silently doing nothing
+    if (nthreads <= 0) return fail(NBX_ERR_INVALID, "nthreads must be >= 1 (the reference would update no particle)");
     return step_bh(e, theta, dt);
 }
 
@@ -442,9 +458,20 @@ int32_t nbx_load(nbx_engine* e, const char* path)
     int32_t hdr[2] = {0, 0};
     bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "NBXCKPT1", 8) == 0 && std::fread(hdr, sizeof hdr, 1, f) == 1 &&
               hdr[0] >= 0;
+    if (ok) {   // the header's count must agree with the file's size BEFORE anything is allocated from it
+        long here = std::ftell(f);
+        ok = here == 16 && std::fseek(f, 0, SEEK_END) == 0;
+        const long size = ok ? std::ftell(f) : -1;
+        ok = ok && size == 16 + 28L * (long)hdr[0] && std::fseek(f, 16, SEEK_SET) == 0;
+    }
     nbx::HostState st;
     if (ok) {
-        st.resize(hdr[0]);
+        try {
+            st.resize(hdr[0]);
+        } catch (const std::bad_alloc&) {
+            std::fclose(f);
+            return fail(NBX_ERR_ALLOC, "out of memory for %d particles", (int)hdr[0]);
+        }
         std::vector<float>* arrs[7] = {&st.px, &st.py, &st.pz, &st.vx, &st.vy, &st.vz, &st.m};
         for (auto* a : arrs) ok = ok && (hdr[0] == 0 || std::fread(a->data(), sizeof(float), (size_t)hdr[0], f) == (size_t)hdr[0]);
     }

@@ -100,7 +100,14 @@ void nb_step_barnes_hut(float theta, float dt, int32_t nthreads)
 {
     std::lock_guard<std::mutex> lk(g_mutex);
     nbx_engine* e = global_engine();
-    if (theta != 0.0f && nthreads <= 0) return;  // reference: integer division by zero panic; here a no-op
+    if (theta != 0.0f && nthreads <= 0) {
+        // Reference: `(0..nthreads).map(..)` is empty -- no worker, no division by nthreads (it sits inside the closure,
+        // nbody.rs:424-428), no particle touched -- but the quadtree has been built by then (:380-417), so its asserts
+        // (depth > 50, mass <= 0, ...) still panic.  Same here: build the host tree for its checks, update nothing.
+        const int rc = nbx_bh_tree_dump(e, nullptr, 0);
+        if (rc == NBX_ERR_TREE_DEPTH || rc == NBX_ERR_TREE) die("nb_step_barnes_hut");
+        return;
+    }
     if (g_group) {
         if (nbx_group_step_barnes_hut(g_group, theta, dt, nthreads) != NBX_OK || nbx_group_synchronize(g_group) != NBX_OK)
             die("nb_step_barnes_hut");

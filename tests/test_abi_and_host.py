@@ -372,6 +372,14 @@ def test_checkpoint_roundtrip(rx, tmp_path):
     with pytest.raises(rx.NBodyError):
         f.load(bad)
     assert f.num_particles() == n           # a failed load leaves the state alone
+    # a header that promises more than the file holds (truncated / corrupt) is rejected BEFORE anything is allocated from it
+    import struct
+    whole = open(path, "rb").read()
+    for blob in (whole[:-4], whole + b"\0" * 4, whole[:8] + struct.pack("<ii", 2**31 - 1, 0) + whole[16:], whole[:8] + struct.pack("<ii", -1, 0)):
+        open(bad, "wb").write(blob)
+        with pytest.raises(rx.NBodyError) as ei:
+            f.load(bad)
+        assert ei.value.code == rx.NBX_ERR_INVALID and f.num_particles() == n
     e.set_particles([], [], [], [], [])
     e.save(path)
     assert f.load(path) == 0

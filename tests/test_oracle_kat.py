@@ -136,9 +136,17 @@ def test_bh_nonpositive_mass_panics(ob):
     assert rc == ob.ORC_PANIC_MASS       # nbody.rs:304
 
 
-def test_bh_nthreads_zero_is_a_panic(ob):
+def test_bh_nthreads_zero_updates_nobody_and_does_not_panic(ob):
+    """nbody.rs:424-428: the division by nthreads sits inside the (0..nthreads).map closure; with nthreads <= 0 the iterator
+    is empty, no worker runs, the state is untouched.  The tree is still built before that (:380-417): its asserts can fire."""
     p = ob.random_disk(10, 1)
-    assert ob.step_barnes_hut(p, 0.5, 0.01, 0) == ob.ORC_PANIC_NTHREADS   # nbody.rs:426
+    q = p.copy()
+    for t in (0, -3):
+        assert ob.step_barnes_hut(q, 0.5, 0.01, t) == 0
+        assert np.array_equal(q.view(np.uint8), p.view(np.uint8))
+    bad = ob.particles([0.0, 1.0], [0.0, 1.0], [0, 0], [0, 0], [1.0, 0.0])
+    assert ob.step_barnes_hut(bad, 0.5, 0.01, 0) == ob.ORC_PANIC_MASS      # the build's assert (:304) still fires
+    assert ob.step_barnes_hut(q, 0.0, 0.01, 0) == 0 and not np.array_equal(q["px"], p["px"])   # theta == 0 never looks at nthreads
 
 
 def test_stable_orbits_preset_shape(ob):
