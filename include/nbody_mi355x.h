@@ -110,7 +110,7 @@ enum nbx_option {
                                     * download) instead of downloading the state. Pixel-identical to the host draw: the
                                     * few tails whose octant sits within 1e-5 of a step of the reference's f32 expression
                                     * (diagonal or near-diagonal velocities) are decided by the host's own atan2f.
-                                    * Default: 0 below 65 536 bodies, 1 from there on (NB_DRAW / this option override) */
+                                    * Default (-1): host below 4096 bodies or while the state is not on the GPU, device otherwise */
     NBX_OPT_BH_TREE = 8,           /* Barnes-Hut tree: 0 = built on the host exactly like the reference (always used by
                                     * the bit-exact mode), 1 = built on the device (bh_build.hip: same node set and leaf
                                     * records incl. the reference's EPS merge of close pairs; interior centres of mass are

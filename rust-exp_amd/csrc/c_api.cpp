@@ -373,8 +373,9 @@ static int draw_on_device(nbx_engine* e, int32_t w, int32_t h, uint32_t* fb)
 int32_t nbx_draw(nbx_engine* e, int32_t w, int32_t h, uint32_t* fb)
 {
     if (!e || !fb || w <= 0 || h <= 0) return fail(NBX_ERR_INVALID, "bad draw arguments");
-    // -1 (default): on the device once the state lives there and a frame would otherwise download >= 65 536 x 32 B
-    const bool on_device = e->draw_device == 1 || (e->draw_device < 0 && e->dev_valid && e->world == 1 && e->n >= 65536);
+    // -1 (default): on the device once the state lives there and has >= 4096 bodies (a frame would otherwise download
+    // n x 32 B and splat on the host: 0.32 ms vs 0.10 ms at the reference's 10 000 bodies, profiles/r02_frame_loop_level1.txt)
+    const bool on_device = e->draw_device == 1 || (e->draw_device < 0 && e->dev_valid && e->world == 1 && e->n >= 4096);
     if (on_device) {
         if (e->world != 1) return fail(NBX_ERR_STATE, "device draw needs the whole state on one GPU");
         return draw_on_device(e, w, h, fb);

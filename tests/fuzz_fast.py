@@ -3,8 +3,9 @@
     python tests/fuzz_fast.py [first_seed] [count]
 Random sizes / scales / mass ranges / clumps as in fuzz_strict.py. Per case: everything finite; fast all-pairs forces
 within 5e-5 max|F| sqrt(N)/64 of the bit-exact kernel's; fast Barnes-Hut (host tree) within 1e-4 max|F| of the bit-exact walk;
-device-built tree vs host tree through the same walk: median relative difference <= 1e-4 (sub-EPS pairs differ by
-design, hence the median)."""
+device-built tree (EPS merge of pairs reproduced; crowded systems fall back to the host build) vs host tree through the same
+walk: 99.9 % of the bodies within 2e-4 max|F| (the reference's own f32 node folds drift by about that much at 150 000 bodies --
+the device's sums are exact -- and a handful of opening decisions flip), everyone within 5e-3 max|F|."""
 import os
 import sys
 import time
@@ -64,11 +65,11 @@ def main():
                     why.append("bh tol %.2e" % (max(np.abs(bfx - bsx).max(), np.abs(bfy - bsy).max()) / bsc))
                 fd = eng("fast", 1)
                 dx_, dy_, _ = fd.forces(theta)
-                rel = np.hypot(dx_ - bfx, dy_ - bfy) / (np.hypot(bfx, bfy) + 1e-30)
+                err = np.maximum(np.abs(dx_ - bfx), np.abs(dy_ - bfy)) / bsc
                 if not np.isfinite(dx_).all():
                     why.append("device tree not finite")
-                elif np.median(rel) > 1e-4:
-                    why.append("device tree median %.2e" % np.median(rel))
+                elif np.percentile(err, 99.9) > 2e-4 or err.max() > 5e-3:
+                    why.append("device tree p99.9 %.2e max %.2e" % (np.percentile(err, 99.9), err.max()))
                 for e in (ff, fd):
                     e.step_barnes_hut(theta, 0.01, 1); e.step_brute_force(0.01)
                     st = e.get_particles()

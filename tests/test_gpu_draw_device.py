@@ -79,7 +79,7 @@ def test_device_draw_adversarial_directions_near_every_octant_step(rx, ob):
 
 def test_device_draw_equals_oracle_on_100000_random_bodies_and_is_the_default_for_large_systems(rx, ob):
     """np.array_equal on the 100 000-body case; then the default engine (no option set) takes the device
-    path for >= 65 536 resident bodies and the host path below -- same pixels either way."""
+    path for >= 4096 resident bodies and the host path below -- same pixels either way."""
     p = ob.stable_orbits(100000, 0.5, 30.0, 3)
     want = ob.draw(p, 512, 512)
     e = eng(rx, p)
@@ -102,9 +102,9 @@ def test_device_draw_equals_oracle_on_100000_random_bodies_and_is_the_default_fo
     d.step_brute_force(0.0)                      # state resident on the GPU (a zero-length step changes nothing)
     assert np.array_equal(d.draw(512, 512), want) and d.get_option(NBX_OPT_DRAW_AMBIGUOUS) >= 0      # ran on the device
     small = rx.NBodyEngine()
-    small.set_particles(p["px"][:5000], p["py"][:5000], p["vx"][:5000], p["vy"][:5000], p["m"][:5000])
+    small.set_particles(p["px"][:4000], p["py"][:4000], p["vx"][:4000], p["vy"][:4000], p["m"][:4000])
     small.step_brute_force(0.0)
-    assert np.array_equal(small.draw(512, 512), ob.draw(p[:5000], 512, 512)) and small.get_option(NBX_OPT_DRAW_AMBIGUOUS) == -1
+    assert np.array_equal(small.draw(512, 512), ob.draw(p[:4000], 512, 512)) and small.get_option(NBX_OPT_DRAW_AMBIGUOUS) == -1
     from rust_exp_amd.engine import NBX_OPT_DRAW_DEVICE
     assert d.get_option(NBX_OPT_DRAW_DEVICE) == -1
 

@@ -142,6 +142,31 @@ def test_bench_gpus_n_plain_invocation_uses_the_group_host(rx):
     assert res["roofline"]["interactions_per_launch"] == 16384.0 * 32767.0
 
 
+def test_bench_under_torch_distributed_run_two_ranks(rx):
+    """The driver's multi-GPU launch line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 ...` (one rank per GPU, torch.distributed moves the slabs).  RCCL when the
+    box has two GPUs; on the single-GPU test box the two ranks share the device and exchange over gloo
+    (NBX_DIST_BACKEND=gloo: control flow, slab kernels side by side, the one-JSON-line contract -- not a measurement)."""
+    import socket
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if rx.device_count() < 2:
+        env["NBX_DIST_BACKEND"] = "gloo"
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "32768", "--steps", "3", "--warmup", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["host"] == "torch" and res["scaling"] == "strong"
+    assert [r["slab"] for r in res["per_gpu"]] == [[0, 16384], [16384, 32768]] and all(r["force_launches"] == 3 for r in res["per_gpu"])
+    assert res["value"] > 0 and 0 < res["roofline"]["frac"] < 1 and "cpu_baseline" not in res
+
+
 def test_bench_default_line_has_roofline_and_measured_traffic(rx):
     """N = 1 (the driver's line, at a small size): roofline + traffic measured by the in-run rocprofv3 passes when the
     profiler is installed."""

@@ -11,6 +11,7 @@
 #   power   tools/power_probe.py: board power during a >= 6 s K1 loop
 #   shapes  launch-shape sweeps (sweep_shapes.py, shard-of-8 shape)
 #   k1ab    K1 kernel variants 5/6/7 A/B (bench lines + board power)
+#   fuzz    the four hand-run fuzz campaigns (tests/fuzz_*.py)
 #   ubench  instruction-issue microbenchmarks
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG="${TAG:-r02}"
@@ -84,6 +85,10 @@ for f in sorted(glob.glob("gpurun_out/*_k1sweep_*.jsonl")):
         d=json.loads(ln); print(f.split("/")[-1], d["config"]["launch"], "%.3e"%d["value"], "frac %.4f"%d["roofline"]["frac"], "k_ms %.3f"%d["roofline"]["kernel_avg_ms"], "step %.3f"%d["ms_per_step"])
 PY
       ;;
+    fuzz)   # hand-run campaigns against the oracle / the bit-exact kernels (FUZZ_N cases each, default 200)
+      N=${FUZZ_N:-200}
+      { timeout 3000 python tests/fuzz_strict.py 0 $N; timeout 3000 python tests/fuzz_fast.py 0 $N; timeout 3000 python tests/fuzz_api.py 0 $((N/4)); timeout 3000 python tests/fuzz_group.py 0 $((N/2)); } > $O/${TAG}_fuzz.txt 2>&1
+      tail -30 $O/${TAG}_fuzz.txt ;;
     ubench) tools/ubench_valu > $O/${TAG}_ubench_valu.txt 2>&1; tools/ubench_banks > $O/${TAG}_ubench_banks.txt 2>&1 ;;
     *) echo "unknown stage $stage" ;;
   esac

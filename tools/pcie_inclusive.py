@@ -15,29 +15,23 @@ for n in (10000, 262144, 1048576):
         e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"]); e.forces() if False else None
     e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
     e.step_brute_force(0.01); e.synchronize()
-    reps = 5
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
-        e.step_brute_force(0.01); e.synchronize()
-    t_set_step = (time.perf_counter() - t0) / reps
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        e.step_brute_force(0.01); e.synchronize()
-    t_step = (time.perf_counter() - t0) / reps
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        e.step_brute_force(0.01); e.get_particles()
-    t_step_get = (time.perf_counter() - t0) / reps
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        e.step_brute_force(0.01); e.draw(512, 512)
-    t_step_draw = (time.perf_counter() - t0) / reps
+    reps = 9
+
+    def med(fn):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    t_set_step = med(lambda: (e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"]), e.step_brute_force(0.01), e.synchronize()))
+    t_step = med(lambda: (e.step_brute_force(0.01), e.synchronize()))
+    t_step_get = med(lambda: (e.step_brute_force(0.01), e.get_particles()))
+    e.set_draw_device(False)
+    e.draw(512, 512)                      # first call of either path allocates its buffers: keep that out of the timing
+    t_step_draw = med(lambda: (e.step_brute_force(0.01), e.draw(512, 512)))
     e.set_draw_device(True)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        e.step_brute_force(0.01); e.draw(512, 512)
-    t_step_ddraw = (time.perf_counter() - t0) / reps
+    e.draw(512, 512)
+    t_step_ddraw = med(lambda: (e.step_brute_force(0.01), e.draw(512, 512)))
     inter = n * (n - 1.0)
     out[str(n)] = {"step_ms": t_step * 1e3, "set+step_ms": t_set_step * 1e3, "step+get_ms": t_step_get * 1e3,
                    "step+host_draw_ms": t_step_draw * 1e3, "step+device_draw_ms": t_step_ddraw * 1e3,
