@@ -33,6 +33,7 @@ def main():
     big = int(os.environ.get("BH_N", "1048576"))
     st = rx.plummer_sphere(big, dim=2)
     e = rx.NBodyEngine(mode="fast")
+    e.set_bh_tree("host")                                      # the reference-faithful insertion build (round 2: no longer the default)
     e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
     e.step_barnes_hut(0.5, 0.01, 1); e.synchronize()          # warm-up (allocations)
     e.profile(True); e.profile_reset(); e.bh_host_timing()
