@@ -117,7 +117,7 @@ def _claim_stdout():
     return real
 
 
-def measure_traffic(argv_tail, kernel_substr, timeout=240):
+def measure_traffic(argv_tail, kernel_substr, timeout=120):
     """HBM bytes per launch of the dominant kernel, measured NOW on this box with rocprofv3 PMC counters exactly as
     /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes
     (TCC slots), unit KiB, FETCH_SIZE doubled on gfx950 (it reports 1/2 of the bytes of 16-B/lane coalesced reads),
@@ -164,7 +164,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=0, help="bodies (default 262144; 1048576 for --workload bh)")
+    ap.add_argument("--n", "--bodies", dest="n", type=int, default=0,
+                    help="bodies (default 262144; 1048576 for --workload bh). Under torch.distributed.run spell it --bodies: the "
+                         "launcher's own parser treats --n as an ambiguous abbreviation of --nnodes / --nproc-per-node")
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--mode", default="fast")
     ap.add_argument("--jsplit", type=int, default=0)
@@ -481,7 +483,11 @@ def main():
                                        + ("_fp16sources" if args.source_bits == 16 else "")
                                        + (f"_rank0_of_{args.shard_of}_slab_only" if args.shard_of > 1 else ""),
                            "bodies": n, "seed": "0x5EED0001", "force_mode": args.mode, "host": host_kind,
-                           "sharding": sharding, "launch": launch},
+                           "sharding": sharding, "launch": launch,
+                           "kernel_note": ("every body of this workload has the same mass, so the unit-mass sweep runs (variant 7: the "
+                                           "per-interaction multiply by m_j is hoisted out of the loop); systems with unequal masses run "
+                                           "variant 6, the same kernel with that multiply: 0.57 of the roofline at this size, "
+                                           "profiles/r02_k1_variants_5_6_7.jsonl") if launch["variant"] == 7 else None},
                 "roofline": {"bound": "valu_fp32",
                              "bound_contract_class": "mfma (dense fp32 peak: the f32 MFMA rate equals the fp32 vector rate, "
                                                      "157.3 TFLOP/s; no MFMA is used)",

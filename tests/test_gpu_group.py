@@ -156,7 +156,7 @@ def test_bench_under_torch_distributed_run_two_ranks(rx):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "32768", "--steps", "3", "--warmup", "1"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "32768", "--steps", "3", "--warmup", "1"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
