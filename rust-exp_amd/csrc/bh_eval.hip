@@ -33,7 +33,7 @@ constexpr int kMaxFrames = 56;
 // nbody.rs:365) needs no test here because a coincident leaf contributes m * 0 / (0 + EPS) = exactly 0.
 // Decisions within 1e-5 of the boundary are re-made with the reference's own arithmetic (take_node), so the fast walks
 // open exactly the nodes the reference opens; they differ from it by rcp-vs-divide, FMA and summation order only.
-// A node that is not taken adds an exact zero (scale 0), so both walks below produce identical bits.
+// Both walks below add a node's term only in the lanes that take it, in walk order: identical bits.
 
 // take (accept an interior node / evaluate a leaf) or open?  q < theta^2 d^2 decides everything outside a 1e-5-wide band
 // around the boundary; inside the band (or with NaNs) the reference's own test runs -- unfused d^2, correctly rounded
@@ -51,8 +51,10 @@ __device__ __forceinline__ bool take_node(const float q, const float s, const fl
 {
     bool take = q < th2_lo * d2;
     const bool below_hi = q <= th2_hi * d2;
-    if (__builtin_expect(below_hi && !take, 0))                                    // in the band: a few decisions per million
-        take = take_node_exact(s, dx, dy, theta);
+    // lane masks combined on the scalar unit (one s_andn2 instead of a third vector compare for "not take")
+    if (__builtin_expect((__ballot(below_hi) & ~__ballot(take)) != 0ull, 0)) {     // somebody in the band: a few decisions per million
+        if (below_hi && !take) take = take_node_exact(s, dx, dy, theta);
+    }
     return take;                                                                   // (NaN d^2: not taken, like s/NaN < theta)
 }
 
@@ -80,9 +82,11 @@ __global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict
         const float dy = a.y - pi.y;
         const float d2 = __builtin_fmaf(dy, dy, dx * dx);
         const bool take = take_node(q, a.w, d2, dx, dy, th2_lo, th2_hi, theta);
-        const float s = take ? a.z * __builtin_amdgcn_rcpf(d2 + kEps) : 0.0f;
-        ax = __builtin_fmaf(s, dx, ax);
-        ay = __builtin_fmaf(s, dy, ay);
+        if (take) {   // under the exec mask: lanes that open the node execute nothing here
+            const float s = a.z * __builtin_amdgcn_rcpf(d2 + kEps);
+            ax = __builtin_fmaf(s, dx, ax);
+            ay = __builtin_fmaf(s, dy, ay);
+        }
         i = take ? skip : i + 1;
     }
     out[it] = make_float2(ax, ay);
@@ -118,7 +122,10 @@ __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* 
     float ax = 0.0f, ay = 0.0f;
     int r = valid ? 0 : 0x7FFFFFFF;   // resume index: the lane takes part in node i iff r <= i
     int i = 0;                        // wave-uniform
-    // (fetching node i+1 ahead of the decision was tried and is slower)
+    // (fetching node i+1 ahead of the decision was tried and is slower; so is giving every wave two independent walks to
+    //  overlap their latencies -- 0.755 vs 0.658 ms at 1 M bodies: the loop is bound by instruction issue, the scalar unit of a
+    //  CU being shared by its four SIMDs, not by the latency of the node load.  Round 2 also cut the vector work per visit
+    //  from 19 to 14 instructions -- exec-masked take block, lane masks combined on the scalar unit -- for no change in time.)
     while (i < n_nodes) {
         typedef float f8 __attribute__((ext_vector_type(8)));
         const f8 rec = *reinterpret_cast<const f8*>(&nodes[(unsigned)__builtin_amdgcn_readfirstlane(i)]);
@@ -129,10 +136,12 @@ __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* 
         const float dy = ny - pi.y;
         const float d2 = __builtin_fmaf(dy, dy, dx * dx);
         const bool take = (r <= i) && take_node(q, rec[3], d2, dx, dy, th2_lo, th2_hi, theta);   // parked lanes take nothing
-        const float s = take ? nm * __builtin_amdgcn_rcpf(d2 + kEps) : 0.0f;
-        ax = __builtin_fmaf(s, dx, ax);
-        ay = __builtin_fmaf(s, dy, ay);
-        r = take ? skip : r;                            // done with this subtree
+        if (take) {   // under the exec mask (no select instructions; lanes that open or are parked execute nothing here)
+            const float s = nm * __builtin_amdgcn_rcpf(d2 + kEps);
+            ax = __builtin_fmaf(s, dx, ax);
+            ay = __builtin_fmaf(s, dy, ay);
+            r = skip;                                   // done with this subtree
+        }
         // lanes still at or before i are the active ones that did not take the node: they want it opened
         i = (__ballot(r <= i) != 0ull) ? i + 1 : skip;
     }
