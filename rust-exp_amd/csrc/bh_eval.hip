@@ -125,7 +125,11 @@ __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* 
     // (fetching node i+1 ahead of the decision was tried and is slower; so is giving every wave two independent walks to
     //  overlap their latencies -- 0.755 vs 0.658 ms at 1 M bodies: the loop is bound by instruction issue, the scalar unit of a
     //  CU being shared by its four SIMDs, not by the latency of the node load.  Round 2 also cut the vector work per visit
-    //  from 19 to 14 instructions -- exec-masked take block, lane masks combined on the scalar unit -- for no change in time.)
+    //  from 19 to 14 instructions -- exec-masked take block, lane masks combined on the scalar unit -- for no change in time,
+    //  and tried the node record through the vector memory path (every lane loads the same 32 bytes, record kept in VGPRs, only
+    //  the skip pointer read back to the scalar unit): 0.86 vs 0.66 ms.  PMC of the shipped walk, profiles/r02_bh_walk_pmc_summary.json:
+    //  13.4 VALU + 12.9 SALU instructions and 4.9 branches per visit, VALU 55 % busy, 66 % of the wave-cycles waiting on the
+    //  scalar load: a dependent chain load -> decide -> next index, 800 cycles per visit with 8 waves per SIMD.)
     while (i < n_nodes) {
         typedef float f8 __attribute__((ext_vector_type(8)));
         const f8 rec = *reinterpret_cast<const f8*>(&nodes[(unsigned)__builtin_amdgcn_readfirstlane(i)]);
