@@ -110,9 +110,14 @@ template <int BPW>
 __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* __restrict__ posm, const int lo,
                                                                   const int n_targets, const BhNode* __restrict__ nodes,
                                                                   const int n_nodes, const float theta,
-                                                                  float2* __restrict__ out, const unsigned* __restrict__ perm)
+                                                                  float2* __restrict__ out, const unsigned* __restrict__ perm,
+                                                                  const int xcd_order)
 {
-    const int t = blockIdx.x * BPW + threadIdx.x;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Handing
+    // XCD k the k-th CONTIGUOUS eighth of the Morton-ordered bodies keeps the part of the tree an L2 sees to that region's
+    // subtrees instead of all of it (gridDim.x is a multiple of 8; see launch_bh_eval).
+    const int blk = xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int t = blk * BPW + threadIdx.x;
     const bool valid = (int)threadIdx.x < BPW && t < n_targets;
     if (__ballot(valid) == 0ull) return;
     const int it = valid ? (perm ? (int)perm[t] - lo : t) : 0;
@@ -435,9 +440,13 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
         // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 8 and 64 bodies each
         int bpw = 64;
         while (bpw > 8 && (n_targets + bpw - 1) / bpw < 4096) bpw >>= 1;
-        const dim3 g((n_targets + bpw - 1) / bpw);
+        // XCD-aware block order (see the kernel): eval 0.634 -> 0.620 ms at 1 M bodies, 0.295 -> 0.252 at 262 144, 0.117 -> 0.111 at 10 000
+        const int xcd_order = 1;
+        const int nblk = (n_targets + bpw - 1) / bpw;
+        const dim3 g(xcd_order ? (unsigned)((nblk + 7) / 8 * 8) : (unsigned)nblk);
         auto go = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, g, dim3(kWaveBlock), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta, force_out, perm);
+            hipLaunchKernelGGL(kernel, g, dim3(kWaveBlock), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta, force_out, perm,
+                               xcd_order);
         };
         if (bpw == 64) go(k_bh_eval_fast_wave<64>);
         else if (bpw == 32) go(k_bh_eval_fast_wave<32>);
