@@ -104,6 +104,14 @@ def lib():
     if _lib is not None:
         return _lib
     build()
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or os.environ.get("NBX_PRELOAD_TORCH"):
+        # One process per GPU under torch.distributed.run: PyTorch's wheel bundles its own HIP runtime, which must be the
+        # first one loaded (loaded second, torch reports "No HIP GPUs"). Import it here so that the order in which the
+        # caller imports things does not matter; single-process hosts never import torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(_SO)
     E = C.c_void_p
     i32 = C.c_int32
