@@ -11,6 +11,7 @@
 #   power   tools/power_probe.py: board power during a >= 6 s K1 loop
 #   shapes  launch-shape sweeps (sweep_shapes.py, shard-of-8 shape)
 #   k1ab    K1 kernel variants 5/6/7 A/B (bench lines + board power)
+#   cfgs    bench.py on BASELINE configs #2 and #5 (one GPU), the 2-D kernel, the bit-exact mode
 #   fuzz    the four hand-run fuzz campaigns (tests/fuzz_*.py)
 #   ubench  instruction-issue microbenchmarks
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -83,6 +84,21 @@ import json,glob
 for f in sorted(glob.glob("gpurun_out/*_k1sweep_*.jsonl")):
     for ln in open(f):
         d=json.loads(ln); print(f.split("/")[-1], d["config"]["launch"], "%.3e"%d["value"], "frac %.4f"%d["roofline"]["frac"], "k_ms %.3f"%d["roofline"]["kernel_avg_ms"], "step %.3f"%d["ms_per_step"])
+PY
+      ;;
+    cfgs)   # the other BASELINE configs on one GPU + the 2-D kernel on the headline size
+      timeout 600 python bench.py --bodies 65536 --steps 20 --warmup 3 --no-traffic > $O/${TAG}_bench_cfg2_20_steps.json 2>> $O/${TAG}_cfgs.err
+      timeout 600 python bench.py --bodies 65536 --steps 400 --warmup 100 --no-traffic > $O/${TAG}_bench_cfg2.json 2>> $O/${TAG}_cfgs.err
+      timeout 600 python bench.py --workload two_galaxies --bodies 524288 --source-bits 16 --no-traffic --cpu-seconds 4 > $O/${TAG}_bench_cfg5_1gpu.json 2>> $O/${TAG}_cfgs.err
+      timeout 600 python bench.py --workload two_galaxies --bodies 524288 --no-traffic --no-cpu-baseline > $O/${TAG}_bench_cfg5_1gpu_fp32.json 2>> $O/${TAG}_cfgs.err
+      timeout 600 python bench.py --dim 2 --no-traffic --no-cpu-baseline > $O/${TAG}_bench_n1_dim2.json 2>> $O/${TAG}_cfgs.err
+      for m in strict; do for nb in 10000 65536 262144; do timeout 600 python bench.py --mode $m --bodies $nb --no-traffic --no-cpu-baseline >> $O/${TAG}_bench_strict.jsonl 2>> $O/${TAG}_cfgs.err; done; done
+      python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/*_bench_cfg*.json")+glob.glob("gpurun_out/*_bench_n1_dim2.json")):
+    d=json.load(open(f)); print(f.split("/")[-1], d["config"]["workload"], "%.3e"%d["value"], "frac %.4f"%d["roofline"]["frac"], d["config"]["launch"])
+for ln in open(glob.glob("gpurun_out/*_bench_strict.jsonl")[0]):
+    d=json.loads(ln); print("strict", d["config"]["bodies"], "%.3e"%d["value"], "frac %.4f"%d["roofline"]["frac"], d["config"]["launch"])
 PY
       ;;
     fuzz)   # hand-run campaigns against the oracle / the bit-exact kernels (FUZZ_N cases each, default 200)
