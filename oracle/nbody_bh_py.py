@@ -128,3 +128,70 @@ def step_barnes_hut(px, py, vx, vy, m, theta, dt):
             vx[i] = F(0.0)
             vy[i] = F(0.0)
     return tree
+
+
+# ---- fp64 arbiter (NOT in the reference), second restatement of orc_bh_forces_exact -------------------------------------
+def build_tree(px, py, m):
+    """The reference tree of nbody.rs:388-415 for float32 arrays (same code path as step_barnes_hut above)."""
+    n = len(px)
+    x1 = y1 = np.finfo(np.float32).max
+    x2 = y2 = np.finfo(np.float32).min
+    for i in range(n):
+        x1 = px[i] if px[i] < x1 else x1
+        y1 = py[i] if py[i] < y1 else y1
+        x2 = px[i] if px[i] > x2 else x2
+        y2 = py[i] if py[i] > y2 else y2
+    tree = Node(F(x1), F(y1), F(x2), F(y2))
+    for i in range(n):
+        tree.insert(px[i], py[i], m[i], 0)
+    return tree
+
+
+def _exact_sums(node, memo):
+    """(mass, mass*x, mass*y) of a node as Python floats (fp64): a leaf is its f32 record, an interior node the sum of its
+    children -- exact to fp64 rounding, free of the reference's f32 running fold."""
+    if node.children is None:
+        v = (float(node.m), float(node.m) * float(node.px), float(node.m) * float(node.py))
+    else:
+        parts = [_exact_sums(c, memo) for c in node.children]
+        v = (sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts))
+    memo[id(node)] = v
+    return v
+
+
+def bh_forces_exact(px, py, m, theta):
+    """Forces through the reference's tree, opening law s/d < theta and pair law, with exact node sums and fp64 arithmetic."""
+    import math
+
+    tree = build_tree(px, py, m)
+    memo = {}
+    _exact_sums(tree, memo)
+    eps = float(EPS)
+    theta = float(F(theta))
+
+    def pair(x, y, mi, cx, cy, mc):
+        dx, dy = cx - x, cy - y
+        f = mi * mc / (dx * dx + dy * dy + eps)
+        return f * dx, f * dy
+
+    def walk(node, x32, y32, x, y, mi):
+        if node.children is not None:
+            mm, mx, my = memo[id(node)]
+            cx, cy = mx / mm, my / mm
+            s = float(node.x2 - node.x1)                   # the f32 box width (nbody.rs:341)
+            d = math.sqrt((cx - x) ** 2 + (cy - y) ** 2)
+            if d > 0.0 and s / d < theta:
+                return pair(x, y, mi, cx, cy, mm)
+            fx = fy = 0.0
+            for c in node.children:
+                ax, ay = walk(c, x32, y32, x, y, mi)
+                fx += ax; fy += ay
+            return fx, fy
+        if (node.px == x32 and node.py == y32) or node.m == F(0.0):    # nbody.rs:365, :368
+            return 0.0, 0.0
+        return pair(x, y, mi, float(node.px), float(node.py), float(node.m))
+
+    out = np.zeros((len(px), 2))
+    for i in range(len(px)):
+        out[i] = walk(tree, px[i], py[i], float(px[i]), float(py[i]), float(m[i]))
+    return out[:, 0], out[:, 1]

@@ -71,3 +71,26 @@ def test_c_oracle_presets_equal_python_restatement(ob, n, seed):
         assert len(got) == len(want)
         for j, k in enumerate(("px", "py", "vx", "vy", "m")):
             assert np.array_equal(got[k].view(np.uint32), want[:, j].view(np.uint32)), k
+
+
+def test_fp64_barnes_hut_arbiter_c_equals_python_restatement(ob):
+    """orc_bh_forces_exact (the fp64 arbiter the device-tree tests lean on) against its own second restatement in Python
+    (oracle/nbody_bh_py.py::bh_forces_exact): same tree, exact node sums, fp64 walk -- equal to fp64 rounding.  And the arbiter
+    really is what the f32 restatement approximates: they agree to f32 accuracy on a small system (no drift to speak of)."""
+    from oracle import nbody_bh_py as bp
+
+    rng = np.random.default_rng(12)
+    for n, theta in ((300, 0.5), (700, 0.85), (40, 0.3)):
+        x = rng.normal(0, 10, n).astype(np.float32); y = rng.normal(0, 10, n).astype(np.float32)
+        x[: n // 10] = x[n // 10: 2 * (n // 10)] + np.float32(3e-5)        # a few sub-EPS pairs: merged blobs are leaves
+        y[: n // 10] = y[n // 10: 2 * (n // 10)]
+        m = rng.uniform(0.5, 2.0, n).astype(np.float32)
+        p = ob.particles(x, y, np.zeros(n), np.zeros(n), m)
+        rc, ex, ey = ob.bh_forces_exact(p, theta, nthreads=3)
+        assert rc == 0
+        qx, qy = bp.bh_forces_exact(x, y, m, theta)
+        scale = max(np.abs(qx).max(), np.abs(qy).max())
+        assert np.abs(ex - qx).max() <= 1e-12 * scale and np.abs(ey - qy).max() <= 1e-12 * scale
+        rc, fx, fy = ob.bh_forces(p, theta, nthreads=2)
+        err = np.maximum(np.abs(fx - ex), np.abs(fy - ey)) / scale
+        assert np.percentile(err, 99) <= 2e-6 and err.max() <= 2e-3      # a flipped opening decision at most
