@@ -195,9 +195,10 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
     // Defaults from the measured launch-shape sweeps (profiles/r01_shapes_sweep*.txt, profiles/r02_k1_wave_split_sweep.txt):
     //  * kernel, >= 32768 sources: the wave-split scalar-cache sweep -- variant 7 (unit-mass: 9 packed ops + 2 rcp per two
     //    interactions) when every body has the same mass, else variant 6 (10 + 2); LDS tiles (variant 1) below that size.
-    //  * variants 6 / 7: 256 targets per workgroup, S = smallest power of two giving >= 64 workgroups per CU, at most 64 and
-    //    at least 4 source tiles per workgroup (one per wave).  N = 262144: S = 16 (67 MB of partial slabs per launch;
-    //    variant 5 wrote 134 MB), 32768 targets x 262144 sources (8-way shard): S = 64.
+    //  * variants 6 / 7: 256 targets per workgroup, S = smallest power of two giving >= 32 workgroups per CU (64 when a GPU
+    //    owns < 131072 targets: tail effect), at most 64 and at least 4 source tiles per workgroup (one per wave).
+    //    N = 262144: S = 8 (34 MB of partial slabs per launch; variant 5 wrote 134 MB; S = 8..32 are within 1 % of each
+    //    other), N = 65536: S = 64, 32768 targets x 262144 sources (8-way shard): S = 64.
     //  * other variants: register blocking 4 (two packed pairs) when a GPU owns >= 32768 targets, else 2; S = smallest power
     //    of two giving >= 32 workgroups per CU (64 for variant 5 with < 131072 targets), capped at 64 and half the tiles.
     *dim = e->dim_opt ? e->dim_opt : (e->any_z ? 3 : 2);
@@ -215,7 +216,7 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
         const int iblocks = (n_targets + per_wg - 1) / per_wg;
         // 64 workgroups per CU only where targets are scarce (sharded shapes: tail effect); 32 otherwise --
         // same speed at N = 262144 on one GPU and half the partial-slab traffic
-        const int want = e->cu_count * ((wave_split || (v == 5 && n_targets < 131072)) ? 64 : 32);
+        const int want = e->cu_count * (((wave_split || v == 5) && n_targets < 131072) ? 64 : 32);
         s = 1;
         while (iblocks * s < want && s < 64) s *= 2;
         // every workgroup keeps >= 2 tiles of sources; a wave-split workgroup >= 4 (one per wave)

@@ -438,3 +438,32 @@ def test_host_worker_pool_serves_concurrent_builds(rx, ob):
     assert not errs, errs
     for k in range(len(ps)):
         assert np.array_equal(got[k], want[k])
+
+
+def test_bench_host_selection_without_a_gpu():
+    """bench.py picks its host from the launch line alone: `--gpus N` without a launcher -> the single-process group (which
+    refuses when the box has fewer devices instead of pretending), WORLD_SIZE set -> one process per GPU, and the two cannot
+    be mixed up.  No GPU needed: every case stops before the first device call (or at it, loudly: no CPU fallback)."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    def run(args, env_extra=None):
+        env = dict(os.environ)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NBX_GROUP_EXCHANGE"):
+            env.pop(k, None)
+        env.update(env_extra or {})
+        return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+
+    import rust_exp_amd as rx
+
+    if rx.device_count() == 0:
+        r = run(["--gpus", "2", "--bodies", "1024", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+        assert r.returncode != 0 and "HIP device" in r.stderr and r.stdout.strip() == ""
+        r = run(["--bodies", "1024", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+        assert r.returncode != 0 and "no CPU fallback" in r.stderr and r.stdout.strip() == ""
+    r = run(["--host", "torch", "--gpus", "4", "--bodies", "1024"])
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 4" in r.stderr
+    r = run(["--host", "single", "--gpus", "2"])
+    assert r.returncode != 0 and "one GPU" in r.stderr
