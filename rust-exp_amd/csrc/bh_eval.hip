@@ -132,7 +132,9 @@ __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* 
     //  CU being shared by its four SIMDs, not by the latency of the node load.  Round 2 also cut the vector work per visit
     //  from 19 to 14 instructions -- exec-masked take block, lane masks combined on the scalar unit -- for no change in time,
     //  and tried the node record through the vector memory path (every lane loads the same 32 bytes, record kept in VGPRs, only
-    //  the skip pointer read back to the scalar unit): 0.86 vs 0.66 ms.  PMC of the shipped walk, profiles/r02_bh_walk_pmc_summary.json:
+    //  the skip pointer read back to the scalar unit): 0.86 vs 0.66 ms; and requested node[skip] speculatively as soon as node i
+    //  had arrived, so that a wave leaving the subtree finds its next record waiting: 0.71 vs 0.62 ms -- every extra scalar load
+    //  costs more than the latency it hides.  PMC of the shipped walk, profiles/r02_bh_walk_pmc_summary.json:
     //  13.4 VALU + 12.9 SALU instructions and 4.9 branches per visit, VALU 55 % busy, 66 % of the wave-cycles waiting on the
     //  scalar load: a dependent chain load -> decide -> next index, 800 cycles per visit with 8 waves per SIMD.)
     while (i < n_nodes) {
