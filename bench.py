@@ -214,8 +214,8 @@ class SingleHost:
         self.engines = [e]
         self.local_only = args.shard_of > 1
 
-    def prepare(self):
-        self.eng.forces(0.0)   # uploads the state, sizes the work buffers; no state change
+    def prepare(self, theta=0.0):
+        self.eng.forces(theta)   # uploads the state, sizes the work buffers (all-pairs or tree walk); no state change
 
     def step_brute(self):
         if self.local_only:
@@ -265,9 +265,9 @@ class GroupHost:
         self.eng = self.engines[0]
         self.devices = devices
 
-    def prepare(self):
+    def prepare(self, theta=0.0):
         for e in self.engines:
-            e.forces(0.0)
+            e.forces(theta)
         # communicator set-up (ncclCommInitAll) outside the timed region: a zero-length step gathers the unchanged positions
         self.group.step_brute_force(0.0)
         self.group.synchronize()
@@ -323,8 +323,8 @@ class TorchHost:
         self.eng = slab.eng
         self.engines = [slab.eng]
 
-    def prepare(self):
-        self.eng.forces(0.0)
+    def prepare(self, theta=0.0):
+        self.eng.forces(theta)
         if self.world > 1:
             self.sim._exchange()   # communicator set-up outside the timed region (re-gathers the initial positions: a no-op on the data)
 
@@ -399,7 +399,7 @@ def main():
 
     # inputs resident in HBM, every buffer allocated and the communicator created before anything is timed, whatever
     # --warmup says; the W warm-up steps follow
-    host.prepare()
+    host.prepare(args.theta if is_bh else 0.0)
     if args.traffic_child:
         for _ in range(3):
             step()
