@@ -206,7 +206,8 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
     if (v < 0) v = (tiles_total * kTile >= 32768) ? 7 : 1;
     if (v == 7 && !(e->n > 0 && e->mass_min == e->mass_max && e->mass_min > 0.0f)) v = 6;   // unit-mass sweep needs equal masses
     *variant = v;
-    const bool wave_split = v == 6 || v == 7;   // 256 targets per workgroup, 4 source quarters per workgroup
+    // 256 targets per workgroup, 4 source quarters per workgroup; the fp16-source kernel (K4) keeps the 1024-target workgroups
+    const bool wave_split = (v == 6 || v == 7) && !e->source_half;
     int b = wave_split ? 4 : (e->bpt ? e->bpt : (n_targets >= 32768 ? 4 : 2));
     if (b != 1 && b != 2 && b != 4) b = 2;
     *bpt = b;

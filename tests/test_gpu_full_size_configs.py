@@ -155,4 +155,8 @@ def test_config5_two_galaxies_524288_fp16_sources(rx):
     b.step_brute_force(0.01)
     lo, hi = e.slab()
     got, want = e.get_particles(), b.get_particles()
-    assert np.abs(got["px"][lo:hi] - want["px"][lo:hi]).max() <= 3e-5   # 5 ulp at |x| ~ 25 (different j-split order)
+    # two fast results (different source splits): each within the SURVEY 8(d) bound computed from this case's max|a|
+    amax = float(np.max(np.hypot(fx.astype(np.float64), fy.astype(np.float64)) / st["m"]))
+    ptol, vtol = fast_tolerances(None, None, 0.01, 1, amax=amax, n=n)
+    assert np.abs(got["px"][lo:hi] - want["px"][lo:hi]).max() <= 2 * ptol, ptol
+    assert np.abs(got["vx"][lo:hi] - want["vx"][lo:hi]).max() <= 2 * vtol, vtol
