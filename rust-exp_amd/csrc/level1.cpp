@@ -41,7 +41,13 @@ static nbx_engine* global_engine()   // engine 0 of the group when NB_GPUS > 1
         const char* gpus = std::getenv("NB_GPUS");
         int want = gpus ? (std::strcmp(gpus, "all") == 0 ? nbx_device_count() : std::atoi(gpus)) : 1;
         if (want > 1) {
-            if (nbx_group_create(&g_group, nullptr, want) != NBX_OK) die("NB_GPUS group creation");
+            // NBX_GROUP_EXCHANGE=copy (peer copies instead of RCCL) lets engines share devices: wrap the ordinals, so that the
+            // group path can be exercised on a box with fewer GPUs than NB_GPUS (tests)
+            const char* xc = std::getenv("NBX_GROUP_EXCHANGE");
+            const int present = nbx_device_count();
+            std::vector<int32_t> devs((size_t)want);
+            for (int i = 0; i < want; i++) devs[(size_t)i] = (xc && std::strcmp(xc, "copy") == 0 && present > 0) ? i % present : i;
+            if (nbx_group_create(&g_group, devs.data(), want) != NBX_OK) die("NB_GPUS group creation");
             for (nbx_engine* e : g_group->eng) apply_env(e);
             g_engine = g_group->eng[0];
             return g_engine;
@@ -63,6 +69,7 @@ static int replicate_preset()
                                           e0->host.vx.data(), e0->host.vy.data(), e0->host.vz.data(), e0->host.m.data());
         if (rc != NBX_OK) return rc;
     }
+    g_group->fp32_stale = false;
     return NBX_OK;
 }
 

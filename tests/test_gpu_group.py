@@ -186,3 +186,41 @@ def test_bench_barnes_hut_workload(rx):
     assert res["unit"] == "body-steps/s" and res["value"] > 0
     assert res["ms_split"]["tree_nodes"] > 100000 and res["ms_split"]["bh_eval_kernel"] > 0
     assert res["cpu_baseline"]["rc"] == 0
+
+
+LEVEL1 = r"""
+import os, sys, json, zlib
+sys.path.insert(0, os.environ["NBX_ROOT"])
+import numpy as np
+import rust_exp_amd as rx
+rx.nb_stable_orbits(6000, 0.5, 30.0)
+frames = []
+for k in range(4):
+    rx.nb_step_barnes_hut(0.85, 0.01, 1)
+    frames.append(zlib.crc32(rx.nb_draw(256, 256).tobytes()))
+rx.nb_step_barnes_hut(0.0, 0.01, 1)            # theta == 0 delegates to brute force (nbody.rs:197-200)
+rx.nb_step_brute_force(0.01)
+frames.append(zlib.crc32(rx.nb_draw(256, 256).tobytes()))
+rx.nb_random_disk(3001)                        # ragged slabs
+rx.nb_step_barnes_hut(0.5, 0.01, 4)
+frames.append(zlib.crc32(rx.nb_draw(128, 96).tobytes()))
+print("RESULT " + json.dumps({"n": rx.nb_num_particles(), "frames": frames}))
+"""
+
+
+def test_six_level1_symbols_through_the_group(rx):
+    """NB_GPUS: the unmodified caller's six nb_* symbols served by the single-process group.  Bit-exact mode, same seed: every
+    frame nb_draw produces must equal the single-engine run's, pixel for pixel (CRC of the framebuffer), through Barnes-Hut steps,
+    the theta == 0 delegation, brute-force steps, a preset change to a ragged body count.  Two / three engines share the one test
+    GPU through the copy exchange (real RCCL when the box has that many GPUs)."""
+    outs = {}
+    for gpus in ("1", "2", "3"):
+        env = dict(os.environ, NBX_ROOT=ROOT, NB_SEED="77", NB_FORCE_MODE="strict", NB_GPUS=gpus)
+        if rx.device_count() < int(gpus):
+            env["NBX_GROUP_EXCHANGE"] = "copy"
+        r = subprocess.run([sys.executable, "-c", LEVEL1], env=env, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+        assert r.returncode == 0 and lines, r.stdout[-1000:] + r.stderr[-3000:]
+        outs[gpus] = json.loads(lines[-1][7:])
+    assert outs["1"]["n"] == 3001 and len(set(outs["1"]["frames"])) == len(outs["1"]["frames"])   # the scene really changes
+    assert outs["2"] == outs["1"] and outs["3"] == outs["1"]
