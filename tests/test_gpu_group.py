@@ -224,3 +224,35 @@ def test_six_level1_symbols_through_the_group(rx):
         outs[gpus] = json.loads(lines[-1][7:])
     assert outs["1"]["n"] == 3001 and len(set(outs["1"]["frames"])) == len(outs["1"]["frames"])   # the scene really changes
     assert outs["2"] == outs["1"] and outs["3"] == outs["1"]
+
+
+LEVEL1_FP16 = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["NBX_ROOT"])
+import numpy as np
+import rust_exp_amd as rx
+rx.nb_stable_orbits(8192, 0.5, 30.0)
+for k in range(5):
+    rx.nb_step_brute_force(0.01)
+fb = rx.nb_draw(256, 256)
+np.save(os.environ["NBX_OUT"], fb)
+print("RESULT ok")
+"""
+
+
+def test_level1_fp16_sources_through_the_group(rx, tmp_path):
+    """BASELINE config #5 as the unmodified caller would run it: NB_GPUS=<n> NB_SOURCE_BITS=16 (fast mode). Five brute-force steps
+    with bodies moving 0.3 per step: with the round-1 bug (stale half4 copies of the other slabs) the frames of 1 and 2 engines
+    would have nothing in common; with the half4 all-gather they differ by a few boundary pixels at most (different launch
+    shapes round differently)."""
+    fbs = {}
+    for gpus in ("1", "2"):
+        out = str(tmp_path / f"fb{gpus}.npy")
+        env = dict(os.environ, NBX_ROOT=ROOT, NB_SEED="78", NB_GPUS=gpus, NB_SOURCE_BITS="16", NBX_OUT=out)
+        if rx.device_count() < int(gpus):
+            env["NBX_GROUP_EXCHANGE"] = "copy"
+        r = subprocess.run([sys.executable, "-c", LEVEL1_FP16], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "RESULT ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+        fbs[gpus] = np.load(out)
+    lit = int((fbs["1"] != 0).sum())
+    assert lit > 3000 and int((fbs["1"] != fbs["2"]).sum()) <= max(20, lit // 200), (lit, int((fbs["1"] != fbs["2"]).sum()))
