@@ -96,7 +96,7 @@ enum nbx_option {
     NBX_OPT_BODIES_PER_THREAD = 2, /* register blocking B in {1,2,4}; 0 = auto */
     NBX_OPT_DIM = 3,               /* 2 or 3; 0 = auto (2 when every z and vz is zero) */
     NBX_OPT_PROFILE = 4,           /* 1 = record a HIP event pair around every kernel launch */
-    NBX_OPT_KERNEL_VARIANT = 5,    /* fast force kernel; -1 = auto (default: 7 / 6 for >= 32768 sources, else 1):
+    NBX_OPT_KERNEL_VARIANT = 5,    /* fast force kernel; -1 = auto (default: 7 / 6 for >= 16384 sources, else 1):
                                     *  7 = 6 for systems whose bodies all have the SAME mass: the per-interaction multiply
                                     *      by m_j leaves the loop (a = m * sum d/(r^2+eps)); falls back to 6 otherwise
                                     *  6 = packed fp32, sources through the scalar cache as SGPR operands (no LDS in the

@@ -193,7 +193,7 @@ int download_velocities(nbx_engine* e)
 void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* variant, int* bpt, int* jsplit, int* dim)
 {
     // Defaults from the measured launch-shape sweeps (profiles/r01_shapes_sweep*.txt, profiles/r02_k1_wave_split_sweep.txt):
-    //  * kernel, >= 32768 sources: the wave-split scalar-cache sweep -- variant 7 (unit-mass: 9 packed ops + 2 rcp per two
+    //  * kernel, >= 16384 sources: the wave-split scalar-cache sweep -- variant 7 (unit-mass: 9 packed ops + 2 rcp per two
     //    interactions) when every body has the same mass, else variant 6 (10 + 2); LDS tiles (variant 1) below that size.
     //  * variants 6 / 7: 256 targets per workgroup, S = smallest power of two giving >= 32 workgroups per CU (64 when a GPU
     //    owns < 131072 targets: tail effect), at most 64 and at least 4 source tiles per workgroup (one per wave).
@@ -203,7 +203,7 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
     //    of two giving >= 32 workgroups per CU (64 for variant 5 with < 131072 targets), capped at 64 and half the tiles.
     *dim = e->dim_opt ? e->dim_opt : (e->any_z ? 3 : 2);
     int v = e->variant;
-    if (v < 0) v = (tiles_total * kTile >= 32768) ? 7 : 1;
+    if (v < 0) v = (tiles_total * kTile >= 16384) ? 7 : 1;   // crossover measured in profiles/r02_small_n_variants.txt
     if (v == 7 && !(e->n > 0 && e->mass_min == e->mass_max && e->mass_min > 0.0f)) v = 6;   // unit-mass sweep needs equal masses
     *variant = v;
     // 256 targets per workgroup, 4 source quarters per workgroup; the fp16-source kernel (K4) keeps the 1024-target workgroups
