@@ -220,8 +220,12 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
         const int want = e->cu_count * (((wave_split || v == 5) && n_targets < 131072) ? 64 : 32);
         s = 1;
         while (iblocks * s < want && s < 64) s *= 2;
-        // every workgroup keeps >= 2 tiles of sources; a wave-split workgroup >= 4 (one per wave)
-        s = std::min(s, std::max(1, tiles_total / (wave_split ? 4 : 2)));
+        // every workgroup keeps >= 2 tiles of sources; a wave-split workgroup >= 4 (one per wave).  Tiny systems (at most one
+        // workgroup per CU even at one tile each) are latency-bound -- a wave alone on its SIMD needs ~8 us per tile -- and
+        // take one tile per workgroup: N <= 4096, 20.5 -> 12.5 us per K1 launch (profiles/r02_small_n_variants.txt)
+        int cap = std::max(1, tiles_total / (wave_split ? 4 : 2));
+        if (!wave_split && iblocks * tiles_total <= e->cu_count) cap = tiles_total;
+        s = std::min(s, cap);
     }
     s = std::max(1, std::min(s, tiles_total));
     *jsplit = s;
