@@ -413,3 +413,25 @@ def test_mode_switch_on_a_live_engine_and_half_source_size(rx, ob):
     assert e.half_sources_bytes() == ((5000 + 255) // 256) * 256 * 8
     from rust_exp_amd.engine import NBX_OPT_FORCE_MODE, NBX_OPT_SOURCE_PRECISION
     assert e.get_option(NBX_OPT_FORCE_MODE) == 0 and e.get_option(NBX_OPT_SOURCE_PRECISION) == 16
+
+
+def test_default_launch_shapes(rx, ob):
+    """The launch heuristic at the sizes the measurements were made on (profiles/r02_k1_wave_split_sweep.txt,
+    r02_small_n_variants.txt): a change of these defaults should be a decision, not an accident."""
+    def shape(n, equal_mass=True, shard=None, dim=3):
+        st = rx.plummer_sphere(n, dim=dim)
+        m = st["m"] if equal_mass else np.linspace(0.5, 2.0, n).astype(np.float32)
+        e = rx.NBodyEngine()
+        if shard:
+            e.set_shard(0, shard)
+        e.set_particles(st["px"], st["py"], st["vx"], st["vy"], m, st["pz"], st["vz"])
+        e.forces()
+        ll = e.last_launch()
+        return ll["variant"], ll["jsplit"], ll["grid"], ll["dim"]
+
+    assert shape(262144) == (7, 8, 8192, 3)                       # headline: unit-mass wave-split sweep, 8 partial slabs
+    assert shape(262144, equal_mass=False) == (6, 8, 8192, 3)     # unequal masses: the same kernel with the m_j multiply
+    assert shape(65536) == (7, 64, 16384, 3)                      # config #2
+    assert shape(262144, shard=8) == (7, 64, 8192, 3)             # one GPU of config #3: 32 768 targets keep the chip full
+    assert shape(16384, dim=2) == (7, 16, 1024, 2)                # first size on the wave-split kernel
+    assert shape(8192)[0] == 1 and shape(4096) == (1, 16, 128, 3)  # LDS tiles below; tiny systems: one tile per workgroup
