@@ -114,3 +114,105 @@ def brute_step(bodies, dt):
         py = add(py, mul(dt, vy))
         out.append([px, py, vx, vy, m])
     return out
+
+
+# ---- Barnes-Hut pieces (rs-src/nbody.rs:203-377) in the same exact model -----------------------------------------------------
+def sqrt(a):
+    """correctly rounded binary32 square root of an exact non-negative rational (Rust's f32::sqrt is IEEE sqrt)"""
+    import math
+
+    if a == 0:
+        return Fraction(0)
+    assert a > 0
+    # scale so that the integer square root carries > 60 significant bits, then round the (inexact) root: a tie is impossible
+    # unless the root is exact, because the square of a 25-bit midpoint would need 50 bits while `a` is a 24-bit value
+    e = a.numerator.bit_length() - a.denominator.bit_length()
+    shift = 140 - e
+    shift += shift & 1                                     # even, so that sqrt(2^shift) is a power of two
+    scaled = a * Fraction(2) ** shift
+    root = math.isqrt(scaled.numerator // scaled.denominator)
+    exact = root * root == scaled                           # (scaled is an integer when exact; harmless otherwise)
+    approx = Fraction(root, 1) / Fraction(2) ** (shift // 2)
+    if exact:
+        return rn(approx)
+    # the true root lies in (approx, approx + 2^-(shift/2)): 70 bits below the leading one, far inside any rounding interval
+    lo, hi = rn(approx), rn(approx + Fraction(1, 2 ** (shift // 2)))
+    assert lo == hi, "root too close to a rounding boundary for this model"
+    return lo
+
+
+HALF = Fraction(1, 2)
+
+
+class XNode:
+    """struct Node (nbody.rs:206-214) with exact-model fields"""
+
+    def __init__(self, x1, y1, x2, y2):
+        self.x1, self.y1, self.x2, self.y2 = x1, y1, x2, y2
+        self.px = self.py = self.m = Fraction(0)
+        self.children = None
+
+    def add_mass(self, px, py, m):                          # :303-320
+        assert m > 0
+        if self.m == 0:
+            self.px, self.py, self.m = px, py, m
+            return
+        inv = div(Fraction(1), add(self.m, m))              # 1.0 / (self.m + m)
+        self.px = mul(add(mul(self.px, self.m), mul(px, m)), inv)
+        self.py = mul(add(mul(self.py, self.m), mul(py, m)), inv)
+        self.m = add(self.m, m)
+
+    def centre(self):
+        return mul(add(self.x1, self.x2), HALF), mul(add(self.y1, self.y2), HALF)   # (x1 + x2) * 0.5
+
+    def quadrant(self, x, y):                               # :322-331 ; [UL, UR, LL, LR]
+        cx, cy = self.centre()
+        if y < cy:
+            return 2 if x < cx else 3
+        return 0 if x < cx else 1
+
+    def create_children(self):                              # :286-301
+        cx, cy = self.centre()
+        self.children = [XNode(self.x1, cy, cx, self.y2), XNode(cx, cy, self.x2, self.y2),
+                         XNode(self.x1, self.y1, cx, cy), XNode(cx, self.y1, self.x2, cy)]
+
+    def insert(self, px, py, m, depth):                     # :226-284
+        assert depth <= 50
+        if self.children is not None:
+            self.add_mass(px, py, m)
+            self.children[self.quadrant(px, py)].insert(px, py, m, depth + 1)
+            return
+        too_close = abs(rn(self.px - px)) < EPS and abs(rn(self.py - py)) < EPS
+        if self.m == 0 or too_close:
+            self.add_mass(px, py, m)
+            return
+        po, qo, mo = self.px, self.py, self.m
+        self.px = self.py = self.m = Fraction(0)
+        self.create_children()
+        self.insert(po, qo, mo, depth + 1)
+        self.insert(px, py, m, depth + 1)
+
+    def compute_force(self, px, py, m, theta):              # :333-377
+        if self.children is not None:
+            s = sub(self.x2, self.x1)
+            dx, dy = sub(self.px, px), sub(self.py, py)
+            d = sqrt(add(mul(dx, dx), mul(dy, dy)))
+            if d != 0 and div(s, d) < theta:                # s / 0 = +inf: never accepted
+                return force(px, py, m, self.px, self.py, self.m)
+            fx = fy = Fraction(0)
+            for c in self.children:
+                ax, ay = c.compute_force(px, py, m, theta)
+                fx, fy = add(fx, ax), add(fy, ay)
+            return fx, fy
+        if (self.px == px and self.py == py) or self.m == 0:
+            return Fraction(0), Fraction(0)
+        return force(px, py, m, self.px, self.py, self.m)
+
+
+def bh_forces(bodies, theta):
+    """forces of nb_step_barnes_hut's traversal on a list of [px, py, vx, vy, m] (exact binary32 values); root box = min/max"""
+    xs, ys = [b[0] for b in bodies], [b[1] for b in bodies]
+    root = XNode(min(xs), min(ys), max(xs), max(ys))        # :388-410
+    for b in bodies:
+        root.insert(b[0], b[1], b[4], 0)
+    return [root.compute_force(b[0], b[1], b[4], theta) for b in bodies], root

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import f32_exact as fx
-from test_oracle_exact_arithmetic import CASES, _same
+from test_oracle_exact_arithmetic import CASES, _same, bh_cases, bh_model
 
 pytestmark = pytest.mark.gpu
 
@@ -38,3 +38,25 @@ def test_strict_gpu_step_equals_exact_binary32_arithmetic(rx, dt_bits):
                 assert all(_same(g, x) for g, x in zip(got, exp)), (k, nb, i, [hex(x) for x in got], [hex(x) for x in exp])
                 checked += 1
     assert checked == 600
+
+
+def test_strict_gpu_barnes_hut_equals_exact_binary32_arithmetic(rx):
+    """The bit-exact Barnes-Hut path (host quadtree + k_bh_eval_strict) against the exact Fraction model of nbody.rs:203-377 on
+    the 40 small systems of the oracle's test: every body's force, bit for bit."""
+    e = rx.NBodyEngine(mode="strict")
+    checked = 0
+    for case, (cols, theta_bits) in enumerate(bh_cases()):
+        n = len(cols)
+        try:
+            want, _ = bh_model(cols, theta_bits)
+        except AssertionError:
+            continue
+        arr = lambda col: np.array(col, dtype=np.uint32).view(np.float32)   # noqa: E731
+        e.set_particles(arr([c[0] for c in cols]), arr([c[1] for c in cols]), np.zeros(n, np.float32), np.zeros(n, np.float32),
+                        arr([c[2] for c in cols]))
+        gx, gy, _ = e.forces(float(np.array([theta_bits], np.uint32).view(np.float32)[0]))
+        for i in range(n):
+            assert _same(int(gx[i:i + 1].view(np.uint32)[0]), fx.to_bits(want[i][0])), (case, i, "fx")
+            assert _same(int(gy[i:i + 1].view(np.uint32)[0]), fx.to_bits(want[i][1])), (case, i, "fy")
+        checked += 1
+    assert checked >= 35

@@ -120,3 +120,58 @@ def test_kick_drift_matches_exact_binary32_arithmetic(ob, dt_bits):
                 got = [int(np.asarray(p[f][i]).view(np.uint32)) for f in ("px", "py", "vx", "vy")]
                 exp = [fx.to_bits(want[i][j]) for j in range(4)]
                 assert all(_same(g, e) for g, e in zip(got, exp)), (k, nb, i, [hex(x) for x in got], [hex(x) for x in exp])
+
+
+def test_sqrt_model():
+    for u in (0x3F800000, 0x40000000, 0x40490FDB, 0x00000001, 0x007FFFFF, 0x7F7FFFFF, 0x3A83126F, 0x411FFFFF):
+        got = fx.to_bits(fx.sqrt(fx.from_bits(u)))
+        want = fx.bits_of_float(float(np.sqrt(np.float32(fx.float_of_bits(u)))))      # numpy's f32 sqrt is IEEE: a cross-check of the model only
+        assert got == want, (hex(u), hex(got), hex(want))
+
+
+def bh_cases():
+    """40 small systems as (columns of bit patterns [x, y, m], theta bits); some with a sub-EPS pair and an exact duplicate"""
+    rng = random.Random(11)
+    out = []
+    for case in range(40):
+        n = rng.choice([2, 3, 5, 9, 17, 30])
+        cols = []
+        for k in range(n):
+            x = ((rng.randint(-3, 4) + 127) << 23) | rng.getrandbits(23) | (rng.getrandbits(1) << 31)
+            y = ((rng.randint(-3, 4) + 127) << 23) | rng.getrandbits(23) | (rng.getrandbits(1) << 31)
+            m = ((rng.randint(-4, 4) + 127) << 23) | rng.getrandbits(23)
+            cols.append([x, y, m])
+        if case % 4 == 1 and n > 3:                 # a pair closer than EPS (merged) and an exact duplicate
+            cols[1] = [cols[0][0] + 3, cols[0][1] - 2, cols[1][2]]
+            cols[2] = list(cols[0])
+        out.append((cols, rng.choice([0x3F000000, 0x3F59999A, 0x3E99999A, 0x3F733333])))    # theta 0.5, 0.85, 0.3, 0.95
+    return out
+
+
+def bh_model(cols, theta_bits):
+    bodies = [[fx.from_bits(c[0]), fx.from_bits(c[1]), Fraction(0), Fraction(0), fx.from_bits(c[2])] for c in cols]
+    return fx.bh_forces(bodies, fx.from_bits(theta_bits))
+
+
+def test_barnes_hut_tree_and_traversal_match_exact_binary32_arithmetic(ob):
+    """The oracle's quadtree (sequential insert, f32 running fold of add_mass, (x1+x2)*0.5 midpoints, EPS merge) and its
+    traversal (sqrt, s/d < theta, hierarchical sums) against the exact Fraction model, bit for bit: forces of every body and the
+    root node's folded mass / centre, on 40 small random systems incl. sub-EPS pairs and duplicates (nbody.rs:203-377)."""
+    checked = 0
+    for case, (cols, theta_bits) in enumerate(bh_cases()):
+        n = len(cols)
+        try:
+            want, root = bh_model(cols, theta_bits)
+        except AssertionError:
+            continue                                 # depth > 50 / rounding-boundary root: outside the model
+        p = ob.particles([fx.float_of_bits(c[0]) for c in cols], [fx.float_of_bits(c[1]) for c in cols], np.zeros(n), np.zeros(n),
+                         [fx.float_of_bits(c[2]) for c in cols])
+        rc, gx, gy = ob.bh_forces(p, fx.float_of_bits(theta_bits))
+        assert rc == 0
+        for i in range(n):
+            assert _same(int(gx[i:i + 1].view(np.uint32)[0]), fx.to_bits(want[i][0])), (case, i, "fx")
+            assert _same(int(gy[i:i + 1].view(np.uint32)[0]), fx.to_bits(want[i][1])), (case, i, "fy")
+        rc, st = ob.bh_tree_stats(p)
+        assert rc == 0 and _same(fx.bits_of_float(st["m"]), fx.to_bits(root.m)) and _same(fx.bits_of_float(st["px"]), fx.to_bits(root.px))
+        checked += 1
+    assert checked >= 35
