@@ -216,3 +216,39 @@ def bh_forces(bodies, theta):
     for b in bodies:
         root.insert(b[0], b[1], b[4], 0)
     return [root.compute_force(b[0], b[1], b[4], theta) for b in bodies], root
+
+
+# ---- nb_draw's viewport transform and colour helpers (rs-src/nbody.rs:494-506, :525-537, :585-617) -------------------------------
+def trunc_i32(q):
+    """`as i32` of a finite in-range value: toward zero"""
+    n = abs(q.numerator) // q.denominator
+    return -n if q < 0 else n
+
+
+def draw_pixel(px, py, w, h):
+    """(x as i32, y as i32) of a body at (px, py) -- every f32 operation of nbody.rs:494-506 and :525-537 rounded once"""
+    W, H = Fraction(w), Fraction(h)                              # `w as f32`: exact for the sizes used
+    vp_wdh, org = Fraction(100), Fraction(0)
+    aspect = div(H, W)
+    half = div(vp_wdh, Fraction(2))
+    x1 = sub(org, half)
+    y1 = mul(sub(org, half), aspect)
+    x2 = add(org, half)
+    y2 = mul(add(org, half), aspect)
+    scalex = mul(div(Fraction(1), sub(x2, x1)), W)
+    scaley = mul(div(Fraction(1), sub(y2, y1)), H)
+    return trunc_i32(mul(sub(px, x1), scalex)), trunc_i32(mul(sub(py, y1), scaley))
+
+
+def rgb_to_abgr32(r, g, b, factor):
+    """nbody.rs:585-593 ; factor an exact binary32 value"""
+    ch = [min(255, trunc_i32(mul(Fraction(c), factor))) for c in (r, g, b)]
+    return ch[0] | (ch[2] << 16) | (ch[1] << 8)
+
+
+def add_abgr32(c1, c2):
+    """nbody.rs:595-617"""
+    out = 0
+    for sh in (24, 16, 8, 0):
+        out |= min(255, ((c1 >> sh) & 0xFF) + ((c2 >> sh) & 0xFF)) << sh
+    return out

@@ -175,3 +175,36 @@ def test_barnes_hut_tree_and_traversal_match_exact_binary32_arithmetic(ob):
         assert rc == 0 and _same(fx.bits_of_float(st["m"]), fx.to_bits(root.m)) and _same(fx.bits_of_float(st["px"]), fx.to_bits(root.px))
         checked += 1
     assert checked >= 35
+
+
+def test_draw_viewport_transform_and_colours_match_exact_arithmetic(ob):
+    """nb_draw's f32 viewport transform (aspect, origin, scale: nbody.rs:494-506), the truncating pixel cast (:536-537) and the
+    colour helpers (:585-617) against the exact model: a single body with velocity (+1, 0) lights its own pixel with the body
+    colour and the pixel to its left with the tail colour (octant 0, :541-554) -- compared for 300 positions across the
+    viewport and five framebuffer shapes, including positions an ulp either side of a pixel boundary."""
+    col_body = fx.rgb_to_abgr32(255, 215, 130, fx.from_bits(fx.bits_of_float(0.3)))
+    col_tail = fx.rgb_to_abgr32(255, 215, 130, fx.from_bits(fx.bits_of_float(0.25)))
+    assert (col_body, col_tail) == (0x0027404C, 0x0020353F)
+    assert ob.lib().orc_rgb_to_abgr32(255, 215, 130, 0.3) == col_body and ob.lib().orc_add_abgr32(0x00F0F0F0, col_body) == fx.add_abgr32(0x00F0F0F0, col_body)
+    rng = random.Random(3)
+    for (w, h) in ((512, 512), (640, 480), (101, 37), (64, 200), (3, 3)):
+        for k in range(60):
+            if k % 3 == 0:       # an ulp around a pixel boundary: boundary x_b = j * 100 / w - 50
+                j = rng.randint(1, w - 1)
+                xb = fx.bits_of_float(j * 100.0 / w - 50.0)
+                xbits = xb + rng.randint(-2, 2)
+            else:
+                xbits = fx.bits_of_float(rng.uniform(-49.5, 49.5))
+            ybits = fx.bits_of_float(rng.uniform(-49.5, 49.5) * h / w)
+            xi, yi = fx.draw_pixel(fx.from_bits(xbits), fx.from_bits(ybits), w, h)
+            p = ob.particles([fx.float_of_bits(xbits)], [fx.float_of_bits(ybits)], [1.0], [0.0], [1.0])
+            fb = ob.draw(p, w, h)
+            want = np.zeros((h, w), np.uint32)
+            if 0 <= xi < w and 0 <= yi < h:
+                want[yi, xi] = fx.add_abgr32(int(want[yi, xi]), col_body)
+            if 0 <= xi - 1 < w and 0 <= yi < h:
+                want[yi, xi - 1] = fx.add_abgr32(int(want[yi, xi - 1]), col_tail)
+            cx, cy = w // 2, h // 2
+            for (a, b) in ((cx, cy), (cx + 1, cy), (cx, cy + 1), (cx - 1, cy), (cx, cy - 1)):
+                want[b, a] = 0x00FF00FF
+            assert np.array_equal(fb, want), (w, h, hex(xbits), hex(ybits), xi, yi)
