@@ -41,7 +41,7 @@ DT = 0.01                    # RustNBodyExperiment.hs:45
 
 KERNEL_NAMES = {0: "k_force_tile", 1: "k_force_tile_pk", 2: "k_force_smem", 3: "k_force_tile_pk", 4: "k_force_tile_pkb",
                 5: "k_force_smem_pk", 6: "k_force_smem_pkw<unit_mass=0>", 7: "k_force_smem_pkw<unit_mass=1>", 16: "k_force_tile_pk_h",
-                -1: "k_force_strict<1>", -2: "k_force_strict<2>", -4: "k_force_strict<4>"}
+                -1: "k_force_strict", -8: "k_force_strict_pc<8,8>", -16: "k_force_strict_pc<16,4>"}
 
 
 def effective_cores():
@@ -172,6 +172,8 @@ def parse_args():
     ap.add_argument("--jsplit", type=int, default=0)
     ap.add_argument("--bpt", type=int, default=0)
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--strict-kernel", type=int, default=0, choices=[0, 1, 8, 16],
+                    help="bit-exact mode: 0 = by size; 16 / 8 = waves per 64-target workgroup; 1 = one thread per body")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="plummer", choices=["plummer", "two_galaxies", "bh"])
@@ -205,6 +207,7 @@ class SingleHost:
         e = rx.NBodyEngine(device=device, mode=args.mode)
         e.set_source_precision(args.source_bits)
         e.set_launch(jsplit=args.jsplit, bodies_per_thread=args.bpt, variant=args.variant)
+        e.set_strict_kernel(args.strict_kernel)
         if args.bh_tree != "default":
             e.set_bh_tree(args.bh_tree)
         if args.shard_of > 1:
@@ -252,11 +255,13 @@ class GroupHost:
         devices = [i % max(have, 1) for i in range(args.gpus)]
         g = rx.NBodyGroup(devices, mode=args.mode)
         g.set_source_precision(args.source_bits)
-        from rust_exp_amd.engine import NBX_OPT_BH_TREE, NBX_OPT_BODIES_PER_THREAD, NBX_OPT_JSPLIT, NBX_OPT_KERNEL_VARIANT
+        from rust_exp_amd.engine import (NBX_OPT_BH_TREE, NBX_OPT_BODIES_PER_THREAD, NBX_OPT_JSPLIT, NBX_OPT_KERNEL_VARIANT,
+                                         NBX_OPT_STRICT_KERNEL)
 
         g.set_option(NBX_OPT_JSPLIT, args.jsplit)
         g.set_option(NBX_OPT_BODIES_PER_THREAD, args.bpt)
         g.set_option(NBX_OPT_KERNEL_VARIANT, args.variant)
+        g.set_option(NBX_OPT_STRICT_KERNEL, args.strict_kernel)
         if args.bh_tree != "default":
             g.set_option(NBX_OPT_BH_TREE, {"host": 0, "device": 1}[args.bh_tree])
         g.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
@@ -316,6 +321,7 @@ class TorchHost:
                 dist.init_process_group(backend)
         slab = rx.sharded.TorchSlabEngine(self.local_rank, mode=args.mode, source_half=args.source_bits == 16)
         slab.eng.set_launch(jsplit=args.jsplit, bodies_per_thread=args.bpt, variant=args.variant)
+        slab.eng.set_strict_kernel(args.strict_kernel)
         if args.bh_tree != "default":
             slab.eng.set_bh_tree(args.bh_tree)
         self.sim = rx.ShardedNBody(slab)

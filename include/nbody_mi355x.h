@@ -124,6 +124,9 @@ enum nbx_option {
                                     * redone on the host since the engine was created */
     NBX_OPT_BH_LAST_TREE = 11,     /* read only: where the tree of the last Barnes-Hut evaluation was built: 0 host, 1 device */
     NBX_OPT_DRAW_AMBIGUOUS = 12,   /* read only: tails the last device draw left to the host; -1 = the last draw ran on the host */
+    NBX_OPT_STRICT_KERNEL = 13,    /* bit-exact all-pairs kernel: 0 = by targets per GPU (default), 16 or 8 = workgroups of that
+                                    * many waves per 64 targets (term producers + one summing wave), 1 = one thread per body.
+                                    * Bit-identical results whichever runs */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };
@@ -271,7 +274,7 @@ int32_t nbx_bh_host_timing(nbx_engine *e, double *ms4, int32_t *steps, int32_t *
 int32_t nbx_bh_work(nbx_engine *e, float theta, uint64_t *node_visits, uint64_t *pair_evals);
 /* launch geometry the last force launch used (for DESIGN/bench reporting); any pointer may be NULL.
  * Bit-exact kernel: jsplit = 1 (the source loop is never split), bodies_per_thread = 1 and
- * variant = -C, C = 1, 2 or 4 adjacent lanes sharing one target (terms in parallel, sums in order). */
+ * variant = -(NBX_OPT_STRICT_KERNEL actually used): -16 / -8 = waves per workgroup of 64 targets, -1 = one thread per body. */
 int32_t nbx_last_launch(const nbx_engine *e, int32_t *grid, int32_t *block, int32_t *jsplit,
                         int32_t *bodies_per_thread, int32_t *dim, int32_t *variant);
 

@@ -90,6 +90,10 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
         case NBX_OPT_KERNEL_VARIANT:
             e->variant = (int)value;
             return NBX_OK;
+        case NBX_OPT_STRICT_KERNEL:
+            if (value != 0 && value != 1 && value != 8 && value != 16) return fail(NBX_ERR_INVALID, "strict kernel must be 0 (auto), 1, 8 or 16");
+            e->strict_kernel = (int)value;
+            return NBX_OK;
         case NBX_OPT_DRAW_DEVICE:
             e->draw_device = value < 0 ? -1 : (value ? 1 : 0);   // -1 = by size (default)
             return NBX_OK;
@@ -124,6 +128,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_DIM: return e->dim_opt;
         case NBX_OPT_PROFILE: return e->profile;
         case NBX_OPT_KERNEL_VARIANT: return e->variant;
+        case NBX_OPT_STRICT_KERNEL: return e->strict_kernel;
         case NBX_OPT_SOURCE_PRECISION: return e->source_half ? 16 : 32;
         case NBX_OPT_DRAW_DEVICE: return e->draw_device;
         case NBX_OPT_BH_TREE: return e->bh_tree_device;
@@ -296,7 +301,7 @@ int32_t nbx_forces(nbx_engine* e, float theta, int32_t cap, float* fx, float* fy
             if (rc != NBX_OK) return rc;
             guard = e->d_guard;
         }
-        HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream, nullptr, guard));
+        HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream, &e->last, guard, e->strict_kernel));
     } else {
         bool on_device = false;
         if (e->use_device_tree()) {

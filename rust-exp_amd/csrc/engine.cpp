@@ -288,7 +288,7 @@ int step_brute(nbx_engine* e, float dt)
                 if (rc != NBX_OK) return rc;
                 guard = e->d_guard;
             }
-            HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream, &e->last, guard));
+            HIP_TRY(nbx::launch_force_strict(e->d_posm, e->n, e->lo, slab, e->d_f2, e->stream, &e->last, guard, e->strict_kernel));
         }
         {
             ProfScope ps(e, NBX_K_INTEGRATE);

@@ -77,7 +77,7 @@ struct nbx_engine {
     int source_half = 0;
 
     // options
-    int force_mode = 0, jsplit = 0, bpt = 0, dim_opt = 0, profile = 0, variant = -1;
+    int force_mode = 0, jsplit = 0, bpt = 0, dim_opt = 0, profile = 0, variant = -1, strict_kernel = 0;
     bool any_z = false;
     float mass_min = 0.0f, mass_max = 0.0f;   // over the current bodies (masses never change during a run)
 

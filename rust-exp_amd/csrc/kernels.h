@@ -53,13 +53,15 @@ hipError_t launch_integrate(float4* posm, int lo, int n_targets, float4* vel, co
 hipError_t launch_reduce_forces(const float4* posm, int lo, int n_targets, const float4* acc_partial, int jsplit,
                                 int acc_stride, float4* out, hipStream_t stream);
 
-// strict (bit-exact) pair: one thread per body, ascending j, IEEE divide, no contraction. 2-D.
-// 1, 2 or 4 adjacent lanes share one target (terms in parallel, sums in order); info->variant = -(group size).
+// strict (bit-exact) pair: ascending j per target, IEEE divide, no contraction. 2-D.
+// kernel: 16 or 8 = workgroups of that many waves per 64 targets (term producers + one summing wave), 1 = one thread per body,
+// anything else = by size (strict_kernel_choice); info->variant = -(kernel). Results are bit-identical whichever runs.
 // guard (optional device word): when given, max|coordinate| of the sources is reduced into it first and the kernel takes
 // the short correctly-rounded division whenever that maximum is <= 1e5 -- the caller passes it only if
 // strict_fastdiv_ok(min mass, max mass); null = always the compiler's IEEE division. Results are identical either way.
 hipError_t launch_force_strict(const float4* posm, int n, int lo, int n_targets, float2* force_out,
-                               hipStream_t stream, ForceLaunch* info = nullptr, unsigned* guard = nullptr);
+                               hipStream_t stream, ForceLaunch* info = nullptr, unsigned* guard = nullptr, int kernel = 0);
+int strict_kernel_choice(int n_targets);
 bool strict_fastdiv_ok(float mass_min, float mass_max);
 // *guard = float bits of max(|x|, |y|, |z|) over posm[0..n_records) (NaN counts as +inf)
 hipError_t launch_max_coord(const float4* posm, int n_records, unsigned* guard, hipStream_t stream);

@@ -37,6 +37,7 @@ NBX_OPT_BH_WAVE = 9
 NBX_OPT_BH_FALLBACKS = 10
 NBX_OPT_BH_LAST_TREE = 11
 NBX_OPT_DRAW_AMBIGUOUS = 12
+NBX_OPT_STRICT_KERNEL = 13
 
 NBX_K_FORCE = 0
 NBX_K_INTEGRATE = 1
@@ -352,6 +353,11 @@ class NBodyEngine:
         self.set_option(NBX_OPT_BODIES_PER_THREAD, bodies_per_thread)
         self.set_option(NBX_OPT_DIM, dim)
         self.set_option(NBX_OPT_KERNEL_VARIANT, variant)
+
+    def set_strict_kernel(self, kernel=0):
+        """bit-exact all-pairs kernel: 0 = by size, 16 / 8 = waves per 64-target workgroup (producers + summing wave),
+        1 = one thread per body; results are bit-identical"""
+        self.set_option(NBX_OPT_STRICT_KERNEL, kernel)
 
     # presets (nbody.rs:39-104) with a seedable generator
     def seed(self, seed):

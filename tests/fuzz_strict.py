@@ -39,6 +39,8 @@ def main():
         p = ob.particles(x, y, rng.normal(0, 1, n), rng.normal(0, 1, n), m)
         theta = float(rng.choice([0.3, 0.5, 0.85, 0.95]))
         e = rx.NBodyEngine(mode="strict")
+        kernel = int(rng.choice([0, 1, 8, 16]))    # NBX_OPT_STRICT_KERNEL: every all-pairs kernel must give the same bits
+        e.set_strict_kernel(kernel)
         e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
         q = p.copy()
         ok = True
@@ -63,7 +65,7 @@ def main():
             print("seed", seed, "exception", repr(ex))
         if not ok:
             bad += 1
-            print("MISMATCH seed", seed, "n", n, "scale", scale, "masses", mk, "theta", theta)
+            print("MISMATCH seed", seed, "n", n, "scale", scale, "masses", mk, "theta", theta, "kernel", kernel)
     print("fuzz: %d cases, %d mismatches, %.1f s" % (count, bad, time.time() - t0))
 
 

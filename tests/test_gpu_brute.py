@@ -91,6 +91,61 @@ def test_strict_full_size_slice_65536(rx, ob):
     assert_bit_equal(fx[-64:], ofx); assert_bit_equal(fy[-64:], ofy)
 
 
+@pytest.mark.parametrize("kernel", [1, 8, 16])
+@pytest.mark.parametrize("n", [1, 2, 3, 55, 56, 57, 59, 60, 61, 63, 64, 65, 111, 112, 113, 119, 120, 121, 255, 256, 257, 1000, 3333])
+def test_every_strict_kernel_is_bit_exact(rx, ob, kernel, n):
+    """NBX_OPT_STRICT_KERNEL: workgroups of 16 or 8 waves per 64 targets (term producers handing 60- / 56-source chunks to one
+    summing wave) and one thread per body all give the oracle's bits -- at sizes on every side of the chunk sizes, the target
+    tile and the 256-record padding."""
+    p = ob.random_disk(n, 100 + n)
+    e = rx.NBodyEngine(mode="strict")
+    e.set_strict_kernel(kernel)
+    load(e, p)
+    fx, fy, _ = e.forces()
+    assert e.last_launch()["variant"] == -kernel
+    ofx, ofy = ob.brute_forces(p)
+    assert_bit_equal(fx, ofx, "fx"); assert_bit_equal(fy, ofy, "fy")
+    q = p.copy()
+    for _ in range(2):
+        e.step_brute_force(DT)
+        ob.step_brute_force(q, DT)
+    st = e.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        assert_bit_equal(st[k], q[k], k)
+
+
+@pytest.mark.parametrize("kernel", [1, 8, 16])
+def test_every_strict_kernel_on_every_slab(rx, ob, kernel):
+    """the same kernels on a slab of the targets (the sharded layout): 5 ranks' slabs of 4001 bodies stitch to the oracle's
+    forces; the slabs start in the middle of chunks and target tiles"""
+    n, world = 4001, 5
+    p = ob.stable_orbits(n, 0.5, 30.0, 12)
+    ofx, ofy = ob.brute_forces(p, nthreads=8)
+    for r in range(world):
+        e = rx.NBodyEngine(mode="strict")
+        e.set_strict_kernel(kernel)
+        e.set_shard(r, world)
+        load(e, p)
+        lo, hi = e.slab()
+        fx, fy, _ = e.forces()
+        assert e.last_launch()["variant"] == -kernel
+        assert_bit_equal(fx[lo:hi] if len(fx) == n else fx, ofx[lo:hi], f"rank {r} fx")
+        assert_bit_equal(fy[lo:hi] if len(fy) == n else fy, ofy[lo:hi], f"rank {r} fy")
+
+
+def test_strict_kernel_chosen_by_targets_per_gpu(rx):
+    """16 waves per workgroup while the 64-target workgroups fit the CUs, 8 up to ~120 000 targets, one thread per body
+    beyond when its waves fill the SIMDs evenly (profiles/r02_strict_kernel_sweep.txt)"""
+    for n, want in ((10000, -16), (16384, -16), (16385, -8), (65536, -8), (131072, -1), (163840, -8), (262144, -1)):
+        st = rx.plummer_sphere(n, dim=2)
+        e = rx.NBodyEngine(mode="strict")
+        e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+        e.forces()
+        assert e.last_launch()["variant"] == want, (n, e.last_launch())
+    with pytest.raises(Exception):
+        e.set_strict_kernel(4)
+
+
 # ---------------------------------------------------------------- fast = stated tolerance
 def rel_err(a, b):
     return np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(b).max(), 1e-30)
@@ -346,8 +401,9 @@ def test_profile_records_kernel_time(rx, ob):
     assert cnt2 == 4 and ms2 > 0 and ms2 < ms
 
 
+@pytest.mark.parametrize("kernel", [1, 8, 16])
 @pytest.mark.parametrize("case", ["edge_of_fast_range", "tiny_masses", "huge_masses", "far_coordinates", "zero_mass", "mixed_16k"])
-def test_strict_division_paths_are_bit_exact(rx, ob, case):
+def test_strict_division_paths_are_bit_exact(rx, ob, case, kernel):
     """The bit-exact kernel divides with the short exact sequence only when the launch has proven that no pair needs the
     scaling / fix-up steps of the IEEE expansion (masses in [1e-10, 1e10], |coordinates| <= 1e5), and with the
     compiler's full expansion otherwise. Both must equal the oracle bit for bit: at the edge of the fast range (mass
@@ -374,9 +430,10 @@ def test_strict_division_paths_are_bit_exact(rx, ob, case):
         m[::4] = 0.0
     p = ob.particles(x, y, rng.normal(0, 1, n), rng.normal(0, 1, n), m)
     e = rx.NBodyEngine(mode="strict")
+    e.set_strict_kernel(kernel)
     e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     fx, fy, _ = e.forces(0.0)
-    wx, wy = ob.brute_forces(p, 0, n)
+    wx, wy = ob.brute_forces(p, 0, n, nthreads=8)
     assert_bit_equal(fx, wx, case + " fx"); assert_bit_equal(fy, wy, case + " fy")
     q = p.copy()
     for _ in range(2):
