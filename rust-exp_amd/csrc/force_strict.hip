@@ -193,6 +193,7 @@ __device__ __forceinline__ void strict_pc_sweep(const float4* __restrict__ posm,
                                                 float2* __restrict__ force_out, float4* __restrict__ terms_raw)
 {
     constexpr int kChunk = (WAVES - 1) * SHARE;    // sources per hand-over
+    constexpr bool kLate = WAVES <= 8;             // see the producers' hand-over
     constexpr int kPairs = kChunk / 2;
     float4 (*terms)[kPairs][64] = reinterpret_cast<float4 (*)[kPairs][64]>(terms_raw);   // [buffer][source pair][target]
     const int lane = threadIdx.x & 63;
@@ -234,7 +235,7 @@ __device__ __forceinline__ void strict_pc_sweep(const float4* __restrict__ posm,
                 if (q > q_last) q = q_last;
                 pc_issue(q, src);                  // the next chunk's records: in flight during the rest of this chunk
                 __builtin_amdgcn_sched_barrier(0);
-                float4* const out = reinterpret_cast<float4*>(out0 + buf);
+                float4 t[SHARE / 2];
 #pragma unroll
                 for (int k = 0; k < SHARE; k += 2) {
                     const v2f_s qj = d[k] * d[k], qk = d[k + 1] * d[k + 1];
@@ -248,11 +249,25 @@ __device__ __forceinline__ void strict_pc_sweep(const float4* __restrict__ posm,
                         if (j == i || j >= n) tj = v2f_s{0.0f, 0.0f};
                         if (j + 1 == i || j + 1 >= n) tk = v2f_s{0.0f, 0.0f};
                     }
-                    out[(k / 2) * 64] = make_float4(tj.x, tj.y, tk.x, tk.y);
+                    t[k / 2] = make_float4(tj.x, tj.y, tk.x, tk.y);
                 }
-                buf ^= (unsigned)(kPairs * 64 * sizeof(float4));
+                // Hand-over.  Two workgroups per CU (kLate): wait, meet the other waves, and only THEN write this chunk's terms --
+                // they drain while the next chunk is computed (the wait covers the previous chunk's writes, issued a whole chunk
+                // ago), and the summing wave reads a chunk two barriers after its arithmetic.  One workgroup per CU: write, wait,
+                // meet -- measured 3 % faster there (profiles/r02_strict_kernel_sweep.txt; the late writes land on the summing
+                // wave's first reads of the round and nothing else on the CU fills the gap).
+                float4* const out = reinterpret_cast<float4*>(out0 + buf);
+                if (!kLate) {
+#pragma unroll
+                    for (int k = 0; k < SHARE / 2; k++) out[k * 64] = t[k];
+                }
                 pc_arrive(src);
                 __syncthreads();
+                if (kLate) {
+#pragma unroll
+                    for (int k = 0; k < SHARE / 2; k++) out[k * 64] = t[k];
+                }
+                buf ^= (unsigned)(kPairs * 64 * sizeof(float4));
             }
         };
         // j0 runs off, off + kChunk, ...: `j0 < c_end * kChunk` holds exactly for the chunks below c_end (off < kChunk)
@@ -260,7 +275,11 @@ __device__ __forceinline__ void strict_pc_sweep(const float4* __restrict__ posm,
         sweep(min(c_self_hi + 1, c_ragged), std::true_type{});
         sweep(c_ragged, std::false_type{});
         sweep(chunks, std::true_type{});
-        __syncthreads();                           // the summing wave's last round
+        if (kLate) {
+            pc_arrive(src);                        // the last chunk's writes
+            __syncthreads();
+        }
+        __syncthreads();                           // (the summing wave's loop ends with one)
     } else {
         // The adds are one dependent chain per target (9.5 cycles per v_pk_add_f32, tools/ubench_chain.hip), so the only thing
         // the summing wave can do about its pace is never to wait for LDS: a chunk's term records are read in groups, two
@@ -275,7 +294,8 @@ __device__ __forceinline__ void strict_pc_sweep(const float4* __restrict__ posm,
 #define NBX_PC_FOLD(SRC)    _Pragma("unroll") for (int u = 0; u < kG; u++) {                                             \
             fxy = fxy + v2f_s{SRC[u].x, SRC[u].y};     /* nbody.rs:141-142, source j     */                               \
             fxy = fxy + v2f_s{SRC[u].z, SRC[u].w}; }   /*                   source j + 1 */
-        __syncthreads();                           // chunk 0 is being produced
+        __syncthreads();                           // chunk 0 is being computed,
+        if (kLate) __syncthreads();                // ... written (see the producers' hand-over)
         for (int c = 0; c < chunks; c++) {
             const float4 (*in)[64] = terms[c & 1];
             NBX_PC_READ(0, ring[0])

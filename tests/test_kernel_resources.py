@@ -1,0 +1,50 @@
+"""Build-time facts about the bit-exact kernels that a silent compiler change would turn into a large slowdown, checked without a
+GPU: no scratch (a spilled summing wave once ran the producer/consumer kernel at 60 % of its speed with identical results) and
+VGPR budgets that keep the intended number of waves per SIMD."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rust-exp_amd", "csrc")
+
+
+def _metadata(tmp_path, source, extra):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "k.s"
+    cmd = [hipcc, "-std=c++17", "-O3", "--offload-arch=gfx950", "-S", "--cuda-device-only", *extra,
+           os.path.join(CSRC, source), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, cwd=CSRC)
+    text = out.read_text()
+    kernels = {}
+    for block in text.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
+                         for k in ("private_segment_fixed_size", "vgpr_count", "sgpr_count", "group_segment_fixed_size",
+                                   "vgpr_spill_count", "sgpr_spill_count")}
+    return kernels
+
+
+def _strict_flags():
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    strict = re.search(r"^STRICT\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    sched = re.search(r"^STRICT_SCHED\s*\?=\s*(.*)$", mk, re.M).group(1).split()
+    return strict + sched
+
+
+def test_bit_exact_all_pairs_kernels_use_no_scratch_and_keep_their_occupancy(tmp_path):
+    k = _metadata(tmp_path, "force_strict.hip", _strict_flags())
+    pc16 = next(v for n, v in k.items() if "k_force_strict_pcILi16ELi4" in n)
+    pc8 = next(v for n, v in k.items() if "k_force_strict_pcILi8ELi8" in n)
+    one = next(v for n, v in k.items() if "k_force_strictE" in n)
+    for v in (pc16, pc8, one):
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0, v
+    assert pc16["vgpr_count"] <= 128 and pc16["group_segment_fixed_size"] == 2 * 30 * 64 * 16      # 16 waves on one CU
+    assert pc8["vgpr_count"] <= 128 and pc8["group_segment_fixed_size"] == 2 * 28 * 64 * 16        # two workgroups per CU
+    assert 2 * pc8["group_segment_fixed_size"] <= 160 * 1024
+    assert one["vgpr_count"] <= 128                                                                 # >= 4 waves per SIMD
