@@ -136,7 +136,12 @@ __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* 
     //  had arrived, so that a wave leaving the subtree finds its next record waiting: 0.71 vs 0.62 ms -- every extra scalar load
     //  costs more than the latency it hides.  PMC of the shipped walk, profiles/r02_bh_walk_pmc_summary.json:
     //  13.4 VALU + 12.9 SALU instructions and 4.9 branches per visit, VALU 55 % busy, 66 % of the wave-cycles waiting on the
-    //  scalar load: a dependent chain load -> decide -> next index, 800 cycles per visit with 8 waves per SIMD.)
+    //  scalar load: a dependent chain load -> decide -> next index, 800 cycles per visit with 8 waves per SIMD.
+    //  Last experiment of round 2: the whole loop hand-written -- 14 scalar instructions per visit instead of the compiler's 22
+    //  (SMEM with a 32-bit register offset, SCC straight from the mask arithmetic, exec set and restored around the take block
+    //  without execz skips), bit-identical results: 0.632 vs 0.618 ms at 1 M bodies, 0.227 vs 0.252 at 262 144, 0.099 vs 0.111 at
+    //  10 000.  Where the tree outgrows the caches the visit is bound by the latency of the dependent scalar load, not by issue; the
+    //  small-tree gain did not justify 60 lines of assembly with hand-placed wait states.  Not shipped.)
     while (i < n_nodes) {
         typedef float f8 __attribute__((ext_vector_type(8)));
         const f8 rec = *reinterpret_cast<const f8*>(&nodes[(unsigned)__builtin_amdgcn_readfirstlane(i)]);

@@ -49,7 +49,7 @@ __device__ __forceinline__ void ref_force(float px1, float py1, float m1, float 
 }
 
 // Two consecutive sources per step with PACKED fp32.  The bit-exact kernels are VALU-bound (one thread per body with scalar
-// instructions: 99.8 % busy at 15.3 instructions per 64 pairs, profiles/r02_strict_pmc_summary.json); v_pk_*_f32 does two
+// instructions: 99.8 % busy at 15.3 instructions per 64 pairs, profiles/r02_strict_pmc_before_packing_262144.json); v_pk_*_f32 does two
 // lanes' worth per instruction: 11.7 per 64 pairs.  Every packed lane is the same correctly rounded IEEE operation as its
 // scalar form, in the same order, and the two terms are added to the running sums in ascending j: bit-identical results.
 typedef float v2f_s __attribute__((ext_vector_type(2)));

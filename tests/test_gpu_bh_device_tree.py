@@ -293,6 +293,41 @@ def test_wave_uniform_walk_is_bit_identical_to_the_per_lane_walk(rx, ob, n, thet
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+@pytest.mark.parametrize("theta", [0.5, 0.25, 1.0])
+def test_wave_uniform_walk_on_a_lattice_takes_the_exact_test_path(rx, ob, theta):
+    """Bodies on a power-of-two lattice put many node centres at distances where s/d equals theta exactly or to within the
+    1e-5 band: those visits take the reference's own sqrt-and-divide test (take_node's exact path). Decisions and sums
+    must still be the per-lane walk's, bit for bit, and the forces must agree with the oracle's Barnes-Hut to the fast-mode
+    tolerance."""
+    from rust_exp_amd.engine import NBX_OPT_BH_WAVE
+
+    side = 64
+    gx, gy = np.meshgrid(np.arange(side, dtype=np.float32), np.arange(side, dtype=np.float32))
+    x = (gx.ravel() - 31.5).astype(np.float32)
+    y = (gy.ravel() - 31.5).astype(np.float32)
+    n = x.size
+    rng = np.random.default_rng(5)
+    order = rng.permutation(n)
+    p = ob.particles(x[order], y[order], np.zeros(n), np.zeros(n), np.ones(n))
+    res = []
+    for wave in (0, 1):
+        e = engines(rx, p)
+        e.set_bh_tree("device")
+        e.set_option(NBX_OPT_BH_WAVE, wave)
+        fx, fy, _ = e.forces(theta)
+        res.append((fx, fy))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # against the oracle: a lattice is all ties, and the device tree's exactly summed centres of mass may land on the other side
+    # of one than the reference's f32 running fold -- each flip replaces a node by its children, an error of the size of the
+    # theta approximation itself; everything else agrees to fp32 rounding
+    rc, ofx, ofy = ob.bh_forces(p, theta)
+    assert rc == 0
+    scale = max(np.abs(ofx).max(), np.abs(ofy).max())
+    err = np.maximum(np.abs(res[1][0] - ofx), np.abs(res[1][1] - ofy)) / scale
+    assert np.median(err) <= 2e-5 and err.max() <= 0.05, (np.median(err), err.max())
+
+
 @pytest.mark.parametrize("case", ["identical", "collinear_x", "collinear_y", "two_clusters_far_apart", "three"])
 def test_device_tree_degenerate_inputs(rx, ob, case):
     """Zero-extent boxes, 31-level chains and bodies that share a key: the scan-based build must stay finite, keep the
