@@ -517,6 +517,12 @@ def main():
             lane_ops_per_visit = 8.4   # 4 VALU lane-ops for the opening test + 6 for the pair law on the ~74 % of visits that take the node
             valu_peak = info["compute_units"] * 4 * info["clock_khz"] * 1e3 * 32.0   # lane-ops/s: 32 lanes per cycle per SIMD
             visits_per_s = wk["node_visits"] / ev_s
+            bh_traffic, bh_traffic_info = None, None
+            if world == 1 and not args.no_traffic:   # HBM bytes of the traversal kernel, measured now (see measure_traffic)
+                tail = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
+                bh_traffic_info = measure_traffic(tail + ["--no-cpu-baseline", "--no-traffic"], "k_bh_eval")
+                if bh_traffic_info:
+                    bh_traffic = bh_traffic_info["bytes_per_launch"]
             out.update({
                 "metric": f"bodies/s through nb_step_barnes_hut (theta={args.theta}) at N={n}",
                 "value": value, "unit": "body-steps/s", "dtype": "f32",
@@ -533,7 +539,8 @@ def main():
                              "node_visits_per_body": wk["node_visits"] / n, "pair_evals_per_body": wk["pair_evals"] / n,
                              "kernel_avg_ms": per[0]["bh_eval_ms"],
                              "hbm_algorithmic_bytes_per_launch": 32.0 * ht["nodes"] + 24.0 * n,
-                             "hbm_frac_of_8TBps": (32.0 * ht["nodes"] + 24.0 * n) / ev_s / 8e12, "traffic": None},
+                             "hbm_frac_of_8TBps": (32.0 * ht["nodes"] + 24.0 * n) / ev_s / 8e12, "traffic": bh_traffic,
+                             "traffic_measurement": bh_traffic_info},
             })
         if world > 1 or host_kind != "single":
             out["per_gpu"] = per
