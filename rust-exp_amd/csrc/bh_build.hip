@@ -379,34 +379,44 @@ __device__ __forceinline__ int group_end(const unsigned long long* __restrict__ 
     return hi;
 }
 
-// one thread per sorted body a: writes all nodes that start at a (pre-order slots base[a] ...)
+// One thread per NODE (pre-order slot k): its first body a is the last one with base[a] <= k (binary search over the scan),
+// its depth follows from k - base[a], its body range from a gallop over the sorted keys, and the whole 32-byte record is
+// written at once.  (Round 2's first version looped per BODY over the chain of nodes that start at it -- up to 31 for a body
+// that opens a deep chain, one for most: 134 us at 1 M bodies, against 28 us like this.)
 __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
                                                 const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const Prefix pre,
                                                 const int n, const int node_cap, BhNode* __restrict__ out)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;   // 64 threads per workgroup for small systems, kTile otherwise
-    if (a >= n) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = pre.base[n];
+    if (k >= total || total > node_cap) return;
+    int a = 0;
+    {
+        int hi = n;                                 // base[a] <= k < base[hi]
+        while (hi - a > 1) {
+            const int mid = (a + hi) >> 1;
+            if (pre.base[mid] <= k) a = mid; else hi = mid;
+        }
+    }
     const int first = pre.base[a];
-    const int count = pre.base[a + 1] - first;
-    if (count == 0 || pre.base[n] > node_cap) return;
+    const int count = pre.base[a + 1] - first;      // > 0: bodies that start no node share base[] with their successor
     const unsigned long long ka = keys[a];
     const int top = a == 0 ? 0 : common_digits(keys[a - 1], ka) + 1;   // depth of the shallowest node starting here
     const int leaf = top + count - 1;
+    const int l = top + (k - first);
     const float4 p = sb[a];
-    // node sizes: replay the body's path with the reference's f32 midpoints (nbody.rs:289-300)
+    // node size: replay the body's path with the reference's f32 midpoints (nbody.rs:289-300)
     float x1 = dec_f32(box[0]), y1 = dec_f32(box[1]), x2 = dec_f32(box[2]), y2 = dec_f32(box[3]);
 #pragma unroll 1
-    for (int l = 0; l < top; l++) descend(x1, y1, x2, y2, p.x, p.y);
-#pragma unroll 1
-    for (int l = top; l <= leaf; l++) {
-        out[first + (l - top)].s = __fsub_rn(x2, x1);   // nbody.rs:341
-        if (l < leaf) descend(x1, y1, x2, y2, p.x, p.y);
-    }
-    // the leaf: this body, or the bodies that share its key (same level-31 cell / EPS-merged pair of entities), folded in
-    // ARRIVAL order like the reference's add_mass (nbody.rs:303-320).  Equal keys come out of the stable sort in index order;
-    // a merged pair of entities is two such ascending segments back to back: fold them as a two-way merge by index.
-    int b = run_end(keys, a, n);
-    {
+    for (int d = 0; d < l; d++) descend(x1, y1, x2, y2, p.x, p.y);
+    BhNode o;
+    o.s = __fsub_rn(x2, x1);                        // nbody.rs:341
+    o.pad1 = 0;
+    if (l == leaf) {
+        // the leaf: this body, or the bodies that share its key (same level-31 cell / EPS-merged pair of entities), folded in
+        // ARRIVAL order like the reference's add_mass (nbody.rs:303-320).  Equal keys come out of the stable sort in index order;
+        // a merged pair of entities is two such ascending segments back to back: fold them as a two-way merge by index.
+        const int b = run_end(keys, a, n);
         int split = b;                              // start of the second ascending segment, if any
         for (int j = a + 1; j < b; j++)
             if (idx[j] < idx[j - 1]) { split = j; break; }
@@ -418,15 +428,11 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
             if (take_u) u++; else v++;
             fold_mass(px, py, m, q.x, q.y, q.w);    // the first one is copied exactly (m == 0 branch)
         }
-        BhNode* o = &out[first + count - 1];
-        o->px = px; o->py = py; o->m = m;
-        o->skip = first + count;
-        o->interior = 0; o->q = -1.0f; o->pad1 = 0;
-    }
-    // interior nodes, deepest first: the group only grows as the prefix gets shorter
-#pragma unroll 1
-    for (int l = leaf - 1; l >= top; l--) {
-        b = group_end(keys, ka, b, n, l);
+        o.px = px; o.py = py; o.m = m;
+        o.skip = first + count;
+        o.interior = 0; o.q = -1.0f;
+    } else {
+        const int b = group_end(keys, ka, a + 1, n, l);
         double m, mx, my;
         if (b - a <= 8) {
             m = 0.0; mx = 0.0; my = 0.0;
@@ -437,13 +443,15 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
         } else {
             m = pre.m[b] - pre.m[a]; mx = pre.mx[b] - pre.mx[a]; my = pre.my[b] - pre.my[a];
         }
-        BhNode* o = &out[first + (l - top)];
-        if (m != 0.0) { o->px = (float)(mx / m); o->py = (float)(my / m); }
-        else          { o->px = p.x; o->py = p.y; }       // massless group: any position, zero contribution
-        o->m = (float)m;
-        o->skip = pre.base[b];
-        o->interior = 1; o->q = __fmul_rn(o->s, o->s); o->pad1 = 0;
+        if (m != 0.0) { o.px = (float)(mx / m); o.py = (float)(my / m); }
+        else          { o.px = p.x; o.py = p.y; }       // massless group: any position, zero contribution
+        o.m = (float)m;
+        o.skip = pre.base[b];
+        o.interior = 1; o.q = __fmul_rn(o.s, o.s);
     }
+    float4* dst = reinterpret_cast<float4*>(&out[k]);
+    dst[0] = make_float4(o.px, o.py, o.m, o.s);
+    dst[1] = make_float4(__int_as_float(o.skip), __int_as_float(o.interior), o.q, __int_as_float(o.pad1));
 }
 
 __global__ void k_init_box(unsigned* box)
@@ -714,8 +722,10 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, k.sb, mk, n, k.block_sums);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kTile), 0, stream, k.block_sums, sb);
     hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, k.sb, mk, n, k.block_sums, k.pre, k.counters);
+    // one thread per node; the node count is only known on the device, so the grid covers the whole pool (threads beyond
+    // base[n] leave at once; the pool check is inside)
     const int eb = n <= 65536 ? 64 : kTile;   // spread a small system's few waves over the CUs
-    hipLaunchKernelGGL(k_emit, dim3((n + eb - 1) / eb), dim3(eb), 0, stream, k.sb, mk, k.idx1, k.box, k.pre, n, node_cap, out);
+    hipLaunchKernelGGL(k_emit, dim3((unsigned)((node_cap + eb - 1) / eb)), dim3(eb), 0, stream, k.sb, mk, k.idx1, k.box, k.pre, n, node_cap, out);
     e = hipMemcpyAsync(host_counters, k.counters, 2 * sizeof(int), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
