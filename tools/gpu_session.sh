@@ -106,8 +106,8 @@ PY
       N=${FUZZ_N:-200}
       { timeout 3000 python tests/fuzz_strict.py 0 $N; timeout 3000 python tests/fuzz_fast.py 0 $N; timeout 3000 python tests/fuzz_api.py 0 $((N/4)); timeout 3000 python tests/fuzz_group.py 0 $((N/2)); } > $O/${TAG}_fuzz.txt 2>&1
       tail -30 $O/${TAG}_fuzz.txt ;;
-    ubench) for u in valu banks chain; do [ -x tools/ubench_$u ] || hipcc --offload-arch=gfx950 -O3 tools/ubench_$u.hip -o tools/ubench_$u; done
-      tools/ubench_valu > $O/${TAG}_ubench_valu.txt 2>&1; tools/ubench_banks > $O/${TAG}_ubench_banks.txt 2>&1; tools/ubench_chain > $O/${TAG}_ubench_chain.txt 2>&1 ;;
+    ubench) for u in valu banks chain sort; do [ -x tools/ubench_$u ] || hipcc --offload-arch=gfx950 -O3 tools/ubench_$u.hip -o tools/ubench_$u; done
+      tools/ubench_valu > $O/${TAG}_ubench_valu.txt 2>&1; tools/ubench_banks > $O/${TAG}_ubench_banks.txt 2>&1; tools/ubench_chain > $O/${TAG}_ubench_chain.txt 2>&1; tools/ubench_sort > $O/${TAG}_ubench_sort.txt 2>&1 ;;
     strict) # bit-exact all-pairs kernels: sweep of the three kernels by size, PMC of the default at three sizes
       TAG=$TAG bash tools/sweep_strict_kernels.sh > /dev/null 2>&1; cat $O/${TAG}_strict_kernel_sweep.txt
       for b in 10000 65536 262144; do rm -rf $O/stpmc_*; TAG=$TAG BODIES=$b bash tools/strict_pmc.sh > /dev/null 2>&1; done; rm -rf $O/stpmc_* ;;
