@@ -216,7 +216,7 @@ int32_t nbx_bh_flat_dump(nbx_engine *e, void *rows, int32_t cap, int32_t threade
 int32_t nbx_set_shard(nbx_engine *e, int32_t rank, int32_t world); /* call before set_particles */
 int32_t nbx_get_slab(const nbx_engine *e, int32_t *lo, int32_t *hi);
 /* Use a caller-owned DEVICE buffer (e.g. a torch tensor handed to torch.distributed) as the
- * (x,y,z,m) float4 array instead of an engine-owned one. bytes >= nbx_positions_bytes(). Call
+ * (x,y,z,m) float4 array instead of an engine-owned one. bytes >= nbx_positions_bytes(), 16-byte aligned. Call
  * after set_particles; the engine copies its current positions into it. */
 int32_t nbx_bind_positions(nbx_engine *e, void *device_ptr, size_t bytes);
 /* fp16 source copy (NBX_OPT_SOURCE_PRECISION = 16): in sharded runs THIS buffer is what the per-step

@@ -1,4 +1,5 @@
 // c_api.cpp -- level 2 of the C ABI (include/nbody_mi355x.h): the handle-based nbx_* entry points.
+#include <cstdint>
 #include <new>
 
 #include "engine_internal.h"
@@ -518,6 +519,7 @@ int32_t nbx_bind_positions(nbx_engine* e, void* device_ptr, size_t bytes)
 {
     if (!e || !device_ptr) return fail(NBX_ERR_INVALID, "null argument");
     if (bytes < nbx_positions_bytes(e)) return fail(NBX_ERR_INVALID, "buffer too small: %zu < %zu", bytes, nbx_positions_bytes(e));
+    if (reinterpret_cast<uintptr_t>(device_ptr) & 15u) return fail(NBX_ERR_INVALID, "positions buffer must be 16-byte aligned (float4 records)");
     int rc = ensure_device(e);
     if (rc != NBX_OK) return rc;
     rc = download_positions(e);   // keep whatever the device currently holds
