@@ -48,3 +48,20 @@ def test_bit_exact_all_pairs_kernels_use_no_scratch_and_keep_their_occupancy(tmp
     assert pc8["vgpr_count"] <= 128 and pc8["group_segment_fixed_size"] == 2 * 28 * 64 * 16        # two workgroups per CU
     assert 2 * pc8["group_segment_fixed_size"] <= 160 * 1024
     assert one["vgpr_count"] <= 128                                                                 # >= 4 waves per SIMD
+
+
+def test_default_fast_kernels_keep_eight_waves_per_simd(tmp_path):
+    """K1's default all-pairs kernels (variants 6 / 7, both dimensions) and the shared Barnes-Hut walk: no scratch and at most 64
+    VGPRs, i.e. the 8 waves per SIMD their latency hiding was measured with."""
+    k = _metadata(tmp_path, "force_tile.hip", [])
+    pkw = [v for n, v in k.items() if "k_force_smem_pkw" in n]
+    assert len(pkw) == 4
+    for v in pkw:
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 and v["vgpr_count"] <= 64, v
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    strict = re.search(r"^STRICT\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    k = _metadata(tmp_path, "bh_eval.hip", strict)
+    walks = [v for n, v in k.items() if "k_bh_eval_fast_wave" in n]
+    assert len(walks) == 4
+    for v in walks:
+        assert v["vgpr_spill_count"] == 0 and v["vgpr_count"] <= 64, v
