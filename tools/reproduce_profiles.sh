@@ -4,8 +4,9 @@
 # and copy the gpurun_out/<TAG>_* files named in profiles/README.md into profiles/.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 T=${TAG:-r02}
-bash tools/gpu_session.sh smoke tests bench bh prof pmc power k1ab k1sweep cfgs shapes ubench fuzz
+bash tools/gpu_session.sh smoke tests bench bh prof pmc power k1ab k1sweep cfgs shapes ubench strict fuzz
 bash tools/bh_walk_pmc.sh > /dev/null
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/nbx_bh_stats -o p --output-format csv -- python $OLDPWD/bench.py --workload bh --no-cpu-baseline --no-traffic --steps 10 > /dev/null 2>&1); find /tmp/nbx_bh_stats -name '*kernel_stats.csv' -exec cp {} gpurun_out/${T}_bh_kernel_stats.csv \;
 python tools/bh_device_tree_probe.py > gpurun_out/${T}_bh_device_tree_probe.log 2>&1; cp gpurun_out/bh_device_tree_probe.json gpurun_out/${T}_bh_device_tree_probe.json
 python tools/scale_model.py > gpurun_out/${T}_scaling_expectation.json
 python tools/bench_bh.py > gpurun_out/${T}_bench_bh_tool.json 2> gpurun_out/bench_bh.err
