@@ -116,7 +116,7 @@ enum nbx_option {
                                     * the bit-exact mode), 1 = built on the device (bh_build.hip: same node set and leaf
                                     * records incl. the reference's EPS merge of close pairs; interior centres of mass are
                                     * roundings of the exact mean instead of the reference's running f32 fold: own tolerance
-                                    * class), -1 (default) = device in the fast mode from 4096 bodies on, else host */
+                                    * class), -1 (default) = device in the fast mode from 512 bodies on, else host */
     NBX_OPT_BH_WAVE = 9,           /* 1 (default): with the device-built tree, walk the tree once per WAVE (node
                                     * records through the scalar cache, lanes park on accepted subtrees); 0: one
                                     * independent walk per lane. Bit-identical results either way */

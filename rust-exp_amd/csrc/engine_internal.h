@@ -58,8 +58,12 @@ struct nbx_engine {
     const unsigned* d_slab_perm = nullptr;  // d_perm restricted to this engine's slab (world > 1)
     void* d_slab_ws = nullptr;
     size_t slab_ws_bytes = 0;
-    int bh_tree_device = -1;       // NBX_OPT_BH_TREE: 0 host, 1 device, -1 (default) device in fast mode for >= 4096 bodies
-    bool use_device_tree() const { return force_mode == 0 && (bh_tree_device == 1 || (bh_tree_device < 0 && n >= 4096)); }
+    // NBX_OPT_BH_TREE: 0 host, 1 device, -1 (default) device in fast mode from 512 bodies on (measured crossover: a step with the
+    // host build costs 0.141 / 0.208 / 0.303 / 0.509 ms at 512 / 1000 / 2000 / 4000 bodies, with the device build 0.124 / 0.135 /
+    // 0.144 / 0.145 ms; below ~400 bodies the host build's few microseconds win: profiles/r02_bh_tree_crossover.txt)
+    int bh_tree_device = -1;
+    static constexpr int kDeviceTreeFrom = 512;
+    bool use_device_tree() const { return force_mode == 0 && (bh_tree_device == 1 || (bh_tree_device < 0 && n >= kDeviceTreeFrom)); }
     int bh_wave = 1;               // wave-uniform traversal when a spatial body order is available
     int bh_last_tree_device = 0;   // where the last evaluated tree was built
     int bh_fallbacks = 0;          // device builds that fell back to the host (node pool exhausted)

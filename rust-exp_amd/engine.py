@@ -419,7 +419,7 @@ class NBodyEngine:
 
     def set_bh_tree(self, where):
         """'host' (reference-faithful insertion build), 'device' (bh_build.hip) or 'auto' (default: device in the fast
-        mode from 4096 bodies on)."""
+        mode from 512 bodies on)."""
         self.set_option(NBX_OPT_BH_TREE, {"host": 0, "device": 1, "auto": -1}[where])
 
     def set_draw_device(self, on=True):

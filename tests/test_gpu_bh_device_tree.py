@@ -1,4 +1,4 @@
-"""GPU: quadtree built ON THE DEVICE (bh_build.hip; the fast mode's default from 4096 bodies on) against the host build,
+"""GPU: quadtree built ON THE DEVICE (bh_build.hip; the fast mode's default from 512 bodies on) against the host build,
 which is node-for-node the oracle's tree.  Tolerance class: same node set / skip pointers / node sizes /
 leaf records exactly -- including the reference's EPS merge of close pairs, decided from the arrival order like the reference
 does; interior masses and centres are roundings of the EXACT sums (the reference's are an f32 running fold that drifts, 6e-4 at a
@@ -193,7 +193,7 @@ def test_device_tree_is_at_least_as_close_to_exact_arithmetic_as_the_reference_f
     rc, ofx, ofy = ob.bh_forces(p, theta, nthreads=16)
     rc2, ex, ey = ob.bh_forces_exact(p, theta, nthreads=16)
     assert rc == 0 and rc2 == 0
-    e = engines(rx, p)                       # default options: fast mode, n >= 4096 -> device tree
+    e = engines(rx, p)                       # default options: fast mode, n >= 512 -> device tree
     fx, fy, _ = e.forces(theta)
     assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1
     scale = max(np.abs(ex).max(), np.abs(ey).max())
@@ -206,11 +206,11 @@ def test_device_tree_is_at_least_as_close_to_exact_arithmetic_as_the_reference_f
 
 
 def test_tree_choice_by_mode_and_size(rx, ob):
-    """NBX_OPT_BH_TREE = -1 (default): device build in the fast mode from 4096 bodies on, host build below and always in the
+    """NBX_OPT_BH_TREE = -1 (default): device build in the fast mode from 512 bodies on, host build below and always in the
     bit-exact mode; 0 / 1 force one or the other."""
     from rust_exp_amd.engine import NBX_OPT_BH_LAST_TREE, NBX_OPT_BH_TREE
 
-    for n, mode, want in ((4096, "fast", 1), (4095, "fast", 0), (20000, "strict", 0)):
+    for n, mode, want in ((4096, "fast", 1), (512, "fast", 1), (511, "fast", 0), (20000, "strict", 0)):
         p = ob.random_disk(n, 3)
         e = rx.NBodyEngine(mode=mode)
         assert e.get_option(NBX_OPT_BH_TREE) == -1
