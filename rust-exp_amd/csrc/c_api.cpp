@@ -1,5 +1,6 @@
 // c_api.cpp -- level 2 of the C ABI (include/nbody_mi355x.h): the handle-based nbx_* entry points.
 #include <cstdint>
+#include <cstring>
 #include <new>
 
 #include "engine_internal.h"
@@ -363,10 +364,20 @@ static int draw_on_device(nbx_engine* e, int32_t w, int32_t h, uint32_t* fb)
     unsigned* d_cnt = static_cast<unsigned*>(e->d_amb);
     nbx::DrawAmbiguous* d_rec = reinterpret_cast<nbx::DrawAmbiguous*>(static_cast<char*>(e->d_amb) + 16);
     HIP_TRY(nbx::launch_draw(e->d_posm, e->d_vel, e->n, w, h, x1, y1, scalex, scaley, e->d_counts, e->d_fb, d_cnt, d_rec, e->stream));
-    unsigned n_amb = 0;
-    HIP_TRY(hipMemcpyAsync(fb, e->d_fb, px * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(&n_amb, d_cnt, sizeof n_amb, hipMemcpyDeviceToHost, e->stream));
+    // The caller's framebuffer is pageable (a mapped GL buffer in the reference's app): a copy straight into it goes through the
+    // runtime's staging path.  Land the image -- and, right behind it, the count of ambiguous tails -- in pinned memory with one
+    // DMA each, then hand it over with a host memcpy.
+    if (px + 4 > e->h_fb_cap) {
+        if (e->h_fb) HIP_TRY(hipHostFree(e->h_fb));
+        e->h_fb = nullptr; e->h_fb_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_fb), (px + 4) * 4, hipHostMallocDefault));
+        e->h_fb_cap = px + 4;
+    }
+    HIP_TRY(hipMemcpyAsync(e->h_fb, e->d_fb, px * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_fb + px, d_cnt, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    std::memcpy(fb, e->h_fb, px * 4);
+    const unsigned n_amb = e->h_fb[px];
     e->draw_ambiguous = (int)n_amb;
     if (n_amb) {
         std::vector<nbx::DrawAmbiguous> rec(n_amb);

@@ -694,6 +694,7 @@ void free_device(nbx_engine* e)
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_fb) (void)hipFree(e->d_fb);
+    if (e->h_fb) (void)hipHostFree(e->h_fb);
     if (e->d_amb) (void)hipFree(e->d_amb);
     if (e->d_posh && !e->posh_external) (void)hipFree(e->d_posh);
     if (e->h_nodes) (void)hipHostFree(e->h_nodes);

@@ -71,6 +71,8 @@ struct nbx_engine {
     size_t counts_cap = 0;         // pixels
     unsigned* d_fb = nullptr;
     size_t fb_cap = 0;
+    unsigned* h_fb = nullptr;      // pinned landing buffer of the device draw (the caller's framebuffer is pageable)
+    size_t h_fb_cap = 0;
     int draw_device = -1;          // nb_draw: 0 host, 1 device, -1 device for >= 4096 bodies resident on one GPU
     void* d_amb = nullptr;         // device draw: counter + list of particles whose tail octant the host decides
     size_t amb_bytes = 0;
