@@ -163,12 +163,27 @@ void nbx_destroy(nbx_engine *e);
 
 int32_t nbx_set_option(nbx_engine *e, int32_t option, int64_t value);
 int64_t nbx_get_option(const nbx_engine *e, int32_t option);
+/* as nbx_get_option with the status apart from the value: -1 is a legitimate value of some options ("by size" of
+ * NBX_OPT_DRAW_DEVICE / NBX_OPT_BH_TREE, "the last draw ran on the host" of NBX_OPT_DRAW_AMBIGUOUS) and also NBX_ERR_INVALID */
+int32_t nbx_query_option(const nbx_engine *e, int32_t option, int64_t *value);
 
 /* Presets: same sampling as nbody.rs:39-104, but from a seedable generator (splitmix64 -> top 24
  * bits -> [0,1) f32, the rand 0.3 `next_f32` construction). */
 int32_t nbx_seed(nbx_engine *e, uint64_t seed);
 int32_t nbx_random_disk(nbx_engine *e, int32_t n);
 int32_t nbx_stable_orbits(nbx_engine *e, int32_t n, float rmin, float rmax);
+
+/* The synthetic workloads BASELINE.json's configs are quoted on (NOT in the reference, whose only
+ * generators are the two presets above), so that any host behind this ABI can run them. Stateless in `seed`: sample k of
+ * the splitmix64 stream -> top 24 bits -> [0,1) f32; IEEE double arithmetic + the C library's sqrt/pow/cos/sin; one
+ * rounding to f32 per stored value. Golden values: tests/golden/workload_*.npz.
+ *   plummer_sphere: scale radius 5, r = 5/sqrt(u^(-2/3) - 1) clipped to 45, isotropic, v = 0, m = 1000/n; dim 2 sets z = 0
+ *   two_galaxies:   two stable_orbits-style disks of n/2 bodies (1000-mass core + unit planets, r in [0.5, 12)), centres
+ *                   (-+15, 0), bulk velocities (+-3, -+1), 2-D */
+#define NBX_SEED_PLUMMER 0x5EED0001ull
+#define NBX_SEED_TWO_GALAXIES 0x5EED0002ull
+int32_t nbx_plummer_sphere(nbx_engine *e, int32_t n, uint64_t seed, int32_t dim);
+int32_t nbx_two_galaxies(nbx_engine *e, int32_t n, uint64_t seed);
 
 /* State in/out (host SoA buffers of n floats each). The 2-D forms set z = vz = 0.
  * get: `cap` = capacity of each output array; returns the particle count or a negative status.
@@ -243,7 +258,12 @@ int32_t nbx_step_local(nbx_engine *e, float dt);
  * calls through nbx_group_engine see them only after such a call.
  * NBX_GROUP_EXCHANGE=copy (environment, read at nbx_group_create): replace the RCCL all-gather by
  * event-ordered hipMemcpyPeerAsync pulls -- no communicator, no librccl, and a device may then be listed more
- * than once (several engines sharing one GPU: how the group logic is tested on a single-GPU box). */
+ * than once (several engines sharing one GPU: how the group logic is tested on a single-GPU box).
+ * If RCCL cannot be used (librccl missing, ncclCommInitAll or a collective fails) the group does NOT die: it switches to
+ * those peer copies (peer access enabled where the devices allow it), redoes the exchange, prints one line on stderr and
+ * reports it through nbx_group_info / nbx_group_exchange_note.
+ * NBX_GROUP_ENQUEUE=threads (or nbx_group_set_enqueue_threads): one persistent host thread per device enqueues that
+ * device's kernels and its share of the exchange, instead of one thread walking the devices in turn. */
 typedef struct nbx_group nbx_group;
 int32_t nbx_group_create(nbx_group **out, const int32_t *devices, int32_t count);
 void nbx_group_destroy(nbx_group *g);
@@ -260,6 +280,16 @@ int32_t nbx_group_step_barnes_hut(nbx_group *g, float theta, float dt, int32_t n
 int32_t nbx_group_synchronize(nbx_group *g);
 int32_t nbx_group_draw(nbx_group *g, int32_t w, int32_t h, uint32_t *fb);
 int32_t nbx_group_exchanges(const nbx_group *g); /* all-gathers issued so far */
+enum nbx_group_info_id {
+    NBX_GROUP_INFO_EXCHANGE = 0,        /* 0 = RCCL all-gather, 1 = peer copies (NBX_GROUP_EXCHANGE=copy), 2 = peer copies
+                                         * because RCCL failed (nbx_group_exchange_note says what failed) */
+    NBX_GROUP_INFO_RCCL_RANKS = 1,      /* ranks ncclCommInitAll was given; 0 while / when no communicator exists */
+    NBX_GROUP_INFO_ENQUEUE_THREADS = 2, /* enqueue threads in use (0 = the caller's thread walks the devices) */
+    NBX_GROUP_INFO_FP32_STALE = 3       /* 1 = only the fp16 source copy was exchanged last; fp32 positions re-gather lazily */
+};
+int64_t nbx_group_info(const nbx_group *g, int32_t what);
+const char *nbx_group_exchange_note(const nbx_group *g); /* "" unless the group fell back to peer copies */
+int32_t nbx_group_set_enqueue_threads(nbx_group *g, int32_t on);
 
 /* ---- profiling: HIP event pairs on the engine's stream around each kernel launch -------------- */
 int32_t nbx_profile_reset(nbx_engine *e);

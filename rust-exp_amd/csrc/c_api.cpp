@@ -103,7 +103,7 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
             e->bh_wave = value ? 1 : 0;
             return NBX_OK;
         case NBX_OPT_BH_TREE:
-            if (value != 0 && value != 1) return fail(NBX_ERR_INVALID, "bh tree must be 0 (host) or 1 (device)");
+            if (value != 0 && value != 1 && value != -1) return fail(NBX_ERR_INVALID, "bh tree must be 0 (host), 1 (device) or -1 (by mode and size)");
             e->bh_tree_device = value < 0 ? -1 : (value ? 1 : 0);   // -1 = by mode and size (default)
             return NBX_OK;
         case NBX_OPT_SOURCE_PRECISION:
@@ -142,6 +142,16 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
     }
 }
 
+// nbx_get_option cannot tell the legitimate value -1 ("auto" of NBX_OPT_DRAW_DEVICE / NBX_OPT_BH_TREE, "host draw" of
+// NBX_OPT_DRAW_AMBIGUOUS) from NBX_ERR_INVALID: this form returns the status and the value separately.
+int32_t nbx_query_option(const nbx_engine* e, int32_t option, int64_t* value)
+{
+    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    if (option < NBX_OPT_FORCE_MODE || option > NBX_OPT_STRICT_KERNEL) return fail(NBX_ERR_INVALID, "unknown option %d", option);
+    if (value) *value = nbx_get_option(e, option);
+    return NBX_OK;
+}
+
 int32_t nbx_seed(nbx_engine* e, uint64_t seed)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
@@ -177,6 +187,30 @@ int32_t nbx_stable_orbits(nbx_engine* e, int32_t n, float rmin, float rmax)
     ensure_seed(e);
     try {
         nbx::preset_stable_orbits(e->host, n, rmin, rmax, e->rng);
+    } catch (const std::bad_alloc&) {
+        return fail(NBX_ERR_ALLOC, "out of memory for %d particles", (int)n);
+    }
+    after_host_state_change(e);
+    return NBX_OK;
+}
+
+int32_t nbx_plummer_sphere(nbx_engine* e, int32_t n, uint64_t seed, int32_t dim)
+{
+    if (!e || n < 0 || (dim != 2 && dim != 3)) return fail(NBX_ERR_INVALID, "bad engine, n or dim (2 | 3)");
+    try {
+        nbx::workload_plummer_sphere(e->host, n, seed, dim);
+    } catch (const std::bad_alloc&) {
+        return fail(NBX_ERR_ALLOC, "out of memory for %d particles", (int)n);
+    }
+    after_host_state_change(e);
+    return NBX_OK;
+}
+
+int32_t nbx_two_galaxies(nbx_engine* e, int32_t n, uint64_t seed)
+{
+    if (!e || n < 0) return fail(NBX_ERR_INVALID, "bad engine or n");
+    try {
+        nbx::workload_two_galaxies(e->host, n, seed);
     } catch (const std::bad_alloc&) {
         return fail(NBX_ERR_ALLOC, "out of memory for %d particles", (int)n);
     }

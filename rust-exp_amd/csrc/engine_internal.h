@@ -63,7 +63,12 @@ struct nbx_engine {
     // 0.144 / 0.145 ms; below ~400 bodies the host build's few microseconds win: profiles/r02_bh_tree_crossover.txt)
     int bh_tree_device = -1;
     static constexpr int kDeviceTreeFrom = 512;
-    bool use_device_tree() const { return force_mode == 0 && (bh_tree_device == 1 || (bh_tree_device < 0 && n >= kDeviceTreeFrom)); }
+    // the device build has none of the reference's tree asserts: a non-positive or NaN mass (nbody.rs:304) always goes to the
+    // host build, which reports NBX_ERR_TREE where the reference panics (mass_min is NaN when any mass is NaN / infinite)
+    bool use_device_tree() const
+    {
+        return force_mode == 0 && mass_min > 0.0f && (bh_tree_device == 1 || (bh_tree_device < 0 && n >= kDeviceTreeFrom));
+    }
     int bh_wave = 1;               // wave-uniform traversal when a spatial body order is available
     int bh_last_tree_device = 0;   // where the last evaluated tree was built
     int bh_fallbacks = 0;          // device builds that fell back to the host (node pool exhausted)
@@ -118,15 +123,22 @@ struct nbx_engine {
     int slab() const { return hi - lo; }
 };
 
+struct GroupWorkers;   // group.cpp: one persistent enqueue thread per engine (optional)
+
 struct nbx_group {
     std::vector<nbx_engine*> eng;
     std::vector<int> devices;
     std::vector<ncclComm_t> comms;
     int exchanges = 0;
     bool fp32_stale = false;                // only the fp16 source copy was exchanged: fp32 positions of other slabs are old
-    bool copy_exchange = false;             // NBX_GROUP_EXCHANGE=copy: peer copies + events instead of RCCL
+    bool copy_exchange = false;             // peer copies + events instead of RCCL (requested, or after RCCL failed)
+    int exchange_kind = 0;                  // NBX_GROUP_INFO_EXCHANGE: 0 RCCL, 1 peer copies requested, 2 peer copies after an RCCL failure
+    int rccl_ranks = 0;                     // ranks ncclCommInitAll was given (0: no communicator exists)
+    int rccl_fail_hook = 0;                 // NBX_GROUP_RCCL_FAIL=init|gather (tests): 1 = communicator creation, 2 = first all-gather "fails"
+    std::string exchange_note;              // why the group fell back to peer copies
     std::vector<hipEvent_t> ev_ready;       // per engine: its slab is updated
     std::vector<hipEvent_t> ev_copied;      // per engine: it has pulled every other slab
+    GroupWorkers* workers = nullptr;        // NBX_GROUP_ENQUEUE=threads / nbx_group_set_enqueue_threads
 };
 
 namespace nbxi {
@@ -232,5 +244,6 @@ int step_bh(nbx_engine* e, float theta, float dt);
 void free_device(nbx_engine* e);
 uint64_t entropy_seed();
 void after_host_state_change(nbx_engine* e);
+int group_replicate_fp32(nbx_group* g);   // group.cpp: fp32 positions of every slab current on every engine
 
 }  // namespace nbxi

@@ -200,6 +200,80 @@ void preset_stable_orbits(HostState& st, int n, float rmin, float rmax, Rng& rng
     }
 }
 
+// ---- benchmark workloads (the build's own generators, NOT in the reference) -----------------------------
+// Sample k (1-based) of the splitmix64 stream of `seed`, as a [0,1) f32 (top 24 bits): stateless, so that any host language
+// reproduces any element.  Everything after the samples is IEEE double arithmetic in the order written (this unit is built
+// with -ffp-contract=off) plus sqrt / pow / cos / sin of the C library, and ONE rounding to f32 per stored value.
+static inline float splitmix_sample(uint64_t seed, uint64_t k)
+{
+    uint64_t z = seed + k * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+void workload_plummer_sphere(HostState& st, int n, uint64_t seed, int dim)
+{
+    // Plummer sphere, scale radius a = 5: r = a / sqrt(u^(-2/3) - 1) clipped to 45 (inside the +-55 kill box of
+    // nbody.rs:466-471), isotropic direction, zero velocities, m = 1000 / n.  Samples: u0 = 1..n, u1 = n+1..2n, u2 = 2n+1..3n.
+    const double a = 5.0, rmax = 45.0, total_mass = 1000.0, two_pi = 2.0 * 3.141592653589793;
+    st.resize(n > 0 ? n : 0);
+    const float mass = n > 0 ? (float)(total_mass / (double)n) : 0.0f;
+    auto body = [&](int i) {
+        const uint64_t un = (uint64_t)n;
+        double u0 = (double)splitmix_sample(seed, 1 + (uint64_t)i);
+        const double u1 = (double)splitmix_sample(seed, 1 + un + (uint64_t)i);
+        const double u2 = (double)splitmix_sample(seed, 1 + 2 * un + (uint64_t)i);
+        u0 = u0 < 1e-7 ? 1e-7 : (u0 > 1.0 - 1e-7 ? 1.0 - 1e-7 : u0);
+        double r = a / std::sqrt(std::pow(u0, -2.0 / 3.0) - 1.0);
+        r = r < rmax ? r : rmax;
+        const double cos_t = 2.0 * u1 - 1.0;
+        const double one_minus = 1.0 - cos_t * cos_t;
+        const double sin_t = std::sqrt(one_minus > 0.0 ? one_minus : 0.0);
+        const double phi = two_pi * u2;
+        st.px[i] = (float)(r * sin_t * std::cos(phi));
+        st.py[i] = (float)(r * sin_t * std::sin(phi));
+        st.pz[i] = dim == 3 ? (float)(r * cos_t) : 0.0f;
+        st.vx[i] = st.vy[i] = st.vz[i] = 0.0f;
+        st.m[i] = mass;
+    };
+    if (n >= 65536) {
+        parallel_for(8, [&](int t) {
+            const int b0 = (int)((long long)n * t / 8), b1 = (int)((long long)n * (t + 1) / 8);
+            for (int i = b0; i < b1; i++) body(i);
+        });
+    } else {
+        for (int i = 0; i < n; i++) body(i);
+    }
+}
+
+void workload_two_galaxies(HostState& st, int n, uint64_t seed)
+{
+    // Two nb_stable_orbits-style disks (nbody.rs:85-102) of n/2 bodies each: a 1000-mass core + unit planets on circular
+    // orbits, radii in [0.5, 12), centres (-+15, 0), bulk velocities (+-3, -+1); 2-D.  Samples: radius = 1..n, angle = n+1..2n.
+    const double rmin = 0.5, rmax = 12.0, two_pi = 2.0 * 3.141592653589793, speed = std::sqrt(1000.0);
+    st.resize(n > 0 ? n : 0);
+    const int half = n / 2;
+    for (int i = 0; i < n; i++) {
+        const int g = i < half ? 0 : 1;
+        const double cx = g ? 15.0 : -15.0, cvx = g ? -3.0 : 3.0, cvy = g ? 1.0 : -1.0;
+        const double u0 = (double)splitmix_sample(seed, 1 + (uint64_t)i);
+        const double u1 = (double)splitmix_sample(seed, 1 + (uint64_t)n + (uint64_t)i);
+        const double r = (rmax - rmin) * u0 + rmin, th = two_pi * u1;
+        const double c = std::cos(th), s = std::sin(th);
+        st.px[i] = (float)(cx + r * c);
+        st.py[i] = (float)(r * s);
+        st.vx[i] = (float)(cvx - speed * s);
+        st.vy[i] = (float)(cvy + speed * c);
+        st.pz[i] = st.vz[i] = 0.0f;
+        st.m[i] = 1.0f;
+        if (i == (g ? half : 0)) {   // the core of each disk
+            st.px[i] = (float)cx; st.py[i] = 0.0f; st.vx[i] = (float)cvx; st.vy[i] = (float)cvy; st.m[i] = 1000.0f;
+        }
+    }
+}
+
 // ---- draw ------------------------------------------------------------------------------------
 
 namespace {

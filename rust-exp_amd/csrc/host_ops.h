@@ -49,6 +49,10 @@ struct Rng {
 void preset_random_disk(HostState& st, int n, Rng& rng);                        // nbody.rs:39-71
 void preset_stable_orbits(HostState& st, int n, float rmin, float rmax, Rng& rng);  // nbody.rs:73-104
 
+// benchmark workloads of BASELINE.json's configs; stateless in the seed
+void workload_plummer_sphere(HostState& st, int n, uint64_t seed, int dim);
+void workload_two_galaxies(HostState& st, int n, uint64_t seed);
+
 // nbody.rs:482-617; fb is w*h ABGR words, cleared here
 void draw_particles(const float* px, const float* py, const float* vx, const float* vy, int n, int32_t w,
                     int32_t h, uint32_t* fb);

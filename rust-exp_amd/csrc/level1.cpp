@@ -113,6 +113,8 @@ void nb_step_barnes_hut(float theta, float dt, int32_t nthreads)
         // Reference: `(0..nthreads).map(..)` is empty -- no worker, no division by nthreads (it sits inside the closure,
         // nbody.rs:424-428), no particle touched -- but the quadtree has been built by then (:380-417), so its asserts
         // (depth > 50, mass <= 0, ...) still panic.  Same here: build the host tree for its checks, update nothing.
+        // (group after fp16-source steps: engine 0's fp32 positions of the other slabs are re-gathered first)
+        if (g_group && group_replicate_fp32(g_group) != NBX_OK) die("nb_step_barnes_hut");
         const int rc = nbx_bh_tree_dump(e, nullptr, 0);
         if (rc == NBX_ERR_TREE_DEPTH || rc == NBX_ERR_TREE) die("nb_step_barnes_hut");
         return;

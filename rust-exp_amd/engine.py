@@ -39,6 +39,11 @@ NBX_OPT_BH_LAST_TREE = 11
 NBX_OPT_DRAW_AMBIGUOUS = 12
 NBX_OPT_STRICT_KERNEL = 13
 
+NBX_GROUP_INFO_EXCHANGE = 0
+NBX_GROUP_INFO_RCCL_RANKS = 1
+NBX_GROUP_INFO_ENQUEUE_THREADS = 2
+NBX_GROUP_INFO_FP32_STALE = 3
+
 NBX_K_FORCE = 0
 NBX_K_INTEGRATE = 1
 NBX_K_BH_EVAL = 2
@@ -149,6 +154,12 @@ def lib():
     L.nbx_random_disk.restype = i32
     L.nbx_stable_orbits.argtypes = [E, i32, C.c_float, C.c_float]
     L.nbx_stable_orbits.restype = i32
+    L.nbx_plummer_sphere.argtypes = [E, i32, C.c_uint64, i32]
+    L.nbx_plummer_sphere.restype = i32
+    L.nbx_two_galaxies.argtypes = [E, i32, C.c_uint64]
+    L.nbx_two_galaxies.restype = i32
+    L.nbx_query_option.argtypes = [E, i32, C.POINTER(C.c_int64)]
+    L.nbx_query_option.restype = i32
     L.nbx_num_particles.argtypes = [E]
     L.nbx_num_particles.restype = i32
     L.nbx_set_particles.argtypes = [E, i32] + [C.c_void_p] * 5
@@ -222,6 +233,12 @@ def lib():
     L.nbx_group_draw.restype = i32
     L.nbx_group_exchanges.argtypes = [G]
     L.nbx_group_exchanges.restype = i32
+    L.nbx_group_info.argtypes = [G, i32]
+    L.nbx_group_info.restype = C.c_int64
+    L.nbx_group_exchange_note.argtypes = [G]
+    L.nbx_group_exchange_note.restype = C.c_char_p
+    L.nbx_group_set_enqueue_threads.argtypes = [G, i32]
+    L.nbx_group_set_enqueue_threads.restype = i32
     L.nbx_profile_reset.argtypes = [E]
     L.nbx_profile_reset.restype = i32
     L.nbx_profile_read.argtypes = [E, i32, C.POINTER(C.c_double), C.POINTER(i32)]
@@ -348,6 +365,12 @@ class NBodyEngine:
     def get_option(self, opt):
         return int(self._L.nbx_get_option(self._h, opt))
 
+    def query_option(self, opt):
+        """Value of an option with the status checked apart from it (-1 is a legitimate value of some options)."""
+        v = C.c_int64()
+        _check(self._L.nbx_query_option(self._h, opt, C.byref(v)))
+        return int(v.value)
+
     def set_launch(self, jsplit=0, bodies_per_thread=0, dim=0, variant=-1):
         self.set_option(NBX_OPT_JSPLIT, jsplit)
         self.set_option(NBX_OPT_BODIES_PER_THREAD, bodies_per_thread)
@@ -368,6 +391,13 @@ class NBodyEngine:
 
     def stable_orbits(self, n, rmin, rmax):
         _check(self._L.nbx_stable_orbits(self._h, n, rmin, rmax))
+
+    # benchmark workloads, generated by the library so that every host language gets the same bytes
+    def plummer_sphere(self, n, seed=0x5EED0001, dim=3):
+        _check(self._L.nbx_plummer_sphere(self._h, n, seed, dim))
+
+    def two_galaxies(self, n, seed=0x5EED0002):
+        _check(self._L.nbx_two_galaxies(self._h, n, seed))
 
     def num_particles(self):
         return _check(self._L.nbx_num_particles(self._h))
@@ -578,3 +608,16 @@ class NBodyGroup:
 
     def exchanges(self):
         return _check(self._L.nbx_group_exchanges(self._h))
+
+    def info(self):
+        """How the per-step exchange runs: kind ('rccl' | 'peer_copy' | 'peer_copy_after_rccl_failure'), the ranks
+        ncclCommInitAll was given, enqueue threads, and why the group fell back (if it did)."""
+        kind = int(self._L.nbx_group_info(self._h, NBX_GROUP_INFO_EXCHANGE))
+        return {"exchange": {0: "rccl", 1: "peer_copy", 2: "peer_copy_after_rccl_failure"}.get(kind, str(kind)),
+                "rccl_ranks": int(self._L.nbx_group_info(self._h, NBX_GROUP_INFO_RCCL_RANKS)),
+                "enqueue_threads": int(self._L.nbx_group_info(self._h, NBX_GROUP_INFO_ENQUEUE_THREADS)),
+                "fp32_stale": bool(self._L.nbx_group_info(self._h, NBX_GROUP_INFO_FP32_STALE)),
+                "note": (self._L.nbx_group_exchange_note(self._h) or b"").decode(errors="replace")}
+
+    def set_enqueue_threads(self, on=True):
+        _check(self._L.nbx_group_set_enqueue_threads(self._h, 1 if on else 0))

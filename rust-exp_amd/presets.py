@@ -38,28 +38,34 @@ def plummer_sphere(n, seed=0x5EED0001, a=5.0, rmax=45.0, total_mass=1000.0, dim=
         "vx": np.zeros(n, np.float32),
         "vy": np.zeros(n, np.float32),
         "vz": np.zeros(n, np.float32),
-        "m": np.full(n, total_mass / n, np.float32),
+        "m": np.full(n, total_mass / max(n, 1), np.float32),
     }
     return out
 
 
 def two_galaxies(n, seed=0x5EED0002, rmin=0.5, rmax=12.0):
     """Two nb_stable_orbits-style disks (n/2 bodies each: a 1000-mass core + unit planets on
-    circular orbits, nbody.rs:85-102), centres (+-15, 0), bulk velocities (-+3, +-1). 2-D."""
+    circular orbits, nbody.rs:85-102), centres (+-15, 0), bulk velocities (-+3, +-1). 2-D.
+    float64 arithmetic on the f32 samples, ONE rounding to f32 per stored value: the same definition as the
+    library's nbx_two_galaxies (c_api.cpp / host_ops.cpp), bit for bit (tests/test_workload_generators.py).
+    (Round 2 evaluated this in numpy float32, whose SIMD sin/cos are not reproducible outside numpy.)"""
     half = n // 2
-    u = splitmix64_uniform(seed, 2 * n).reshape(2, n)
-    px = np.zeros(n, np.float32); py = np.zeros(n, np.float32)
-    vx = np.zeros(n, np.float32); vy = np.zeros(n, np.float32)
+    u = splitmix64_uniform(seed, 2 * n).astype(np.float64).reshape(2, n)
+    g = (np.arange(n) >= half)
+    cx = np.where(g, 15.0, -15.0)
+    cvx = np.where(g, -3.0, 3.0)
+    cvy = np.where(g, 1.0, -1.0)
+    speed = np.sqrt(1000.0)
+    r = (rmax - rmin) * u[0] + rmin
+    th = 2.0 * np.pi * u[1]
+    c, s = np.cos(th), np.sin(th)
+    px = (cx + r * c).astype(np.float32)
+    py = (r * s).astype(np.float32)
+    vx = (cvx - speed * s).astype(np.float32)
+    vy = (cvy + speed * c).astype(np.float32)
     m = np.ones(n, np.float32)
-    speed = np.float32(np.sqrt(1000.0))
-    for g, (lo, hi) in enumerate(((0, half), (half, n))):
-        cx, cvx, cvy = ((-15.0, 3.0, -1.0), (15.0, -3.0, 1.0))[g]
-        r = (rmax - rmin) * u[0, lo:hi] + rmin
-        th = 2.0 * np.pi * u[1, lo:hi]
-        px[lo:hi] = cx + r * np.cos(th)
-        py[lo:hi] = r * np.sin(th)
-        vx[lo:hi] = cvx - speed * np.sin(th)
-        vy[lo:hi] = cvy + speed * np.cos(th)
-        px[lo], py[lo], vx[lo], vy[lo], m[lo] = cx, 0.0, cvx, cvy, 1000.0
+    for lo in ((0, half) if n > 1 else (0,) if n == 1 else ()):
+        if lo < n:
+            px[lo], py[lo], vx[lo], vy[lo], m[lo] = cx[lo], 0.0, cvx[lo], cvy[lo], 1000.0
     z = np.zeros(n, np.float32)
     return {"px": px, "py": py, "pz": z, "vx": vx, "vy": vy, "vz": z.copy(), "m": m}
