@@ -186,16 +186,157 @@ def parse_args():
     ap.add_argument("--shard-of", type=int, default=0,
                     help="single GPU: run only rank 0's slab of an N-way shard (per-GPU shape of an N-GPU run; not the metric)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC passes (roofline.traffic = null)")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=None,
+                    help="after the timed loop: --verify-steps more steps on this host AND on one plain engine from the same state; "
+                         "bit-exact mode must agree bit for bit, fast mode within the stated tolerance (default: on when --gpus > 1)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--verify-steps", type=int, default=2)
+    ap.add_argument("--steady-seconds", type=float, default=3.0,
+                    help="single GPU: after the official steps, a back-to-back loop of at least this many seconds for the "
+                         "steady_state block (clock and socket power from rocm-smi); 0 = skip")
+    ap.add_argument("--no-general-masses", action="store_true",
+                    help="skip the general_masses block (the same run on random masses: the kernel with the m_j multiply)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
 def make_state(args, rx):
+    """The workload from the library's own C-ABI generators (nbx_plummer_sphere / nbx_two_galaxies: what any host behind
+    the boundary gets; bit-identical to rust-exp_amd/presets.py, tests/test_workload_generators.py)."""
+    e = rx.NBodyEngine()
     if args.workload == "bh":
-        return rx.plummer_sphere(args.n, dim=2)   # the reference (and its quadtree) is 2-D
-    if args.workload == "plummer":
-        return rx.plummer_sphere(args.n, dim=args.dim)
-    return rx.two_galaxies(args.n)
+        e.plummer_sphere(args.n, dim=2)   # the reference (and its quadtree) is 2-D
+    elif args.workload == "plummer":
+        e.plummer_sphere(args.n, dim=args.dim)
+    else:
+        e.two_galaxies(args.n)
+    st = e.get_particles()
+    e.close()
+    return st
+
+
+class RocmSmiSampler:
+    """sclk and socket power while a loop runs: `rocm-smi --showpower --showclocks --json` polled from a thread (the only
+    power/clock source that read plausibly on these boxes: profiles/r02_power_k1.json; the hwmon node reads a flat 248 W)."""
+
+    def __init__(self):
+        import threading
+
+        self.exe = shutil.which("rocm-smi")
+        self.rows, self._stop = [], threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True) if self.exe else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            t = time.perf_counter()
+            try:
+                r = subprocess.run([self.exe, "--showpower", "--showclocks", "--json"], stdout=subprocess.PIPE,
+                                   stderr=subprocess.DEVNULL, timeout=20)
+                txt = r.stdout.decode(errors="replace")
+                js = json.loads(txt[txt.index("{"):])
+                card = js.get("card0") or next(iter(js.values()))
+                sclk = w = None
+                for k, v in card.items():
+                    kl = k.lower()
+                    if kl.startswith("sclk clock speed"):
+                        sclk = float(str(v).strip("()").lower().replace("mhz", ""))
+                    elif "power (w)" in kl and "cap" not in kl:
+                        w = float(v)
+                self.rows.append((t, sclk, w))
+            except Exception:   # noqa: BLE001 (a probe: no sample)
+                pass
+            self._stop.wait(0.05)
+
+    def start(self):
+        if self._th:
+            self._th.start()
+
+    def stop(self, t_from, t_to):
+        if not self._th:
+            return {"sclk_mhz": None, "socket_w": None, "samples": 0, "source": "rocm-smi not found"}
+        self._stop.set()
+        self._th.join(timeout=30)
+        rows = [r for r in self.rows if t_from <= r[0] <= t_to]
+        ck = [r[1] for r in rows if r[1]]
+        pw = [r[2] for r in rows if r[2]]
+        return {"sclk_mhz": float(np.mean(ck)) if ck else None, "sclk_mhz_min": float(np.min(ck)) if ck else None,
+                "socket_w": float(np.mean(pw)) if pw else None, "socket_w_max": float(np.max(pw)) if pw else None,
+                "samples": len(rows), "source": "rocm-smi --showpower --showclocks --json, polled during the loop"}
+
+
+def steady_state(host, step, seconds):
+    """The same step back to back for >= `seconds` s AFTER the official timed window (which, at 0.25 s, measures whatever
+    thermal / clock state the box happens to be in): ms per step over the window past its first half second."""
+    smp = RocmSmiSampler()
+    smp.start()
+    host.sync()
+    t0 = time.perf_counter()
+    marks = []
+    while True:
+        for _ in range(10):
+            step()
+        host.sync()
+        now = time.perf_counter()
+        marks.append(now)
+        if now - t0 >= seconds:
+            break
+    t1 = marks[-1]
+    k0 = next((k for k, t in enumerate(marks) if t - t0 >= 0.5), 0)
+    if k0 >= len(marks) - 1:
+        k0 = 0
+    ms = (marks[-1] - marks[k0]) / (10 * (len(marks) - 1 - k0)) * 1e3 if len(marks) - 1 > k0 else (t1 - t0) / (10 * len(marks)) * 1e3
+    out = {"ms_per_step": ms, "steps": 10 * len(marks), "window_s": t1 - t0,
+           "note": "back-to-back steps after the official window; ms_per_step excludes the first 0.5 s"}
+    out.update(smp.stop(t0 + 0.5, t1))
+    return out
+
+
+def verify_against_plain_engine(host, args, rx, step, is_bh, device):
+    """Self-validation of whatever host ran the timed loop (a group over RCCL, one process per GPU, ...): from the state
+    the timed loop left, `--verify-steps` more steps here AND on ONE plain engine holding all bodies. Bit-exact mode: every
+    position and velocity bit-equal. Fast mode: within the stated tolerance (rust-exp_amd/tolerances.py), x2 because two
+    fast results are compared (each is within the bound of the reference arithmetic). Every rank calls this; rank 0 judges."""
+    kv = max(1, args.verify_steps)
+    host.sync(); host.barrier()
+    s0 = host.get_state()
+    for _ in range(kv):
+        step()
+    host.sync(); host.barrier()
+    s1 = host.get_state()
+    if host.rank != 0:
+        return None
+    ref = rx.NBodyEngine(device=device, mode=args.mode)
+    ref.set_source_precision(args.source_bits)
+    ref.set_strict_kernel(args.strict_kernel)
+    if args.bh_tree != "default":
+        ref.set_bh_tree(args.bh_tree)
+    ref.set_particles(s0["px"], s0["py"], s0["vx"], s0["vy"], s0["m"], s0["pz"], s0["vz"])
+    n = len(s0["px"])
+    fx, fy, fz = ref.forces(args.theta if is_bh else 0.0)
+    a = np.sqrt(fx.astype(np.float64) ** 2 + fy.astype(np.float64) ** 2 + fz.astype(np.float64) ** 2) / np.maximum(s0["m"].astype(np.float64), 1e-30)
+    amax = float(a.max()) if n else 0.0
+    for _ in range(kv):
+        if is_bh:
+            ref.step_barnes_hut(args.theta, DT, 1)
+        else:
+            ref.step_brute_force(DT)
+    r1 = ref.get_particles()
+    ref.close()
+    dp = max(float(np.abs(s1[k] - r1[k]).max()) if n else 0.0 for k in ("px", "py", "pz"))
+    dv = max(float(np.abs(s1[k] - r1[k]).max()) if n else 0.0 for k in ("vx", "vy", "vz"))
+    bit_equal = all(np.array_equal(s1[k].view(np.uint32), r1[k].view(np.uint32)) for k in ("px", "py", "pz", "vx", "vy", "vz"))
+    moved = max(float(np.abs(s1[k] - s0[k]).max()) if n else 0.0 for k in ("px", "py", "pz"))
+    from rust_exp_amd.tolerances import fast_step_tolerances
+
+    ptol, vtol = fast_step_tolerances(amax, n, DT, kv)
+    ptol, vtol = 2.0 * ptol, 2.0 * vtol
+    finite = all(np.isfinite(s1[k]).all() for k in ("px", "py", "pz", "vx", "vy", "vz"))
+    ok = finite and (bit_equal if args.mode == "strict" else (dp <= ptol and dv <= vtol))
+    return {"ok": bool(ok), "steps": kv, "mode": args.mode, "bit_equal": bool(bit_equal), "max_dp": dp, "max_dv": dv,
+            "tol_dp": None if args.mode == "strict" else ptol, "tol_dv": None if args.mode == "strict" else vtol,
+            "max_displacement": moved, "max_accel": amax,
+            "how": f"{kv} more steps on this host and on one plain engine (all {n} bodies, GPU {device}) from the state the timed loop "
+                   "left; strict = bit-equal, fast = 2 x the stated tolerance (two fast results are compared)"}
 
 
 class SingleHost:
@@ -228,6 +369,9 @@ class SingleHost:
 
     def step_bh(self, theta):
         self.eng.step_barnes_hut(theta, DT, 1)
+
+    def get_state(self):
+        return self.eng.get_particles()
 
     def sync(self):
         self.eng.synchronize()
@@ -282,6 +426,9 @@ class GroupHost:
 
     def step_bh(self, theta):
         self.group.step_barnes_hut(theta, DT, 1)
+
+    def get_state(self):
+        return self.group.get_particles()
 
     def sync(self):
         self.group.synchronize()
@@ -339,6 +486,9 @@ class TorchHost:
 
     def step_bh(self, theta):
         self.sim.step_barnes_hut(theta, DT, 1)
+
+    def get_state(self):
+        return self.sim.gather_state()   # collective: every rank calls it
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -446,10 +596,48 @@ def main():
                 "bh_eval_ms": r[5], "bh_eval_launches": int(r[6]), "exchange_us": None, "exchanges": 0} for r in rows]
         per[0]["exchange_us"] = None   # torch's collective runs on ProcessGroupNCCL's own stream: see ms_per_step minus kernels
 
+    engine = host.eng
+    launch = engine.last_launch()   # of the timed loop (the blocks below launch other shapes)
+    dev0 = getattr(host, "local_rank", 0)
+    do_verify = args.verify if args.verify is not None else (world > 1)
+    verify = None
+    if do_verify and args.shard_of <= 1:
+        verify = verify_against_plain_engine(host, args, rx, step, is_bh, dev0)
+    steady = None
+    if host_kind == "single" and args.steady_seconds > 0 and args.shard_of <= 1:
+        steady = steady_state(host, step, args.steady_seconds)
+    general = None
+    if (host_kind == "single" and not is_bh and args.shard_of <= 1 and not args.no_general_masses and args.mode == "fast"
+            and args.variant < 0 and args.source_bits == 32 and launch["variant"] == 7):
+        # The same run on UNEQUAL masses (nb_random_disk's range, nbody.rs:62): positions unchanged, every body its own mass
+        # -> no common mass -> the wave-split kernel WITH the per-interaction multiply by m_j (variant 6). What a caller
+        # whose masses are all different gets; the headline workload (and nb_stable_orbits: one common mass + the sun) runs 7.
+        g = SingleHost(args, rx, dict(st, m=np.random.default_rng(0x5EED).uniform(0.1, 1.5, n).astype(np.float32)))
+        g.prepare()
+        for _ in range(max(args.warmup, 2)):
+            g.step_brute()
+        g.sync()
+        g.eng.profile(True); g.eng.profile_reset()
+        tg0 = time.perf_counter()
+        for _ in range(args.steps):
+            g.step_brute()
+        g.sync()
+        tg1 = time.perf_counter()
+        gk_ms, gk_cnt = g.eng.profile_read(rx.NBX_K_FORCE)
+        g.eng.profile(False)
+        gl = g.eng.last_launch()
+        g_flops = FLOPS_PER_INTERACTION if gl["dim"] == 3 else 12
+        g_peak = rx.device_info(dev0)["peak_fp32_flops"] / 1e12
+        g_ach = float(n) * float(n - 1) * g_flops / (gk_ms / max(gk_cnt, 1) * 1e-3) / 1e12
+        general = {"value": float(n) * float(n - 1) * args.steps / (tg1 - tg0), "unit": "interactions/s",
+                   "ms_per_step": (tg1 - tg0) / args.steps * 1e3, "kernel": KERNEL_NAMES.get(gl["variant"], "k_force"),
+                   "launch": gl, "kernel_avg_ms": gk_ms / max(gk_cnt, 1), "achieved": g_ach, "frac": g_ach / g_peak,
+                   "flops_per_interaction": g_flops, "flops_executed_per_interaction": g_flops,
+                   "masses": "uniform [0.1, 1.5) (nb_random_disk's range, nbody.rs:62), same positions, same steps/warmup, timed in this run"}
+        g.eng.close()
+
     if rank == 0:
-        info = rx.device_info(getattr(host, "local_rank", 0))
-        engine = host.eng
-        launch = engine.last_launch()
+        info = rx.device_info(dev0)
         peak = info["peak_fp32_flops"] / 1e12
         ms_per_step = elapsed / args.steps * 1e3
         out = {"n_gpus": world if host_kind != "single" else 1, "steps": args.steps, "warmup": args.warmup,
@@ -466,6 +654,8 @@ def main():
                 interactions_per_step = float(hi - lo) * float(n - 1)
             value = interactions_per_step * args.steps / elapsed
             flops_per_inter = FLOPS_PER_INTERACTION if launch["dim"] == 3 else 12
+            # variant 7 (one common mass): the multiply by m_j leaves the loop -> one flop fewer EXECUTED per interaction
+            flops_executed = flops_per_inter - (1 if launch["variant"] == 7 else 0)
             # dominant kernel: K1. Roofline from the SLOWEST rank's launches (the step waits for it).
             worst = max(per, key=lambda r: r["force_ms"])
             inter_per_launch = float(worst["slab"][1] - worst["slab"][0]) * float(n - 1)
@@ -491,9 +681,11 @@ def main():
                            "bodies": n, "seed": "0x5EED0001", "force_mode": args.mode, "host": host_kind,
                            "sharding": sharding, "launch": launch,
                            "kernel_note": ("every body of this workload has the same mass, so the unit-mass sweep runs (variant 7: the "
-                                           "per-interaction multiply by m_j is hoisted out of the loop); systems with unequal masses run "
-                                           "variant 6, the same kernel with that multiply: 0.57 of the roofline at this size, "
-                                           "profiles/r02_k1_variants_5_6_7.jsonl") if launch["variant"] == 7 else None},
+                                           "per-interaction multiply by m_j is hoisted out of the loop: 16 flops executed of the 17 "
+                                           "counted, see roofline.frac_executed). It also serves 'one common mass + a handful of "
+                                           "exceptions' (nb_stable_orbits: unit planets + the sun). Systems whose masses all differ run "
+                                           "variant 6, the same kernel with that multiply: timed in this run under general_masses")
+                                          if launch["variant"] == 7 else None},
                 "roofline": {"bound": "valu_fp32",
                              "bound_contract_class": "mfma (dense fp32 peak: the f32 MFMA rate equals the fp32 vector rate, "
                                                      "157.3 TFLOP/s; no MFMA is used)",
@@ -501,7 +693,9 @@ def main():
                              "traffic": traffic, "traffic_measurement": traffic_info,
                              "kernel": KERNEL_NAMES.get(launch["variant"], "k_force"),
                              "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": worst["force_launches"],
-                             "flops_per_interaction": flops_per_inter, "interactions_per_launch": inter_per_launch,
+                             "flops_per_interaction": flops_per_inter, "flops_executed_per_interaction": flops_executed,
+                             "frac_executed": achieved / peak * flops_executed / flops_per_inter,
+                             "interactions_per_launch": inter_per_launch,
                              "hbm_algorithmic_bytes_per_launch": algorithmic,
                              "partial_slab_bytes_written_per_launch": 16.0 * slab_rows * launch.get("acc_slabs", launch["jsplit"]),
                              "note": "VALU-bound path (arithmetic intensity ~1e5 flop/B): peak = CUs*clock*256 flop/clk "
@@ -509,6 +703,8 @@ def main():
                                      "slowest rank's kernel (its slab x all sources per launch)"},
                 "integrate_kernel_avg_ms": per[0]["integrate_ms"],
             })
+            if general:
+                out["general_masses"] = general
         else:
             value = float(n) * args.steps / elapsed
             ht = engine.bh_host_timing()
@@ -544,8 +740,27 @@ def main():
             })
         if world > 1 or host_kind != "single":
             out["per_gpu"] = per
+            kk = "bh_eval_ms" if is_bh else "force_ms"
+            out["rank_skew"] = {"kernel_ms_min": min(r[kk] for r in per), "kernel_ms_max": max(r[kk] for r in per),
+                                "note": "per-rank average of the dominant kernel inside the timed loop (HIP events on each rank's stream)"}
             if host_kind == "group":
                 out["all_gather_us_per_step"] = float(np.mean([r["exchange_us"] for r in per]))
+                xs = [r["exchange_us"] for r in per]
+                out["rank_skew"].update({"exchange_us_min": min(xs), "exchange_us_max": max(xs),
+                                         "exchange_note": "as seen from each rank's stream: includes the wait for the slowest peer"})
+                gi = host.group.info()
+                out["exchange"] = gi["exchange"]
+                out["rccl_ranks"] = gi["rccl_ranks"]
+                out["enqueue_threads"] = gi["enqueue_threads"]
+                if gi["note"]:
+                    out["exchange_note"] = gi["note"]
+            elif host_kind == "torch":
+                out["exchange"] = "torch.distributed " + os.environ.get("NBX_DIST_BACKEND", "nccl")
+                out["rccl_ranks"] = world if os.environ.get("NBX_DIST_BACKEND", "nccl") == "nccl" else 0
+        if verify is not None:
+            out["verify"] = verify
+        if steady is not None:
+            out["steady_state"] = steady
         out.update({"device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],
                     "clock_khz": info["clock_khz"]})
         if not args.no_cpu_baseline and world == 1 and args.shard_of <= 1:
@@ -560,6 +775,9 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(st, args.cpu_seconds)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     host.close()
+    if verify is not None and not verify["ok"]:
+        sys.stderr.write("bench.py: VERIFY FAILED: %s\n" % json.dumps(verify))
+        sys.exit(3)   # a sharded result that differs from the plain engine's is not a measurement
 
 
 if __name__ == "__main__":

@@ -41,3 +41,4 @@ from .engine import (  # noqa: F401
 )
 from .presets import plummer_sphere, splitmix64_uniform, two_galaxies  # noqa: F401
 from .sharded import ShardedNBody, reference_slab  # noqa: F401
+from .tolerances import fast_step_tolerances  # noqa: F401

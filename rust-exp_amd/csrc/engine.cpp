@@ -147,6 +147,20 @@ int upload(nbx_engine* e)
         HIP_TRY(hipMemcpyAsync(e->d_vel, tmp, sizeof(float4) * (size_t)slab, hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
+    if (!e->exc_idx.empty()) {   // the exceptional sources of the unit-mass sweep: indices + weights m_j - mass_common
+        const size_t k = e->exc_idx.size();
+        if (k > e->exc_cap_dev) {
+            if (e->d_exc_idx) HIP_TRY(hipFree(e->d_exc_idx));
+            if (e->d_exc_w) HIP_TRY(hipFree(e->d_exc_w));
+            e->d_exc_idx = nullptr; e->d_exc_w = nullptr; e->exc_cap_dev = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_exc_idx), sizeof(int) * k));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_exc_w), sizeof(float) * k));
+            e->exc_cap_dev = k;
+        }
+        HIP_TRY(hipMemcpyAsync(e->d_exc_idx, e->exc_idx.data(), sizeof(int) * k, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->d_exc_w, e->exc_w.data(), sizeof(float) * k, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     e->dev_valid = true;
     if (e->source_half) {
         rc = refresh_half_sources(e, 0, e->n_pad);
@@ -204,7 +218,7 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
     *dim = e->dim_opt ? e->dim_opt : (e->any_z ? 3 : 2);
     int v = e->variant;
     if (v < 0) v = (tiles_total * kTile >= 16384) ? 7 : 1;   // crossover measured in profiles/r02_small_n_variants.txt
-    if (v == 7 && !(e->n > 0 && e->mass_min == e->mass_max && e->mass_min > 0.0f)) v = 6;   // unit-mass sweep needs equal masses
+    if (v == 7 && !e->unit_sweep_ok()) v = 6;   // unit-mass sweep needs one common mass (+ at most a handful of exceptions)
     *variant = v;
     // 256 targets per workgroup, 4 source quarters per workgroup; the fp16-source kernel (K4) keeps the 1024-target workgroups
     const bool wave_split = (v == 6 || v == 7) && !e->source_half;
@@ -252,7 +266,7 @@ int launch_forces_fast(nbx_engine* e)
     }
     if (variant == 6 || variant == 7) {
         ProfScope ps(e, NBX_K_FORCE);
-        HIP_TRY(nbx::launch_force_wave_split(e->d_posm, e->lo, slab, tiles_total, e->n, jsplit, dim, variant == 7, e->mass_min,
+        HIP_TRY(nbx::launch_force_wave_split(e->d_posm, e->lo, slab, tiles_total, e->n, jsplit, dim, variant == 7, e->mass_common,
                                              e->d_acc, stride, e->stream, &e->last));
         return NBX_OK;
     }
@@ -262,6 +276,13 @@ int launch_forces_fast(nbx_engine* e)
                                        variant == 4 ? e->d_guard : nullptr, e->stream, &e->last));
     }
     return NBX_OK;
+}
+
+// the exceptional sources K2 / the force readout must add after a unit-mass sweep (variant 7) of a system with exceptions
+nbx::MassExceptions exceptions_of(const nbx_engine* e)
+{
+    if (e->last.variant != 7 || e->exc_idx.empty()) return nbx::MassExceptions{nullptr, nullptr, 0, e->last.dim};
+    return nbx::MassExceptions{e->d_exc_idx, e->d_exc_w, (int)e->exc_idx.size(), e->last.dim};
 }
 
 // NBX_LOG=1: one stderr line per step (the reference has no logging on this path; its Haskell shell has Trace.hs)
@@ -304,7 +325,7 @@ int step_brute(nbx_engine* e, float dt)
         const int stride = ((slab + kTile - 1) / kTile) * kTile;
         ProfScope ps(e, NBX_K_INTEGRATE);
         HIP_TRY(nbx::launch_integrate(e->d_posm, e->lo, slab, e->d_vel, e->d_acc, e->last.jsplit, stride, dt,
-                                      e->stream));
+                                      e->stream, exceptions_of(e)));
         if (e->source_half) {   // refresh this slab's slot of the fp16 source copy (the all-gather send slot)
             rc = refresh_half_sources(e, e->lo, slab);
             if (rc != NBX_OK) return rc;
@@ -689,6 +710,8 @@ void free_device(nbx_engine* e)
     if (e->d_out4) (void)hipFree(e->d_out4);
     if (e->d_nodes) (void)hipFree(e->d_nodes);
     if (e->d_guard) (void)hipFree(e->d_guard);
+    if (e->d_exc_idx) (void)hipFree(e->d_exc_idx);
+    if (e->d_exc_w) (void)hipFree(e->d_exc_w);
     if (e->d_tree_ws) (void)hipFree(e->d_tree_ws);
     if (e->d_slab_ws) (void)hipFree(e->d_slab_ws);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
@@ -734,6 +757,30 @@ void after_host_state_change(nbx_engine* e)
     const float nan = std::numeric_limits<float>::quiet_NaN();
     e->mass_min = bad ? nan : lo;
     e->mass_max = bad ? nan : hi;
+    // common mass = the majority value (Boyer-Moore vote, one pass), exceptions = everybody else, if they are few
+    e->mass_common = 0.0f;
+    e->exc_idx.clear();
+    e->exc_w.clear();
+    if (!bad && e->n > 0 && lo > 0.0f) {
+        float cand = e->host.m[0];
+        int votes = 0;
+        for (int i = 0; i < e->n; i++) {
+            const float m = e->host.m[i];
+            if (votes == 0) { cand = m; votes = 1; }
+            else if (m == cand) votes++;
+            else votes--;
+        }
+        const int cap = nbx_engine::exc_cap(e->n);
+        bool few = true;
+        for (int i = 0; i < e->n && few; i++)
+            if (e->host.m[i] != cand) {
+                if ((int)e->exc_idx.size() >= cap) { few = false; break; }
+                e->exc_idx.push_back(i);
+                e->exc_w.push_back(e->host.m[i] - cand);
+            }
+        if (few) e->mass_common = cand;
+        else { e->exc_idx.clear(); e->exc_w.clear(); }
+    }
 }
 
 

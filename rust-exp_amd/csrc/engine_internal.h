@@ -91,6 +91,17 @@ struct nbx_engine {
     int force_mode = 0, jsplit = 0, bpt = 0, dim_opt = 0, profile = 0, variant = -1, strict_kernel = 0;
     bool any_z = false;
     float mass_min = 0.0f, mass_max = 0.0f;   // over the current bodies (masses never change during a run)
+    // "one common mass + a handful of exceptions" (the reference's own nb_stable_orbits: unit planets + a 1000-mass sun,
+    // nbody.rs:85-102): the unit-mass sweep (variant 7) runs with every source weightless at mass_common and K2 adds the
+    // exceptional sources with weight m_j - mass_common.  mass_common = 0: no usable common mass (variant 6 runs).
+    float mass_common = 0.0f;
+    std::vector<int> exc_idx;        // bodies whose mass differs from mass_common (at most exc_cap(n))
+    std::vector<float> exc_w;        // m_j - mass_common
+    int* d_exc_idx = nullptr;
+    float* d_exc_w = nullptr;
+    size_t exc_cap_dev = 0;
+    static int exc_cap(int n) { return std::min(n / 64, std::max(32, n / 1024)); }   // 1 024 bodies: 16, 10 000: 32, 262 144: 256
+    bool unit_sweep_ok() const { return n > 0 && mass_common > 0.0f; }
 
     nbx::Rng rng{0};
     bool seeded = false;
@@ -231,6 +242,7 @@ int download_positions(nbx_engine* e);
 int download_velocities(nbx_engine* e);
 void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* variant, int* bpt, int* jsplit, int* dim);
 int launch_forces_fast(nbx_engine* e);
+nbx::MassExceptions exceptions_of(const nbx_engine* e);
 int step_brute(nbx_engine* e, float dt);
 int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also = nullptr, int n_also = 0, bool order_bodies = false);
 int build_tree_on_device_begin(nbx_engine* e);

@@ -528,13 +528,35 @@ __global__ __launch_bounds__(kTile) void k_force_smem(const float4* __restrict__
     }
 }
 
+// The exceptional sources of a unit-mass sweep (kernels.h MassExceptions): a handful of bodies (the reference's
+// nb_stable_orbits has ONE: the 1000-mass sun among unit planets, nbody.rs:85-102) whose weight m_j - m_common the sweep
+// left out.  Wave-uniform indices: the records arrive through the scalar cache.  Same pair law, same rcp.
+__device__ __forceinline__ void add_exceptions(const float4* __restrict__ posm, const MassExceptions exc, const float4 p, float4& a)
+{
+    for (int k = 0; k < exc.count; k++) {
+        const float4 s = posm[exc.idx[k]];
+        const float dx = s.x - p.x, dy = s.y - p.y;
+        float r2 = __builtin_fmaf(dx, dx, kEps);
+        r2 = __builtin_fmaf(dy, dy, r2);
+        float dz = 0.0f;
+        if (exc.dim == 3) {
+            dz = s.z - p.z;
+            r2 = __builtin_fmaf(dz, dz, r2);
+        }
+        const float sc = exc.w[k] * __builtin_amdgcn_rcpf(r2);
+        a.x = __builtin_fmaf(sc, dx, a.x);
+        a.y = __builtin_fmaf(sc, dy, a.y);
+        a.z = __builtin_fmaf(sc, dz, a.z);
+    }
+}
+
 // K2: a_i = sum over splits in FIXED ascending order (deterministic), then the reference's
 // kick-drift (nbody.rs:153-160) with F/m == a:  v += dt*a ; p += dt*v_new.  Products and sums are
 // kept unfused (mul then add, as rustc emits them).
 __global__ __launch_bounds__(kTile) void k_integrate(float4* __restrict__ posm, const int lo, const int n_targets,
                                                      float4* __restrict__ vel,
                                                      const float4* __restrict__ acc_partial, const int jsplit,
-                                                     const int acc_stride, const float dt)
+                                                     const int acc_stride, const float dt, const MassExceptions exc)
 {
     const int i = blockIdx.x * kTile + threadIdx.x;
     if (i >= n_targets) return;
@@ -545,6 +567,7 @@ __global__ __launch_bounds__(kTile) void k_integrate(float4* __restrict__ posm, 
     }
     float4 v = vel[i];
     float4 p = posm[lo + i];
+    add_exceptions(posm, exc, p, a);
     v.x = __fadd_rn(v.x, __fmul_rn(dt, a.x));
     v.y = __fadd_rn(v.y, __fmul_rn(dt, a.y));
     v.z = __fadd_rn(v.z, __fmul_rn(dt, a.z));
@@ -558,7 +581,7 @@ __global__ __launch_bounds__(kTile) void k_integrate(float4* __restrict__ posm, 
 __global__ __launch_bounds__(kTile) void k_reduce_forces(const float4* __restrict__ posm, const int lo,
                                                          const int n_targets,
                                                          const float4* __restrict__ acc_partial, const int jsplit,
-                                                         const int acc_stride, float4* __restrict__ out)
+                                                         const int acc_stride, float4* __restrict__ out, const MassExceptions exc)
 {
     const int i = blockIdx.x * kTile + threadIdx.x;
     if (i >= n_targets) return;
@@ -567,7 +590,9 @@ __global__ __launch_bounds__(kTile) void k_reduce_forces(const float4* __restric
         const float4 q = acc_partial[(size_t)s * acc_stride + i];
         a.x += q.x; a.y += q.y; a.z += q.z;
     }
-    const float m = posm[lo + i].w;
+    const float4 p = posm[lo + i];
+    add_exceptions(posm, exc, p, a);
+    const float m = p.w;
     out[i] = make_float4(m * a.x, m * a.y, m * a.z, 0.0f);
 }
 
@@ -651,20 +676,20 @@ hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tile
 }
 
 hipError_t launch_integrate(float4* posm, int lo, int n_targets, float4* vel, const float4* acc_partial, int jsplit,
-                            int acc_stride, float dt, hipStream_t stream)
+                            int acc_stride, float dt, hipStream_t stream, MassExceptions exc)
 {
     if (n_targets <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_integrate, dim3((n_targets + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, lo, n_targets,
-                       vel, acc_partial, jsplit, acc_stride, dt);
+                       vel, acc_partial, jsplit, acc_stride, dt, exc);
     return hipGetLastError();
 }
 
 hipError_t launch_reduce_forces(const float4* posm, int lo, int n_targets, const float4* acc_partial, int jsplit,
-                                int acc_stride, float4* out, hipStream_t stream)
+                                int acc_stride, float4* out, hipStream_t stream, MassExceptions exc)
 {
     if (n_targets <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_reduce_forces, dim3((n_targets + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, lo,
-                       n_targets, acc_partial, jsplit, acc_stride, out);
+                       n_targets, acc_partial, jsplit, acc_stride, out, exc);
     return hipGetLastError();
 }
 

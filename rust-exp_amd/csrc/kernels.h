@@ -45,13 +45,24 @@ hipError_t launch_force_tile_half(const float4* posm, const void* posh, int lo, 
 // posh[first..first+count) = half(posm[...]) (round to nearest even)
 hipError_t launch_pack_half(const float4* posm, void* posh, int first, int count, hipStream_t stream);
 
-// K2: reduce partials in fixed order, kick-drift, write positions in place (slab slot of posm).
+// Sources whose mass differs from the common mass of a unit-mass sweep (variant 7): after the sweep gave every source the
+// common mass, body idx[k] still owes (w[k] = m - m_common) * d / (|d|^2 + eps) to every target.  count = 0: none.
+struct MassExceptions {
+    const int* idx;
+    const float* w;
+    int count;
+    int dim;
+};
+
+// K2: reduce partials in fixed order (+ the exceptional sources), kick-drift, write positions in place (slab slot of posm).
 hipError_t launch_integrate(float4* posm, int lo, int n_targets, float4* vel, const float4* acc_partial,
-                            int jsplit, int acc_stride, float dt, hipStream_t stream);
+                            int jsplit, int acc_stride, float dt, hipStream_t stream,
+                            MassExceptions exc = MassExceptions{nullptr, nullptr, 0, 3});
 
 // forces-only readout: F_i = m_i * a_i into float4 out[n_targets]
 hipError_t launch_reduce_forces(const float4* posm, int lo, int n_targets, const float4* acc_partial, int jsplit,
-                                int acc_stride, float4* out, hipStream_t stream);
+                                int acc_stride, float4* out, hipStream_t stream,
+                                MassExceptions exc = MassExceptions{nullptr, nullptr, 0, 3});
 
 // strict (bit-exact) pair: ascending j per target, IEEE divide, no contraction. 2-D.
 // kernel: 16 or 8 = workgroups of that many waves per 64 targets (term producers + one summing wave), 1 = one thread per body,

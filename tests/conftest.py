@@ -76,10 +76,21 @@ def fast_tolerances(ob, p, dt, steps=1, amax=None, n=None):
         fx, fy = ob.brute_forces(p, nthreads=8)
         m = np.asarray(p["m"], np.float64)
         amax = float(np.max(np.hypot(fx / m, fy / m))) if n else 0.0
-    v1 = 1e-5 * amax * dt * max(1.0, np.sqrt(n) / 64.0)
-    # positions follow from p' = p + dt * v': a velocity difference dv moves a body by dt * dv (the survey's flat 1e-5 is that
-    # on its 4 096-body case; the sqrt(N) growth of the velocity bound carries over at half a million bodies)
-    p1 = max(1e-5, dt * v1 + 4e-6)
-    if steps <= 1:
-        return p1, v1
-    return p1 * steps, 2.5 * steps * v1
+    from rust_exp_amd.tolerances import fast_step_tolerances
+
+    return fast_step_tolerances(amax, n, dt, steps)
+
+
+def fp64_forces_sample(st, idx, dim=3, chunk=16):
+    """F_i = m_i * sum_j m_j d / (|d|^2 + 1e-4) (the pair law of nbody.rs:174-183, z added for dim 3) in numpy float64 for
+    the targets `idx` against ALL sources: the neutral arbiter at sizes where the f32 oracle needs minutes. [len(idx), 3]."""
+    P = np.stack([st["px"], st["py"], st["pz"] if dim == 3 else np.zeros_like(st["px"])], 1).astype(np.float64)
+    m = np.asarray(st["m"], np.float64)
+    idx = np.asarray(idx)
+    out = np.zeros((len(idx), 3))
+    for a in range(0, len(idx), chunk):
+        ii = idx[a:a + chunk]
+        d = P[None, :, :] - P[ii, None, :]
+        w = m[None, :] / ((d * d).sum(-1) + 1e-4)
+        out[a:a + chunk] = (w[:, :, None] * d).sum(1) * m[ii, None]
+    return out

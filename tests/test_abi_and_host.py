@@ -406,6 +406,44 @@ def test_group_host_side_without_device(rx):
         rx.NBodyGroup([0, 0])                 # the same device twice
 
 
+def test_group_info_threads_and_option_queries_without_device(rx, monkeypatch):
+    """Host-side facts of the group added in round 3: how the exchange runs (nothing created yet: kind 'rccl', 0 ranks), the
+    enqueue-thread switch (threads start and stop without a device), NBX_GROUP_EXCHANGE=copy, and the option round trips of
+    ADVICE r02 (NBX_OPT_BH_TREE accepts -1 again; nbx_query_option tells the value -1 from an error)."""
+    from rust_exp_amd.engine import NBX_OPT_BH_TREE, NBX_OPT_DRAW_AMBIGUOUS, NBX_OPT_DRAW_DEVICE
+
+    monkeypatch.delenv("NBX_GROUP_EXCHANGE", raising=False)
+    if rx.device_count() == 0:
+        g = rx.NBodyGroup([0, 1, 2, 3])
+        assert g.info() == {"exchange": "rccl", "rccl_ranks": 0, "enqueue_threads": 0, "fp32_stale": False, "note": ""}
+        g.set_enqueue_threads(True)
+        assert g.info()["enqueue_threads"] == 4
+        g.set_particles(np.zeros(9), np.zeros(9), np.zeros(9), np.zeros(9), np.ones(9))
+        with pytest.raises(rx.NBodyError) as ei:      # the worker threads' failure text reaches this thread
+            g.step_brute_force(0.01)
+        assert ei.value.code == rx.NBX_ERR_NO_DEVICE and "no HIP device" in str(ei.value)
+        g.set_enqueue_threads(False)
+        assert g.info()["enqueue_threads"] == 0
+        g.close()
+        monkeypatch.setenv("NBX_GROUP_ENQUEUE", "threads")
+        g = rx.NBodyGroup([0, 1])
+        assert g.info()["enqueue_threads"] == 2
+        g.close()
+    monkeypatch.setenv("NBX_GROUP_EXCHANGE", "copy")
+    g = rx.NBodyGroup([0, 0, 0])              # engines may share a device with the copy exchange
+    assert g.info()["exchange"] == "peer_copy" and g.size() == 3
+    g.close()
+    e = rx.NBodyEngine()
+    for where, val in (("host", 0), ("device", 1), ("auto", -1)):
+        e.set_bh_tree(where)
+        assert e.query_option(NBX_OPT_BH_TREE) == val
+    with pytest.raises(rx.NBodyError):
+        e.set_option(NBX_OPT_BH_TREE, 2)
+    assert e.query_option(NBX_OPT_DRAW_DEVICE) == -1 and e.query_option(NBX_OPT_DRAW_AMBIGUOUS) == 0
+    with pytest.raises(rx.NBodyError):
+        e.query_option(99)
+
+
 def test_host_worker_pool_serves_concurrent_builds(rx, ob):
     """Several engines building big trees at the same time from different caller threads (ctypes drops the GIL): the
     shared worker pool must neither deadlock nor mix results -- every dump equals the single-threaded one."""

@@ -247,6 +247,112 @@ def test_unit_mass_sweep_in_3d_against_fp64(rx):
     assert np.abs(got - F).max() <= 1e-5 * np.abs(F).max()
 
 
+def _with_exceptions(p, k, seed):
+    """All bodies at mass 0.37 except k of them (a 1000-mass 'sun' first, then heavier and LIGHTER bodies), at positions
+    that include the first and the last index."""
+    q = p.copy()
+    q["m"][:] = np.float32(0.37)
+    n = len(q)
+    if k == 0:
+        return q, []
+    rng = np.random.default_rng(seed)
+    where = [0, n - 1][:k] + list(rng.choice(np.arange(1, n - 1), size=max(0, k - 2), replace=False))
+    vals = ([1000.0, 0.01] + list(rng.uniform(0.05, 40.0, size=max(0, k - 2))))[:k]
+    for i, v in zip(where, vals):
+        q["m"][i] = np.float32(v)
+    return q, sorted(where)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("k", [0, 1, 17])
+def test_unit_mass_sweep_with_exceptional_masses(rx, ob, k, dim):
+    """'One common mass + a handful of exceptions' -- the shape of the reference's own nb_stable_orbits (unit planets + a
+    1000-mass sun, nbody.rs:85-102): the unit-mass sweep (variant 7) runs over weightless sources at the common mass and
+    K2 / the force readout add the k exceptional sources with weight m_j - m_common.  Forces and one step against the
+    oracle, 0 / 1 / 17 exceptions (VERDICT r02 next #2)."""
+    n = 20000
+    q, where = _with_exceptions(ob.random_disk(n, 23), k, 5)
+    ofx, ofy = ob.brute_forces(q, nthreads=8)
+    scale = max(np.abs(ofx).max(), np.abs(ofy).max())
+    e = rx.NBodyEngine(mode="fast")
+    load(e, q)
+    e.set_launch(dim=dim)                       # default kernel choice: >= 16 384 sources -> the wave-split sweep
+    fx, fy, fz = e.forces()
+    ll = e.last_launch()
+    assert ll["variant"] == 7 and ll["dim"] == dim, ll
+    assert np.abs(fx - ofx).max() <= 1e-5 * scale and np.abs(fy - ofy).max() <= 1e-5 * scale and not fz.any()
+    ptol, vtol = fast_tolerances(ob, q, DT, 1)
+    e.step_brute_force(DT)
+    r = q.copy(); ob.step_brute_force(r, DT, nthreads=8)
+    st = e.get_particles()
+    for kk in ("px", "py"):
+        assert np.abs(st[kk] - r[kk]).max() <= ptol, (k, kk)
+    for kk in ("vx", "vy"):
+        assert np.abs(st[kk] - r[kk]).max() <= vtol, (k, kk)
+    # the general-mass kernel on the same system agrees with the corrected sweep to the same bound
+    e6 = rx.NBodyEngine(mode="fast")
+    load(e6, q)
+    e6.set_launch(dim=dim, variant=6)
+    gx, gy, _ = e6.forces()
+    assert e6.last_launch()["variant"] == 6
+    assert np.abs(gx - fx).max() <= 2e-5 * scale and np.abs(gy - fy).max() <= 2e-5 * scale
+
+
+def test_unit_mass_sweep_exceptions_in_3d_and_on_slabs(rx):
+    """The same with real z coordinates (fp64 arbiter) and on every slab of a 3-way shard (targets in a slab, exceptional
+    sources anywhere)."""
+    from conftest import fp64_forces_sample
+
+    n = 24576
+    st = rx.plummer_sphere(n)
+    m = st["m"].copy()
+    exc = [0, 5000, 12288, 20000, n - 1]
+    m[exc] = np.float32([1000.0, 3.0, 1e-3, 77.0, 0.5])
+    st = dict(st, m=m)
+    idx = np.arange(0, n, 97)
+    F = fp64_forces_sample(st, idx)
+    for world in (1, 3):
+        for rank in range(world):
+            e = rx.NBodyEngine()
+            e.set_shard(rank, world)
+            e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
+            fx, fy, fz = e.forces()
+            assert e.last_launch()["variant"] == 7 and e.last_launch()["dim"] == 3
+            lo, hi = e.slab()
+            sel = (idx >= lo) & (idx < hi)
+            got = np.stack([fx, fy, fz], 1)[idx[sel] - lo]
+            assert np.abs(got - F[sel]).max() <= 1e-5 * np.abs(F).max(), (world, rank)
+
+
+def test_too_many_exceptions_run_the_general_kernel(rx, ob):
+    """More exceptional masses than the cap (max(32, n/1024), at most n/64): no common mass, variant 6."""
+    n = 20000
+    q, _ = _with_exceptions(ob.random_disk(n, 29), 40, 7)
+    e = rx.NBodyEngine(mode="fast")
+    load(e, q)
+    fx, fy, _ = e.forces()
+    assert e.last_launch()["variant"] == 6
+    ofx, ofy = ob.brute_forces(q, nthreads=8)
+    assert np.abs(fx - ofx).max() <= 1e-5 * max(np.abs(ofx).max(), np.abs(ofy).max())
+
+
+def test_stable_orbits_preset_takes_the_unit_mass_sweep(rx, ob):
+    """nb_stable_orbits itself (seeded): 19 999 unit planets + the sun -> variant 7 with one exception, step == oracle
+    within the stated tolerance."""
+    e = rx.NBodyEngine(mode="fast")
+    e.seed(4)
+    e.stable_orbits(20000, 0.5, 30.0)
+    s0 = e.get_particles()
+    p = ob.particles(s0["px"], s0["py"], s0["vx"], s0["vy"], s0["m"])
+    e.step_brute_force(DT)
+    assert e.last_launch()["variant"] == 7
+    ptol, vtol = fast_tolerances(ob, p, DT, 1)
+    ob.step_brute_force(p, DT, nthreads=8)
+    st = e.get_particles()
+    assert np.abs(st["px"] - p["px"]).max() <= ptol and np.abs(st["py"] - p["py"]).max() <= ptol
+    assert np.abs(st["vx"] - p["vx"]).max() <= vtol and np.abs(st["vy"] - p["vy"]).max() <= vtol
+
+
 @pytest.mark.parametrize("scale,expect_batched", [(1.0, True), (200.0, True), (1000.0, False), (1.0e6, False)])
 def test_batched_reciprocal_guard(rx, ob, scale, expect_batched):
     """Variant 4 multiplies four softened squared distances before its single v_rcp_f32: safe only while

@@ -37,33 +37,77 @@ def test_config2_plummer_65536_fast_vs_fp64_sample_and_step_invariants(rx, ob):
     assert np.all(np.abs(mom) <= 1e-4 * (p["m"].astype(np.float64) * np.abs(p["vx"])).sum() + 1e-6)
 
 
-def test_config3_262144_eight_slabs_stitch_to_the_unsharded_step(rx):
+def _sample_targets(lo, hi, count=512):
+    return lo + (np.arange(count, dtype=np.int64) * (hi - lo)) // count
+
+
+@pytest.mark.parametrize("masses", ["equal", "random"])
+def test_headline_kernel_at_the_headline_shape_against_fp64(rx, masses):
+    """The kernel bench.py times, at the shape it times it: N = 262 144, dim 3, DEFAULT launch =
+    k_force_smem_pkw, S = 8, 8 192 workgroups -- variant 7 (every Plummer body has the same mass) and variant 6 (random
+    masses, what `general_masses` in the bench line times).  512 targets spread over the whole range x ALL 262 144 sources
+    against a float64 sum (nbody.rs:174-183 with z), bound 1e-5 * max|F|."""
+    from conftest import fp64_forces_sample
+
+    n = 262144
+    st = rx.plummer_sphere(n)
+    if masses == "random":
+        st = dict(st, m=np.random.default_rng(11).uniform(0.1, 1.5, n).astype(np.float32))   # nb_random_disk's range, nbody.rs:62
+    e = rx.NBodyEngine()
+    e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
+    fx, fy, fz = e.forces()
+    ll = e.last_launch()
+    assert (ll["variant"], ll["jsplit"], ll["grid"], ll["dim"], ll["block"]) == (7 if masses == "equal" else 6, 8, 8192, 3, 256), ll
+    idx = _sample_targets(0, n)
+    F = fp64_forces_sample(st, idx)
+    got = np.stack([fx[idx], fy[idx], fz[idx]], 1).astype(np.float64)
+    err = np.abs(got - F).max() / np.abs(F).max()
+    assert err <= 1e-5, (masses, err)
+    # and the step built on it: one kick-drift from those accelerations, against the float64 forces of the sample
+    e.step_brute_force(0.01)
+    assert e.last_launch() == ll
+    p = e.get_particles()
+    a = F / st["m"][idx].astype(np.float64)[:, None]
+    vnew = np.stack([st["vx"][idx], st["vy"][idx], st["vz"][idx]], 1) + 0.01 * a
+    pnew = np.stack([st["px"][idx], st["py"][idx], st["pz"][idx]], 1) + 0.01 * vnew
+    amax = float(np.max(np.sqrt((a * a).sum(1))))
+    ptol, vtol = fast_tolerances(None, None, 0.01, 1, amax=amax, n=n)
+    assert np.abs(np.stack([p["vx"][idx], p["vy"][idx], p["vz"][idx]], 1) - vnew).max() <= vtol
+    assert np.abs(np.stack([p["px"][idx], p["py"][idx], p["pz"][idx]], 1) - pnew).max() <= ptol
+
+
+def test_config3_262144_eight_slabs_against_fp64(rx):
+    """One GPU's share of config #3 (32 768 targets x 262 144 sources; first, middle and last slab of the reference split
+    nbody.rs:426-428) at the launch shape an 8-GPU run uses, each against the float64 sum on 512 of its targets -- an
+    external check per slab shape (round 2 compared fast slabs with the fast unsharded step), then the slab's own step."""
+    from conftest import fp64_forces_sample
+
     n, world = 262144, 8
     st = rx.plummer_sphere(n)
-    ref = rx.NBodyEngine()
-    ref.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
-    # tolerance from the data; at this size max|a| comes from the engine's own force evaluation (the oracle
-    # needs minutes for 6.9e10 pairs) -- it only scales the bound. Two fast results are compared, each within the bound
-    # of the oracle: hence the factor 2.
-    fx, fy, fz = ref.forces()
-    amax = float(np.max(np.sqrt(fx.astype(np.float64) ** 2 + fy.astype(np.float64) ** 2 + fz.astype(np.float64) ** 2) / st["m"]))
-    ptol, vtol = fast_tolerances(None, None, 0.01, 1, amax=amax, n=n)
-    ref.step_brute_force(0.01)
-    want = ref.get_particles()
-    for r in (0, 3, 7):      # first, middle, last slab (each is 32 768 targets x 262 144 sources)
+    for r in (0, 3, 7):
         e = rx.NBodyEngine()
         e.set_shard(r, world)
         e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
-        e.step_local(0.01)
         lo, hi = e.slab()
         assert (lo, hi) == (r * 32768, (r + 1) * 32768)
-        got = e.get_particles()
-        for k in ("px", "py", "pz"):
-            assert np.abs(got[k][lo:hi] - want[k][lo:hi]).max() <= 2 * ptol, (r, k)
-        for k in ("vx", "vy", "vz"):
-            assert np.abs(got[k][lo:hi] - want[k][lo:hi]).max() <= 2 * vtol, (r, k, vtol)
+        fx, fy, fz = e.forces()
         ll = e.last_launch()
-        assert ll["grid"] >= 2048 and ll["dim"] == 3      # the j-split keeps the chip full with 32 768 targets
+        assert (ll["variant"], ll["jsplit"], ll["grid"], ll["dim"]) == (7, 64, 8192, 3), ll   # the j-split keeps the chip full
+        idx = _sample_targets(lo, hi)
+        F = fp64_forces_sample(st, idx)
+        got = np.stack([fx[idx - lo], fy[idx - lo], fz[idx - lo]], 1).astype(np.float64)
+        assert np.abs(got - F).max() <= 1e-5 * np.abs(F).max(), r
+        e.step_local(0.01)
+        p = e.get_particles()
+        a = F / st["m"][idx].astype(np.float64)[:, None]
+        vnew = 0.01 * a                                     # the Plummer workload starts at rest
+        pnew = np.stack([st["px"][idx], st["py"][idx], st["pz"][idx]], 1) + 0.01 * vnew
+        ptol, vtol = fast_tolerances(None, None, 0.01, 1, amax=float(np.max(np.sqrt((a * a).sum(1)))), n=n)
+        assert np.abs(np.stack([p["vx"][idx], p["vy"][idx], p["vz"][idx]], 1) - vnew).max() <= vtol, r
+        assert np.abs(np.stack([p["px"][idx], p["py"][idx], p["pz"][idx]], 1) - pnew).max() <= ptol, r
+        # bodies outside the slab are untouched by a local step
+        out = np.r_[0:lo, hi:n]
+        assert np.array_equal(p["px"][out], st["px"][out])
 
 
 @pytest.mark.parametrize("tree", ["host", "device"])

@@ -94,6 +94,69 @@ def test_group_fp16_and_fp32_exchange_on_one_gpu(rx, ob, monkeypatch, G, n):
     _check_group_against_plain_engine(rx, ob, [0] * G, n, 90 + G)
 
 
+@pytest.mark.parametrize("hook", ["init", "gather"])
+def test_group_falls_back_to_peer_copies_when_rccl_fails(rx, ob, monkeypatch, hook):
+    """VERDICT r02 next #1b: a failing ncclCommInitAll (or a failing collective) must not kill the run -- the group switches
+    to the event-ordered peer-copy exchange, redoes the exchange, and says so. The failure is simulated
+    (NBX_GROUP_RCCL_FAIL=init|gather: the only way to meet it on a single-GPU box; 'gather' needs a real communicator, so on
+    one GPU it runs with one rank); the state must equal the oracle's bit for bit either way."""
+    monkeypatch.delenv("NBX_GROUP_EXCHANGE", raising=False)
+    monkeypatch.setenv("NBX_GROUP_RCCL_FAIL", hook)
+    have = rx.device_count()
+    G = 3 if hook == "init" else min(have, 4)
+    devices = [0] * G if hook == "init" else list(range(G))      # 'init': RCCL is never entered, engines may share the GPU
+    n = G * 1500 + 1
+    p = ob.stable_orbits(n, 0.5, 30.0, 31)
+    g = rx.NBodyGroup(devices, mode="strict")
+    assert g.info()["exchange"] == "rccl" and g.info()["rccl_ranks"] == 0     # nothing created yet
+    g.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    q = p.copy()
+    for _ in range(3):
+        g.step_brute_force(0.01); ob.step_brute_force(q, 0.01, nthreads=8)
+    got = g.get_particles()
+    for k in KEYS:
+        assert_bit_equal(got[k], q[k], f"fallback({hook}) G={G} {k}")
+    info = g.info()
+    assert info["exchange"] == "peer_copy_after_rccl_failure" and info["rccl_ranks"] == 0 and "simulated" in info["note"], info
+    assert g.exchanges() == 3
+    g.close()
+
+
+@pytest.mark.parametrize("bits,mode", [(32, "strict"), (32, "fast"), (16, "fast")])
+def test_group_with_one_enqueue_thread_per_device(rx, ob, monkeypatch, bits, mode):
+    """VERDICT r02 next #1c: one persistent host thread per engine enqueues that engine's K1 + K2 + its share of the
+    exchange (nbx_group_set_enqueue_threads / NBX_GROUP_ENQUEUE=threads). Same results as the single enqueue thread:
+    bit for bit (the kernels and their order per stream are the same), ragged slabs included."""
+    monkeypatch.setenv("NBX_GROUP_EXCHANGE", "copy")
+    G, n = 4, 4 * 2000 + 3
+    p = ob.stable_orbits(n, 0.5, 30.0, 41)
+    outs = []
+    for threads in (False, True):
+        g = rx.NBodyGroup([0] * G, mode=mode)
+        g.set_source_precision(bits)
+        g.set_enqueue_threads(threads)
+        assert g.info()["enqueue_threads"] == (G if threads else 0)
+        g.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+        for _ in range(4):
+            g.step_brute_force(0.01)
+        g.step_barnes_hut(0.6, 0.01, 1)
+        g.step_brute_force(0.01)
+        g.synchronize()
+        outs.append(g.get_particles())
+        assert g.info()["exchange"] == "peer_copy"
+        g.close()
+    for k in KEYS:
+        assert_bit_equal(outs[0][k], outs[1][k], f"enqueue threads {mode} {bits} {k}")
+    if mode == "strict":
+        q = p.copy()
+        for _ in range(4):
+            ob.step_brute_force(q, 0.01, nthreads=8)
+        assert ob.step_barnes_hut(q, 0.6, 0.01, 4) == 0
+        ob.step_brute_force(q, 0.01, nthreads=8)
+        for k in KEYS:
+            assert_bit_equal(outs[1][k], q[k], f"threads strict vs oracle {k}")
+
+
 def test_group_over_rccl_with_two_or_more_gpus(rx, ob):
     """Real RCCL, G > 1 (ncclCommInitAll, in-place ncclAllGather of float4 and of half4, per-owner broadcasts for the ragged
     split): strict group == plain engine == oracle bit for bit; fast and fp16 within their tolerance classes."""
@@ -142,6 +205,39 @@ def test_bench_gpus_n_plain_invocation_uses_the_group_host(rx):
     assert res["roofline"]["interactions_per_launch"] == 16384.0 * 32767.0
 
 
+@pytest.mark.parametrize("extra_env", [{}, {"NBX_GROUP_ENQUEUE": "threads"}, {"NBX_GROUP_RCCL_FAIL": "init"}])
+def test_bench_gpus_8_verifies_itself(rx, extra_env):
+    """VERDICT r02 next #1 'done' line: `NBX_GROUP_EXCHANGE=copy python bench.py --gpus 8 --verify` on the 1-GPU box -- eight
+    engines (sharing the GPU unless the box has eight), the timed loop, then the self-check: the group's state after more
+    steps against ONE plain engine from the same state, in the JSON line. Also with one enqueue thread per device, and with a
+    simulated RCCL failure (the run must survive on peer copies and say so)."""
+    env = dict(extra_env)
+    if rx.device_count() < 8 and "NBX_GROUP_RCCL_FAIL" not in env:
+        env["NBX_GROUP_EXCHANGE"] = "copy"
+    res = _run_bench(["--gpus", "8", "--n", "65536", "--steps", "3", "--warmup", "1", "--verify", "--no-cpu-baseline"], env)
+    assert res["n_gpus"] == 8 and len(res["per_gpu"]) == 8
+    v = res["verify"]
+    assert v["ok"] and v["steps"] == 2 and v["max_dp"] <= v["tol_dp"] and v["max_dv"] <= v["tol_dv"] and v["max_displacement"] > 0, v
+    if "NBX_GROUP_RCCL_FAIL" in env:
+        assert res["exchange"] == "peer_copy_after_rccl_failure" and res["rccl_ranks"] == 0 and "simulated" in res["exchange_note"]
+    elif rx.device_count() >= 8:
+        assert res["exchange"] == "rccl" and res["rccl_ranks"] == 8
+    else:
+        assert res["exchange"] == "peer_copy" and res["rccl_ranks"] == 0
+    assert res["enqueue_threads"] == (8 if env.get("NBX_GROUP_ENQUEUE") == "threads" else 0)
+    assert res["rank_skew"]["kernel_ms_max"] >= res["rank_skew"]["kernel_ms_min"] > 0
+
+
+def test_bench_verify_strict_and_barnes_hut_through_the_group(rx):
+    """The same self-check in the bit-exact mode (must be bit-equal) and for the Barnes-Hut workload."""
+    env = {} if rx.device_count() >= 3 else {"NBX_GROUP_EXCHANGE": "copy"}
+    res = _run_bench(["--gpus", "3", "--n", "10001", "--steps", "2", "--warmup", "1", "--mode", "strict", "--verify", "--no-cpu-baseline"], env)
+    assert res["verify"]["ok"] and res["verify"]["bit_equal"] and res["verify"]["max_dp"] == 0.0, res["verify"]
+    res = _run_bench(["--gpus", "2", "--workload", "bh", "--n", "50000", "--theta", "0.6", "--steps", "2", "--warmup", "1", "--verify",
+                      "--no-cpu-baseline", "--no-traffic"], env)
+    assert res["verify"]["ok"], res["verify"]
+
+
 def test_bench_under_torch_distributed_run_two_ranks(rx):
     """The driver's multi-GPU launch line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
     127.0.0.1 --master-port P bench.py --gpus 2 ...` (one rank per GPU, torch.distributed moves the slabs).  RCCL when the
@@ -165,6 +261,7 @@ def test_bench_under_torch_distributed_run_two_ranks(rx):
     assert res["n_gpus"] == 2 and res["config"]["host"] == "torch" and res["scaling"] == "strong"
     assert [r["slab"] for r in res["per_gpu"]] == [[0, 16384], [16384, 32768]] and all(r["force_launches"] == 3 for r in res["per_gpu"])
     assert res["value"] > 0 and 0 < res["roofline"]["frac"] < 1 and "cpu_baseline" not in res
+    assert res["verify"]["ok"] and res["verify"]["steps"] == 2, res["verify"]     # on by default with more than one GPU
 
 
 def test_bench_default_line_has_roofline_and_measured_traffic(rx):
@@ -179,6 +276,11 @@ def test_bench_default_line_has_roofline_and_measured_traffic(rx):
     if shutil.which("rocprofv3"):
         assert rl["traffic"] is not None and rl["traffic"] >= 0.5 * rl["hbm_algorithmic_bytes_per_launch"], rl
     assert res["cpu_baseline"]["kind"] == "port"
+    assert rl["flops_executed_per_interaction"] == 16 and abs(rl["frac_executed"] - rl["frac"] * 16 / 17) < 1e-12
+    gm = res["general_masses"]
+    assert gm["launch"]["variant"] == 6 and 0 < gm["frac"] < 1 and gm["value"] > 0
+    ss = res["steady_state"]
+    assert ss["window_s"] >= 3.0 and ss["ms_per_step"] > 0
 
 
 def test_bench_barnes_hut_workload(rx):

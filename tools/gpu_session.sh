@@ -16,7 +16,7 @@
 #   ubench  instruction-issue microbenchmarks
 #   strict  bit-exact all-pairs kernels: kernel sweep by size + PMC summaries
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-TAG="${TAG:-r02}"
+TAG="${TAG:-r03}"
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
@@ -111,6 +111,14 @@ PY
     strict) # bit-exact all-pairs kernels: sweep of the three kernels by size, PMC of the default at three sizes
       TAG=$TAG bash tools/sweep_strict_kernels.sh > /dev/null 2>&1; cat $O/${TAG}_strict_kernel_sweep.txt
       for b in 10000 65536 262144; do rm -rf $O/stpmc_*; TAG=$TAG BODIES=$b bash tools/strict_pmc.sh > /dev/null 2>&1; done; rm -rf $O/stpmc_* ;;
+    xlat)   # software floor of the per-step exchange on one GPU + the scaling bound built on it
+      timeout 1200 python tools/exchange_latency.py > $O/${TAG}_exchange_latency.json 2> $O/${TAG}_exchange_latency.err; echo "xlat rc=$?"; cut -c1-1200 $O/${TAG}_exchange_latency.json
+      mkdir -p profiles; cp $O/${TAG}_exchange_latency.json profiles/${TAG}_exchange_latency.json
+      timeout 1500 python tools/scale_model.py > $O/${TAG}_scaling_bound.json 2> $O/${TAG}_scaling_bound.err; echo "scale rc=$?"; cut -c1-600 $O/${TAG}_scaling_bound.json ;;
+    verify8)   # the self-validating multi-GPU line on whatever this box has (8 engines share one GPU through peer copies otherwise)
+      if [ "$(python -c 'import rust_exp_amd as r; print(r.device_count())' 2>/dev/null)" -ge 8 ]; then X=""; else X="NBX_GROUP_EXCHANGE=copy"; fi
+      env $X timeout 900 python bench.py --gpus 8 --verify --no-cpu-baseline > $O/${TAG}_bench_group8_verify.json 2> $O/${TAG}_bench_group8_verify.err; echo "verify8 rc=$?"; cut -c1-800 $O/${TAG}_bench_group8_verify.json
+      env $X NBX_GROUP_ENQUEUE=threads timeout 900 python bench.py --gpus 8 --verify --no-cpu-baseline > $O/${TAG}_bench_group8_verify_threads.json 2>> $O/${TAG}_bench_group8_verify.err; echo "verify8 threads rc=$?" ;;
     *) echo "unknown stage $stage" ;;
   esac
 done

@@ -3,8 +3,9 @@
 
 Runs the brute-force step of the bench workload (N = 262 144 Plummer, 3-D) back to back for >= SECONDS seconds and samples,
 from a thread, every source of socket power this box exposes:
-  * the amdgpu hwmon node (power1_average / power1_input, microwatts)      -- every 10 ms
   * `rocm-smi --showpower --showclocks --json`                              -- as fast as the tool answers
+    (round 3: the amdgpu hwmon power1_input series is gone -- it read a flat 248 W beside rocm-smi's 1350 W, the wrong
+    sensor; only the board's power cap is still taken from hwmon)
   * `amd-smi metric --power --clock --json`                                 -- idem
 Prints one JSON object: average / max watts per source, the power cap if the box reports one, interactions/s,
 joules per interaction, and the shader clock the tools saw.  Usage: python tools/power_probe.py [SECONDS] [--variant V] [--idle]
@@ -102,29 +103,11 @@ def main():
     e.synchronize()
     nodes = hwmon_nodes()
     node = nodes[0] if nodes else {}
-    pw_path = node.get("power1_average") or node.get("power1_input")
     samplers = []
     if shutil.which("rocm-smi"):
         samplers.append(ToolSampler("rocm-smi", ["rocm-smi", "--showpower", "--showclocks", "--json"]))
     if shutil.which("amd-smi"):
         samplers.append(ToolSampler("amd-smi", ["amd-smi", "metric", "--power", "--clock", "--json"]))
-    hw = []
-    stop = threading.Event()
-
-    def hw_loop():
-        while not stop.is_set():
-            v = read_int(pw_path) if pw_path else None
-            f = read_int(node["freq1_input"]) if "freq1_input" in node else None
-            hw.append((time.perf_counter(), v, f))
-            stop.wait(0.01)
-
-    th = threading.Thread(target=hw_loop, daemon=True)
-    idle_w = None
-    if pw_path:   # idle reading first
-        time.sleep(0.5)
-        vals = [read_int(pw_path) for _ in range(20)]
-        idle_w = float(np.mean([v for v in vals if v is not None])) * 1e-6 if any(v is not None for v in vals) else None
-    th.start()
     for s in samplers:
         s.start()
     t0 = time.perf_counter()
@@ -138,28 +121,18 @@ def main():
             e.synchronize()
             steps += 10
     t1 = time.perf_counter()
-    stop.set()
     for s in samplers:
         s.stop_.set()
-    th.join()
     for s in samplers:
         s.join(timeout=30)
     inter = float(n) * (n - 1) * steps
     out = {"workload": f"plummer N={n} 3-D brute force, back-to-back steps for {t1 - t0:.2f} s", "steps": steps,
-           "interactions_per_s": inter / (t1 - t0) if steps else 0.0, "launch": e.last_launch(), "idle_w_before": idle_w,
-           "hwmon": {k: v for k, v in node.items()}}
+           "interactions_per_s": inter / (t1 - t0) if steps else 0.0, "launch": e.last_launch()}
     if "power1_cap" in node:
         out["power_cap_w"] = (read_int(node["power1_cap"]) or 0) * 1e-6
     if "power1_cap_max" in node:
         out["power_cap_max_w"] = (read_int(node["power1_cap_max"]) or 0) * 1e-6
-    # skip the first 0.5 s (ramp)
-    w = [v * 1e-6 for (t, v, f) in hw if v is not None and t0 + 0.5 <= t <= t1]
-    f = [x * 1e-6 for (t, v, x) in hw if x is not None and t0 + 0.5 <= t <= t1]
-    if w:
-        out["hwmon_power"] = {"avg_w": float(np.mean(w)), "max_w": float(np.max(w)), "min_w": float(np.min(w)), "samples": len(w),
-                              "joules_per_interaction": float(np.mean(w)) * (t1 - t0) / inter if steps else None}
-    if f:
-        out["hwmon_sclk_mhz"] = {"avg": float(np.mean(f)), "min": float(np.min(f)), "max": float(np.max(f))}
+    # samples of the first 0.5 s (ramp) are skipped
     for s in samplers:
         pw, ck = [], []
         for (t, js) in s.rows:
