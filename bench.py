@@ -393,7 +393,8 @@ class GroupHost:
     def __init__(self, args, rx, st):
         self.rx, self.world, self.rank = rx, args.gpus, 0
         have = rx.device_count()
-        if have < args.gpus and os.environ.get("NBX_GROUP_EXCHANGE") != "copy":
+        shared_ok = os.environ.get("NBX_GROUP_EXCHANGE") == "copy" or os.environ.get("NBX_GROUP_RCCL_FAIL") == "init"
+        if have < args.gpus and not shared_ok:
             sys.exit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible (set NBX_GROUP_EXCHANGE=copy to let "
                      f"the engines of the group share devices: control-flow check only, not a measurement)")
         devices = [i % max(have, 1) for i in range(args.gpus)]

@@ -152,9 +152,11 @@ int upload(nbx_engine* e)
         if (k > e->exc_cap_dev) {
             if (e->d_exc_idx) HIP_TRY(hipFree(e->d_exc_idx));
             if (e->d_exc_w) HIP_TRY(hipFree(e->d_exc_w));
-            e->d_exc_idx = nullptr; e->d_exc_w = nullptr; e->exc_cap_dev = 0;
+            if (e->d_exc_rec) HIP_TRY(hipFree(e->d_exc_rec));
+            e->d_exc_idx = nullptr; e->d_exc_w = nullptr; e->d_exc_rec = nullptr; e->exc_cap_dev = 0;
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_exc_idx), sizeof(int) * k));
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_exc_w), sizeof(float) * k));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_exc_rec), sizeof(float4) * k));
             e->exc_cap_dev = k;
         }
         HIP_TRY(hipMemcpyAsync(e->d_exc_idx, e->exc_idx.data(), sizeof(int) * k, hipMemcpyHostToDevice, e->stream));
@@ -266,8 +268,9 @@ int launch_forces_fast(nbx_engine* e)
     }
     if (variant == 6 || variant == 7) {
         ProfScope ps(e, NBX_K_FORCE);
+        const int n_exc = variant == 7 ? (int)e->exc_idx.size() : 0;
         HIP_TRY(nbx::launch_force_wave_split(e->d_posm, e->lo, slab, tiles_total, e->n, jsplit, dim, variant == 7, e->mass_common,
-                                             e->d_acc, stride, e->stream, &e->last));
+                                             e->d_acc, stride, e->stream, &e->last, e->d_exc_idx, e->d_exc_w, e->d_exc_rec, n_exc));
         return NBX_OK;
     }
     {
@@ -281,8 +284,8 @@ int launch_forces_fast(nbx_engine* e)
 // the exceptional sources K2 / the force readout must add after a unit-mass sweep (variant 7) of a system with exceptions
 nbx::MassExceptions exceptions_of(const nbx_engine* e)
 {
-    if (e->last.variant != 7 || e->exc_idx.empty()) return nbx::MassExceptions{nullptr, nullptr, 0, e->last.dim};
-    return nbx::MassExceptions{e->d_exc_idx, e->d_exc_w, (int)e->exc_idx.size(), e->last.dim};
+    if (e->last.variant != 7 || e->exc_idx.empty()) return nbx::MassExceptions{nullptr, 0, e->last.dim};
+    return nbx::MassExceptions{e->d_exc_rec, (int)e->exc_idx.size(), e->last.dim};
 }
 
 // NBX_LOG=1: one stderr line per step (the reference has no logging on this path; its Haskell shell has Trace.hs)
@@ -712,6 +715,7 @@ void free_device(nbx_engine* e)
     if (e->d_guard) (void)hipFree(e->d_guard);
     if (e->d_exc_idx) (void)hipFree(e->d_exc_idx);
     if (e->d_exc_w) (void)hipFree(e->d_exc_w);
+    if (e->d_exc_rec) (void)hipFree(e->d_exc_rec);
     if (e->d_tree_ws) (void)hipFree(e->d_tree_ws);
     if (e->d_slab_ws) (void)hipFree(e->d_slab_ws);
     if (e->h_counters) (void)hipHostFree(e->h_counters);

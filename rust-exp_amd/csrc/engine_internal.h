@@ -99,6 +99,7 @@ struct nbx_engine {
     std::vector<float> exc_w;        // m_j - mass_common
     int* d_exc_idx = nullptr;
     float* d_exc_w = nullptr;
+    float4* d_exc_rec = nullptr;     // (x, y, z, m_j - mass_common) snapshot written by the sweep kernel for K2
     size_t exc_cap_dev = 0;
     static int exc_cap(int n) { return std::min(n / 64, std::max(32, n / 1024)); }   // 1 024 bodies: 16, 10 000: 32, 262 144: 256
     bool unit_sweep_ok() const { return n > 0 && mass_common > 0.0f; }

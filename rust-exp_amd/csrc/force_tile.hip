@@ -423,11 +423,18 @@ template <int DIM, int UNROLL, bool UNIT_MASS>
 __global__ __launch_bounds__(kTile) void k_force_smem_pkw(const float4* __restrict__ posm, const int lo,
                                                           const int n_targets, const int tiles_total, const int n_sources,
                                                           const int jsplit, float4* __restrict__ acc_partial,
-                                                          const int acc_stride, const float unit_mass)
+                                                          const int acc_stride, const float unit_mass,
+                                                          const int* __restrict__ exc_idx, const float* __restrict__ exc_w,
+                                                          float4* __restrict__ exc_rec, const int exc_count)
 {
     constexpr int P = 2;
     __shared__ float red[4][3][kTile];
     const int tid = threadIdx.x;
+    if (UNIT_MASS && blockIdx.x == 0)   // snapshot of the exceptional sources for K2 (MassExceptions); usually 0 or 1 record
+        for (int k = tid; k < exc_count; k += kTile) {
+            const float4 s = posm[exc_idx[k]];
+            exc_rec[k] = make_float4(s.x, s.y, s.z, exc_w[k]);
+        }
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x % jsplit;
@@ -530,11 +537,12 @@ __global__ __launch_bounds__(kTile) void k_force_smem(const float4* __restrict__
 
 // The exceptional sources of a unit-mass sweep (kernels.h MassExceptions): a handful of bodies (the reference's
 // nb_stable_orbits has ONE: the 1000-mass sun among unit planets, nbody.rs:85-102) whose weight m_j - m_common the sweep
-// left out.  Wave-uniform indices: the records arrive through the scalar cache.  Same pair law, same rcp.
-__device__ __forceinline__ void add_exceptions(const float4* __restrict__ posm, const MassExceptions exc, const float4 p, float4& a)
+// left out.  Their records were snapshot by the sweep kernel (K2 moves bodies in place, so it cannot read them from posm);
+// wave-uniform reads: they arrive through the scalar cache.  Same pair law, same rcp.
+__device__ __forceinline__ void add_exceptions(const MassExceptions exc, const float4 p, float4& a)
 {
     for (int k = 0; k < exc.count; k++) {
-        const float4 s = posm[exc.idx[k]];
+        const float4 s = exc.rec[k];
         const float dx = s.x - p.x, dy = s.y - p.y;
         float r2 = __builtin_fmaf(dx, dx, kEps);
         r2 = __builtin_fmaf(dy, dy, r2);
@@ -543,7 +551,7 @@ __device__ __forceinline__ void add_exceptions(const float4* __restrict__ posm, 
             dz = s.z - p.z;
             r2 = __builtin_fmaf(dz, dz, r2);
         }
-        const float sc = exc.w[k] * __builtin_amdgcn_rcpf(r2);
+        const float sc = s.w * __builtin_amdgcn_rcpf(r2);
         a.x = __builtin_fmaf(sc, dx, a.x);
         a.y = __builtin_fmaf(sc, dy, a.y);
         a.z = __builtin_fmaf(sc, dz, a.z);
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(kTile) void k_integrate(float4* __restrict__ posm, 
     }
     float4 v = vel[i];
     float4 p = posm[lo + i];
-    add_exceptions(posm, exc, p, a);
+    add_exceptions(exc, p, a);
     v.x = __fadd_rn(v.x, __fmul_rn(dt, a.x));
     v.y = __fadd_rn(v.y, __fmul_rn(dt, a.y));
     v.z = __fadd_rn(v.z, __fmul_rn(dt, a.z));
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(kTile) void k_reduce_forces(const float4* __restric
         a.x += q.x; a.y += q.y; a.z += q.z;
     }
     const float4 p = posm[lo + i];
-    add_exceptions(posm, exc, p, a);
+    add_exceptions(exc, p, a);
     const float m = p.w;
     out[i] = make_float4(m * a.x, m * a.y, m * a.z, 0.0f);
 }
@@ -633,7 +641,7 @@ static hipError_t launch_variant(int variant, dim3 grid, hipStream_t stream, con
 // variants 6 / 7: one workgroup = 256 targets x 4 source quarters; `jsplit` partial slabs
 hipError_t launch_force_wave_split(const float4* posm, int lo, int n_targets, int tiles_total, int n_sources, int jsplit, int dim,
                                    bool unit_mass, float mass, float4* acc_partial, int acc_stride, hipStream_t stream,
-                                   ForceLaunch* info)
+                                   ForceLaunch* info, const int* exc_idx, const float* exc_w, float4* exc_rec, int exc_count)
 {
     if (n_targets <= 0 || tiles_total <= 0) return hipSuccess;
     if (jsplit < 1) jsplit = 1;
@@ -643,7 +651,7 @@ hipError_t launch_force_wave_split(const float4* posm, int lo, int n_targets, in
     if (info) *info = ForceLaunch{(int)grid.x, kTile, jsplit, 4, dim, unit_mass ? 7 : 6};
 #define NBX_WS(DD, UM) \
     hipLaunchKernelGGL((k_force_smem_pkw<DD, 8, UM>), grid, dim3(kTile), 0, stream, posm, lo, n_targets, tiles_total, n_sources, \
-                       jsplit, acc_partial, acc_stride, mass)
+                       jsplit, acc_partial, acc_stride, mass, exc_idx, exc_w, exc_rec, exc_count)
     if (dim == 3) { if (unit_mass) NBX_WS(3, true); else NBX_WS(3, false); }
     else          { if (unit_mass) NBX_WS(2, true); else NBX_WS(2, false); }
 #undef NBX_WS
