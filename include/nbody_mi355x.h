@@ -115,8 +115,8 @@ enum nbx_option {
     NBX_OPT_BH_TREE = 8,           /* Barnes-Hut tree: 0 = built on the host exactly like the reference (always used by
                                     * the bit-exact mode), 1 = built on the device (bh_build.hip: same node set and leaf
                                     * records incl. the reference's EPS merge of close pairs; interior centres of mass are
-                                    * roundings of the exact mean instead of the reference's running f32 fold: own tolerance
-                                    * class), -1 (default) = device in the fast mode from 512 bodies on, else host */
+                                    * the reference's running f32 fold up to 65 536 bodies, roundings of the exact mean above:
+                                    * NBX_OPT_BH_FOLD), -1 (default) = device in the fast mode from 512 bodies on, else host */
     NBX_OPT_BH_WAVE = 9,           /* 1 (default): with the device-built tree, walk the tree once per WAVE (node
                                     * records through the scalar cache, lanes park on accepted subtrees); 0: one
                                     * independent walk per lane. Bit-identical results either way */
@@ -127,6 +127,11 @@ enum nbx_option {
     NBX_OPT_STRICT_KERNEL = 13,    /* bit-exact all-pairs kernel: 0 = by targets per GPU (default), 16 or 8 = workgroups of that
                                     * many waves per 64 targets (term producers + one summing wave), 1 = one thread per body.
                                     * Bit-identical results whichever runs */
+    NBX_OPT_BH_FOLD = 14,          /* device-built tree, interior nodes: 1 = the reference's own f32 running fold of masses and
+                                    * centres in ARRIVAL order (nbody.rs:303-320) -- the host tree's records bit for bit; systems
+                                    * with EPS clusters the device merge cannot reproduce node for node go to the host build;
+                                    * 0 = roundings of the exact sums (own tolerance class);
+                                    * -1 (default) = 1 up to 65 536 bodies (the root's fold is n serial steps), 0 above */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };

@@ -383,9 +383,18 @@ __device__ __forceinline__ int group_end(const unsigned long long* __restrict__ 
 // its depth follows from k - base[a], its body range from a gallop over the sorted keys, and the whole 32-byte record is
 // written at once.  (Round 2's first version looped per BODY over the chain of nodes that start at it -- up to 31 for a body
 // that opens a deep chain, one for most: 134 us at 1 M bodies, against 28 us like this.)
+//
+// fold (round 3): how an interior node's mass and centre are obtained.
+//   0 = exact: fp64 sums over the node's bodies, rounded once (round 2; systems above kFoldFaithfulMax bodies)
+//   1 = faithful: the reference's own f32 running fold (nbody.rs:303-320) over the node's bodies in ARRIVAL (index) order --
+//       what sequential insertion leaves in every node, bit for bit.  Nodes of at most kFoldSmall bodies are folded right
+//       here (selection of the next index among <= kFoldSmall); bigger ones are queued for k_fold_big (one wave per node).
+constexpr int kFoldSmall = 8;
+
 __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
                                                 const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const Prefix pre,
-                                                const int n, const int node_cap, BhNode* __restrict__ out)
+                                                const int n, const int node_cap, BhNode* __restrict__ out, const int fold,
+                                                int4* __restrict__ big, const int big_cap, int* __restrict__ counters)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = pre.base[n];
@@ -431,6 +440,39 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
         o.px = px; o.py = py; o.m = m;
         o.skip = first + count;
         o.interior = 0; o.q = -1.0f;
+        if (fold == 1 && b - a > 1 && (px != p.x || py != p.y)) {
+            // A merged blob travels by its OWN centre in the reference (the split re-inserts (px, py), nbody.rs:271-281); this
+            // leaf sits on the path of the blob's first member.  The same leaf unless the centre left the member's cell:
+            float u1 = dec_f32(box[0]), v1 = dec_f32(box[1]), u2 = dec_f32(box[2]), v2 = dec_f32(box[3]);
+#pragma unroll 1
+            for (int d = 0; d < l; d++) descend(u1, v1, u2, v2, px, py);
+            if (u1 != x1 || v1 != y1 || u2 != x2 || v2 != y2) atomicAdd(&counters[1], 1);   // counted as "crowded": host build
+        }
+    } else if (fold == 1) {
+        const int b = group_end(keys, ka, a + 1, n, l);
+        o.skip = pre.base[b];
+        o.interior = 1; o.q = __fmul_rn(o.s, o.s);
+        o.px = p.x; o.py = p.y; o.m = 0.0f;
+        if (b - a <= kFoldSmall) {
+            // the node's bodies in index order: pick the smallest index above the last one, b - a times
+            float px = 0.0f, py = 0.0f, m = 0.0f;
+            unsigned last = 0;
+            for (int t = 0; t < b - a; t++) {
+                unsigned best = 0xFFFFFFFFu;
+                int bj = a;
+                for (int j = a; j < b; j++) {
+                    const unsigned v = idx[j];
+                    if ((t == 0 || v > last) && v < best) { best = v; bj = j; }
+                }
+                const float4 q = sb[bj];
+                fold_mass(px, py, m, q.x, q.y, q.w);
+                last = best;
+            }
+            o.px = px; o.py = py; o.m = m;
+        } else {
+            const int slot = atomicAdd(&counters[2], 1);
+            if (slot < big_cap) big[slot] = make_int4(k, a, b, 0);
+        }
     } else {
         const int b = group_end(keys, ka, a + 1, n, l);
         double m, mx, my;
@@ -452,6 +494,227 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
     float4* dst = reinterpret_cast<float4*>(&out[k]);
     dst[0] = make_float4(o.px, o.py, o.m, o.s);
     dst[1] = make_float4(__int_as_float(o.skip), __int_as_float(o.interior), o.q, __int_as_float(o.pad1));
+}
+
+// The reference's running fold for ONE queued node per workgroup of two waves (fold = 1).  The node's bodies are the sorted
+// range [a, b); the fold needs them in index order:
+//   * the root (b - a == n): every body, in the order of posm itself
+//   * up to kFoldRank bodies: every lane ranks its bodies' indices against all others (LDS broadcast) -> ordered list
+//   * more: the bodies are marked in an LDS bitmap over a window of 65 536 body indices and the bitmap is walked 2 048 indices
+//     at a time, compacting the set bits into an ordered list
+// and folds them 64 at a time, as a pipeline of the two waves (one __syncthreads per chunk):
+//   wave 0   gathers the chunk's records (two chunks ahead), runs the m chain  m_t = m_(t-1) + mass_t  (serial: f32 addition
+//            does not associate), then in parallel  inv_t = 1 / m_t (IEEE), (x m)_t, (y m)_t  -> rec[chunk parity]
+//   wave 1   runs the p chain of the PREVIOUS chunk:  p_t = (p_(t-1) * m_(t-1) + (x m)_t) * inv_t , three packed (x, y)
+//            operations per member, operands broadcast out of LDS sixteen members ahead of their use
+// exactly the operations and the order of add_mass (nbody.rs:315-318); the first member is copied (:305-311).  The root's p
+// chain -- n members, ~3 dependent packed operations each -- is the critical path of the whole build; every other node runs
+// beside it on its own pair of waves.
+typedef float fold_v2 __attribute__((ext_vector_type(2)));
+constexpr int kFoldRank = 256;
+
+struct FoldShared {
+    unsigned bitmap[2048];        // 65 536 body indices per window          (rank path: the indices being ranked)
+    unsigned short lst[2048];     // the set bits of 64 bitmap words, in order (rank path: sorted positions in index order)
+    float4 rec[2][64];            // per member of a chunk: m_(t-1), 1 / m_t, x m, y m
+    alignas(16) float mass_in[64];
+    alignas(16) float mass_run[64];
+    float2 first_xy;
+    int cnt[2];
+};
+
+// p chain over rec[t0 .. cnt): operands fetched kAhead members ahead of the dependent chain
+__device__ __forceinline__ fold_v2 fold_p_chain(const float4* __restrict__ rec, const int t0, const int cnt, fold_v2 pc)
+{
+    constexpr int kAhead = 16;
+    if (t0 == 0 && cnt == 64) {
+        float4 r[kAhead], nx[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) r[u] = rec[u];
+#pragma unroll
+        for (int t = 0; t < 64; t += kAhead) {
+            if (t + kAhead < 64) {
+#pragma unroll
+                for (int u = 0; u < kAhead; u++) nx[u] = rec[t + kAhead + u];
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; u++) pc = ((pc * fold_v2{r[u].x, r[u].x}) + fold_v2{r[u].z, r[u].w}) * fold_v2{r[u].y, r[u].y};
+#pragma unroll
+            for (int u = 0; u < kAhead; u++) r[u] = nx[u];
+        }
+        return pc;
+    }
+#pragma unroll 4
+    for (int t = t0; t < cnt; t++) {
+        const float4 r = rec[t];
+        pc = ((pc * fold_v2{r.x, r.x}) + fold_v2{r.z, r.w}) * fold_v2{r.y, r.y};
+    }
+    return pc;
+}
+
+__global__ __launch_bounds__(128) void k_fold_big(const float4* __restrict__ posm, const float4* __restrict__ sb,
+                                                  const unsigned* __restrict__ idx, const int4* __restrict__ big, const int big_cap,
+                                                  const int* __restrict__ counters, const int n, BhNode* __restrict__ out)
+{
+    __shared__ FoldShared sh;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int count = counters[2];
+    if (count > big_cap) count = big_cap;
+    for (int w = blockIdx.x; w < count; w += gridDim.x) {
+        const int4 nd = big[w];
+        const int a = nd.y, b = nd.z, size = b - a;
+        const int kind = size == n ? 0 : (size <= kFoldRank ? 1 : 2);     // member source: identity / rank / bitmap
+        // ---- producer state (wave 0) ----
+        float m = 0.0f;
+        bool any = false;
+        int next_pos = 0;                              // identity / rank path: next member
+        int base = 0, g = 0, total = 0, c0 = 0;        // bitmap path: window, next group, members listed, next member
+        bool window_ready = false;
+        // next chunk of (at most 64) members in index order: every lane's record and the chunk's size (0 = no more)
+        auto fetch = [&](float4& r, int& cnt) {
+            r = make_float4(0.f, 0.f, 0.f, 0.f);
+            cnt = 0;
+            if (kind == 0) {
+                cnt = n - next_pos < 64 ? n - next_pos : 64;
+                if (lane < cnt) r = posm[next_pos + lane];
+                next_pos += cnt;
+            } else if (kind == 1) {
+                cnt = size - next_pos < 64 ? size - next_pos : 64;
+                if (lane < cnt) r = sb[a + (int)sh.lst[next_pos + lane]];
+                next_pos += cnt;
+            } else {
+                while (c0 >= total) {                  // the list is used up: next group of 64 bitmap words / next window
+                    if (!window_ready) {
+                        if (base >= n) return;
+                        for (int t = lane; t < 2048; t += 64) sh.bitmap[t] = 0u;
+                        for (int j = a + lane; j < b; j += 64) {
+                            const unsigned v = idx[j] - (unsigned)base;
+                            if (v < 65536u) atomicOr(&sh.bitmap[v >> 5], 1u << (v & 31u));
+                        }
+                        window_ready = true;
+                        g = 0;
+                    }
+                    if (g == 32) { window_ready = false; base += 65536; continue; }
+                    unsigned word = sh.bitmap[g * 64 + lane];
+                    const int c = __popc(word);
+                    int incl = c;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int o = __shfl_up(incl, off);
+                        if (lane >= off) incl += o;
+                    }
+                    total = __shfl(incl, 63);
+                    c0 = 0;
+                    int pos = incl - c;
+                    while (word) {
+                        const int bit = __ffs((int)word) - 1;
+                        word &= word - 1u;
+                        sh.lst[pos++] = (unsigned short)(lane * 32 + bit);
+                    }
+                    g++;
+                }
+                cnt = total - c0 < 64 ? total - c0 : 64;
+                if (lane < cnt) r = posm[base + (g - 1) * 2048 + (int)sh.lst[c0 + lane]];
+                c0 += 64;
+            }
+        };
+        // ---- consumer state (wave 1) ----
+        fold_v2 pc = {0.0f, 0.0f};
+        bool started = false;
+
+        float4 q_cur = make_float4(0.f, 0.f, 0.f, 0.f), q_nxt = q_cur;
+        int cnt_cur = 0, cnt_nxt = 0;
+        if (wave == 0) {
+            if (kind == 1) {
+                // rank path: every lane ranks up to four of the node's indices against all of them
+                unsigned mine[4];
+                int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = a + u * 64 + lane;
+                    mine[u] = j < b ? idx[j] : 0xFFFFFFFFu;
+                    sh.bitmap[u * 64 + lane] = mine[u];
+                }
+                for (int t = 0; t < size; t++) {
+                    const unsigned v = sh.bitmap[t];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) rank[u] += v < mine[u] ? 1 : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (a + u * 64 + lane < b) sh.lst[rank[u]] = (unsigned short)(u * 64 + lane);   // position inside [a, b)
+            }
+            fetch(q_cur, cnt_cur);
+            fetch(q_nxt, cnt_nxt);
+        }
+        // One round = wave 0 produces chunk i while wave 1 consumes chunk i - 1; the first empty chunk ends the loop.
+        for (int i = 0;; i++) {
+            const int buf = i & 1;
+            if (wave == 0) {
+                float4 q2;
+                int cnt2;
+                fetch(q2, cnt2);                       // chunk i + 2: in flight during this round
+                if (cnt_cur > 0) {
+                    sh.mass_in[lane] = q_cur.w;
+                    if (cnt_cur == 64) {               // m chain, operands read at once
+                        float4 mi[16], mo[16];
+                        const float4* in4 = reinterpret_cast<const float4*>(sh.mass_in);
+                        float4* out4 = reinterpret_cast<float4*>(sh.mass_run);
+#pragma unroll
+                        for (int u = 0; u < 16; u++) mi[u] = in4[u];
+                        float mr = m;                  // 0 + mass = mass exactly: the copy of the first member (nbody.rs:305-311)
+#pragma unroll
+                        for (int u = 0; u < 16; u++) {
+                            mo[u].x = __fadd_rn(mr, mi[u].x);
+                            mo[u].y = __fadd_rn(mo[u].x, mi[u].y);
+                            mo[u].z = __fadd_rn(mo[u].y, mi[u].z);
+                            mo[u].w = __fadd_rn(mo[u].z, mi[u].w);
+                            mr = mo[u].w;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; u++) out4[u] = mo[u];
+                    } else {
+                        float mr = m;
+                        for (int t = 0; t < cnt_cur; t++) {
+                            mr = __fadd_rn(mr, sh.mass_in[t]);
+                            sh.mass_run[t] = mr;
+                        }
+                    }
+                    if (lane < cnt_cur) {
+                        const float mt = sh.mass_run[lane];
+                        const float mp = lane == 0 ? m : sh.mass_run[lane - 1];
+                        sh.rec[buf][lane] = make_float4(mp, 1.0f / mt, __fmul_rn(q_cur.x, q_cur.w), __fmul_rn(q_cur.y, q_cur.w));
+                    }
+                    if (!any) {
+                        if (lane == 0) sh.first_xy = make_float2(q_cur.x, q_cur.y);
+                        any = true;
+                    }
+                    m = sh.mass_run[cnt_cur - 1];
+                }
+                if (lane == 0) sh.cnt[buf] = cnt_cur;
+                q_cur = q_nxt; cnt_cur = cnt_nxt;
+                q_nxt = q2; cnt_nxt = cnt2;
+            } else if (i > 0) {
+                const int pb = (i - 1) & 1;
+                const int cnt = sh.cnt[pb];
+                int t0 = 0;
+                if (!started) {                        // nbody.rs:305-311: the first body is copied, not folded
+                    const float2 f = sh.first_xy;
+                    pc = fold_v2{f.x, f.y};
+                    started = true;
+                    t0 = 1;
+                }
+                pc = fold_p_chain(sh.rec[pb], t0, cnt, pc);
+            }
+            __syncthreads();
+            if (sh.cnt[buf] == 0) break;
+        }
+        float* o = reinterpret_cast<float*>(&out[nd.x]);
+        if (wave == 1 && lane == 0) { o[0] = pc.x; o[1] = pc.y; }
+        if (wave == 0 && lane == 0) o[2] = m;
+        __syncthreads();                               // the next node reuses the LDS
+    }
 }
 
 __global__ void k_init_box(unsigned* box)
@@ -478,6 +741,7 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     add(sizeof(ScanItem) * (nb + 1));                  // block sums
     add((size_t)n);                                    // EPS-merge links
     add(256);                                          // counters + box
+    add(sizeof(int4) * (size_t)n);                     // nodes queued for k_fold_big (a body is in at most 31 nodes of > 8 bodies: <= 31 n / 9 ... the queue holds n, more -> host build)
     return bytes;
 }
 
@@ -490,8 +754,9 @@ struct Workspace {
     Prefix pre;
     ScanItem* block_sums;
     unsigned char* link;
-    int* counters;   // [0] node count; [4..7] box (as unsigned)
+    int* counters;   // [0] node count, [1] bodies the pairs-only merge left behind, [2] nodes queued for k_fold_big; [4..7] box (as unsigned)
     unsigned* box;
+    int4* big;
 };
 Workspace carve(void* workspace, int n, size_t sort_tmp)
 {
@@ -512,6 +777,7 @@ Workspace carve(void* workspace, int n, size_t sort_tmp)
     k.link = reinterpret_cast<unsigned char*>(take((size_t)n));
     k.counters = reinterpret_cast<int*>(take(256));
     k.box = reinterpret_cast<unsigned*>(k.counters + 4);
+    k.big = reinterpret_cast<int4*>(take(sizeof(int4) * (size_t)n));
     return k;
 }
 
@@ -699,7 +965,7 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 //          nodes (nothing usable was written), 2 when more than max(16, n/2000) bodies sit in clusters of >= 3 within EPS
 //          (the caller should build on the host: the reference's multi-body merges are not reproduced here)
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
-                                   int* host_counters /* pinned, >= 4 ints */, const unsigned** perm_dev, hipStream_t stream)
+                                   int* host_counters /* pinned, >= 4 ints */, const unsigned** perm_dev, hipStream_t stream, int fold)
 {
     *perm_dev = nullptr;
     if (n <= 0) return hipSuccess;
@@ -725,13 +991,20 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     // one thread per node; the node count is only known on the device, so the grid covers the whole pool (threads beyond
     // base[n] leave at once; the pool check is inside)
     const int eb = n <= 65536 ? 64 : kTile;   // spread a small system's few waves over the CUs
-    hipLaunchKernelGGL(k_emit, dim3((unsigned)((node_cap + eb - 1) / eb)), dim3(eb), 0, stream, k.sb, mk, k.idx1, k.box, k.pre, n, node_cap, out);
-    e = hipMemcpyAsync(host_counters, k.counters, 2 * sizeof(int), hipMemcpyDeviceToHost, stream);
+    hipLaunchKernelGGL(k_emit, dim3((unsigned)((node_cap + eb - 1) / eb)), dim3(eb), 0, stream, k.sb, mk, k.idx1, k.box, k.pre, n, node_cap, out,
+                       fold, k.big, n, k.counters);
+    if (fold == 1) {
+        // one wave per queued node; the count lives on the device: enough blocks for every plausible queue (a uniform system
+        // queues ~n/45 nodes), the blocks loop when there are more
+        const int fb = n / 4 + 64;
+        hipLaunchKernelGGL(k_fold_big, dim3((unsigned)(fb < 8192 ? fb : 8192)), dim3(128), 0, stream, posm, k.sb, k.idx1, k.big, n, k.counters, n, out);
+    }
+    e = hipMemcpyAsync(host_counters, k.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
-hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status, hipStream_t stream)
+hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status, hipStream_t stream, int fold)
 {
     *status = 0;
     *n_nodes_host = 0;
@@ -741,7 +1014,10 @@ hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, 
     if (host_counters[0] > node_cap) { *status = 1; return hipSuccess; }   // node pool exhausted (pathological input)
     // Many bodies in clusters of three or more within EPS: the reference grows multi-body blobs there (nbody.rs:249-260) that
     // the pairs-only merge does not reproduce -- leave such systems to the reference-faithful host build.
-    if (host_counters[1] > (n / 2000 > 16 ? n / 2000 : 16)) { *status = 2; return hipSuccess; }
+    // The faithful fold promises the reference's tree node for node: ANY body the pairs-only merge left behind (or a blob whose
+    // centre left its first member's cell) sends the step to the host build.
+    if (host_counters[1] > (fold == 1 ? 0 : (n / 2000 > 16 ? n / 2000 : 16))) { *status = 2; return hipSuccess; }
+    if (fold == 1 && host_counters[2] > n) { *status = 1; return hipSuccess; }   // fold queue overflow (cannot happen: <= 31 n / 33)
     *n_nodes_host = host_counters[0];
     return hipSuccess;
 }

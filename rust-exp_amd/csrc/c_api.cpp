@@ -106,6 +106,10 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
             if (value != 0 && value != 1 && value != -1) return fail(NBX_ERR_INVALID, "bh tree must be 0 (host), 1 (device) or -1 (by mode and size)");
             e->bh_tree_device = value < 0 ? -1 : (value ? 1 : 0);   // -1 = by mode and size (default)
             return NBX_OK;
+        case NBX_OPT_BH_FOLD:
+            if (value != 0 && value != 1 && value != -1) return fail(NBX_ERR_INVALID, "bh fold must be 0 (exact sums), 1 (reference fold) or -1 (by size)");
+            e->bh_fold = (int)value;
+            return NBX_OK;
         case NBX_OPT_SOURCE_PRECISION:
             if (value != 16 && value != 32) return fail(NBX_ERR_INVALID, "source precision must be 16 or 32");
             e->source_half = value == 16;
@@ -135,6 +139,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_DRAW_DEVICE: return e->draw_device;
         case NBX_OPT_BH_TREE: return e->bh_tree_device;
         case NBX_OPT_BH_WAVE: return e->bh_wave;
+        case NBX_OPT_BH_FOLD: return e->bh_fold;
         case NBX_OPT_BH_FALLBACKS: return e->bh_fallbacks;
         case NBX_OPT_BH_LAST_TREE: return e->bh_last_tree_device;
         case NBX_OPT_DRAW_AMBIGUOUS: return e->draw_ambiguous;
@@ -147,7 +152,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
 int32_t nbx_query_option(const nbx_engine* e, int32_t option, int64_t* value)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
-    if (option < NBX_OPT_FORCE_MODE || option > NBX_OPT_STRICT_KERNEL) return fail(NBX_ERR_INVALID, "unknown option %d", option);
+    if (option < NBX_OPT_FORCE_MODE || option > NBX_OPT_BH_FOLD) return fail(NBX_ERR_INVALID, "unknown option %d", option);
     if (value) *value = nbx_get_option(e, option);
     return NBX_OK;
 }

@@ -518,7 +518,7 @@ int build_tree_on_device_begin(nbx_engine* e)
     const int rc = grow(&e->d_nodes, &e->nodes_cap, (size_t)node_cap);
     if (rc != NBX_OK) return rc;
     HIP_TRY(nbx::device_tree_build_begin(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes, e->h_counters,
-                                         &e->d_perm, e->stream));
+                                         &e->d_perm, e->stream, e->effective_fold()));
     return NBX_OK;
 }
 
@@ -528,10 +528,14 @@ int build_tree_on_device_end(nbx_engine* e, bool* done)
     HIP_TRY(hipSetDevice(e->device));
     const int node_cap = 4 * e->n + 1024;
     int n_nodes = 0, status = 0;
-    HIP_TRY(nbx::device_tree_build_end(e->n, node_cap, e->h_counters, &n_nodes, &status, e->stream));
+    HIP_TRY(nbx::device_tree_build_end(e->n, node_cap, e->h_counters, &n_nodes, &status, e->stream, e->effective_fold()));
     if (status != 0) {
         e->bh_fallbacks++;
         e->d_perm = nullptr;
+        if (std::getenv("NBX_LOG"))
+            std::fprintf(stderr, "[nbx] device tree build of %d bodies handed over to the host build: status %d (1 = pool / queue overflow, 2 = EPS "
+                                 "clusters), nodes %d of %d, left-behind bodies %d, queued folds %d\n", e->n, status, e->h_counters[0], node_cap,
+                         e->h_counters[1], e->h_counters[2]);
         return NBX_OK;   // caller takes the host path
     }
     e->n_flat = (size_t)n_nodes;

@@ -69,6 +69,10 @@ struct nbx_engine {
     {
         return force_mode == 0 && mass_min > 0.0f && (bh_tree_device == 1 || (bh_tree_device < 0 && n >= kDeviceTreeFrom));
     }
+    // NBX_OPT_BH_FOLD: interior nodes of the DEVICE-built tree: 1 = the reference's f32 running fold in arrival order (the host
+    // tree's records bit for bit), 0 = roundings of exact sums (round 2), -1 (default) = faithful up to kFoldFaithfulMax bodies
+    int bh_fold = -1;
+    int effective_fold() const { return bh_fold >= 0 ? bh_fold : (n <= nbx::kFoldFaithfulMax ? 1 : 0); }
     int bh_wave = 1;               // wave-uniform traversal when a spatial body order is available
     int bh_last_tree_device = 0;   // where the last evaluated tree was built
     int bh_fallbacks = 0;          // device builds that fell back to the host (node pool exhausted)

@@ -114,10 +114,14 @@ hipError_t device_route_and_scatter(const float4* posm, int warm, int rest, cons
 size_t device_slab_order_workspace_bytes(int n);
 hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* workspace, size_t workspace_bytes,
                              const unsigned** slab_perm, hipStream_t stream);
+// fold: 0 = interior masses / centres are roundings of exact fp64 sums (own tolerance class); 1 = the reference's f32 running
+// fold in arrival order (nbody.rs:303-320): the host tree's interior records bit for bit; any cluster the pairs-only EPS merge
+// cannot reproduce then reports status 2 (caller builds on the host).
+constexpr int kFoldFaithfulMax = 65536;   // default: faithful fold up to this many bodies (the root's chain is n serial steps)
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
-                                   int* host_counters, const unsigned** perm_dev, hipStream_t stream);
+                                   int* host_counters, const unsigned** perm_dev, hipStream_t stream, int fold = 0);
 hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int fold = 0);
 
 // nb_draw on the device: counts (uint2 per pixel: body hits, tail hits) -> ABGR framebuffer. Particles whose tail octant
 // cannot be decided safely on the device (see draw.hip) are appended to amb[0..*amb_count) (capacity n) with their body

@@ -38,6 +38,7 @@ NBX_OPT_BH_FALLBACKS = 10
 NBX_OPT_BH_LAST_TREE = 11
 NBX_OPT_DRAW_AMBIGUOUS = 12
 NBX_OPT_STRICT_KERNEL = 13
+NBX_OPT_BH_FOLD = 14
 
 NBX_GROUP_INFO_EXCHANGE = 0
 NBX_GROUP_INFO_RCCL_RANKS = 1
@@ -451,6 +452,11 @@ class NBodyEngine:
         """'host' (reference-faithful insertion build), 'device' (bh_build.hip) or 'auto' (default: device in the fast
         mode from 512 bodies on)."""
         self.set_option(NBX_OPT_BH_TREE, {"host": 0, "device": 1, "auto": -1}[where])
+
+    def set_bh_fold(self, how):
+        """Interior nodes of the device-built tree: 'reference' (the f32 running fold in arrival order, nbody.rs:303-320: the host
+        tree bit for bit), 'exact' (roundings of exact sums) or 'auto' (reference up to 65 536 bodies)."""
+        self.set_option(NBX_OPT_BH_FOLD, {"exact": 0, "reference": 1, "auto": -1}[how])
 
     def set_draw_device(self, on=True):
         """True / False force the device / host draw; None = by size (the default)."""

@@ -1,19 +1,97 @@
 """GPU: quadtree built ON THE DEVICE (bh_build.hip; the fast mode's default from 512 bodies on) against the host build,
-which is node-for-node the oracle's tree.  Tolerance class: same node set / skip pointers / node sizes /
-leaf records exactly -- including the reference's EPS merge of close pairs, decided from the arrival order like the reference
-does; interior masses and centres are roundings of the EXACT sums (the reference's are an f32 running fold that drifts, 6e-4 at a
-million bodies), so forces are compared with the oracle AND with the fp64 arbiter (oracle/nbody_oracle.c orc_bh_forces_exact):
-the device tree must be at least as close to exact arithmetic as the reference itself."""
+which is node-for-node the oracle's tree.  Two classes (NBX_OPT_BH_FOLD):
+  * fold = reference (round 3; the default up to 65 536 bodies): interior masses and centres are the reference's own f32 running
+    fold in arrival order (nbody.rs:303-320) -> the flattened tree equals the host tree BIT FOR BIT, or the build reports EPS
+    clusters it cannot reproduce node for node and the step runs on the host tree;
+  * fold = exact (round 2; the default above): same node set / skip pointers / node sizes / leaf records -- including the
+    reference's EPS merge of close pairs -- with interior records that are roundings of the EXACT sums (the reference's fold
+    drifts, 6e-4 at a million bodies), so forces are compared with the oracle AND with the fp64 arbiter
+    (oracle/nbody_oracle.c orc_bh_forces_exact)."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-def engines(rx, p):
+def engines(rx, p, fold=None):
     e = rx.NBodyEngine()
+    if fold:
+        e.set_bh_fold(fold)
     e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     return e
+
+
+def _bit_equal_trees(host, dev):
+    assert len(host) == len(dev), (len(host), len(dev))
+    for k in ("skip", "interior"):
+        assert np.array_equal(host[k], dev[k]), k
+    for k in ("px", "py", "m", "s", "q"):
+        bad = np.flatnonzero(host[k].view(np.uint32) != dev[k].view(np.uint32))
+        assert bad.size == 0, (k, bad.size, bad[:5], host[k][bad[:5]], dev[k][bad[:5]])
+
+
+@pytest.mark.parametrize("make,n", [("disk", 600), ("disk", 5000), ("orbits", 10000), ("orbits", 20000), ("plummer", 65536),
+                                    ("disk", 65536), ("plummer", 100000)])
+def test_device_tree_with_the_reference_fold_equals_the_host_tree_bit_for_bit(rx, ob, make, n):
+    """every record of the device-built flattened tree -- interior (px, py, m) included -- equals the host
+    (= oracle) tree's, bit for bit: the f32 running fold of nbody.rs:303-320 replayed in arrival order per node (k_emit for
+    nodes of <= 8 bodies, k_fold_big: rank / bitmap ordering + the m and p chains).  100 000 bodies: the same with the fold
+    forced on above its default range (two index windows of the bitmap path)."""
+    from rust_exp_amd.engine import NBX_OPT_BH_FOLD
+
+    if make == "disk":
+        p = ob.random_disk(n, 41)
+    elif make == "orbits":
+        p = ob.stable_orbits(n, 0.5, 30.0, 42)
+    else:
+        st = rx.plummer_sphere(n, dim=2)
+        p = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    e = engines(rx, p, fold="reference" if n > 65536 else None)
+    assert e.query_option(NBX_OPT_BH_FOLD) == (1 if n > 65536 else -1)
+    _bit_equal_trees(e.bh_flat_dump(False), e.bh_flat_dump("device"))
+    # and the forces through it are the host-tree forces bit for bit (same walk over the same records), hence within the
+    # fast mode's 2e-5 of the oracle for EVERY body
+    a = engines(rx, p); a.set_bh_tree("host")
+    b = engines(rx, p, fold="reference"); b.set_bh_tree("device")
+    from rust_exp_amd.engine import NBX_OPT_BH_LAST_TREE
+
+    for theta in (0.5, 0.85):
+        fx, fy, _ = a.forces(theta)
+        gx, gy, _ = b.forces(theta)
+        assert a.get_option(NBX_OPT_BH_LAST_TREE) == 0 and b.get_option(NBX_OPT_BH_LAST_TREE) == 1
+        assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
+        if n <= 20000:
+            rc, ofx, ofy = ob.bh_forces(p, theta, nthreads=8)
+            scale = max(np.abs(ofx).max(), np.abs(ofy).max())
+            assert rc == 0 and np.abs(gx - ofx).max() <= 2e-5 * scale and np.abs(gy - ofy).max() <= 2e-5 * scale
+
+
+def test_device_tree_reference_fold_hands_eps_clusters_to_the_host_build(rx, ob):
+    """What the pairs-only EPS merge cannot reproduce node for node (a third body within EPS, a blob whose centre leaves its
+    first member's cell) is DETECTED in the reference-fold class, however few bodies it concerns, and the step runs on the host
+    tree: the result is then the host-tree result bit for bit.  (The exact-sum class tolerates up to max(16, n/2000) such bodies.)"""
+    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+
+    rng = np.random.default_rng(17)
+    x = rng.uniform(-20, 20, 6000).astype(np.float32); y = rng.uniform(-20, 20, 6000).astype(np.float32)
+    # three triples within EPS of each other
+    x = np.concatenate([x, x[:3] + np.float32(3e-5), x[:3] - np.float32(2e-5)])
+    y = np.concatenate([y, y[:3] + np.float32(1e-5), y[:3] + np.float32(4e-5)])
+    n = len(x)
+    p = ob.particles(x, y, np.zeros(n), np.zeros(n), rng.uniform(0.5, 2.0, n))
+    a = engines(rx, p); a.set_bh_tree("host")
+    b = engines(rx, p)                                   # default: device tree, reference fold
+    c = engines(rx, p, fold="exact")
+    fx, fy, _ = a.forces(0.5)
+    gx, gy, _ = b.forces(0.5)
+    hx, hy, _ = c.forces(0.5)
+    assert b.get_option(NBX_OPT_BH_FALLBACKS) == 1 and b.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    assert c.get_option(NBX_OPT_BH_FALLBACKS) == 0 and c.get_option(NBX_OPT_BH_LAST_TREE) == 1
+    assert np.array_equal(gx.view(np.uint32), fx.view(np.uint32)) and np.array_equal(gy.view(np.uint32), fy.view(np.uint32))
+    with pytest.raises(rx.NBodyError):
+        b.bh_flat_dump("device")                         # the dump refuses too: there is no faithful device tree for this system
+    scale = max(np.abs(fx).max(), np.abs(fy).max())
+    assert np.abs(hx - fx).max() <= 2e-3 * scale
 
 
 @pytest.mark.parametrize("make,n", [("disk", 5000), ("orbits", 20000), ("plummer", 100000), ("tiny", 2), ("one", 1)])
@@ -37,7 +115,7 @@ def test_device_tree_has_the_host_trees_structure(rx, ob, make, n):
         keep = np.ones(len(p), bool)
         keep[pairs[:, 1]] = False
         p = p[keep]
-    e = engines(rx, p)
+    e = engines(rx, p, fold="exact")
     host = e.bh_flat_dump(False)
     dev = e.bh_flat_dump("device")
     assert len(host) == len(dev)
@@ -63,7 +141,8 @@ def test_device_tree_has_the_host_trees_structure(rx, ob, make, n):
 @pytest.mark.parametrize("theta", [0.5, 0.85])
 def test_device_tree_forces_and_step_match_host_tree(rx, ob, theta):
     p = ob.stable_orbits(50000, 0.5, 30.0, 44)
-    a, b = engines(rx, p), engines(rx, p)
+    a, b = engines(rx, p), engines(rx, p, fold="exact")
+    a.set_bh_tree("host")
     b.set_bh_tree("device")
     fx, fy, _ = a.forces(theta)
     gx, gy, _ = b.forces(theta)
@@ -79,7 +158,7 @@ def test_device_tree_forces_and_step_match_host_tree(rx, ob, theta):
     assert np.median(np.abs(pa["vx"] - pb["vx"])) <= 1e-4 and np.abs(pa["vx"] - pb["vx"]).max() <= 0.5
     # the velocity-kill box (nbody.rs:466-471) applies on this path too
     q = ob.particles([0.0, 56.0, 3.0], [0.0, 0.0, 3.0], [0.0, 1.0, 0.0], [0.0, 1.0, 0.0], [1000.0, 1.0, 1.0])
-    c = engines(rx, q)
+    c = engines(rx, q, fold="exact")
     c.set_bh_tree("device")
     c.step_barnes_hut(0.5, 0.01, 1)
     st = c.get_particles()
@@ -117,10 +196,17 @@ def test_device_tree_reproduces_the_reference_eps_merge_in_arrival_order(rx, ob,
     x, y = x[perm], y[perm]
     n = len(x)
     p = ob.particles(x, y, np.zeros(n), np.zeros(n), rng.uniform(0.5, 2.0, n))
-    e = engines(rx, p)
+    e = engines(rx, p, fold="exact")
     host, dev = e.bh_flat_dump(False), e.bh_flat_dump("device")
     leaves = _structure_equal(host, dev)
     assert n - k <= leaves < n - k // 2          # most pairs merged (those split by a cell boundary at arrival time did not)
+    # reference-fold class on the same system: the whole tree bit for bit, unless a blob's centre left its first member's cell
+    # (then the build says so and the caller takes the host tree)
+    r = engines(rx, p, fold="reference")
+    try:
+        _bit_equal_trees(host, r.bh_flat_dump("device"))
+    except rx.NBodyError as ex:
+        assert "fell back" in str(ex)
     rc, ofx, ofy = ob.bh_forces(p, 0.5, nthreads=8)
     e.set_bh_tree("device")
     fx, fy, _ = e.forces(0.5)
@@ -147,7 +233,7 @@ def test_device_tree_duplicates_with_partners_and_crowded_clusters(rx, ob):
     y = np.concatenate([y, y[:500], y[:100], y[:100]])
     n = len(x)
     p = ob.particles(x, y, np.zeros(n), np.zeros(n), rng.uniform(0.5, 2.0, n))
-    e = engines(rx, p)
+    e = engines(rx, p, fold="exact")
     leaves = _structure_equal(e.bh_flat_dump(False), e.bh_flat_dump("device"))
     assert leaves == 3000                       # 500 pairs, 100 of them with two more bodies on top: one leaf each
     e.set_bh_tree("device")
@@ -161,7 +247,7 @@ def test_device_tree_duplicates_with_partners_and_crowded_clusters(rx, ob):
     pts = (c[rng.integers(0, 40, 30000)] + rng.normal(0, 2e-4, (30000, 2))).astype(np.float32)      # 40 clumps ~ 2 EPS wide
     p = ob.particles(pts[:, 0], pts[:, 1], np.zeros(30000), np.zeros(30000), np.ones(30000))
     a = engines(rx, p); a.set_bh_tree("host")
-    b = engines(rx, p); b.set_bh_tree("device")
+    b = engines(rx, p, fold="exact"); b.set_bh_tree("device")
     fx, fy, _ = a.forces(0.3)
     gx, gy, _ = b.forces(0.3)
     assert b.get_option(NBX_OPT_BH_FALLBACKS) == 1 and b.get_option(NBX_OPT_BH_LAST_TREE) == 0
@@ -173,7 +259,7 @@ def test_device_tree_duplicates_with_partners_and_crowded_clusters(rx, ob):
 
 @pytest.mark.parametrize("make,n", [("orbits", 50000), ("disk", 20000), ("plummer", 262144)])
 @pytest.mark.parametrize("theta", [0.5, 0.85])
-def test_device_tree_is_at_least_as_close_to_exact_arithmetic_as_the_reference_fold(rx, ob, make, n, theta):
+def test_device_tree_exact_sums_are_at_least_as_close_to_exact_arithmetic_as_the_reference_fold(rx, ob, make, n, theta):
     """Forces through the fast walk of the device-built tree vs (a) the oracle and (b) the fp64 arbiter (the reference's tree
     and laws with exact node sums).  The reference's interior masses / centres are an f32 running fold over up to n bodies
     (nbody.rs:303-320) and drift; the device's are exact sums rounded once.  Stated tolerance of this path:
@@ -193,10 +279,16 @@ def test_device_tree_is_at_least_as_close_to_exact_arithmetic_as_the_reference_f
     rc, ofx, ofy = ob.bh_forces(p, theta, nthreads=16)
     rc2, ex, ey = ob.bh_forces_exact(p, theta, nthreads=16)
     assert rc == 0 and rc2 == 0
-    e = engines(rx, p)                       # default options: fast mode, n >= 512 -> device tree
+    e = engines(rx, p, fold="exact")         # fast mode, n >= 512 -> device tree; exact sums (the default only above 65 536)
     fx, fy, _ = e.forces(theta)
     assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1
     scale = max(np.abs(ex).max(), np.abs(ey).max())
+    if n <= 65536:
+        # the DEFAULT at this size (reference fold): within the fast mode's 2e-5 of the oracle for every single body
+        d = engines(rx, p)
+        dx, dy, _ = d.forces(theta)
+        assert d.get_option(NBX_OPT_BH_LAST_TREE) == 1
+        assert max(np.abs(dx - ofx).max(), np.abs(dy - ofy).max()) <= 2e-5 * max(np.abs(ofx).max(), np.abs(ofy).max())
     dev_arb = np.maximum(np.abs(fx - ex), np.abs(fy - ey)) / scale
     orc_arb = np.maximum(np.abs(ofx - ex), np.abs(ofy - ey)) / scale
     dev_orc = np.maximum(np.abs(fx - ofx), np.abs(fy - ofy)) / scale
@@ -256,7 +348,7 @@ def test_device_tree_node_pool_overflow_falls_back_to_host_build(rx, ob):
     n = len(x2)
     p = ob.particles(x2, y2, np.zeros(n), np.zeros(n), np.ones(n))
     a = rx.NBodyEngine(); a.set_bh_tree("host"); a.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
-    b = rx.NBodyEngine(); b.set_bh_tree("device"); b.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    b = rx.NBodyEngine(); b.set_bh_tree("device"); b.set_bh_fold("exact"); b.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     fx, fy, _ = a.forces(0.5)
     assert a.get_option(NBX_OPT_BH_LAST_TREE) == 0 and a.get_option(NBX_OPT_BH_FALLBACKS) == 0
     gx, gy, _ = b.forces(0.5)
@@ -311,7 +403,7 @@ def test_wave_uniform_walk_on_a_lattice_takes_the_exact_test_path(rx, ob, theta)
     p = ob.particles(x[order], y[order], np.zeros(n), np.zeros(n), np.ones(n))
     res = []
     for wave in (0, 1):
-        e = engines(rx, p)
+        e = engines(rx, p, fold="exact")
         e.set_bh_tree("device")
         e.set_option(NBX_OPT_BH_WAVE, wave)
         fx, fy, _ = e.forces(theta)
@@ -352,7 +444,7 @@ def test_device_tree_degenerate_inputs(rx, ob, case):
         x = np.array([0.0, 1.0, 1.0], np.float32); y = np.array([0.0, 0.0, 1.0], np.float32)
     m = rng.uniform(0.5, 2.0, n).astype(np.float32)
     p = ob.particles(x, y, np.zeros(n), np.zeros(n), m)
-    e = engines(rx, p)
+    e = engines(rx, p, fold="exact")
     e.set_bh_tree("device")
     dev = e.bh_flat_dump("device")
     k = len(dev)
@@ -370,6 +462,7 @@ def test_device_tree_degenerate_inputs(rx, ob, case):
     # an ulp off their position, so each feels a spurious m*M*ulp/EPS pull; and the opening test uses the x-extent
     # only (nbody.rs:341), so a vertical line of bodies (s = 0 everywhere) accepts the root for everyone.
     h = engines(rx, p)
+    h.set_bh_tree("host")
     hx, hy, _ = h.forces(1e-3)
     scale = max(np.abs(hx).max(), np.abs(hy).max(), 1e-6)
     # 1e-3: the host's centres of mass carry the reference's running-fold drift (up to 6e-4 relative), the device's are
