@@ -394,7 +394,8 @@ constexpr int kFoldSmall = 8;
 __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
                                                 const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const Prefix pre,
                                                 const int n, const int node_cap, BhNode* __restrict__ out, const int fold,
-                                                int4* __restrict__ big, const int big_cap, int* __restrict__ counters)
+                                                int4* __restrict__ big, const int big_cap, int* __restrict__ counters,
+                                                const int root_aside)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = pre.base[n];
@@ -469,6 +470,12 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
                 last = best;
             }
             o.px = px; o.py = py; o.m = m;
+        } else if (k == 0 && root_aside) {
+            // the root's fold runs on the side stream (k_fold_root) and writes (px, py, m) of this record itself
+            float4* dst = reinterpret_cast<float4*>(&out[0]);
+            reinterpret_cast<float*>(dst)[3] = o.s;
+            dst[1] = make_float4(__int_as_float(o.skip), __int_as_float(o.interior), o.q, __int_as_float(o.pad1));
+            return;
         } else {
             const int slot = atomicAdd(&counters[2], 1);
             if (slot < big_cap) big[slot] = make_int4(k, a, b, 0);
@@ -552,168 +559,183 @@ __device__ __forceinline__ fold_v2 fold_p_chain(const float4* __restrict__ rec, 
     return pc;
 }
 
+// fold of the sorted range [a, b) (the whole workgroup of two waves takes part); o[0..2] = px, py, m
+__device__ __forceinline__ void fold_one(FoldShared& sh, const float4* __restrict__ posm, const float4* __restrict__ sb,
+                                         const unsigned* __restrict__ idx, const int a, const int b, const int n, float* __restrict__ o)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int size = b - a;
+    const int kind = size == n ? 0 : (size <= kFoldRank ? 1 : 2);     // member source: identity / rank / bitmap
+    // ---- producer state (wave 0) ----
+    float m = 0.0f;
+    bool any = false;
+    int next_pos = 0;                              // identity / rank path: next member
+    int base = 0, g = 0, total = 0, c0 = 0;        // bitmap path: window, next group, members listed, next member
+    bool window_ready = false;
+    // next chunk of (at most 64) members in index order: every lane's record and the chunk's size (0 = no more)
+    auto fetch = [&](float4& r, int& cnt) {
+        r = make_float4(0.f, 0.f, 0.f, 0.f);
+        cnt = 0;
+        if (kind == 0) {
+            cnt = n - next_pos < 64 ? n - next_pos : 64;
+            if (lane < cnt) r = posm[next_pos + lane];
+            next_pos += cnt;
+        } else if (kind == 1) {
+            cnt = size - next_pos < 64 ? size - next_pos : 64;
+            if (lane < cnt) r = sb[a + (int)sh.lst[next_pos + lane]];
+            next_pos += cnt;
+        } else {
+            while (c0 >= total) {                  // the list is used up: next group of 64 bitmap words / next window
+                if (!window_ready) {
+                    if (base >= n) return;
+                    for (int t = lane; t < 2048; t += 64) sh.bitmap[t] = 0u;
+                    for (int j = a + lane; j < b; j += 64) {
+                        const unsigned v = idx[j] - (unsigned)base;
+                        if (v < 65536u) atomicOr(&sh.bitmap[v >> 5], 1u << (v & 31u));
+                    }
+                    window_ready = true;
+                    g = 0;
+                }
+                if (g == 32) { window_ready = false; base += 65536; continue; }
+                unsigned word = sh.bitmap[g * 64 + lane];
+                const int c = __popc(word);
+                int incl = c;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(incl, off);
+                    if (lane >= off) incl += o;
+                }
+                total = __shfl(incl, 63);
+                c0 = 0;
+                int pos = incl - c;
+                while (word) {
+                    const int bit = __ffs((int)word) - 1;
+                    word &= word - 1u;
+                    sh.lst[pos++] = (unsigned short)(lane * 32 + bit);
+                }
+                g++;
+            }
+            cnt = total - c0 < 64 ? total - c0 : 64;
+            if (lane < cnt) r = posm[base + (g - 1) * 2048 + (int)sh.lst[c0 + lane]];
+            c0 += 64;
+        }
+    };
+    // ---- consumer state (wave 1) ----
+    fold_v2 pc = {0.0f, 0.0f};
+    bool started = false;
+
+    float4 q_cur = make_float4(0.f, 0.f, 0.f, 0.f), q_nxt = q_cur;
+    int cnt_cur = 0, cnt_nxt = 0;
+    if (wave == 0) {
+        if (kind == 1) {
+            // rank path: every lane ranks up to four of the node's indices against all of them
+            unsigned mine[4];
+            int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = a + u * 64 + lane;
+                mine[u] = j < b ? idx[j] : 0xFFFFFFFFu;
+                sh.bitmap[u * 64 + lane] = mine[u];
+            }
+            for (int t = 0; t < size; t++) {
+                const unsigned v = sh.bitmap[t];
+#pragma unroll
+                for (int u = 0; u < 4; u++) rank[u] += v < mine[u] ? 1 : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (a + u * 64 + lane < b) sh.lst[rank[u]] = (unsigned short)(u * 64 + lane);   // position inside [a, b)
+        }
+        fetch(q_cur, cnt_cur);
+        fetch(q_nxt, cnt_nxt);
+    }
+    // One round = wave 0 produces chunk i while wave 1 consumes chunk i - 1; the first empty chunk ends the loop.
+    for (int i = 0;; i++) {
+        const int buf = i & 1;
+        if (wave == 0) {
+            float4 q2;
+            int cnt2;
+            fetch(q2, cnt2);                       // chunk i + 2: in flight during this round
+            if (cnt_cur > 0) {
+                sh.mass_in[lane] = q_cur.w;
+                if (cnt_cur == 64) {               // m chain, operands read at once
+                    float4 mi[16], mo[16];
+                    const float4* in4 = reinterpret_cast<const float4*>(sh.mass_in);
+                    float4* out4 = reinterpret_cast<float4*>(sh.mass_run);
+#pragma unroll
+                    for (int u = 0; u < 16; u++) mi[u] = in4[u];
+                    float mr = m;                  // 0 + mass = mass exactly: the copy of the first member (nbody.rs:305-311)
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        mo[u].x = __fadd_rn(mr, mi[u].x);
+                        mo[u].y = __fadd_rn(mo[u].x, mi[u].y);
+                        mo[u].z = __fadd_rn(mo[u].y, mi[u].z);
+                        mo[u].w = __fadd_rn(mo[u].z, mi[u].w);
+                        mr = mo[u].w;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; u++) out4[u] = mo[u];
+                } else {
+                    float mr = m;
+                    for (int t = 0; t < cnt_cur; t++) {
+                        mr = __fadd_rn(mr, sh.mass_in[t]);
+                        sh.mass_run[t] = mr;
+                    }
+                }
+                if (lane < cnt_cur) {
+                    const float mt = sh.mass_run[lane];
+                    const float mp = lane == 0 ? m : sh.mass_run[lane - 1];
+                    sh.rec[buf][lane] = make_float4(mp, 1.0f / mt, __fmul_rn(q_cur.x, q_cur.w), __fmul_rn(q_cur.y, q_cur.w));
+                }
+                if (!any) {
+                    if (lane == 0) sh.first_xy = make_float2(q_cur.x, q_cur.y);
+                    any = true;
+                }
+                m = sh.mass_run[cnt_cur - 1];
+            }
+            if (lane == 0) sh.cnt[buf] = cnt_cur;
+            q_cur = q_nxt; cnt_cur = cnt_nxt;
+            q_nxt = q2; cnt_nxt = cnt2;
+        } else if (i > 0) {
+            const int pb = (i - 1) & 1;
+            const int cnt = sh.cnt[pb];
+            int t0 = 0;
+            if (!started) {                        // nbody.rs:305-311: the first body is copied, not folded
+                const float2 f = sh.first_xy;
+                pc = fold_v2{f.x, f.y};
+                started = true;
+                t0 = 1;
+            }
+            pc = fold_p_chain(sh.rec[pb], t0, cnt, pc);
+        }
+        __syncthreads();
+        if (sh.cnt[buf] == 0) break;
+    }
+    if (wave == 1 && lane == 0) { o[0] = pc.x; o[1] = pc.y; }
+    if (wave == 0 && lane == 0) o[2] = m;
+    __syncthreads();                               // the next node reuses the LDS
+}
+
+// The ROOT's fold needs nothing but the bodies in index order -- not the keys, not the sort -- and is the longest chain of
+// the build (n members): it runs on a side stream from the very start of the build, beside everything else -- the other
+// nodes' folds included -- and writes (px, py, m) of the root's record itself (k_emit leaves those three words alone).
+__global__ __launch_bounds__(128) void k_fold_root(const float4* __restrict__ posm, const int n, BhNode* __restrict__ out)
+{
+    __shared__ FoldShared sh;
+    fold_one(sh, posm, nullptr, nullptr, 0, n, n, reinterpret_cast<float*>(&out[0]));
+}
+
 __global__ __launch_bounds__(128) void k_fold_big(const float4* __restrict__ posm, const float4* __restrict__ sb,
                                                   const unsigned* __restrict__ idx, const int4* __restrict__ big, const int big_cap,
                                                   const int* __restrict__ counters, const int n, BhNode* __restrict__ out)
 {
     __shared__ FoldShared sh;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int count = counters[2];
     if (count > big_cap) count = big_cap;
     for (int w = blockIdx.x; w < count; w += gridDim.x) {
         const int4 nd = big[w];
-        const int a = nd.y, b = nd.z, size = b - a;
-        const int kind = size == n ? 0 : (size <= kFoldRank ? 1 : 2);     // member source: identity / rank / bitmap
-        // ---- producer state (wave 0) ----
-        float m = 0.0f;
-        bool any = false;
-        int next_pos = 0;                              // identity / rank path: next member
-        int base = 0, g = 0, total = 0, c0 = 0;        // bitmap path: window, next group, members listed, next member
-        bool window_ready = false;
-        // next chunk of (at most 64) members in index order: every lane's record and the chunk's size (0 = no more)
-        auto fetch = [&](float4& r, int& cnt) {
-            r = make_float4(0.f, 0.f, 0.f, 0.f);
-            cnt = 0;
-            if (kind == 0) {
-                cnt = n - next_pos < 64 ? n - next_pos : 64;
-                if (lane < cnt) r = posm[next_pos + lane];
-                next_pos += cnt;
-            } else if (kind == 1) {
-                cnt = size - next_pos < 64 ? size - next_pos : 64;
-                if (lane < cnt) r = sb[a + (int)sh.lst[next_pos + lane]];
-                next_pos += cnt;
-            } else {
-                while (c0 >= total) {                  // the list is used up: next group of 64 bitmap words / next window
-                    if (!window_ready) {
-                        if (base >= n) return;
-                        for (int t = lane; t < 2048; t += 64) sh.bitmap[t] = 0u;
-                        for (int j = a + lane; j < b; j += 64) {
-                            const unsigned v = idx[j] - (unsigned)base;
-                            if (v < 65536u) atomicOr(&sh.bitmap[v >> 5], 1u << (v & 31u));
-                        }
-                        window_ready = true;
-                        g = 0;
-                    }
-                    if (g == 32) { window_ready = false; base += 65536; continue; }
-                    unsigned word = sh.bitmap[g * 64 + lane];
-                    const int c = __popc(word);
-                    int incl = c;
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const int o = __shfl_up(incl, off);
-                        if (lane >= off) incl += o;
-                    }
-                    total = __shfl(incl, 63);
-                    c0 = 0;
-                    int pos = incl - c;
-                    while (word) {
-                        const int bit = __ffs((int)word) - 1;
-                        word &= word - 1u;
-                        sh.lst[pos++] = (unsigned short)(lane * 32 + bit);
-                    }
-                    g++;
-                }
-                cnt = total - c0 < 64 ? total - c0 : 64;
-                if (lane < cnt) r = posm[base + (g - 1) * 2048 + (int)sh.lst[c0 + lane]];
-                c0 += 64;
-            }
-        };
-        // ---- consumer state (wave 1) ----
-        fold_v2 pc = {0.0f, 0.0f};
-        bool started = false;
-
-        float4 q_cur = make_float4(0.f, 0.f, 0.f, 0.f), q_nxt = q_cur;
-        int cnt_cur = 0, cnt_nxt = 0;
-        if (wave == 0) {
-            if (kind == 1) {
-                // rank path: every lane ranks up to four of the node's indices against all of them
-                unsigned mine[4];
-                int rank[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int j = a + u * 64 + lane;
-                    mine[u] = j < b ? idx[j] : 0xFFFFFFFFu;
-                    sh.bitmap[u * 64 + lane] = mine[u];
-                }
-                for (int t = 0; t < size; t++) {
-                    const unsigned v = sh.bitmap[t];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) rank[u] += v < mine[u] ? 1 : 0;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (a + u * 64 + lane < b) sh.lst[rank[u]] = (unsigned short)(u * 64 + lane);   // position inside [a, b)
-            }
-            fetch(q_cur, cnt_cur);
-            fetch(q_nxt, cnt_nxt);
-        }
-        // One round = wave 0 produces chunk i while wave 1 consumes chunk i - 1; the first empty chunk ends the loop.
-        for (int i = 0;; i++) {
-            const int buf = i & 1;
-            if (wave == 0) {
-                float4 q2;
-                int cnt2;
-                fetch(q2, cnt2);                       // chunk i + 2: in flight during this round
-                if (cnt_cur > 0) {
-                    sh.mass_in[lane] = q_cur.w;
-                    if (cnt_cur == 64) {               // m chain, operands read at once
-                        float4 mi[16], mo[16];
-                        const float4* in4 = reinterpret_cast<const float4*>(sh.mass_in);
-                        float4* out4 = reinterpret_cast<float4*>(sh.mass_run);
-#pragma unroll
-                        for (int u = 0; u < 16; u++) mi[u] = in4[u];
-                        float mr = m;                  // 0 + mass = mass exactly: the copy of the first member (nbody.rs:305-311)
-#pragma unroll
-                        for (int u = 0; u < 16; u++) {
-                            mo[u].x = __fadd_rn(mr, mi[u].x);
-                            mo[u].y = __fadd_rn(mo[u].x, mi[u].y);
-                            mo[u].z = __fadd_rn(mo[u].y, mi[u].z);
-                            mo[u].w = __fadd_rn(mo[u].z, mi[u].w);
-                            mr = mo[u].w;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 16; u++) out4[u] = mo[u];
-                    } else {
-                        float mr = m;
-                        for (int t = 0; t < cnt_cur; t++) {
-                            mr = __fadd_rn(mr, sh.mass_in[t]);
-                            sh.mass_run[t] = mr;
-                        }
-                    }
-                    if (lane < cnt_cur) {
-                        const float mt = sh.mass_run[lane];
-                        const float mp = lane == 0 ? m : sh.mass_run[lane - 1];
-                        sh.rec[buf][lane] = make_float4(mp, 1.0f / mt, __fmul_rn(q_cur.x, q_cur.w), __fmul_rn(q_cur.y, q_cur.w));
-                    }
-                    if (!any) {
-                        if (lane == 0) sh.first_xy = make_float2(q_cur.x, q_cur.y);
-                        any = true;
-                    }
-                    m = sh.mass_run[cnt_cur - 1];
-                }
-                if (lane == 0) sh.cnt[buf] = cnt_cur;
-                q_cur = q_nxt; cnt_cur = cnt_nxt;
-                q_nxt = q2; cnt_nxt = cnt2;
-            } else if (i > 0) {
-                const int pb = (i - 1) & 1;
-                const int cnt = sh.cnt[pb];
-                int t0 = 0;
-                if (!started) {                        // nbody.rs:305-311: the first body is copied, not folded
-                    const float2 f = sh.first_xy;
-                    pc = fold_v2{f.x, f.y};
-                    started = true;
-                    t0 = 1;
-                }
-                pc = fold_p_chain(sh.rec[pb], t0, cnt, pc);
-            }
-            __syncthreads();
-            if (sh.cnt[buf] == 0) break;
-        }
-        float* o = reinterpret_cast<float*>(&out[nd.x]);
-        if (wave == 1 && lane == 0) { o[0] = pc.x; o[1] = pc.y; }
-        if (wave == 0 && lane == 0) o[2] = m;
-        __syncthreads();                               // the next node reuses the LDS
+        fold_one(sh, posm, sb, idx, nd.y, nd.z, n, reinterpret_cast<float*>(&out[nd.x]));
     }
 }
 
@@ -965,14 +987,25 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 //          nodes (nothing usable was written), 2 when more than max(16, n/2000) bodies sit in clusters of >= 3 within EPS
 //          (the caller should build on the host: the reference's multi-body merges are not reproduced here)
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
-                                   int* host_counters /* pinned, >= 4 ints */, const unsigned** perm_dev, hipStream_t stream, int fold)
+                                   int* host_counters /* pinned, >= 4 ints */, const unsigned** perm_dev, hipStream_t stream, int fold,
+                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done)
 {
     *perm_dev = nullptr;
     if (n <= 0) return hipSuccess;
     size_t sort_tmp = 0;
     if (device_tree_workspace_bytes(n, node_cap, &sort_tmp) > workspace_bytes) return hipErrorInvalidValue;
     const Workspace k = carve(workspace, n, sort_tmp);
-    hipError_t e = sort_bodies(posm, n, k, sort_tmp, stream);
+    const bool root_aside = fold == 1 && side && ev_go && ev_done && n > kFoldSmall;
+    hipError_t e;
+    if (root_aside) {
+        // the root's fold -- n serial steps, needs only the bodies in index order -- starts NOW on the side stream, beside
+        // the sort, the scans and the other nodes' folds; the main stream picks its result up before k_fold_big
+        if ((e = hipEventRecord(ev_go, stream)) != hipSuccess) return e;           // the positions are final on `stream` here
+        if ((e = hipStreamWaitEvent(side, ev_go, 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_fold_root, dim3(1), dim3(128), 0, side, posm, n, out);
+        if ((e = hipEventRecord(ev_done, side)) != hipSuccess) return e;
+    }
+    e = sort_bodies(posm, n, k, sort_tmp, stream);
     if (e != hipSuccess) return e;
     *perm_dev = k.idx1;
     const int nb = (n + kTile - 1) / kTile;
@@ -992,12 +1025,13 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     // base[n] leave at once; the pool check is inside)
     const int eb = n <= 65536 ? 64 : kTile;   // spread a small system's few waves over the CUs
     hipLaunchKernelGGL(k_emit, dim3((unsigned)((node_cap + eb - 1) / eb)), dim3(eb), 0, stream, k.sb, mk, k.idx1, k.box, k.pre, n, node_cap, out,
-                       fold, k.big, n, k.counters);
+                       fold, k.big, n, k.counters, root_aside ? 1 : 0);
     if (fold == 1) {
         // one wave per queued node; the count lives on the device: enough blocks for every plausible queue (a uniform system
         // queues ~n/45 nodes), the blocks loop when there are more
         const int fb = n / 4 + 64;
         hipLaunchKernelGGL(k_fold_big, dim3((unsigned)(fb < 8192 ? fb : 8192)), dim3(128), 0, stream, posm, k.sb, k.idx1, k.big, n, k.counters, n, out);
+        if (root_aside && (e = hipStreamWaitEvent(stream, ev_done, 0)) != hipSuccess) return e;   // the tree is complete on `stream` from here
     }
     e = hipMemcpyAsync(host_counters, k.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return e;

@@ -517,8 +517,14 @@ int build_tree_on_device_begin(nbx_engine* e)
     if (!e->h_counters) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_counters), 64, hipHostMallocDefault));
     const int rc = grow(&e->d_nodes, &e->nodes_cap, (size_t)node_cap);
     if (rc != NBX_OK) return rc;
+    const int fold = e->effective_fold();
+    if (fold == 1 && !e->side_stream && !std::getenv("NBX_NO_SIDE_STREAM")) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_side_go, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_side_done, hipEventDisableTiming));
+    }
     HIP_TRY(nbx::device_tree_build_begin(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes, e->h_counters,
-                                         &e->d_perm, e->stream, e->effective_fold()));
+                                         &e->d_perm, e->stream, fold, e->side_stream, e->ev_side_go, e->ev_side_done));
     return NBX_OK;
 }
 
@@ -723,6 +729,9 @@ void free_device(nbx_engine* e)
     if (e->d_tree_ws) (void)hipFree(e->d_tree_ws);
     if (e->d_slab_ws) (void)hipFree(e->d_slab_ws);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
+    if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
+    if (e->ev_side_go) (void)hipEventDestroy(e->ev_side_go);
+    if (e->ev_side_done) (void)hipEventDestroy(e->ev_side_done);
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_fb) (void)hipFree(e->d_fb);
     if (e->h_fb) (void)hipHostFree(e->h_fb);

@@ -118,8 +118,11 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 // fold in arrival order (nbody.rs:303-320): the host tree's interior records bit for bit; any cluster the pairs-only EPS merge
 // cannot reproduce then reports status 2 (caller builds on the host).
 constexpr int kFoldFaithfulMax = 65536;   // default: faithful fold up to this many bodies (the root's chain is n serial steps)
+// side / ev_go / ev_done (optional, fold = 1): a second stream and two events of the same device -- the root's fold then runs
+// on `side` from the start of the build, beside everything else (it is the longest chain and needs only the bodies)
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
-                                   int* host_counters, const unsigned** perm_dev, hipStream_t stream, int fold = 0);
+                                   int* host_counters, const unsigned** perm_dev, hipStream_t stream, int fold = 0,
+                                   hipStream_t side = nullptr, hipEvent_t ev_go = nullptr, hipEvent_t ev_done = nullptr);
 hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status,
                                  hipStream_t stream, int fold = 0);
 
