@@ -52,8 +52,12 @@ __device__ __forceinline__ float dec_f32(unsigned u)
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
-// box[0..3] = enc(min x), enc(min y), enc(max x), enc(max y); initialised to {~0,~0,0,0} by the launcher
-__global__ __launch_bounds__(kTile) void k_bbox(const float4* __restrict__ posm, const int n, unsigned* box)
+// box[0..3] = enc(min x), enc(min y), enc(max x), enc(max y).  One launch, no initialisation kernel: every workgroup leaves its
+// partial box in part[], takes a ticket, and the LAST one to finish folds the partials (fixed order) and publishes the box
+// (round 2: k_init_box + atomicMin/Max into a pre-initialised word).  The ticket word must be zero at launch: the last
+// workgroup clears it again (the engine zeroes it once when the workspace is allocated).
+__global__ __launch_bounds__(kTile) void k_bbox(const float4* __restrict__ posm, const int n, unsigned* __restrict__ box,
+                                                float4* __restrict__ part, int* __restrict__ ticket)
 {
     float x1 = 3.40282347e+38f, y1 = 3.40282347e+38f, x2 = -3.40282347e+38f, y2 = -3.40282347e+38f;
     for (int i = blockIdx.x * kTile + threadIdx.x; i < n; i += gridDim.x * kTile) {
@@ -65,9 +69,8 @@ __global__ __launch_bounds__(kTile) void k_bbox(const float4* __restrict__ posm,
         x1 = fminf(x1, __shfl_xor(x1, off)); y1 = fminf(y1, __shfl_xor(y1, off));
         x2 = fmaxf(x2, __shfl_xor(x2, off)); y2 = fmaxf(y2, __shfl_xor(y2, off));
     }
-    // one set of atomics per WORKGROUP (the launcher caps the grid at 256 blocks): per-wave atomics on four
-    // words cost 0.19 ms at 1 M bodies
     __shared__ float red[4][4];
+    __shared__ int last;
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[wave][0] = x1; red[wave][1] = y1; red[wave][2] = x2; red[wave][3] = y2; }
     __syncthreads();
@@ -75,8 +78,32 @@ __global__ __launch_bounds__(kTile) void k_bbox(const float4* __restrict__ posm,
         for (int w = 1; w < 4; w++) {
             x1 = fminf(x1, red[w][0]); y1 = fminf(y1, red[w][1]); x2 = fmaxf(x2, red[w][2]); y2 = fmaxf(y2, red[w][3]);
         }
-        atomicMin(&box[0], enc_f32(x1)); atomicMin(&box[1], enc_f32(y1));
-        atomicMax(&box[2], enc_f32(x2)); atomicMax(&box[3], enc_f32(y2));
+        part[blockIdx.x] = make_float4(x1, y1, x2, y2);
+        __threadfence();
+        last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    x1 = 3.40282347e+38f; y1 = 3.40282347e+38f; x2 = -3.40282347e+38f; y2 = -3.40282347e+38f;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += kTile) {     // at most 256 partials (the launcher caps the grid)
+        const float4 q = part[b];
+        x1 = fminf(x1, q.x); y1 = fminf(y1, q.y); x2 = fmaxf(x2, q.z); y2 = fmaxf(y2, q.w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x1 = fminf(x1, __shfl_xor(x1, off)); y1 = fminf(y1, __shfl_xor(y1, off));
+        x2 = fmaxf(x2, __shfl_xor(x2, off)); y2 = fmaxf(y2, __shfl_xor(y2, off));
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = x1; red[wave][1] = y1; red[wave][2] = x2; red[wave][3] = y2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) {
+            x1 = fminf(x1, red[w][0]); y1 = fminf(y1, red[w][1]); x2 = fmaxf(x2, red[w][2]); y2 = fmaxf(y2, red[w][3]);
+        }
+        box[0] = enc_f32(x1); box[1] = enc_f32(y1); box[2] = enc_f32(x2); box[3] = enc_f32(y2);
+        *ticket = 0;
     }
 }
 
@@ -93,9 +120,11 @@ __device__ __forceinline__ int descend(float& x1, float& y1, float& x2, float& y
 
 __global__ __launch_bounds__(kTile) void k_keys(const float4* __restrict__ posm, const int n,
                                                 const unsigned* __restrict__ box, unsigned long long* __restrict__ keys,
-                                                unsigned* __restrict__ idx)
+                                                unsigned* __restrict__ idx, int* __restrict__ counters)
 {
     const int i = blockIdx.x * kTile + threadIdx.x;
+    // this build's counters and tickets (see Workspace): cleared here instead of by a memset of their own
+    if (i < 4) counters[i] = 0;
     if (i >= n) return;
     float x1 = dec_f32(box[0]), y1 = dec_f32(box[1]), x2 = dec_f32(box[2]), y2 = dec_f32(box[3]);
     const float4 p = posm[i];
@@ -189,17 +218,21 @@ __device__ __forceinline__ int run_start(const unsigned long long* __restrict__ 
     return r;
 }
 
-__global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
+// Also gathers the bodies into sorted order (sb[j] = posm[idx[j]]: round 2 had a kernel of its own for that).
+__global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict__ posm, float4* __restrict__ sb,
+                                                       const unsigned long long* __restrict__ keys,
                                                        const unsigned* __restrict__ idx, const int n,
                                                        unsigned char* __restrict__ close)
 {
     const int j = blockIdx.x * kTile + threadIdx.x;
     if (j >= n) return;
+    const float4 b = posm[idx[j]];
+    sb[j] = b;
     unsigned char out = 0;
     if (j > 0 && keys[j - 1] != keys[j]) {
         // the entity's position is its first arrival's (later arrivals of the same cell are < 5e-8 of the box away)
         const int r = run_start(keys, j - 1);
-        const float4 a = sb[r], b = sb[j];
+        const float4 a = posm[idx[r]];
         if (fabsf(__fsub_rn(a.x, b.x)) < kEps && fabsf(__fsub_rn(a.y, b.y)) < kEps) {   // nbody.rs:249
             const int c = common_digits(keys[j - 1], keys[j]);
             const unsigned ia = idx[r], ib = idx[j];           // first arrival of either entity (stable sort: run start)
@@ -246,13 +279,6 @@ __global__ __launch_bounds__(kTile) void k_merge_keys(const unsigned long long* 
     out[j] = k;
 }
 
-__global__ __launch_bounds__(kTile) void k_gather(const float4* __restrict__ posm, const unsigned* __restrict__ idx,
-                                                  const int n, float4* __restrict__ sb)
-{
-    const int j = blockIdx.x * kTile + threadIdx.x;
-    if (j < n) sb[j] = posm[idx[j]];
-}
-
 __device__ __forceinline__ ScanItem scan_item(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
                                               const int j, const int n)
 {
@@ -292,8 +318,13 @@ __device__ __forceinline__ ScanItem block_exclusive(const ScanItem mine, ScanIte
     return scan_add(before, ex);
 }
 
+// exclusive scan of the block sums in place (one workgroup); block_sums[nb] = grand total
+__device__ __forceinline__ void scan_blocks(ScanItem* __restrict__ block_sums, const int nb);
+
+// Block sums, then -- in the LAST workgroup to finish (ticket) -- their exclusive scan: the fixed summation tree of round 2's
+// separate k_scan_blocks launch (same bits on every run), without the launch.
 __global__ __launch_bounds__(kTile) void k_scan_reduce(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
-                                                       const int n, ScanItem* __restrict__ block_sums)
+                                                       const int n, ScanItem* __restrict__ block_sums, int* __restrict__ ticket)
 {
     const int j0 = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
     ScanItem s = scan_item(sb, keys, j0, n);
@@ -301,11 +332,19 @@ __global__ __launch_bounds__(kTile) void k_scan_reduce(const float4* __restrict_
     for (int u = 1; u < kScanPerThread; u++) s = scan_add(s, scan_item(sb, keys, j0 + u, n));
     ScanItem total;
     (void)block_exclusive(s, &total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = total;
+        __threadfence();
+        last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    scan_blocks(block_sums, (int)gridDim.x);
 }
 
-// one workgroup: exclusive scan of the block sums in place; block_sums[nb] = grand total
-__global__ __launch_bounds__(kTile) void k_scan_blocks(ScanItem* __restrict__ block_sums, const int nb)
+__device__ __forceinline__ void scan_blocks(ScanItem* __restrict__ block_sums, const int nb)
 {
     const int chunk = (nb + kTile - 1) / kTile;
     const int a = threadIdx.x * chunk, b = min(a + chunk, nb);
@@ -383,6 +422,10 @@ __device__ __forceinline__ int group_end(const unsigned long long* __restrict__ 
 // its depth follows from k - base[a], its body range from a gallop over the sorted keys, and the whole 32-byte record is
 // written at once.  (Round 2's first version looped per BODY over the chain of nodes that start at it -- up to 31 for a body
 // that opens a deep chain, one for most: 134 us at 1 M bodies, against 28 us like this.)
+__device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
+                                          const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const Prefix pre,
+                                          const int n, BhNode* __restrict__ out, const int fold, int4* __restrict__ big,
+                                          const int big_cap, int* __restrict__ counters, const int root_aside, const int k);
 //
 // fold (round 3): how an interior node's mass and centre are obtained.
 //   0 = exact: fp64 sums over the node's bodies, rounded once (round 2; systems above kFoldFaithfulMax bodies)
@@ -399,7 +442,14 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = pre.base[n];
-    if (k >= total || total > node_cap) return;
+    if (k < total && total <= node_cap) emit_node(sb, keys, idx, box, pre, n, out, fold, big, big_cap, counters, root_aside, k);
+}
+
+__device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
+                                          const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const Prefix pre,
+                                          const int n, BhNode* __restrict__ out, const int fold, int4* __restrict__ big,
+                                          const int big_cap, int* __restrict__ counters, const int root_aside, const int k)
+{
     int a = 0;
     {
         int hi = n;                                 // base[a] <= k < base[hi]
@@ -530,24 +580,26 @@ struct FoldShared {
     int cnt[2];
 };
 
-// p chain over rec[t0 .. cnt): operands fetched kAhead members ahead of the dependent chain
-__device__ __forceinline__ fold_v2 fold_p_chain(const float4* __restrict__ rec, const int t0, const int cnt, fold_v2 pc)
+// p chain over rec[t0 .. cnt): operands fetched kFoldAhead members ahead of the dependent chain; `first` = rec[0 .. kFoldAhead)
+// already in registers (read right behind the barrier that published the chunk, together with its size)
+constexpr int kFoldAhead = 16;
+__device__ __forceinline__ fold_v2 fold_p_chain(const float4* __restrict__ rec, const float4 (&first)[kFoldAhead], const int t0,
+                                                const int cnt, fold_v2 pc)
 {
-    constexpr int kAhead = 16;
     if (t0 == 0 && cnt == 64) {
-        float4 r[kAhead], nx[kAhead];
+        float4 r[kFoldAhead], nx[kFoldAhead];
 #pragma unroll
-        for (int u = 0; u < kAhead; u++) r[u] = rec[u];
+        for (int u = 0; u < kFoldAhead; u++) r[u] = first[u];
 #pragma unroll
-        for (int t = 0; t < 64; t += kAhead) {
-            if (t + kAhead < 64) {
+        for (int t = 0; t < 64; t += kFoldAhead) {
+            if (t + kFoldAhead < 64) {
 #pragma unroll
-                for (int u = 0; u < kAhead; u++) nx[u] = rec[t + kAhead + u];
+                for (int u = 0; u < kFoldAhead; u++) nx[u] = rec[t + kFoldAhead + u];
             }
 #pragma unroll
-            for (int u = 0; u < kAhead; u++) pc = ((pc * fold_v2{r[u].x, r[u].x}) + fold_v2{r[u].z, r[u].w}) * fold_v2{r[u].y, r[u].y};
+            for (int u = 0; u < kFoldAhead; u++) pc = ((pc * fold_v2{r[u].x, r[u].x}) + fold_v2{r[u].z, r[u].w}) * fold_v2{r[u].y, r[u].y};
 #pragma unroll
-            for (int u = 0; u < kAhead; u++) r[u] = nx[u];
+            for (int u = 0; u < kFoldAhead; u++) r[u] = nx[u];
         }
         return pc;
     }
@@ -624,6 +676,10 @@ __device__ __forceinline__ void fold_one(FoldShared& sh, const float4* __restric
     // ---- consumer state (wave 1) ----
     fold_v2 pc = {0.0f, 0.0f};
     bool started = false;
+    float4 first[kFoldAhead];                      // the first records of the chunk to consume next, and its size
+    int cnt_c = 0;
+#pragma unroll
+    for (int u = 0; u < kFoldAhead; u++) first[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     float4 q_cur = make_float4(0.f, 0.f, 0.f, 0.f), q_nxt = q_cur;
     int cnt_cur = 0, cnt_nxt = 0;
@@ -653,6 +709,7 @@ __device__ __forceinline__ void fold_one(FoldShared& sh, const float4* __restric
     // One round = wave 0 produces chunk i while wave 1 consumes chunk i - 1; the first empty chunk ends the loop.
     for (int i = 0;; i++) {
         const int buf = i & 1;
+        int produced = 0;
         if (wave == 0) {
             float4 q2;
             int cnt2;
@@ -695,11 +752,11 @@ __device__ __forceinline__ void fold_one(FoldShared& sh, const float4* __restric
                 m = sh.mass_run[cnt_cur - 1];
             }
             if (lane == 0) sh.cnt[buf] = cnt_cur;
+            produced = cnt_cur;
             q_cur = q_nxt; cnt_cur = cnt_nxt;
             q_nxt = q2; cnt_nxt = cnt2;
         } else if (i > 0) {
             const int pb = (i - 1) & 1;
-            const int cnt = sh.cnt[pb];
             int t0 = 0;
             if (!started) {                        // nbody.rs:305-311: the first body is copied, not folded
                 const float2 f = sh.first_xy;
@@ -707,10 +764,18 @@ __device__ __forceinline__ void fold_one(FoldShared& sh, const float4* __restric
                 started = true;
                 t0 = 1;
             }
-            pc = fold_p_chain(sh.rec[pb], t0, cnt, pc);
+            pc = fold_p_chain(sh.rec[pb], first, t0, cnt_c, pc);
         }
         __syncthreads();
-        if (sh.cnt[buf] == 0) break;
+        if (wave == 0) {
+            if (produced == 0) break;
+        } else {
+            // the chunk just published: its size and its first records in one LDS round trip, off the next round's chain
+            cnt_c = sh.cnt[buf];
+#pragma unroll
+            for (int u = 0; u < kFoldAhead; u++) first[u] = sh.rec[buf][u];
+            if (cnt_c == 0) break;
+        }
     }
     if (wave == 1 && lane == 0) { o[0] = pc.x; o[1] = pc.y; }
     if (wave == 0 && lane == 0) o[2] = m;
@@ -728,9 +793,16 @@ __global__ __launch_bounds__(128) void k_fold_root(const float4* __restrict__ po
 
 __global__ __launch_bounds__(128) void k_fold_big(const float4* __restrict__ posm, const float4* __restrict__ sb,
                                                   const unsigned* __restrict__ idx, const int4* __restrict__ big, const int big_cap,
-                                                  const int* __restrict__ counters, const int n, BhNode* __restrict__ out)
+                                                  const int* __restrict__ counters, const int n, BhNode* __restrict__ out,
+                                                  int* __restrict__ host_counters)
 {
     __shared__ FoldShared sh;
+    // the build's counters (node count, left-behind bodies, queued folds) are final when this kernel starts: workgroup 0 hands
+    // them to the host through pinned memory (no copy command of its own behind the build)
+    if (blockIdx.x == 0 && threadIdx.x < 3) {
+        host_counters[threadIdx.x] = counters[threadIdx.x];
+        __threadfence_system();
+    }
     int count = counters[2];
     if (count > big_cap) count = big_cap;
     for (int w = blockIdx.x; w < count; w += gridDim.x) {
@@ -739,10 +811,10 @@ __global__ __launch_bounds__(128) void k_fold_big(const float4* __restrict__ pos
     }
 }
 
-__global__ void k_init_box(unsigned* box)
-{
-    box[0] = 0xFFFFFFFFu; box[1] = 0xFFFFFFFFu; box[2] = 0u; box[3] = 0u;
-}
+// Workspace header (the first 4 KiB + 256 B): ints [0] node count, [1] bodies the pairs-only EPS merge left behind (or blobs whose
+// centre left their first member's cell), [2] nodes queued for k_fold_big, [3] ticket of k_scan_reduce -- all cleared by k_keys at every build -- [8] ticket of k_bbox (self-clearing; zeroed once by device_tree_workspace_init),
+// [12..15] the root box (encoded); then 256 float4 partial boxes of k_bbox.
+constexpr size_t kHeaderBytes = 256 + 256 * sizeof(float4);
 
 size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
 {
@@ -754,6 +826,7 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     const size_t nb = ((size_t)n + kScanBlock - 1) / kScanBlock;
     size_t bytes = 0;
     auto add = [&](size_t b) { bytes += (b + 255) & ~(size_t)255; };
+    add(kHeaderBytes);                                 // counters, tickets, box, partial boxes
     add(sizeof(unsigned long long) * (size_t)n * 2);   // keys in/out
     add(sizeof(unsigned) * (size_t)n * 2);             // idx in/out
     add(tmp);
@@ -762,13 +835,21 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     add(sizeof(int) * ((size_t)n + 1));                // pre-order base
     add(sizeof(ScanItem) * (nb + 1));                  // block sums
     add((size_t)n);                                    // EPS-merge links
-    add(256);                                          // counters + box
-    add(sizeof(int4) * (size_t)n);                     // nodes queued for k_fold_big (a body is in at most 31 nodes of > 8 bodies: <= 31 n / 9 ... the queue holds n, more -> host build)
+    add(sizeof(int4) * (size_t)n);                     // nodes queued for k_fold_big (more than n of them -> host build)
     return bytes;
+}
+
+// once per (re)allocation of the workspace: the self-clearing ticket of k_bbox starts at zero
+hipError_t device_tree_workspace_init(void* workspace, hipStream_t stream)
+{
+    return hipMemsetAsync(workspace, 0, 256, stream);
 }
 
 namespace {
 struct Workspace {
+    int* counters;
+    unsigned* box;
+    float4* part;
     unsigned long long *keys0, *keys1;
     unsigned *idx0, *idx1;
     void* sort_tmp;
@@ -776,8 +857,6 @@ struct Workspace {
     Prefix pre;
     ScanItem* block_sums;
     unsigned char* link;
-    int* counters;   // [0] node count, [1] bodies the pairs-only merge left behind, [2] nodes queued for k_fold_big; [4..7] box (as unsigned)
-    unsigned* box;
     int4* big;
 };
 Workspace carve(void* workspace, int n, size_t sort_tmp)
@@ -786,6 +865,10 @@ Workspace carve(void* workspace, int n, size_t sort_tmp)
     auto take = [&](size_t b) { char* p = w; w += (b + 255) & ~(size_t)255; return p; };
     const size_t nb = ((size_t)n + kScanBlock - 1) / kScanBlock;
     Workspace k;
+    char* header = take(kHeaderBytes);
+    k.counters = reinterpret_cast<int*>(header);
+    k.box = reinterpret_cast<unsigned*>(k.counters + 12);
+    k.part = reinterpret_cast<float4*>(header + 256);
     k.keys0 = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * (size_t)n * 2));
     k.keys1 = k.keys0 + n;
     k.idx0 = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * (size_t)n * 2));
@@ -797,8 +880,6 @@ Workspace carve(void* workspace, int n, size_t sort_tmp)
     k.pre.base = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)n + 1)));
     k.block_sums = reinterpret_cast<ScanItem*>(take(sizeof(ScanItem) * (nb + 1)));
     k.link = reinterpret_cast<unsigned char*>(take((size_t)n));
-    k.counters = reinterpret_cast<int*>(take(256));
-    k.box = reinterpret_cast<unsigned*>(k.counters + 4);
     k.big = reinterpret_cast<int4*>(take(sizeof(int4) * (size_t)n));
     return k;
 }
@@ -807,9 +888,8 @@ Workspace carve(void* workspace, int n, size_t sort_tmp)
 hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sort_tmp, hipStream_t stream)
 {
     const int nb = (n + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_init_box, dim3(1), dim3(1), 0, stream, k.box);
-    hipLaunchKernelGGL(k_bbox, dim3(nb < 256 ? nb : 256), dim3(kTile), 0, stream, posm, n, k.box);
-    hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, k.box, k.keys0, k.idx0);
+    hipLaunchKernelGGL(k_bbox, dim3(nb < 256 ? nb : 256), dim3(kTile), 0, stream, posm, n, k.box, k.part, k.counters + 8);
+    hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, k.box, k.keys0, k.idx0, k.counters);
     return rocprim::radix_sort_pairs(k.sort_tmp, sort_tmp, k.keys0, k.keys1, k.idx0, k.idx1, (size_t)n, 0, 2 * kLevels, stream);
 }
 }  // namespace
@@ -1010,16 +1090,12 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     *perm_dev = k.idx1;
     const int nb = (n + kTile - 1) / kTile;
     const int sb = (n + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(k_gather, dim3(nb), dim3(kTile), 0, stream, posm, k.idx1, n, k.sb);
-    // EPS merge (pairs): links from the sorted keys + arrival order, then both members of a pair share one key (keys0 is free
-    // again after the sort); everything below works on the merged keys
-    hipLaunchKernelGGL(k_merge_links, dim3(nb), dim3(kTile), 0, stream, k.sb, k.keys1, k.idx1, n, k.link);
-    hipError_t me = hipMemsetAsync(k.counters, 0, 4 * sizeof(int), stream);
-    if (me != hipSuccess) return me;
+    // EPS merge (pairs): links from the sorted keys + arrival order (this kernel also gathers the bodies into sorted order), then
+    // both members of a pair share one key (keys0 is free again after the sort); everything below works on the merged keys
+    hipLaunchKernelGGL(k_merge_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link);
     hipLaunchKernelGGL(k_merge_keys, dim3(nb), dim3(kTile), 0, stream, k.keys1, k.idx1, k.link, n, k.keys0, k.counters + 1);
     const unsigned long long* mk = k.keys0;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, k.sb, mk, n, k.block_sums);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kTile), 0, stream, k.block_sums, sb);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, k.sb, mk, n, k.block_sums, k.counters + 3);
     hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, k.sb, mk, n, k.block_sums, k.pre, k.counters);
     // one thread per node; the node count is only known on the device, so the grid covers the whole pool (threads beyond
     // base[n] leave at once; the pool check is inside)
@@ -1027,14 +1103,15 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     hipLaunchKernelGGL(k_emit, dim3((unsigned)((node_cap + eb - 1) / eb)), dim3(eb), 0, stream, k.sb, mk, k.idx1, k.box, k.pre, n, node_cap, out,
                        fold, k.big, n, k.counters, root_aside ? 1 : 0);
     if (fold == 1) {
-        // one wave per queued node; the count lives on the device: enough blocks for every plausible queue (a uniform system
-        // queues ~n/45 nodes), the blocks loop when there are more
+        // one pair of waves per queued node; the count lives on the device: enough workgroups for every plausible queue
+        // (a uniform system queues ~n/5 nodes), they loop when there are more
         const int fb = n / 4 + 64;
-        hipLaunchKernelGGL(k_fold_big, dim3((unsigned)(fb < 8192 ? fb : 8192)), dim3(128), 0, stream, posm, k.sb, k.idx1, k.big, n, k.counters, n, out);
+        hipLaunchKernelGGL(k_fold_big, dim3((unsigned)(fb < 8192 ? fb : 8192)), dim3(128), 0, stream, posm, k.sb, k.idx1, k.big, n, k.counters, n, out,
+                           host_counters);
         if (root_aside && (e = hipStreamWaitEvent(stream, ev_done, 0)) != hipSuccess) return e;   // the tree is complete on `stream` from here
+    } else if ((e = hipMemcpyAsync(host_counters, k.counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) {
+        return e;
     }
-    e = hipMemcpyAsync(host_counters, k.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, stream);
-    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -513,6 +513,7 @@ int build_tree_on_device_begin(nbx_engine* e)
         e->tree_ws_bytes = 0;
         HIP_TRY(hipMalloc(&e->d_tree_ws, need));
         e->tree_ws_bytes = need;
+        HIP_TRY(nbx::device_tree_workspace_init(e->d_tree_ws, e->stream));
     }
     if (!e->h_counters) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_counters), 64, hipHostMallocDefault));
     const int rc = grow(&e->d_nodes, &e->nodes_cap, (size_t)node_cap);
@@ -571,6 +572,7 @@ int spatial_order(nbx_engine* e)
         e->tree_ws_bytes = 0;
         HIP_TRY(hipMalloc(&e->d_tree_ws, need));
         e->tree_ws_bytes = need;
+        HIP_TRY(nbx::device_tree_workspace_init(e->d_tree_ws, e->stream));
     }
     HIP_TRY(nbx::device_spatial_order(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, &e->d_perm, e->stream));
     return NBX_OK;

@@ -101,6 +101,8 @@ hipError_t launch_bh_count(const float4* posm, int lo, int n_targets, const BhNo
 
 // Quadtree build on the device (bh_build.hip): same node set as the host build, flattened straight into `out`.
 size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes);
+// call once after every (re)allocation of the workspace, before its first use (clears the header's self-clearing ticket)
+hipError_t device_tree_workspace_init(void* workspace, hipStream_t stream);
 hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size_t workspace_bytes, const unsigned** perm_dev,
                                 hipStream_t stream);
 // Routing + stable scatter for the host quadtree build (see bh_build.hip): top_host = ntop records of (x1, y1, x2, y2,
