@@ -41,6 +41,7 @@ DT = 0.01                    # RustNBodyExperiment.hs:45
 
 KERNEL_NAMES = {0: "k_force_tile", 1: "k_force_tile_pk", 2: "k_force_smem", 3: "k_force_tile_pk", 4: "k_force_tile_pkb",
                 5: "k_force_smem_pk", 6: "k_force_smem_pkw<unit_mass=0>", 7: "k_force_smem_pkw<unit_mass=1>", 16: "k_force_tile_pk_h",
+                17: "k_force_smem_pkw<unit_mass=0,self_image=1> on the widened fp16 copy", 18: "k_force_smem_pkw<unit_mass=1,self_image=1> on the widened fp16 copy",
                 -1: "k_force_strict", -8: "k_force_strict_pc<8,8>", -16: "k_force_strict_pc<16,4>"}
 
 
@@ -656,7 +657,7 @@ def main():
             value = interactions_per_step * args.steps / elapsed
             flops_per_inter = FLOPS_PER_INTERACTION if launch["dim"] == 3 else 12
             # variant 7 (one common mass): the multiply by m_j leaves the loop -> one flop fewer EXECUTED per interaction
-            flops_executed = flops_per_inter - (1 if launch["variant"] == 7 else 0)
+            flops_executed = flops_per_inter - (1 if launch["variant"] in (7, 18) else 0)
             # dominant kernel: K1. Roofline from the SLOWEST rank's launches (the step waits for it).
             worst = max(per, key=lambda r: r["force_ms"])
             inter_per_launch = float(worst["slab"][1] - worst["slab"][0]) * float(n - 1)

@@ -147,20 +147,17 @@ int upload(nbx_engine* e)
         HIP_TRY(hipMemcpyAsync(e->d_vel, tmp, sizeof(float4) * (size_t)slab, hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
-    if (!e->exc_idx.empty()) {   // the exceptional sources of the unit-mass sweep: indices + weights m_j - mass_common
+    if (!e->exc_idx.empty()) {   // the exceptional sources of the unit-mass sweep (their weights m_j - mass_common follow on the device)
         const size_t k = e->exc_idx.size();
         if (k > e->exc_cap_dev) {
             if (e->d_exc_idx) HIP_TRY(hipFree(e->d_exc_idx));
-            if (e->d_exc_w) HIP_TRY(hipFree(e->d_exc_w));
             if (e->d_exc_rec) HIP_TRY(hipFree(e->d_exc_rec));
-            e->d_exc_idx = nullptr; e->d_exc_w = nullptr; e->d_exc_rec = nullptr; e->exc_cap_dev = 0;
+            e->d_exc_idx = nullptr; e->d_exc_rec = nullptr; e->exc_cap_dev = 0;
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_exc_idx), sizeof(int) * k));
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_exc_w), sizeof(float) * k));
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_exc_rec), sizeof(float4) * k));
             e->exc_cap_dev = k;
         }
         HIP_TRY(hipMemcpyAsync(e->d_exc_idx, e->exc_idx.data(), sizeof(int) * k, hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipMemcpyAsync(e->d_exc_w, e->exc_w.data(), sizeof(float) * k, hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
     e->dev_valid = true;
@@ -223,7 +220,7 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
     if (v == 7 && !e->unit_sweep_ok()) v = 6;   // unit-mass sweep needs one common mass (+ at most a handful of exceptions)
     *variant = v;
     // 256 targets per workgroup, 4 source quarters per workgroup; the fp16-source kernel (K4) keeps the 1024-target workgroups
-    const bool wave_split = (v == 6 || v == 7) && !e->source_half;
+    const bool wave_split = (v == 6 || v == 7);
     int b = wave_split ? 4 : (e->bpt ? e->bpt : (n_targets >= 32768 ? 4 : 2));
     if (b != 1 && b != 2 && b != 4) b = 2;
     *bpt = b;
@@ -260,17 +257,28 @@ int launch_forces_fast(nbx_engine* e)
         rc = grow(&e->d_guard, &e->guard_cap, 1);
         if (rc != NBX_OK) return rc;
     }
-    if (e->source_half) {
+    if (e->source_half && !(variant == 6 || variant == 7)) {   // small systems: the LDS-tile sweep on the half4 copy
         ProfScope ps(e, NBX_K_FORCE);
         HIP_TRY(nbx::launch_force_tile_half(e->d_posm, e->d_posh, e->lo, slab, tiles_total, jsplit, bpt, dim, e->d_acc,
                                             stride, e->stream, &e->last));
         return NBX_OK;
     }
     if (variant == 6 || variant == 7) {
+        const float4* widened = nullptr;
+        float mass = e->mass_common;
+        if (e->source_half) {
+            // K4 on the wave-split kernels: the half4 copy widened to float4 once per step (exact), then the same sweep with those
+            // records as sources; the common mass is the fp16 image of the bodies' mass, like every source's
+            rc = grow(&e->d_src4, &e->src4_cap, (size_t)e->n_pad);
+            if (rc != NBX_OK) return rc;
+            widened = e->d_src4;
+            mass = nbx::half_image(e->mass_common);
+        }
         ProfScope ps(e, NBX_K_FORCE);
+        if (widened) HIP_TRY(nbx::launch_widen_half(e->d_posh, e->d_src4, e->n_pad, e->stream));
         const int n_exc = variant == 7 ? (int)e->exc_idx.size() : 0;
-        HIP_TRY(nbx::launch_force_wave_split(e->d_posm, e->lo, slab, tiles_total, e->n, jsplit, dim, variant == 7, e->mass_common,
-                                             e->d_acc, stride, e->stream, &e->last, e->d_exc_idx, e->d_exc_w, e->d_exc_rec, n_exc));
+        HIP_TRY(nbx::launch_force_wave_split(e->d_posm, e->lo, slab, tiles_total, e->n, jsplit, dim, variant == 7, mass,
+                                             e->d_acc, stride, e->stream, &e->last, e->d_exc_idx, e->d_exc_rec, n_exc, widened));
         return NBX_OK;
     }
     {
@@ -284,8 +292,8 @@ int launch_forces_fast(nbx_engine* e)
 // the exceptional sources K2 / the force readout must add after a unit-mass sweep (variant 7) of a system with exceptions
 nbx::MassExceptions exceptions_of(const nbx_engine* e)
 {
-    if (e->last.variant != 7 || e->exc_idx.empty()) return nbx::MassExceptions{nullptr, 0, e->last.dim};
-    return nbx::MassExceptions{e->d_exc_rec, (int)e->exc_idx.size(), e->last.dim};
+    if ((e->last.variant != 7 && e->last.variant != 18) || e->exc_idx.empty()) return nbx::MassExceptions{nullptr, nullptr, 0, e->last.dim};
+    return nbx::MassExceptions{e->d_exc_rec, e->d_exc_idx, (int)e->exc_idx.size(), e->last.dim};
 }
 
 // NBX_LOG=1: one stderr line per step (the reference has no logging on this path; its Haskell shell has Trace.hs)
@@ -726,7 +734,7 @@ void free_device(nbx_engine* e)
     if (e->d_nodes) (void)hipFree(e->d_nodes);
     if (e->d_guard) (void)hipFree(e->d_guard);
     if (e->d_exc_idx) (void)hipFree(e->d_exc_idx);
-    if (e->d_exc_w) (void)hipFree(e->d_exc_w);
+    if (e->d_src4) (void)hipFree(e->d_src4);
     if (e->d_exc_rec) (void)hipFree(e->d_exc_rec);
     if (e->d_tree_ws) (void)hipFree(e->d_tree_ws);
     if (e->d_slab_ws) (void)hipFree(e->d_slab_ws);
@@ -779,7 +787,6 @@ void after_host_state_change(nbx_engine* e)
     // common mass = the majority value (Boyer-Moore vote, one pass), exceptions = everybody else, if they are few
     e->mass_common = 0.0f;
     e->exc_idx.clear();
-    e->exc_w.clear();
     if (!bad && e->n > 0 && lo > 0.0f) {
         float cand = e->host.m[0];
         int votes = 0;
@@ -795,10 +802,9 @@ void after_host_state_change(nbx_engine* e)
             if (e->host.m[i] != cand) {
                 if ((int)e->exc_idx.size() >= cap) { few = false; break; }
                 e->exc_idx.push_back(i);
-                e->exc_w.push_back(e->host.m[i] - cand);
             }
         if (few) e->mass_common = cand;
-        else { e->exc_idx.clear(); e->exc_w.clear(); }
+        else e->exc_idx.clear();
     }
 }
 

@@ -92,6 +92,8 @@ struct nbx_engine {
     bool posh_external = false;
     size_t posh_cap = 0;           // records
     int source_half = 0;
+    float4* d_src4 = nullptr;      // the fp16 source copy widened to float4, rewritten before every wave-split sweep (K4)
+    size_t src4_cap = 0;
 
     // options
     int force_mode = 0, jsplit = 0, bpt = 0, dim_opt = 0, profile = 0, variant = -1, strict_kernel = 0;
@@ -102,9 +104,7 @@ struct nbx_engine {
     // exceptional sources with weight m_j - mass_common.  mass_common = 0: no usable common mass (variant 6 runs).
     float mass_common = 0.0f;
     std::vector<int> exc_idx;        // bodies whose mass differs from mass_common (at most exc_cap(n))
-    std::vector<float> exc_w;        // m_j - mass_common
     int* d_exc_idx = nullptr;
-    float* d_exc_w = nullptr;
     float4* d_exc_rec = nullptr;     // (x, y, z, m_j - mass_common) snapshot written by the sweep kernel for K2
     size_t exc_cap_dev = 0;
     static int exc_cap(int n) { return std::min(n / 64, std::max(32, n / 1024)); }   // 1 024 bodies: 16, 10 000: 32, 262 144: 256

@@ -151,6 +151,25 @@ __global__ __launch_bounds__(kTile) void k_pack_half(const float4* __restrict__ 
     posh[first + i] = v;
 }
 
+// half4 -> float4, exact: the source array the wave-split sweep reads through the scalar cache (the scalar unit of gfx950 has
+// no f16 conversion, so the copy is widened once per step -- 24 B of traffic per body -- instead of once per source per wave)
+__global__ __launch_bounds__(kTile) void k_widen_half(const h4* __restrict__ posh, float4* __restrict__ out, const int count)
+{
+    const int i = blockIdx.x * kTile + threadIdx.x;
+    if (i >= count) return;
+    const h4 v = posh[i];
+    out[i] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+
+float half_image(float v) { return (float)(_Float16)v; }
+
+hipError_t launch_widen_half(const void* posh, float4* widened, int count, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_widen_half, dim3((count + kTile - 1) / kTile), dim3(kTile), 0, stream, static_cast<const h4*>(posh), widened, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_half(const float4* posm, void* posh, int first, int count, hipStream_t stream)
 {
     if (count <= 0) return hipSuccess;

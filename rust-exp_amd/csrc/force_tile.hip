@@ -419,12 +419,16 @@ __global__ __launch_bounds__(kTile) void k_force_smem_pk(const float4* __restric
 // the per-interaction v_pk_mul (m_j * inv) leaves the loop -- 9 packed ops + 2 rcp per 2 interactions instead of 10 + 2 --
 // and the common mass multiplies the finished sums.  Sources are then weightless, so the zero-mass padding records cannot be
 // swept: the source loop ends at the true body count.
-template <int DIM, int UNROLL, bool UNIT_MASS>
-__global__ __launch_bounds__(kTile) void k_force_smem_pkw(const float4* __restrict__ posm, const int lo,
+// SELF_IMAGE (K4, fp16 sources): `src` is not posm but the widened fp16 copy of it, so a target's own source record is NOT at
+// the target's fp32 position and its term is no exact zero: it is recomputed with the sweep's arithmetic and subtracted by the
+// wave whose source quarter holds it.
+template <int DIM, int UNROLL, bool UNIT_MASS, bool SELF_IMAGE>
+__global__ __launch_bounds__(kTile) void k_force_smem_pkw(const float4* __restrict__ posm, const float4* __restrict__ src,
+                                                          const int lo,
                                                           const int n_targets, const int tiles_total, const int n_sources,
                                                           const int jsplit, float4* __restrict__ acc_partial,
                                                           const int acc_stride, const float unit_mass,
-                                                          const int* __restrict__ exc_idx, const float* __restrict__ exc_w,
+                                                          const int* __restrict__ exc_idx,
                                                           float4* __restrict__ exc_rec, const int exc_count)
 {
     constexpr int P = 2;
@@ -432,8 +436,8 @@ __global__ __launch_bounds__(kTile) void k_force_smem_pkw(const float4* __restri
     const int tid = threadIdx.x;
     if (UNIT_MASS && blockIdx.x == 0)   // snapshot of the exceptional sources for K2 (MassExceptions); usually 0 or 1 record
         for (int k = tid; k < exc_count; k += kTile) {
-            const float4 s = posm[exc_idx[k]];
-            exc_rec[k] = make_float4(s.x, s.y, s.z, exc_w[k]);
+            const float4 s = src[exc_idx[k]];
+            exc_rec[k] = make_float4(s.x, s.y, s.z, s.w - unit_mass);   // the weight the sweep left out
         }
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(kTile) void k_force_smem_pkw(const float4* __restri
     }
 #pragma unroll UNROLL
     for (int j = ja; j < jb; j++) {
-        const float4 s = posm[j];
+        const float4 s = src[j];
         const v2f sx = {s.x, s.x}, sy = {s.y, s.y}, sz = {s.z, s.z}, sm = {s.w, s.w};
         const v2f eps = {kEps, kEps};
 #pragma unroll
@@ -480,6 +484,38 @@ __global__ __launch_bounds__(kTile) void k_force_smem_pkw(const float4* __restri
             ax[p] = __builtin_elementwise_fma(sc, dx, ax[p]);
             ay[p] = __builtin_elementwise_fma(sc, dy, ay[p]);
             if (DIM == 3) az[p] = __builtin_elementwise_fma(sc, dz, az[p]);
+        }
+    }
+    if (SELF_IMAGE) {
+        // each target's interaction with its OWN source image, with the sweep's arithmetic (weight 1 in the unit-mass sweep)
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int it = iblk * kTile + (2 * p + h) * 64 + lane;
+                const int g = lo + it;
+                if (it < n_targets && g >= ja && g < jb) {
+                    const float4 s = src[g];
+                    const float x = h ? xi[p].y : xi[p].x, y = h ? yi[p].y : yi[p].x, z = h ? zi[p].y : zi[p].x;
+                    const float dx = s.x - x, dy = s.y - y;
+                    float r2 = __builtin_fmaf(dx, dx, kEps);
+                    r2 = __builtin_fmaf(dy, dy, r2);
+                    float dz = 0.f;
+                    if (DIM == 3) {
+                        dz = s.z - z;
+                        r2 = __builtin_fmaf(dz, dz, r2);
+                    }
+                    float sc = __builtin_amdgcn_rcpf(r2);
+                    if (!UNIT_MASS) sc = s.w * sc;
+                    if (h) {
+                        ax[p].y = __builtin_fmaf(-sc, dx, ax[p].y); ay[p].y = __builtin_fmaf(-sc, dy, ay[p].y);
+                        if (DIM == 3) az[p].y = __builtin_fmaf(-sc, dz, az[p].y);
+                    } else {
+                        ax[p].x = __builtin_fmaf(-sc, dx, ax[p].x); ay[p].x = __builtin_fmaf(-sc, dy, ay[p].x);
+                        if (DIM == 3) az[p].x = __builtin_fmaf(-sc, dz, az[p].x);
+                    }
+                }
+            }
         }
     }
 #pragma unroll
@@ -539,9 +575,10 @@ __global__ __launch_bounds__(kTile) void k_force_smem(const float4* __restrict__
 // nb_stable_orbits has ONE: the 1000-mass sun among unit planets, nbody.rs:85-102) whose weight m_j - m_common the sweep
 // left out.  Their records were snapshot by the sweep kernel (K2 moves bodies in place, so it cannot read them from posm);
 // wave-uniform reads: they arrive through the scalar cache.  Same pair law, same rcp.
-__device__ __forceinline__ void add_exceptions(const MassExceptions exc, const float4 p, float4& a)
+__device__ __forceinline__ void add_exceptions(const MassExceptions exc, const float4 p, const int self, float4& a)
 {
     for (int k = 0; k < exc.count; k++) {
+        if (exc.idx[k] == self) continue;   // a body owes itself nothing (with fp16 source images the term would not be an exact zero)
         const float4 s = exc.rec[k];
         const float dx = s.x - p.x, dy = s.y - p.y;
         float r2 = __builtin_fmaf(dx, dx, kEps);
@@ -575,7 +612,7 @@ __global__ __launch_bounds__(kTile) void k_integrate(float4* __restrict__ posm, 
     }
     float4 v = vel[i];
     float4 p = posm[lo + i];
-    add_exceptions(exc, p, a);
+    add_exceptions(exc, p, lo + i, a);
     v.x = __fadd_rn(v.x, __fmul_rn(dt, a.x));
     v.y = __fadd_rn(v.y, __fmul_rn(dt, a.y));
     v.z = __fadd_rn(v.z, __fmul_rn(dt, a.z));
@@ -599,7 +636,7 @@ __global__ __launch_bounds__(kTile) void k_reduce_forces(const float4* __restric
         a.x += q.x; a.y += q.y; a.z += q.z;
     }
     const float4 p = posm[lo + i];
-    add_exceptions(exc, p, a);
+    add_exceptions(exc, p, lo + i, a);
     const float m = p.w;
     out[i] = make_float4(m * a.x, m * a.y, m * a.z, 0.0f);
 }
@@ -641,19 +678,26 @@ static hipError_t launch_variant(int variant, dim3 grid, hipStream_t stream, con
 // variants 6 / 7: one workgroup = 256 targets x 4 source quarters; `jsplit` partial slabs
 hipError_t launch_force_wave_split(const float4* posm, int lo, int n_targets, int tiles_total, int n_sources, int jsplit, int dim,
                                    bool unit_mass, float mass, float4* acc_partial, int acc_stride, hipStream_t stream,
-                                   ForceLaunch* info, const int* exc_idx, const float* exc_w, float4* exc_rec, int exc_count)
+                                   ForceLaunch* info, const int* exc_idx, float4* exc_rec, int exc_count, const float4* widened)
 {
     if (n_targets <= 0 || tiles_total <= 0) return hipSuccess;
     if (jsplit < 1) jsplit = 1;
     if (jsplit > tiles_total) jsplit = tiles_total;
     const int iblocks = (n_targets + kTile - 1) / kTile;
     const dim3 grid((unsigned)(iblocks * jsplit));
-    if (info) *info = ForceLaunch{(int)grid.x, kTile, jsplit, 4, dim, unit_mass ? 7 : 6};
-#define NBX_WS(DD, UM) \
-    hipLaunchKernelGGL((k_force_smem_pkw<DD, 8, UM>), grid, dim3(kTile), 0, stream, posm, lo, n_targets, tiles_total, n_sources, \
-                       jsplit, acc_partial, acc_stride, mass, exc_idx, exc_w, exc_rec, exc_count)
-    if (dim == 3) { if (unit_mass) NBX_WS(3, true); else NBX_WS(3, false); }
-    else          { if (unit_mass) NBX_WS(2, true); else NBX_WS(2, false); }
+    // variant codes: 6 / 7 = fp32 sources (general / unit-mass sweep); 17 / 18 = the same kernels on the widened fp16 copy (K4)
+    if (info) *info = ForceLaunch{(int)grid.x, kTile, jsplit, 4, dim, (widened ? 11 : 0) + (unit_mass ? 7 : 6)};
+    const float4* src = widened ? widened : posm;
+#define NBX_WS(DD, UM, SI) \
+    hipLaunchKernelGGL((k_force_smem_pkw<DD, 8, UM, SI>), grid, dim3(kTile), 0, stream, posm, src, lo, n_targets, tiles_total, n_sources, \
+                       jsplit, acc_partial, acc_stride, mass, exc_idx, exc_rec, exc_count)
+    if (widened) {
+        if (dim == 3) { if (unit_mass) NBX_WS(3, true, true); else NBX_WS(3, false, true); }
+        else          { if (unit_mass) NBX_WS(2, true, true); else NBX_WS(2, false, true); }
+    } else {
+        if (dim == 3) { if (unit_mass) NBX_WS(3, true, false); else NBX_WS(3, false, false); }
+        else          { if (unit_mass) NBX_WS(2, true, false); else NBX_WS(2, false, false); }
+    }
 #undef NBX_WS
     return hipGetLastError();
 }

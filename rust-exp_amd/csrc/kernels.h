@@ -34,17 +34,23 @@ hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tile
 // K1, variants 6 / 7 (k_force_smem_pkw): the four waves of a workgroup share 256 targets and split the workgroup's source
 // range; partial sums meet in LDS, so only `jsplit` slabs are written for 4 * jsplit source ranges. unit_mass: every body
 // has mass `mass` (the per-interaction multiply leaves the loop); n_sources = true body count (no padding swept).
-// exc_idx / exc_w / exc_rec (unit_mass only, exc_count > 0): workgroup 0 also copies posm[exc_idx[k]] with weight exc_w[k]
-// into exc_rec[k] -- the snapshot K2 / the force readout add afterwards (MassExceptions).
+// exc_idx / exc_rec (unit_mass only, exc_count > 0): workgroup 0 also copies the source record of body exc_idx[k], with the
+// weight (its mass - mass) the sweep leaves out, into exc_rec[k] -- the snapshot K2 / the force readout add afterwards.
+// widened (K4, fp16 sources): the sources are read from this float4 array -- the half4 copy widened by launch_widen_half --
+// instead of posm (targets stay posm), and every target's interaction with its own image is taken out again;
+// info->variant = 17 / 18 then.
 hipError_t launch_force_wave_split(const float4* posm, int lo, int n_targets, int tiles_total, int n_sources, int jsplit, int dim,
                                    bool unit_mass, float mass, float4* acc_partial, int acc_stride, hipStream_t stream,
-                                   ForceLaunch* info, const int* exc_idx = nullptr, const float* exc_w = nullptr,
-                                   float4* exc_rec = nullptr, int exc_count = 0);
+                                   ForceLaunch* info, const int* exc_idx = nullptr, float4* exc_rec = nullptr, int exc_count = 0,
+                                   const float4* widened = nullptr);
+// widened[i] = float4(posh[i]) for i < count: the fp16 source copy as fp32 records, once per step (K4)
+hipError_t launch_widen_half(const void* posh, float4* widened, int count, hipStream_t stream);
 
 // K4: the packed sweep with sources read from a half4 (x,y,z,m) copy (8 B/body), targets fp32.
 hipError_t launch_force_tile_half(const float4* posm, const void* posh, int lo, int n_targets, int tiles_total,
                                   int jsplit, int bpt, int dim, float4* acc_partial, int acc_stride, hipStream_t stream,
                                   ForceLaunch* info);
+float half_image(float v);   // (float)(_Float16)v, on the host: the value a source's fp16 copy carries
 // posh[first..first+count) = half(posm[...]) (round to nearest even)
 hipError_t launch_pack_half(const float4* posm, void* posh, int first, int count, hipStream_t stream);
 
@@ -53,6 +59,7 @@ hipError_t launch_pack_half(const float4* posm, void* posh, int first, int count
 // of exceptional body k, SNAPSHOT by the sweep kernel itself (K2 moves bodies in place while it reads these).  count = 0: none.
 struct MassExceptions {
     const float4* rec;
+    const int* idx;      // body index of every record (a target skips its own)
     int count;
     int dim;
 };
@@ -60,12 +67,12 @@ struct MassExceptions {
 // K2: reduce partials in fixed order (+ the exceptional sources), kick-drift, write positions in place (slab slot of posm).
 hipError_t launch_integrate(float4* posm, int lo, int n_targets, float4* vel, const float4* acc_partial,
                             int jsplit, int acc_stride, float dt, hipStream_t stream,
-                            MassExceptions exc = MassExceptions{nullptr, 0, 3});
+                            MassExceptions exc = MassExceptions{nullptr, nullptr, 0, 3});
 
 // forces-only readout: F_i = m_i * a_i into float4 out[n_targets]
 hipError_t launch_reduce_forces(const float4* posm, int lo, int n_targets, const float4* acc_partial, int jsplit,
                                 int acc_stride, float4* out, hipStream_t stream,
-                                MassExceptions exc = MassExceptions{nullptr, 0, 3});
+                                MassExceptions exc = MassExceptions{nullptr, nullptr, 0, 3});
 
 // strict (bit-exact) pair: ascending j per target, IEEE divide, no contraction. 2-D.
 // kernel: 16 or 8 = workgroups of that many waves per 64 targets (term producers + one summing wave), 1 = one thread per body,

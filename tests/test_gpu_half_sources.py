@@ -41,6 +41,38 @@ def test_half_sources_exact_to_fp32_rounding_against_fp64_model(rx, kind, n, bpt
     assert np.abs(got - F).max() <= 1e-5 * np.abs(F).max()
 
 
+@pytest.mark.parametrize("kind,n,jsplit,masses", [("plummer", 20000, 0, "equal"), ("plummer", 16384, 5, "random"),
+                                                  ("galaxies", 24576, 0, "preset"), ("galaxies", 20001, 3, "preset")])
+def test_half_sources_on_the_wave_split_kernels_against_fp64_model(rx, kind, n, jsplit, masses):
+    """Round 3: from 16 384 sources on, K4 runs on the wave-split kernels -- the half4 copy widened to
+    float4 once per step, sources through the scalar cache, every target's interaction with its own fp16 image taken out
+    again; 'one common mass + exceptions' (the two galaxy cores) takes the unit-mass sweep (variant 18), anything else the
+    general one (17).  Same bound as the LDS-tile K4 kernel: exact to fp32 rounding against an fp64 model that uses the
+    SAME fp16-rounded sources."""
+    st = rx.plummer_sphere(n) if kind == "plummer" else rx.two_galaxies(n)
+    if masses == "random":
+        st = dict(st, m=np.random.default_rng(3).uniform(0.1, 1.5, n).astype(np.float32))
+    dim = 3 if kind == "plummer" else 2
+    e = rx.NBodyEngine()
+    e.set_source_precision(16)
+    e.set_launch(jsplit=jsplit)
+    e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])
+    fx, fy, fz = e.forces()
+    ll = e.last_launch()
+    assert ll["dim"] == dim and ll["variant"] == (17 if masses == "random" else 18), ll
+    idx = np.arange(0, n, 41)
+    if kind == "galaxies":
+        idx = np.unique(np.r_[idx, 0, n // 2])          # the two cores: exceptional sources AND targets
+    F = model_f64(st, idx, dim)
+    got = np.stack([fx[idx], fy[idx], fz[idx]], 1)
+    assert np.isfinite(got).all()
+    assert np.abs(got - F).max() <= 1e-5 * np.abs(F).max()
+    # a step on it stays finite and moves the bodies; the fp32 state keeps its masses
+    e.step_brute_force(0.01)
+    p = e.get_particles()
+    assert np.isfinite(p["px"]).all() and np.array_equal(p["m"], st["m"])
+
+
 def test_half_sources_accuracy_class_vs_fp32(rx):
     st = rx.two_galaxies(32768)
     a = rx.NBodyEngine()
