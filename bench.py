@@ -160,6 +160,40 @@ def measure_traffic(argv_tail, kernel_substr, timeout=120):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def measure_counters(argv_tail, kernel_substr, groups, timeout=180):
+    """Average per-launch value of every counter in `groups` (one rocprofv3 --pmc pass per group: counters of one block share
+    its slots) for the kernels whose name contains `kernel_substr`, on a 3-step child run of this command. dict | None."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    import csv
+
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="nbx_pmc_", dir="/tmp")
+    try:
+        for gi, group in enumerate(groups):
+            d = os.path.join(tmp, f"g{gi}")
+            cmd = [exe, "--kernel-trace", "--pmc"] + group.split() + ["-d", d, "-o", "p", "--output-format", "csv", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--traffic-child"] + argv_tail
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               timeout=timeout)
+            if r.returncode != 0:
+                return None
+            vals = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_substr in row["Kernel_Name"]:
+                        vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for k, v in vals.items():
+                out[k] = float(np.mean(v))
+                out[k + "_launches"] = len(v)
+        return out or None
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -712,15 +746,29 @@ def main():
             ht = engine.bh_host_timing()
             wk = engine.bh_work(args.theta)
             ev_s = max(per[0]["bh_eval_ms"], 1e-9) * 1e-3
-            lane_ops_per_visit = 8.4   # 4 VALU lane-ops for the opening test + 6 for the pair law on the ~74 % of visits that take the node
+            lane_ops_per_visit = 8.4   # modelled (round 2): 4 VALU lane-ops for the opening test + 6 for the pair law on ~74 % of the visits
             valu_peak = info["compute_units"] * 4 * info["clock_khz"] * 1e3 * 32.0   # lane-ops/s: 32 lanes per cycle per SIMD
             visits_per_s = wk["node_visits"] / ev_s
-            bh_traffic, bh_traffic_info = None, None
+            bh_traffic, bh_traffic_info, issue = None, None, None
             if world == 1 and not args.no_traffic:   # HBM bytes of the traversal kernel, measured now (see measure_traffic)
                 tail = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
                 bh_traffic_info = measure_traffic(tail + ["--no-cpu-baseline", "--no-traffic"], "k_bh_eval")
                 if bh_traffic_info:
                     bh_traffic = bh_traffic_info["bytes_per_launch"]
+                # ... and its instruction issue, from counters of this run instead of a modelled constant (VERDICT r02 next #5b)
+                pm = measure_counters(tail + ["--no-cpu-baseline", "--no-traffic"], "k_bh_eval",
+                                      ["SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVES", "GRBM_GUI_ACTIVE"])
+                if pm and pm.get("GRBM_GUI_ACTIVE") and pm.get("SQ_ACTIVE_INST_VALU") and pm.get("SQ_INSTS_SMEM"):
+                    n_simd = info["compute_units"] * 4
+                    cyc = pm["GRBM_GUI_ACTIVE"] / 8.0                # the counter is summed over the 8 XCDs
+                    issue = {"valu_busy_frac": 4.0 * pm["SQ_ACTIVE_INST_VALU"] / n_simd / cyc,   # SQ_ACTIVE_INST_* count quad-cycles
+                             "valu_issue_frac": 4.0 * pm["SQ_INSTS_VALU"] / n_simd / cyc,       # a wave64 VALU instruction holds its SIMD 4 cycles
+                             "valu_insts_per_wave_visit": pm["SQ_INSTS_VALU"] / pm["SQ_INSTS_SMEM"],   # one scalar node load per visit
+                             "salu_insts_per_wave_visit": pm["SQ_INSTS_SALU"] / pm["SQ_INSTS_SMEM"],
+                             "wave_visits_per_launch": pm["SQ_INSTS_SMEM"], "waves": pm.get("SQ_WAVES"),
+                             "kernel_cycles": cyc, "launches_sampled": pm.get("SQ_INSTS_VALU_launches"),
+                             "how": "rocprofv3 --kernel-trace --pmc, two passes (SQ_*; GRBM_GUI_ACTIVE) on a 3-step child run of this "
+                                    "command; GRBM_GUI_ACTIVE / 8 = kernel cycles, 1024 SIMDs"}
             out.update({
                 "metric": f"bodies/s through nb_step_barnes_hut (theta={args.theta}) at N={n}",
                 "value": value, "unit": "body-steps/s", "dtype": "f32",
@@ -732,8 +780,12 @@ def main():
                              "upload_wait": ht["upload_ms"], "tree_nodes": ht["nodes"]},
                 "roofline": {"bound": "valu_issue", "bound_contract_class": "neither hbm nor mfma: a serial per-wave tree walk, bounded by "
                              "instruction issue (DESIGN.md K3)", "kernel": "k_bh_eval_*",
-                             "achieved": visits_per_s * lane_ops_per_visit / 1e12, "peak": valu_peak / 1e12, "unit": "T lane-op/s",
-                             "frac": visits_per_s * lane_ops_per_visit / valu_peak,
+                             "achieved": (issue["valu_busy_frac"] * valu_peak if issue else visits_per_s * lane_ops_per_visit) / 1e12,
+                             "peak": valu_peak / 1e12, "unit": "T lane-op/s",
+                             "frac": issue["valu_busy_frac"] if issue else visits_per_s * lane_ops_per_visit / valu_peak,
+                             "frac_source": "measured: VALU busy cycles of the traversal kernel (SQ_ACTIVE_INST_VALU) over its SIMD-cycles, this run"
+                                            if issue else "modelled: 8.4 lane-ops per body-visit (no rocprofv3 / --no-traffic)",
+                             "frac_modelled": visits_per_s * lane_ops_per_visit / valu_peak, "issue_counters": issue,
                              "node_visits_per_body": wk["node_visits"] / n, "pair_evals_per_body": wk["pair_evals"] / n,
                              "kernel_avg_ms": per[0]["bh_eval_ms"],
                              "hbm_algorithmic_bytes_per_launch": 32.0 * ht["nodes"] + 24.0 * n,

@@ -1,36 +1,42 @@
-// bh_build.hip -- quadtree build ON THE DEVICE (opt-in, NBX_OPT_BH_TREE = 1).
+// bh_build.hip -- quadtree build ON THE DEVICE.  The fast mode's DEFAULT from 512 bodies on
+// (NBX_OPT_BH_TREE); the bit-exact mode always builds on the host.
 //
-// The default Barnes-Hut path builds the tree on the host exactly as the reference does (nbody.rs:388-415:
-// sequential insertion, running centre of mass) -- bit-faithful but ~60 ms per step at 1 M bodies.  This file
-// builds the SAME tree shape without leaving the GPU:
+// The host build (host_ops.cpp) inserts the bodies one by one exactly as the reference does (nbody.rs:388-415); at 1 M bodies that
+// is 13-16 ms per step, at the reference's 10 000 bodies 0.5 ms.  This file builds the SAME flattened tree without leaving the GPU:
 //
 //   1. root AABB = min/max of positions (exact; nbody.rs:388-398)
 //   2. per body: the path of quadrant choices, replaying quadrant_from_point / create_children with the
 //      reference's own f32 midpoint arithmetic (cx = (x1+x2)*0.5, nbody.rs:289-290, :324-331) for 31 levels
 //      -> 62-bit key, 2 bits per level, quadrant order [UL,UR,LL,LR] = 0..3 like the reference's child array
 //   3. radix sort (rocPRIM) of (key, body index)
+//   3b. the reference's EPS merge of close PAIRS, decided from the sorted keys and the arrival order (see there)
 //   4. nodes straight from the sorted keys: every node is (first body a, depth l); how many nodes start at each body
 //      follows from the digits it shares with its two neighbours, an exclusive scan of those counts gives every node's
 //      PRE-ORDER slot, and a node's skip pointer is the slot of the first node after its bodies (see "the tree from
 //      the sorted keys" below) -- no level-by-level sweep, no host round trips, one read-back of the node count
-//   5. centres of mass from deterministic fp64 prefix sums over the sorted bodies (exact products, one rounding to
-//      f32 per node); node sizes by replaying the first body's path with the reference's f32 midpoints
+//   5. interior masses and centres of mass, two classes (NBX_OPT_BH_FOLD):
+//      fold = 1 (default up to 65 536 bodies): the reference's f32 running fold over the node's bodies in ARRIVAL order
+//               (nbody.rs:303-320) -- small nodes in k_emit, the others in k_fold_big (one pair of waves per node: m chain, IEEE
+//               reciprocals, p chain), the root on a side stream from the start of the build.  The flattened tree then equals the
+//               host tree BIT FOR BIT; whatever the pairs-only merge cannot reproduce node for node (a third body within EPS,
+//               a blob whose centre leaves its first member's cell) is detected and the step goes to the host build.
+//      fold = 0 (above 65 536 bodies): deterministic fp64 prefix sums over the sorted bodies, one rounding to f32 per node.
+//      Node sizes: the first body's path replayed with the reference's f32 midpoints.
 //
-// Same node set, same s = x2-x1 per node (box replayed with the same f32 arithmetic), same leaf records as the
-// host build + flatten, INCLUDING the reference's EPS merge for pairs (nbody.rs:249-260): two bodies closer than EPS in both
-// axes become one leaf (mass sum, centre folded in arrival order) exactly when the reference would have merged them --
-// i.e. when the later arrival finds the earlier one still alone in a leaf that contains both, which depends on which OTHER
-// bodies arrived before (step 3b below replays that condition from the sorted keys and the body indices).
-// What still differs (its own tolerance class):
+// fold = 0 is its own tolerance class.  Same node set, same s = x2-x1 per node, same leaf records as the
+// host build + flatten, INCLUDING the reference's EPS merge for pairs (nbody.rs:249-260); what differs there:
 //   * interior centres of mass are the f32 rounding of the exact weighted mean instead of the reference's
-//     particle-by-particle f32 running fold (nbody.rs:303-320, which drifts by up to ~6e-4 relative at 100 k bodies);
+//     particle-by-particle f32 running fold (which drifts by up to ~6e-4 relative at 100 k bodies);
 //   * a merged pair's leaf sits on the path of its FIRST-arrived member, the reference's on the path of the blob's centre
 //     (different only when a third body shares the pair's last common cell, <= EPS-sized);
 //   * clusters of three or more bodies within EPS: the reference folds arrivals into one blob while each stays within EPS
 //     of the blob's current centre; here only the first two of a run of mutually-close sorted neighbours merge (bodies whose
 //     62-bit keys are identical -- the same level-31 cell, 4.7e-8 of the box -- always share one leaf, any number of them);
+//     more than max(16, n/2000) such bodies send the step to the host build;
 //   * no depth-50 panic (nbody.rs:230-232): keys stop at level 31.
-// Hence: fast mode only; the bit-exact mode keeps the host build.
+// Known hole of BOTH classes: a pair within EPS whose members are not neighbours in key order (they straddle a cell boundary
+// high up) merges in the reference only if every body between them in key order arrived later -- i.e. the pair are the first
+// bodies of a big cell; only neighbouring entities are examined here.
 #include <cstring>   // rocPRIM's texture_cache_iterator.hpp calls memset() without including it
 
 #include <rocprim/device/device_radix_sort.hpp>

@@ -294,6 +294,10 @@ def test_bench_barnes_hut_workload(rx):
     if t is not None:
         alg = res["roofline"]["hbm_algorithmic_bytes_per_launch"]
         assert 0.0 < t <= 12.0 * alg, (t, alg)
+        # ... and so is its VALU issue (round 3: counters of this run instead of a modelled constant)
+        ic = res["roofline"]["issue_counters"]
+        assert ic is not None and 0.0 < ic["valu_busy_frac"] < 1.0 and res["roofline"]["frac"] == ic["valu_busy_frac"]
+        assert 5.0 < ic["valu_insts_per_wave_visit"] < 40.0 and 5.0 < ic["salu_insts_per_wave_visit"] < 40.0, ic
 
 
 LEVEL1 = r"""
