@@ -620,10 +620,12 @@ def main():
         i_ms, i_cnt = e.profile_read(rx.NBX_K_INTEGRATE)
         b_ms, b_cnt = e.profile_read(rx.NBX_K_BH_EVAL)
         x_ms, x_cnt = e.profile_read(rx.NBX_K_EXCHANGE)
+        t_ms, t_cnt = e.profile_read(rx.NBX_K_TREE_BUILD)
         lo, hi = e.slab()
         per.append({"slab": [lo, hi], "force_ms": k_ms / max(k_cnt, 1), "force_launches": k_cnt,
                     "integrate_ms": i_ms / max(i_cnt, 1), "bh_eval_ms": b_ms / max(b_cnt, 1), "bh_eval_launches": b_cnt,
-                    "exchange_us": 1e3 * x_ms / max(x_cnt, 1), "exchanges": x_cnt})
+                    "exchange_us": 1e3 * x_ms / max(x_cnt, 1), "exchanges": x_cnt,
+                    "device_tree_build_ms": t_ms / max(t_cnt, 1), "device_tree_builds": t_cnt})
         e.profile(False)
     if host_kind == "torch" and world > 1:
         rows = host.gather_floats([per[0]["slab"][0], per[0]["slab"][1], per[0]["force_ms"], per[0]["force_launches"],
@@ -776,7 +778,10 @@ def main():
                            "seed": "0x5EED0001", "force_mode": args.mode, "host": host_kind, "sharding": sharding,
                            "tree": {0: "host (reference-faithful insertion build)", 1: "device (bh_build.hip)"}[engine.get_option(rx.engine.NBX_OPT_BH_LAST_TREE)]},
                 "ms_split": {"bh_eval_kernel": per[0]["bh_eval_ms"], "integrate_kernel": per[0]["integrate_ms"],
-                             "host_download": ht["download_ms"], "tree_build": ht["build_ms"], "flatten": ht["flatten_ms"],
+                             "host_download": ht["download_ms"],
+                             # device tree: GPU time of the build, first launch to last (HIP events); host tree: host wall time
+                             "tree_build": per[0]["device_tree_build_ms"] if per[0].get("device_tree_builds") else ht["build_ms"],
+                             "flatten": ht["flatten_ms"],
                              "upload_wait": ht["upload_ms"], "tree_nodes": ht["nodes"]},
                 "roofline": {"bound": "valu_issue", "bound_contract_class": "neither hbm nor mfma: a serial per-wave tree walk, bounded by "
                              "instruction issue (DESIGN.md K3)", "kernel": "k_bh_eval_*",

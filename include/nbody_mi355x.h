@@ -132,6 +132,10 @@ enum nbx_option {
                                     * with EPS clusters the device merge cannot reproduce node for node go to the host build;
                                     * 0 = roundings of the exact sums (own tolerance class);
                                     * -1 (default) = 1 up to 65 536 bodies (the root's fold is n serial steps), 0 above */
+    NBX_OPT_BH_ASYNC = 15,         /* 1 (default): a Barnes-Hut step on the device-built tree is enqueued without waiting for the
+                                    * build's verdict (node count, EPS clusters); walk and kick-drift check it on the device, the
+                                    * host at the next call that needs the state (nbx_synchronize, get, draw, the next step) and
+                                    * redoes the step on the host tree if the build had to refuse. 0: wait inside the step */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };
@@ -142,7 +146,8 @@ enum nbx_kernel_id {
     NBX_K_BH_EVAL = 2,   /* Barnes-Hut traversal + kick-drift + velocity-kill */
     NBX_K_EXCHANGE = 3,  /* nbx_group_*: the per-step all-gather as seen from this engine's stream (includes the wait
                           * for the slowest peer) */
-    NBX_K_COUNT = 4
+    NBX_K_TREE_BUILD = 4, /* the device quadtree build, first launch to last (GPU time on the engine's stream) */
+    NBX_K_COUNT = 5
 };
 
 typedef struct nbx_device_info {

@@ -24,6 +24,7 @@ from .engine import (  # noqa: F401
     NBX_K_EXCHANGE,
     NBX_K_FORCE,
     NBX_K_INTEGRATE,
+    NBX_K_TREE_BUILD,
     NBodyEngine,
     NBodyError,
     NBodyGroup,

@@ -818,7 +818,7 @@ __global__ __launch_bounds__(128) void k_fold_big(const float4* __restrict__ pos
 }
 
 // Workspace header (the first 4 KiB + 256 B): ints [0] node count, [1] bodies the pairs-only EPS merge left behind (or blobs whose
-// centre left their first member's cell), [2] nodes queued for k_fold_big, [3] ticket of k_scan_reduce -- all cleared by k_keys at every build -- [8] ticket of k_bbox (self-clearing; zeroed once by device_tree_workspace_init),
+// centre left their first member's cell), [2] nodes queued for k_fold_big, [3] ticket of k_scan_reduce -- all cleared by k_keys at every build -- [9] the "poison" flag of the gated steps (kernels.h), [8] ticket of k_bbox (self-clearing; zeroed once by device_tree_workspace_init),
 // [12..15] the root box (encoded); then 256 float4 partial boxes of k_bbox.
 constexpr size_t kHeaderBytes = 256 + 256 * sizeof(float4);
 
@@ -1121,6 +1121,16 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     return hipGetLastError();
 }
 
+int* device_tree_counters(void* workspace) { return static_cast<int*>(workspace); }   // the header comes first (carve)
+
+void device_tree_limits(int n, int fold, int* crowd_limit, int* queue_limit)
+{
+    // fold = 1 promises the reference's tree node for node: ANY body the pairs-only merge left behind (or a blob whose centre
+    // left its first member's cell) sends the step to the host build; fold = 0 tolerates a few (its own tolerance class)
+    *crowd_limit = fold == 1 ? 0 : (n / 2000 > 16 ? n / 2000 : 16);
+    *queue_limit = fold == 1 ? n : 0x7FFFFFFF;
+}
+
 hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status, hipStream_t stream, int fold)
 {
     *status = 0;
@@ -1131,10 +1141,10 @@ hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, 
     if (host_counters[0] > node_cap) { *status = 1; return hipSuccess; }   // node pool exhausted (pathological input)
     // Many bodies in clusters of three or more within EPS: the reference grows multi-body blobs there (nbody.rs:249-260) that
     // the pairs-only merge does not reproduce -- leave such systems to the reference-faithful host build.
-    // The faithful fold promises the reference's tree node for node: ANY body the pairs-only merge left behind (or a blob whose
-    // centre left its first member's cell) sends the step to the host build.
-    if (host_counters[1] > (fold == 1 ? 0 : (n / 2000 > 16 ? n / 2000 : 16))) { *status = 2; return hipSuccess; }
-    if (fold == 1 && host_counters[2] > n) { *status = 1; return hipSuccess; }   // fold queue overflow (cannot happen: <= 31 n / 33)
+    int crowd_limit = 0, queue_limit = 0;
+    device_tree_limits(n, fold, &crowd_limit, &queue_limit);
+    if (host_counters[1] > crowd_limit) { *status = 2; return hipSuccess; }
+    if (host_counters[2] > queue_limit) { *status = 1; return hipSuccess; }   // fold queue overflow
     *n_nodes_host = host_counters[0];
     return hipSuccess;
 }

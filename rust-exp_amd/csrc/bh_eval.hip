@@ -27,6 +27,29 @@ namespace nbx {
 
 constexpr int kMaxFrames = 56;
 
+// Device-side gate of a step enqueued BEHIND a device tree build whose outcome the host has not read yet (engine.cpp,
+// speculative step): counters = the build's {node count, left-behind bodies, queued folds}; the walk and the kick-drift run
+// only if the build produced a usable tree, exactly the test device_tree_build_end makes on the host -- otherwise they leave the
+// state untouched and the host redoes the step on the host tree.  counters == nullptr: no gate (n_nodes comes from the host).
+// counters[kTreePoisonWord]: an EARLIER gated step was refused and the host has not redone it yet -- nothing may run on the
+// state until it has.  The kick-drift of a refused step raises it (mark = true).
+struct BuildGate {
+    int* counters;
+    int node_cap, crowd_limit, queue_limit;
+};
+__device__ __forceinline__ bool gate_open(const BuildGate g, int& n_nodes, const bool mark = false)
+{
+    if (!g.counters) return true;
+    if (g.counters[kTreePoisonWord] != 0) return false;
+    const int nn = g.counters[0];
+    if (nn > g.node_cap || g.counters[1] > g.crowd_limit || g.counters[2] > g.queue_limit) {
+        if (mark) g.counters[kTreePoisonWord] = 1;
+        return false;
+    }
+    n_nodes = nn;
+    return true;
+}
+
 // The fast kernels decide "take or open" without the square root and without a node-type branch:
 //     take = q < theta^2 * d^2,   q = s*s (interior)  or  -1 (leaf)            (BhNode::q, set when the tree is flattened)
 // interior: s/d < theta <=> s*s < theta^2 d^2 for s, d >= 0 (d = 0 -> open, as in the reference where s/0 = +inf; a
@@ -61,11 +84,11 @@ __device__ __forceinline__ bool take_node(const float q, const float s, const fl
 
 __global__ __launch_bounds__(kTile) void k_bh_eval_fast(const float4* __restrict__ posm, const int lo,
                                                         const int n_targets, const BhNode* __restrict__ nodes,
-                                                        const int n_nodes, const float theta,
-                                                        float2* __restrict__ out, const unsigned* __restrict__ perm)
+                                                        int n_nodes, const float theta,
+                                                        float2* __restrict__ out, const unsigned* __restrict__ perm, const BuildGate gate)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;   // 64 threads per workgroup for small systems, kTile otherwise
-    if (t >= n_targets) return;
+    if (t >= n_targets || !gate_open(gate, n_nodes)) return;
     // perm (optional): a spatial (Morton) order of the bodies, so the 64 lanes of a wave walk nearly the same
     // nodes; it only changes which thread handles which body, never a result
     const int it = perm ? (int)perm[t] - lo : t;
@@ -110,10 +133,11 @@ constexpr int kWaveBlock = 64;
 template <int BPW>
 __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* __restrict__ posm, const int lo,
                                                                   const int n_targets, const BhNode* __restrict__ nodes,
-                                                                  const int n_nodes, const float theta,
+                                                                  int n_nodes, const float theta,
                                                                   float2* __restrict__ out, const unsigned* __restrict__ perm,
-                                                                  const int xcd_order)
+                                                                  const int xcd_order, const BuildGate gate)
 {
+    if (!gate_open(gate, n_nodes)) return;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Handing
     // XCD k the k-th CONTIGUOUS eighth of the Morton-ordered bodies keeps the part of the tree an L2 sees to that region's
     // subtrees instead of all of it (gridDim.x is a multiple of 8; see launch_bh_eval).
@@ -333,10 +357,13 @@ __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_strict_wave(const float4
 // optional velocity kill (nbody.rs:466-471).
 __global__ __launch_bounds__(kTile) void k_integrate_f2(float4* __restrict__ posm, const int lo, const int n_targets,
                                                         float4* __restrict__ vel, const float2* __restrict__ force,
-                                                        const float dt, const int is_accel, const int killbox)
+                                                        const float dt, const int is_accel, const int killbox, const BuildGate gate)
 {
     const int i = blockIdx.x * kTile + threadIdx.x;
-    if (i >= n_targets) return;
+    int unused = 0;
+    // (every thread reads the flag BEFORE thread 0 may raise it?  no: a thread that runs later would see the flag and leave, which
+    //  is the same outcome -- refused or poisoned, nobody moves a body)
+    if (!gate_open(gate, unused, i == 0) || i >= n_targets) return;
     const float2 f = force[i];
     float4 v = vel[i];
     float4 p = posm[lo + i];
@@ -424,9 +451,12 @@ hipError_t launch_bh_count(const float4* posm, int lo, int n_targets, const BhNo
 }
 
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
-                          int mode, float2* force_out, hipStream_t stream, const unsigned* perm)
+                          int mode, float2* force_out, hipStream_t stream, const unsigned* perm, int* gate_counters,
+                          int gate_node_cap, int gate_crowd_limit, int gate_queue_limit)
 {
     if (n_targets <= 0) return hipSuccess;
+    const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit};
+    if (gate_counters && !(mode == 0 || (mode == 2 && perm))) return hipErrorInvalidValue;   // only the fast walks are gated
     // per-lane walks: one wave per workgroup while the system is too small to fill the chip (spreads the waves over the CUs)
     const int block = n_targets <= 65536 ? 64 : kTile;
     const dim3 grid((n_targets + block - 1) / block);
@@ -454,7 +484,7 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
         const dim3 g(xcd_order ? (unsigned)((nblk + 7) / 8 * 8) : (unsigned)nblk);
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, g, dim3(kWaveBlock), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta, force_out, perm,
-                               xcd_order);
+                               xcd_order, gate);
         };
         if (bpw == 64) go(k_bh_eval_fast_wave<64>);
         else if (bpw == 32) go(k_bh_eval_fast_wave<32>);
@@ -463,16 +493,18 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
     }
     else
         hipLaunchKernelGGL(k_bh_eval_fast, grid, dim3(block), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
-                           force_out, perm);
+                           force_out, perm, gate);
     return hipGetLastError();
 }
 
 hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel, const float2* force, float dt,
-                               int is_accel, int killbox, hipStream_t stream)
+                               int is_accel, int killbox, hipStream_t stream, int* gate_counters, int gate_node_cap,
+                               int gate_crowd_limit, int gate_queue_limit)
 {
     if (n_targets <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_integrate_f2, dim3((n_targets + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, lo,
-                       n_targets, vel, force, dt, is_accel, killbox);
+                       n_targets, vel, force, dt, is_accel, killbox,
+                       BuildGate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit});
     return hipGetLastError();
 }
 

@@ -106,6 +106,9 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
             if (value != 0 && value != 1 && value != -1) return fail(NBX_ERR_INVALID, "bh tree must be 0 (host), 1 (device) or -1 (by mode and size)");
             e->bh_tree_device = value < 0 ? -1 : (value ? 1 : 0);   // -1 = by mode and size (default)
             return NBX_OK;
+        case NBX_OPT_BH_ASYNC:
+            e->bh_async = value ? 1 : 0;
+            return NBX_OK;
         case NBX_OPT_BH_FOLD:
             if (value != 0 && value != 1 && value != -1) return fail(NBX_ERR_INVALID, "bh fold must be 0 (exact sums), 1 (reference fold) or -1 (by size)");
             e->bh_fold = (int)value;
@@ -127,6 +130,8 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
 int64_t nbx_get_option(const nbx_engine* e, int32_t option)
 {
     if (!e) return NBX_ERR_INVALID;
+    if (e->any_pending() && (option == NBX_OPT_BH_FALLBACKS || option == NBX_OPT_BH_LAST_TREE))
+        (void)resolve_pending(const_cast<nbx_engine*>(e));   // what the last step ran on is known once its build's verdict is read
     switch (option) {
         case NBX_OPT_FORCE_MODE: return e->force_mode;
         case NBX_OPT_JSPLIT: return e->jsplit;
@@ -140,6 +145,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_BH_TREE: return e->bh_tree_device;
         case NBX_OPT_BH_WAVE: return e->bh_wave;
         case NBX_OPT_BH_FOLD: return e->bh_fold;
+        case NBX_OPT_BH_ASYNC: return e->bh_async;
         case NBX_OPT_BH_FALLBACKS: return e->bh_fallbacks;
         case NBX_OPT_BH_LAST_TREE: return e->bh_last_tree_device;
         case NBX_OPT_DRAW_AMBIGUOUS: return e->draw_ambiguous;
@@ -152,7 +158,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
 int32_t nbx_query_option(const nbx_engine* e, int32_t option, int64_t* value)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
-    if (option < NBX_OPT_FORCE_MODE || option > NBX_OPT_BH_FOLD) return fail(NBX_ERR_INVALID, "unknown option %d", option);
+    if (option < NBX_OPT_FORCE_MODE || option > NBX_OPT_BH_ASYNC) return fail(NBX_ERR_INVALID, "unknown option %d", option);
     if (value) *value = nbx_get_option(e, option);
     return NBX_OK;
 }
@@ -302,6 +308,8 @@ int32_t nbx_synchronize(nbx_engine* e)
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
     if (!e->dev_ready) return NBX_OK;
     HIP_TRY(hipSetDevice(e->device));
+    const int prc = resolve_pending(e);
+    if (prc != NBX_OK) return prc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     return NBX_OK;
 }
@@ -626,6 +634,8 @@ int32_t nbx_profile_reset(nbx_engine* e)
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
     if (e->dev_ready) {
         HIP_TRY(hipSetDevice(e->device));
+        const int prc = resolve_pending(e);
+        if (prc != NBX_OK) return prc;
         prof_fold(e, true);
     }
     for (int k = 0; k < NBX_K_COUNT; k++) { e->prof_ms[k] = 0.0; e->prof_n[k] = 0; }
@@ -637,6 +647,8 @@ int32_t nbx_profile_read(nbx_engine* e, int32_t kernel_id, double* total_ms, int
     if (!e || kernel_id < 0 || kernel_id >= NBX_K_COUNT) return fail(NBX_ERR_INVALID, "bad kernel id");
     if (e->dev_ready) {
         HIP_TRY(hipSetDevice(e->device));
+        const int prc = resolve_pending(e);
+        if (prc != NBX_OK) return prc;
         prof_fold(e, true);
         if (!e->prof.empty()) return fail(NBX_ERR_HIP, "profiling events could not be read");
     }
@@ -675,6 +687,10 @@ int32_t nbx_bh_work(nbx_engine* e, float theta, uint64_t* node_visits, uint64_t*
 int32_t nbx_bh_host_timing(nbx_engine* e, double* ms4, int32_t* steps, int32_t* nodes)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    if (e->dev_ready) {
+        const int prc = resolve_pending(e);
+        if (prc != NBX_OK) return prc;
+    }
     if (ms4) for (int i = 0; i < 4; i++) ms4[i] = e->host_ms[i];
     if (steps) *steps = e->host_steps;
     if (nodes) *nodes = (int32_t)e->n_flat;

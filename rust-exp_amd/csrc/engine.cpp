@@ -45,7 +45,7 @@ int ensure_device(nbx_engine* e)
 {
     if (e->dev_ready) {
         HIP_TRY(hipSetDevice(e->device));
-        return NBX_OK;
+        return e->any_pending() ? resolve_pending(e) : NBX_OK;
     }
     int count = 0;
     hipError_t err = hipGetDeviceCount(&count);
@@ -508,7 +508,7 @@ static constexpr int kDeviceTreeMaxBodies = 1 << 25;
 // quadtree on the device (bh_build.hip), in two halves so that a group can start every device's build before it waits
 // for any: begin enqueues the build, end waits for it. *done = false when the node pool overflowed (the caller falls
 // back to the host build).
-int build_tree_on_device_begin(nbx_engine* e)
+int build_tree_on_device_begin(nbx_engine* e, int* host_counters)
 {
     HIP_TRY(hipSetDevice(e->device));
     e->tree_t0 = std::chrono::steady_clock::now();
@@ -532,8 +532,10 @@ int build_tree_on_device_begin(nbx_engine* e)
         HIP_TRY(hipEventCreateWithFlags(&e->ev_side_go, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_side_done, hipEventDisableTiming));
     }
-    HIP_TRY(nbx::device_tree_build_begin(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes, e->h_counters,
-                                         &e->d_perm, e->stream, fold, e->side_stream, e->ev_side_go, e->ev_side_done));
+    ProfScope ps(e, NBX_K_TREE_BUILD);
+    HIP_TRY(nbx::device_tree_build_begin(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes,
+                                         host_counters ? host_counters : e->h_counters, &e->d_perm, e->stream, fold, e->side_stream,
+                                         e->ev_side_go, e->ev_side_done));
     return NBX_OK;
 }
 
@@ -604,9 +606,16 @@ int slab_order(nbx_engine* e)
 }
 
 // traversal + kick-drift of this engine's slab against the node array it holds (e->d_nodes, e->n_flat)
-int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm)
+int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm, bool gated)
 {
     HIP_TRY(hipSetDevice(e->device));
+    int* gate = nullptr;
+    int node_cap = 0, crowd_limit = 0, queue_limit = 0;
+    if (gated) {   // the device build's verdict is still on the device: the kernels check it themselves
+        gate = nbx::device_tree_counters(e->d_tree_ws);
+        node_cap = 4 * e->n + 1024;
+        nbx::device_tree_limits(e->n, e->effective_fold(), &crowd_limit, &queue_limit);
+    }
     const int slab = e->slab();
     if (slab == 0) return NBX_OK;
     int rc = grow(&e->d_f2, &e->f2_cap, (size_t)slab);
@@ -627,14 +636,14 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
         ProfScope ps(e, NBX_K_BH_EVAL);
         HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta,
                                     wave ? (e->force_mode == 0 ? 2 : 3) : e->force_mode, e->d_f2,
-                                    e->stream, perm));
+                                    e->stream, perm, gate, node_cap, crowd_limit, queue_limit));
     }
     {
         ProfScope ps(e, NBX_K_INTEGRATE);
         HIP_TRY(nbx::launch_integrate_f2(e->d_posm, e->lo, slab, e->d_vel, e->d_f2, dt, e->force_mode == 0 ? 1 : 0, 1,
-                                         e->stream));
+                                         e->stream, gate, node_cap, crowd_limit, queue_limit));
     }
-    if (e->source_half) {
+    if (e->source_half && !gated) {
         rc = refresh_half_sources(e, e->lo, slab);
         if (rc != NBX_OK) return rc;
     }
@@ -647,11 +656,102 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
     return NBX_OK;
 }
 
+// ---- Barnes-Hut steps without a host wait in the middle (NBX_OPT_BH_ASYNC) --------------------------------------------------
+// A step on the device tree = build + walk + kick-drift, all enqueued at once: walk and kick-drift check the build's verdict
+// (node count, EPS clusters) on the device (bh_eval.hip BuildGate) and leave the state untouched when the build had to refuse;
+// the kick-drift then raises a device flag ("poison") that makes every later gated kernel do nothing as well.  The host reads a
+// step's verdict only AFTER it has enqueued the next step (two slots), so neither a wait in the middle of a step nor one
+// between steps leaves the GPU idle.  A refused step (rare: EPS clusters, exhausted node pool) is redone on the host tree once
+// its verdict is read, and the step enqueued behind it -- which the flag turned into a no-op -- is enqueued again.
+static int verdict_of(const nbx_engine* e, int slot)
+{
+    const int* c = e->h_verdict[slot];
+    int crowd = 0, queue = 0;
+    nbx::device_tree_limits(e->n, e->pending[slot].fold, &crowd, &queue);
+    if (c[0] > e->pending[slot].node_cap) return 1;
+    if (c[1] > crowd) return 2;
+    if (c[2] > queue) return 1;
+    return 0;
+}
+
+static int resolve_slot(nbx_engine* e, int slot)
+{
+    if (!e->pending[slot].active) return NBX_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(e->ev_step[slot]));
+    const nbx_engine::PendingStep p = e->pending[slot];
+    e->pending[slot].active = false;
+    const int status = verdict_of(e, slot);
+    if (status == 0) {
+        e->n_flat = (size_t)e->h_verdict[slot][0];
+        e->bh_last_tree_device = 1;
+        e->host_steps++;
+        return NBX_OK;
+    }
+    // refused: this step's gated kernels did nothing and poisoned the step behind it (if one is in flight)
+    e->bh_fallbacks++;
+    e->d_perm = nullptr;
+    const int other = slot ^ 1;
+    const bool redo_later = e->pending[other].active;
+    const nbx_engine::PendingStep later = e->pending[other];
+    e->pending[other].active = false;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (std::getenv("NBX_LOG"))
+        std::fprintf(stderr, "[nbx] device tree build of %d bodies refused (status %d: nodes %d of %d, left-behind bodies %d, queued folds %d): "
+                             "step redone on the host tree%s\n", e->n, status, e->h_verdict[slot][0], p.node_cap, e->h_verdict[slot][1],
+                     e->h_verdict[slot][2], redo_later ? ", the step behind it enqueued again" : "");
+    HIP_TRY(hipMemsetAsync(nbx::device_tree_counters(e->d_tree_ws) + nbx::kTreePoisonWord, 0, sizeof(int), e->stream));
+    const bool want_order = e->bh_wave && e->n >= 65536;
+    int rc = build_and_upload_tree(e, nullptr, 0, want_order);
+    if (rc != NBX_OK) return rc;
+    rc = bh_eval_and_integrate(e, p.theta, p.dt, false, want_order && e->d_perm != nullptr);
+    if (rc != NBX_OK) return rc;
+    return redo_later ? step_bh(e, later.theta, later.dt) : NBX_OK;
+}
+
+int resolve_pending(nbx_engine* e)
+{
+    for (int k = 0; k < 2; k++) {   // oldest first: pend_next is the slot the next step would take, i.e. the older one
+        const int rc = resolve_slot(e, e->pend_next ^ (k & 1));
+        if (rc != NBX_OK) return rc;
+    }
+    return NBX_OK;
+}
+
+static int step_bh_async(nbx_engine* e, float theta, float dt)
+{
+    HIP_TRY(hipSetDevice(e->device));
+    for (int s = 0; s < 2; s++)
+        if (!e->h_verdict[s]) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_verdict[s]), 64, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&e->ev_step[s], hipEventDisableTiming));
+        }
+    const int slot = e->pend_next;
+    int rc = resolve_slot(e, slot);                 // the slot must be free (only the case when two steps are already in flight)
+    if (rc != NBX_OK) return rc;
+    rc = build_tree_on_device_begin(e, e->h_verdict[slot]);
+    if (rc != NBX_OK) return rc;
+    e->pending[slot].theta = theta; e->pending[slot].dt = dt;
+    e->pending[slot].node_cap = 4 * e->n + 1024;
+    e->pending[slot].fold = e->effective_fold();
+    rc = bh_eval_and_integrate(e, theta, dt, true, true, /*gated=*/true);
+    if (rc != NBX_OK) return rc;
+    HIP_TRY(hipEventRecord(e->ev_step[slot], e->stream));
+    e->pending[slot].active = true;
+    e->pend_next = slot ^ 1;
+    return resolve_slot(e, slot ^ 1);               // the step BEFORE this one: its verdict is (nearly) there by now
+}
+
 int step_bh(nbx_engine* e, float theta, float dt)
 {
-    int rc = upload(e);
-    if (rc != NBX_OK) return rc;
+    int rc = NBX_OK;
+    const bool async_ok = e->bh_async && e->world == 1 && !e->source_half && e->n <= kDeviceTreeMaxBodies && e->use_device_tree();
+    if (!(async_ok && e->dev_ready && e->dev_valid && e->n > 0)) {   // (a live device state needs no upload, and no verdict read)
+        rc = upload(e);
+        if (rc != NBX_OK) return rc;
+    }
     if (e->n == 0) return NBX_OK;
+    if (async_ok) return step_bh_async(e, theta, dt);
     bool on_device = false;
     if (e->use_device_tree()) {
         rc = build_tree_on_device(e, &on_device);
@@ -717,6 +817,11 @@ int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt)
 void free_device(nbx_engine* e)
 {
     if (!e->dev_ready) return;
+    e->pending[0].active = e->pending[1].active = false;
+    for (int k = 0; k < 2; k++) {
+        if (e->h_verdict[k]) (void)hipHostFree(e->h_verdict[k]);
+        if (e->ev_step[k]) (void)hipEventDestroy(e->ev_step[k]);
+    }
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& r : e->prof) {
@@ -764,6 +869,14 @@ uint64_t entropy_seed()
 
 void after_host_state_change(nbx_engine* e)
 {
+    if (e->any_pending()) {   // the state is being replaced: whatever the pending steps' verdicts, their results are discarded
+        if (e->dev_ready) {
+            (void)hipSetDevice(e->device);
+            (void)hipStreamSynchronize(e->stream);
+            if (e->d_tree_ws) (void)hipMemsetAsync(nbx::device_tree_counters(e->d_tree_ws) + nbx::kTreePoisonWord, 0, sizeof(int), e->stream);
+        }
+        e->pending[0].active = e->pending[1].active = false;
+    }
     e->n = e->host.n();
     compute_slab(e);
     e->host_pos_valid = e->host_vel_valid = true;

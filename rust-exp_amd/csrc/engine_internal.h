@@ -76,6 +76,20 @@ struct nbx_engine {
     int bh_fold = -1;
     int effective_fold() const { return bh_fold >= 0 ? bh_fold : (n <= nbx::kFoldFaithfulMax ? 1 : 0); }
     int bh_wave = 1;               // wave-uniform traversal when a spatial body order is available
+    // A Barnes-Hut step on the device tree is enqueued WITHOUT waiting for the build's verdict (node count, EPS clusters): walk
+    // and kick-drift are gated on the device by the build's own counters.  The host reads the verdict at the next call that
+    // needs the state (resolve_pending) and, in the rare case the build had to refuse, redoes the step on the host tree --
+    // the gated kernels left the state untouched.  NBX_OPT_BH_ASYNC = 0 waits inside the step as rounds 1-2 did.
+    struct PendingStep {
+        bool active = false;
+        float theta = 0.f, dt = 0.f;
+        int node_cap = 0, fold = 0;
+    } pending[2];                   // up to two steps in flight: the next one is enqueued before the previous verdict is read
+    int pend_next = 0;              // slot the next step takes (= the OLDER one when both are active)
+    int* h_verdict[2] = {nullptr, nullptr};       // pinned: each slot's build counters
+    hipEvent_t ev_step[2] = {nullptr, nullptr};   // each slot's step is complete on the stream
+    bool any_pending() const { return pending[0].active || pending[1].active; }
+    int bh_async = 1;
     int bh_last_tree_device = 0;   // where the last evaluated tree was built
     int bh_fallbacks = 0;          // device builds that fell back to the host (node pool exhausted)
     void* d_counts = nullptr;      // device draw: uint2 hit counters per pixel
@@ -252,14 +266,15 @@ int launch_forces_fast(nbx_engine* e);
 nbx::MassExceptions exceptions_of(const nbx_engine* e);
 int step_brute(nbx_engine* e, float dt);
 int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also = nullptr, int n_also = 0, bool order_bodies = false);
-int build_tree_on_device_begin(nbx_engine* e);
+int build_tree_on_device_begin(nbx_engine* e, int* host_counters = nullptr);
 int build_tree_on_device_end(nbx_engine* e, bool* done);
 int build_tree_on_device(nbx_engine* e, bool* done);
-int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm);
+int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm, bool gated = false);
 int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt);
 int spatial_order(nbx_engine* e);
 int slab_order(nbx_engine* e);
 int step_bh(nbx_engine* e, float theta, float dt);
+int resolve_pending(nbx_engine* e);   // the verdicts of the speculatively enqueued Barnes-Hut steps, oldest first (no-op when none)
 void free_device(nbx_engine* e);
 uint64_t entropy_seed();
 void after_host_state_change(nbx_engine* e);

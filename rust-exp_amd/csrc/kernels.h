@@ -88,8 +88,11 @@ bool strict_fastdiv_ok(float mass_min, float mass_max);
 hipError_t launch_max_coord(const float4* posm, int n_records, unsigned* guard, hipStream_t stream);
 // kick-drift from a per-body force (v += (dt*F)/m, nbody.rs:155) or acceleration (is_accel: v += dt*a),
 // optional velocity kill box (nbody.rs:466-471).
+// gate_* (optional; see bh_eval.hip BuildGate): the kernel runs only if the device tree build whose counters these are
+// produced a usable tree -- for steps enqueued before the host has read the build's outcome
 hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel, const float2* force, float dt,
-                               int is_accel, int killbox, hipStream_t stream);
+                               int is_accel, int killbox, hipStream_t stream, int* gate_counters = nullptr,
+                               int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0);
 
 // K3: Barnes-Hut traversal. mode 0 = fast (sequential pre-order accumulation, rcp),
 // mode 1 = strict (hierarchical summation order of nbody.rs:354-360 via an explicit frame stack,
@@ -97,8 +100,11 @@ hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel,
 // (need perm: bodies in a spatial order); same results as 0 / 1.
 // perm (optional): thread t evaluates body perm[t] -- a GLOBAL body index inside the slab
 // [lo, lo + n_targets) -- instead of body lo + t (spatial order => coherent waves); force_out is indexed by body - lo
+// gate_* (fast walks only): as launch_integrate_f2; n_nodes is then read from gate_counters[0] on the device
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
-                          int mode, float2* force_out, hipStream_t stream, const unsigned* perm = nullptr);
+                          int mode, float2* force_out, hipStream_t stream, const unsigned* perm = nullptr,
+                          int* gate_counters = nullptr, int gate_node_cap = 0, int gate_crowd_limit = 0,
+                          int gate_queue_limit = 0);
 
 // planar (x, y) of posm[0..n) into device-visible pinned host arrays (input of the host quadtree build)
 hipError_t launch_split_xy(const float4* posm, int n, float* xs_host_pinned, float* ys_host_pinned, hipStream_t stream);
@@ -134,6 +140,12 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
                                    hipStream_t side = nullptr, hipEvent_t ev_go = nullptr, hipEvent_t ev_done = nullptr);
 hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status,
                                  hipStream_t stream, int fold = 0);
+// the device-side view of the same verdict: where the build's counters live (for launch_bh_eval / launch_integrate_f2 gates)
+// and the limits device_tree_build_end applies to counters[1] (left-behind bodies) and counters[2] (queued folds)
+int* device_tree_counters(void* workspace);
+constexpr int kTreePoisonWord = 9;   // device_tree_counters()[9]: set by a gated kick-drift whose build was refused; while it is set
+                                     // every gated kernel is a no-op (the host clears it when it redoes the refused step)
+void device_tree_limits(int n, int fold, int* crowd_limit, int* queue_limit);
 
 // nb_draw on the device: counts (uint2 per pixel: body hits, tail hits) -> ABGR framebuffer. Particles whose tail octant
 // cannot be decided safely on the device (see draw.hip) are appended to amb[0..*amb_count) (capacity n) with their body

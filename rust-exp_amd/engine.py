@@ -39,6 +39,7 @@ NBX_OPT_BH_LAST_TREE = 11
 NBX_OPT_DRAW_AMBIGUOUS = 12
 NBX_OPT_STRICT_KERNEL = 13
 NBX_OPT_BH_FOLD = 14
+NBX_OPT_BH_ASYNC = 15
 
 NBX_GROUP_INFO_EXCHANGE = 0
 NBX_GROUP_INFO_RCCL_RANKS = 1
@@ -49,6 +50,7 @@ NBX_K_FORCE = 0
 NBX_K_INTEGRATE = 1
 NBX_K_BH_EVAL = 2
 NBX_K_EXCHANGE = 3
+NBX_K_TREE_BUILD = 4
 
 
 class NBodyError(RuntimeError):

@@ -479,3 +479,66 @@ def test_device_tree_degenerate_inputs(rx, ob, case):
     e.step_barnes_hut(0.5, 0.01, 1)
     st = e.get_particles()
     assert np.isfinite(st["px"]).all() and np.isfinite(st["vx"]).all()
+
+
+@pytest.mark.parametrize("fold", ["reference", "exact"])
+def test_steps_enqueued_without_waiting_for_the_build_verdict(rx, ob, fold):
+    """NBX_OPT_BH_ASYNC (round 3, default on): a Barnes-Hut step on the device tree is enqueued without a host wait in the
+    middle -- walk and kick-drift check the build's verdict on the device -- and the host reads the verdict at the next call
+    that needs the state.  Same state as the waiting form (NBX_OPT_BH_ASYNC = 0), bit for bit, over several back-to-back steps;
+    and when the build must refuse (EPS triples under the reference fold, an exhausted node pool under either), the gated
+    kernels leave the state alone and the step is redone on the host tree: the host-tree result, bit for bit."""
+    from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+
+    p = ob.stable_orbits(12000, 0.5, 30.0, 51)
+    outs = []
+    for async_ in (1, 0):
+        e = engines(rx, p, fold=fold)
+        e.set_option(NBX_OPT_BH_ASYNC, async_)
+        for _ in range(6):
+            e.step_barnes_hut(0.7, 0.01, 1)
+        assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1 and e.get_option(NBX_OPT_BH_FALLBACKS) == 0
+        outs.append(e.get_particles())
+    for k in ("px", "py", "vx", "vy"):
+        assert np.array_equal(outs[0][k].view(np.uint32), outs[1][k].view(np.uint32)), k
+    assert np.abs(outs[0]["px"] - p["px"]).max() > 0.1
+
+    # a system the device build refuses: thousands of pairs 2e-4 apart in x (no EPS merge) -> ~18-level chains, more nodes than
+    # the pool holds (both classes); plus EPS triples (refused by the reference fold alone)
+    rng = np.random.default_rng(8)
+    x = rng.uniform(-20, 20, 4000).astype(np.float32); y = rng.uniform(-20, 20, 4000).astype(np.float32)
+    x2 = np.concatenate([x, x + np.float32(2e-4), x[:3] + np.float32(3e-5), x[:3] - np.float32(2e-5)])
+    y2 = np.concatenate([y, y, y[:3] + np.float32(1e-5), y[:3] + np.float32(4e-5)])
+    n = len(x2)
+    q = ob.particles(x2, y2, rng.normal(0, 1, n), rng.normal(0, 1, n), np.ones(n))
+    h = engines(rx, q); h.set_bh_tree("host")
+    d = engines(rx, q, fold=fold); d.set_bh_tree("device")
+    h.step_barnes_hut(0.5, 0.01, 1)
+    # three steps enqueued back to back: the first is refused (and poisons the second, which is enqueued again after the redo);
+    # the bodies have moved apart by then, so the later builds succeed
+    for _ in range(3):
+        d.step_barnes_hut(0.5, 0.01, 1)
+    assert d.get_option(NBX_OPT_BH_FALLBACKS) >= 1
+    e1 = engines(rx, q, fold=fold); e1.set_bh_tree("device"); e1.set_option(NBX_OPT_BH_ASYNC, 0)
+    e1.step_barnes_hut(0.5, 0.01, 1)
+    a, b = h.get_particles(), e1.get_particles()
+    assert e1.get_option(NBX_OPT_BH_FALLBACKS) == 1 and e1.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    for k in ("px", "py", "vx", "vy"):                       # the refused step == the host-tree step, bit for bit
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    for _ in range(2):
+        e1.step_barnes_hut(0.5, 0.01, 1)
+    a, b = e1.get_particles(), d.get_particles()             # waiting form == pipelined form over the whole sequence
+    assert e1.get_option(NBX_OPT_BH_FALLBACKS) == d.get_option(NBX_OPT_BH_FALLBACKS)
+    for k in ("px", "py", "vx", "vy"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    fb = d.get_option(NBX_OPT_BH_FALLBACKS)
+    # new state, new verdict: a well-separated system right behind it stays on the device, nothing is left pending
+    d.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    d.step_barnes_hut(0.5, 0.01, 1)
+    d.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])      # replaces the state while that step's verdict is still unread
+    d.step_barnes_hut(0.5, 0.01, 1)
+    assert d.get_option(NBX_OPT_BH_LAST_TREE) == 1 and d.get_option(NBX_OPT_BH_FALLBACKS) == fb
+    ref = engines(rx, p, fold=fold); ref.set_option(NBX_OPT_BH_ASYNC, 0); ref.step_barnes_hut(0.5, 0.01, 1)
+    a, b = ref.get_particles(), d.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
