@@ -329,7 +329,7 @@ int32_t nbx_forces(nbx_engine* e, float theta, int32_t cap, float* fx, float* fy
         if (rc != NBX_OK) return rc;
         const int stride = ((slab + kTile - 1) / kTile) * kTile;
         HIP_TRY(nbx::launch_reduce_forces(e->d_posm, e->lo, slab, e->d_acc, e->last.jsplit, stride, e->d_out4, e->stream,
-                                          exceptions_of(e)));
+                                          exceptions_of(e), self_image_of(e)));
         std::vector<float4> tmp((size_t)slab);
         HIP_TRY(hipMemcpyAsync(tmp.data(), e->d_out4, sizeof(float4) * (size_t)slab, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));

@@ -296,6 +296,13 @@ nbx::MassExceptions exceptions_of(const nbx_engine* e)
     return nbx::MassExceptions{e->d_exc_rec, e->d_exc_idx, (int)e->exc_idx.size(), e->last.dim};
 }
 
+// K4 on the wave-split kernels (variants 17 / 18): what K2 / the force readout must take out of every target's sum
+nbx::SelfImage self_image_of(const nbx_engine* e)
+{
+    if (e->last.variant != 17 && e->last.variant != 18) return nbx::SelfImage{nullptr, 0.0f, e->last.dim};
+    return nbx::SelfImage{e->d_src4, e->last.variant == 18 ? nbx::half_image(e->mass_common) : 0.0f, e->last.dim};
+}
+
 // NBX_LOG=1: one stderr line per step (the reference has no logging on this path; its Haskell shell has Trace.hs)
 static bool log_enabled()
 {
@@ -336,7 +343,7 @@ int step_brute(nbx_engine* e, float dt)
         const int stride = ((slab + kTile - 1) / kTile) * kTile;
         ProfScope ps(e, NBX_K_INTEGRATE);
         HIP_TRY(nbx::launch_integrate(e->d_posm, e->lo, slab, e->d_vel, e->d_acc, e->last.jsplit, stride, dt,
-                                      e->stream, exceptions_of(e)));
+                                      e->stream, exceptions_of(e), self_image_of(e)));
         if (e->source_half) {   // refresh this slab's slot of the fp16 source copy (the all-gather send slot)
             rc = refresh_half_sources(e, e->lo, slab);
             if (rc != NBX_OK) return rc;

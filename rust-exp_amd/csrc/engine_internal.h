@@ -264,6 +264,7 @@ int download_velocities(nbx_engine* e);
 void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* variant, int* bpt, int* jsplit, int* dim);
 int launch_forces_fast(nbx_engine* e);
 nbx::MassExceptions exceptions_of(const nbx_engine* e);
+nbx::SelfImage self_image_of(const nbx_engine* e);
 int step_brute(nbx_engine* e, float dt);
 int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also = nullptr, int n_also = 0, bool order_bodies = false);
 int build_tree_on_device_begin(nbx_engine* e, int* host_counters = nullptr);

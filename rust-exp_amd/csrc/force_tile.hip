@@ -419,10 +419,10 @@ __global__ __launch_bounds__(kTile) void k_force_smem_pk(const float4* __restric
 // the per-interaction v_pk_mul (m_j * inv) leaves the loop -- 9 packed ops + 2 rcp per 2 interactions instead of 10 + 2 --
 // and the common mass multiplies the finished sums.  Sources are then weightless, so the zero-mass padding records cannot be
 // swept: the source loop ends at the true body count.
-// SELF_IMAGE (K4, fp16 sources): `src` is not posm but the widened fp16 copy of it, so a target's own source record is NOT at
-// the target's fp32 position and its term is no exact zero: it is recomputed with the sweep's arithmetic and subtracted by the
-// wave whose source quarter holds it.
-template <int DIM, int UNROLL, bool UNIT_MASS, bool SELF_IMAGE>
+// K4 (fp16 sources): `src` is not posm but the widened fp16 copy of it, so a target's own source record is NOT at the target's
+// fp32 position and its term is no exact zero: K2 / the force readout recompute it with the sweep's arithmetic and take it out
+// (SelfImage) -- the sweep itself is the same kernel, instruction for instruction.
+template <int DIM, int UNROLL, bool UNIT_MASS>
 __global__ __launch_bounds__(kTile) void k_force_smem_pkw(const float4* __restrict__ posm, const float4* __restrict__ src,
                                                           const int lo,
                                                           const int n_targets, const int tiles_total, const int n_sources,
@@ -484,38 +484,6 @@ __global__ __launch_bounds__(kTile) void k_force_smem_pkw(const float4* __restri
             ax[p] = __builtin_elementwise_fma(sc, dx, ax[p]);
             ay[p] = __builtin_elementwise_fma(sc, dy, ay[p]);
             if (DIM == 3) az[p] = __builtin_elementwise_fma(sc, dz, az[p]);
-        }
-    }
-    if (SELF_IMAGE) {
-        // each target's interaction with its OWN source image, with the sweep's arithmetic (weight 1 in the unit-mass sweep)
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int it = iblk * kTile + (2 * p + h) * 64 + lane;
-                const int g = lo + it;
-                if (it < n_targets && g >= ja && g < jb) {
-                    const float4 s = src[g];
-                    const float x = h ? xi[p].y : xi[p].x, y = h ? yi[p].y : yi[p].x, z = h ? zi[p].y : zi[p].x;
-                    const float dx = s.x - x, dy = s.y - y;
-                    float r2 = __builtin_fmaf(dx, dx, kEps);
-                    r2 = __builtin_fmaf(dy, dy, r2);
-                    float dz = 0.f;
-                    if (DIM == 3) {
-                        dz = s.z - z;
-                        r2 = __builtin_fmaf(dz, dz, r2);
-                    }
-                    float sc = __builtin_amdgcn_rcpf(r2);
-                    if (!UNIT_MASS) sc = s.w * sc;
-                    if (h) {
-                        ax[p].y = __builtin_fmaf(-sc, dx, ax[p].y); ay[p].y = __builtin_fmaf(-sc, dy, ay[p].y);
-                        if (DIM == 3) az[p].y = __builtin_fmaf(-sc, dz, az[p].y);
-                    } else {
-                        ax[p].x = __builtin_fmaf(-sc, dx, ax[p].x); ay[p].x = __builtin_fmaf(-sc, dy, ay[p].x);
-                        if (DIM == 3) az[p].x = __builtin_fmaf(-sc, dz, az[p].x);
-                    }
-                }
-            }
         }
     }
 #pragma unroll
@@ -595,13 +563,34 @@ __device__ __forceinline__ void add_exceptions(const MassExceptions exc, const f
     }
 }
 
+// K4's self-image term (kernels.h SelfImage): target i's interaction with its own widened fp16 source record, with the sweep's
+// arithmetic, taken out of the finished sum.
+__device__ __forceinline__ void remove_self_image(const SelfImage si, const float4 p, const int self, float4& a)
+{
+    if (!si.src) return;
+    const float4 s = si.src[self];
+    const float dx = s.x - p.x, dy = s.y - p.y;
+    float r2 = __builtin_fmaf(dx, dx, kEps);
+    r2 = __builtin_fmaf(dy, dy, r2);
+    float dz = 0.0f;
+    if (si.dim == 3) {
+        dz = s.z - p.z;
+        r2 = __builtin_fmaf(dz, dz, r2);
+    }
+    const float sc = (si.unit_mass > 0.0f ? si.unit_mass : s.w) * __builtin_amdgcn_rcpf(r2);
+    a.x = __builtin_fmaf(-sc, dx, a.x);
+    a.y = __builtin_fmaf(-sc, dy, a.y);
+    a.z = __builtin_fmaf(-sc, dz, a.z);
+}
+
 // K2: a_i = sum over splits in FIXED ascending order (deterministic), then the reference's
 // kick-drift (nbody.rs:153-160) with F/m == a:  v += dt*a ; p += dt*v_new.  Products and sums are
 // kept unfused (mul then add, as rustc emits them).
 __global__ __launch_bounds__(kTile) void k_integrate(float4* __restrict__ posm, const int lo, const int n_targets,
                                                      float4* __restrict__ vel,
                                                      const float4* __restrict__ acc_partial, const int jsplit,
-                                                     const int acc_stride, const float dt, const MassExceptions exc)
+                                                     const int acc_stride, const float dt, const MassExceptions exc,
+                                                     const SelfImage si)
 {
     const int i = blockIdx.x * kTile + threadIdx.x;
     if (i >= n_targets) return;
@@ -612,6 +601,7 @@ __global__ __launch_bounds__(kTile) void k_integrate(float4* __restrict__ posm, 
     }
     float4 v = vel[i];
     float4 p = posm[lo + i];
+    remove_self_image(si, p, lo + i, a);
     add_exceptions(exc, p, lo + i, a);
     v.x = __fadd_rn(v.x, __fmul_rn(dt, a.x));
     v.y = __fadd_rn(v.y, __fmul_rn(dt, a.y));
@@ -626,7 +616,8 @@ __global__ __launch_bounds__(kTile) void k_integrate(float4* __restrict__ posm, 
 __global__ __launch_bounds__(kTile) void k_reduce_forces(const float4* __restrict__ posm, const int lo,
                                                          const int n_targets,
                                                          const float4* __restrict__ acc_partial, const int jsplit,
-                                                         const int acc_stride, float4* __restrict__ out, const MassExceptions exc)
+                                                         const int acc_stride, float4* __restrict__ out, const MassExceptions exc,
+                                                         const SelfImage si)
 {
     const int i = blockIdx.x * kTile + threadIdx.x;
     if (i >= n_targets) return;
@@ -636,6 +627,7 @@ __global__ __launch_bounds__(kTile) void k_reduce_forces(const float4* __restric
         a.x += q.x; a.y += q.y; a.z += q.z;
     }
     const float4 p = posm[lo + i];
+    remove_self_image(si, p, lo + i, a);
     add_exceptions(exc, p, lo + i, a);
     const float m = p.w;
     out[i] = make_float4(m * a.x, m * a.y, m * a.z, 0.0f);
@@ -688,16 +680,11 @@ hipError_t launch_force_wave_split(const float4* posm, int lo, int n_targets, in
     // variant codes: 6 / 7 = fp32 sources (general / unit-mass sweep); 17 / 18 = the same kernels on the widened fp16 copy (K4)
     if (info) *info = ForceLaunch{(int)grid.x, kTile, jsplit, 4, dim, (widened ? 11 : 0) + (unit_mass ? 7 : 6)};
     const float4* src = widened ? widened : posm;
-#define NBX_WS(DD, UM, SI) \
-    hipLaunchKernelGGL((k_force_smem_pkw<DD, 8, UM, SI>), grid, dim3(kTile), 0, stream, posm, src, lo, n_targets, tiles_total, n_sources, \
+#define NBX_WS(DD, UM) \
+    hipLaunchKernelGGL((k_force_smem_pkw<DD, 8, UM>), grid, dim3(kTile), 0, stream, posm, src, lo, n_targets, tiles_total, n_sources, \
                        jsplit, acc_partial, acc_stride, mass, exc_idx, exc_rec, exc_count)
-    if (widened) {
-        if (dim == 3) { if (unit_mass) NBX_WS(3, true, true); else NBX_WS(3, false, true); }
-        else          { if (unit_mass) NBX_WS(2, true, true); else NBX_WS(2, false, true); }
-    } else {
-        if (dim == 3) { if (unit_mass) NBX_WS(3, true, false); else NBX_WS(3, false, false); }
-        else          { if (unit_mass) NBX_WS(2, true, false); else NBX_WS(2, false, false); }
-    }
+    if (dim == 3) { if (unit_mass) NBX_WS(3, true); else NBX_WS(3, false); }
+    else          { if (unit_mass) NBX_WS(2, true); else NBX_WS(2, false); }
 #undef NBX_WS
     return hipGetLastError();
 }
@@ -728,20 +715,20 @@ hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tile
 }
 
 hipError_t launch_integrate(float4* posm, int lo, int n_targets, float4* vel, const float4* acc_partial, int jsplit,
-                            int acc_stride, float dt, hipStream_t stream, MassExceptions exc)
+                            int acc_stride, float dt, hipStream_t stream, MassExceptions exc, SelfImage si)
 {
     if (n_targets <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_integrate, dim3((n_targets + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, lo, n_targets,
-                       vel, acc_partial, jsplit, acc_stride, dt, exc);
+                       vel, acc_partial, jsplit, acc_stride, dt, exc, si);
     return hipGetLastError();
 }
 
 hipError_t launch_reduce_forces(const float4* posm, int lo, int n_targets, const float4* acc_partial, int jsplit,
-                                int acc_stride, float4* out, hipStream_t stream, MassExceptions exc)
+                                int acc_stride, float4* out, hipStream_t stream, MassExceptions exc, SelfImage si)
 {
     if (n_targets <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_reduce_forces, dim3((n_targets + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, lo,
-                       n_targets, acc_partial, jsplit, acc_stride, out, exc);
+                       n_targets, acc_partial, jsplit, acc_stride, out, exc, si);
     return hipGetLastError();
 }
 

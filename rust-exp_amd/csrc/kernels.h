@@ -37,8 +37,8 @@ hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tile
 // exc_idx / exc_rec (unit_mass only, exc_count > 0): workgroup 0 also copies the source record of body exc_idx[k], with the
 // weight (its mass - mass) the sweep leaves out, into exc_rec[k] -- the snapshot K2 / the force readout add afterwards.
 // widened (K4, fp16 sources): the sources are read from this float4 array -- the half4 copy widened by launch_widen_half --
-// instead of posm (targets stay posm), and every target's interaction with its own image is taken out again;
-// info->variant = 17 / 18 then.
+// instead of posm (targets stay posm); every target's interaction with its own image is then taken out by K2 / the
+// force readout (SelfImage); info->variant = 17 / 18.
 hipError_t launch_force_wave_split(const float4* posm, int lo, int n_targets, int tiles_total, int n_sources, int jsplit, int dim,
                                    bool unit_mass, float mass, float4* acc_partial, int acc_stride, hipStream_t stream,
                                    ForceLaunch* info, const int* exc_idx = nullptr, float4* exc_rec = nullptr, int exc_count = 0,
@@ -64,15 +64,25 @@ struct MassExceptions {
     int dim;
 };
 
-// K2: reduce partials in fixed order (+ the exceptional sources), kick-drift, write positions in place (slab slot of posm).
+// K4 on the wave-split kernels: the sources were a widened fp16 copy (src), so every target's sum holds its interaction with
+// its OWN image; K2 / the force readout take it out. unit_mass > 0: the sweep weighted every source with it; else with src.w.
+struct SelfImage {
+    const float4* src;
+    float unit_mass;
+    int dim;
+};
+
+// K2: reduce partials in fixed order (- the self image, + the exceptional sources), kick-drift, write positions in place.
 hipError_t launch_integrate(float4* posm, int lo, int n_targets, float4* vel, const float4* acc_partial,
                             int jsplit, int acc_stride, float dt, hipStream_t stream,
-                            MassExceptions exc = MassExceptions{nullptr, nullptr, 0, 3});
+                            MassExceptions exc = MassExceptions{nullptr, nullptr, 0, 3},
+                            SelfImage si = SelfImage{nullptr, 0.0f, 3});
 
 // forces-only readout: F_i = m_i * a_i into float4 out[n_targets]
 hipError_t launch_reduce_forces(const float4* posm, int lo, int n_targets, const float4* acc_partial, int jsplit,
                                 int acc_stride, float4* out, hipStream_t stream,
-                                MassExceptions exc = MassExceptions{nullptr, nullptr, 0, 3});
+                                MassExceptions exc = MassExceptions{nullptr, nullptr, 0, 3},
+                                SelfImage si = SelfImage{nullptr, 0.0f, 3});
 
 // strict (bit-exact) pair: ascending j per target, IEEE divide, no contraction. 2-D.
 // kernel: 16 or 8 = workgroups of that many waves per 64 targets (term producers + one summing wave), 1 = one thread per body,

@@ -51,8 +51,8 @@ def test_bit_exact_all_pairs_kernels_use_no_scratch_and_keep_their_occupancy(tmp
 
 
 def test_default_fast_kernels_keep_eight_waves_per_simd(tmp_path):
-    """K1's default all-pairs kernels (variants 6 / 7, both dimensions) and the shared Barnes-Hut walk: no scratch and at most 64
-    VGPRs, i.e. the 8 waves per SIMD their latency hiding was measured with."""
+    """K1's default all-pairs kernels (variants 6 / 7, both dimensions; K4 runs the same four on the widened fp16 copy) and the
+    shared Barnes-Hut walk: no scratch and at most 64 VGPRs, i.e. the 8 waves per SIMD their latency hiding was measured with."""
     k = _metadata(tmp_path, "force_tile.hip", [])
     pkw = [v for n, v in k.items() if "k_force_smem_pkw" in n]
     assert len(pkw) == 4
@@ -65,3 +65,17 @@ def test_default_fast_kernels_keep_eight_waves_per_simd(tmp_path):
     assert len(walks) == 4
     for v in walks:
         assert v["vgpr_spill_count"] == 0 and v["vgpr_count"] <= 64, v
+
+
+def test_fold_kernels_of_the_device_tree_build(tmp_path):
+    """k_fold_big / k_fold_root (reference fold of the device-built tree): two waves per workgroup, no register spills (a few
+    bytes of scratch hold the chunk bookkeeping the compiler indexes dynamically), LDS small enough for eight workgroups per
+    CU (every queued node gets its own pair of waves at once)."""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    strict = re.search(r"^STRICT\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    k = _metadata(tmp_path, "bh_build.hip", strict)
+    folds = [v for n, v in k.items() if "k_fold_big" in n or "k_fold_root" in n]
+    assert len(folds) == 2
+    for v in folds:
+        assert v["private_segment_fixed_size"] <= 16 and v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0, v
+        assert 8 * v["group_segment_fixed_size"] <= 160 * 1024 and v["vgpr_count"] <= 256, v
