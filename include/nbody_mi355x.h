@@ -36,7 +36,8 @@ extern "C" {
 /* Environment knobs read once at first use: NB_DEVICE (ordinal, default 0), NB_GPUS (n | all:   */
 /* single-process multi-GPU group, see nbx_group_*), NB_SEED (u64,                               */
 /* default: OS entropy, as the reference's thread_rng), NB_FORCE_MODE=fast|strict,                */
-/* NB_DRAW=host|device, NB_BH_TREE=host|device (both default: by size), NB_SOURCE_BITS=16 (fp16   */
+/* NB_DRAW=host|device, NB_BH_TREE=host|device (both default: by size), NB_BH_FOLD=reference|exact  */
+/* (NBX_OPT_BH_FOLD; default: reference up to 65 536 bodies), NB_SOURCE_BITS=16 (fp16               */
 /* source copy for the all-pairs sweep, BASELINE config #5; default 32).                          */
 /* Both levels: NBX_HOST_THREADS (workers of the host quadtree build / flatten / draw; default   */
 /* min(hardware threads, 32)), NBX_GROUP_EXCHANGE=copy (see nbx_group_*), NBX_LOG=1 (one stderr   */

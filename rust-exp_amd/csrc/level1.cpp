@@ -30,6 +30,9 @@ static void apply_env(nbx_engine* e)
     const char* tree = std::getenv("NB_BH_TREE");
     if (tree && std::strcmp(tree, "device") == 0) e->bh_tree_device = 1;
     if (tree && std::strcmp(tree, "host") == 0) e->bh_tree_device = 0;
+    const char* fold = std::getenv("NB_BH_FOLD");   // device tree interior nodes: reference (f32 running fold) | exact (sums rounded once)
+    if (fold && std::strcmp(fold, "exact") == 0) e->bh_fold = 0;
+    if (fold && std::strcmp(fold, "reference") == 0) e->bh_fold = 1;
     const char* bits = std::getenv("NB_SOURCE_BITS");   // 16: all-pairs sources from the half4 copy (BASELINE config #5)
     if (bits && std::atoi(bits) == 16) e->source_half = 1;
     const char* draw = std::getenv("NB_DRAW");

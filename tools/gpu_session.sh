@@ -90,7 +90,7 @@ PY
     cfgs)   # the other BASELINE configs on one GPU + the 2-D kernel on the headline size
       timeout 600 python bench.py --bodies 65536 --steps 20 --warmup 3 --no-traffic > $O/${TAG}_bench_cfg2_20_steps.json 2>> $O/${TAG}_cfgs.err
       timeout 600 python bench.py --bodies 65536 --steps 400 --warmup 100 --no-traffic > $O/${TAG}_bench_cfg2.json 2>> $O/${TAG}_cfgs.err
-      timeout 600 python bench.py --workload two_galaxies --bodies 524288 --source-bits 16 --no-traffic --cpu-seconds 4 > $O/${TAG}_bench_cfg5_1gpu.json 2>> $O/${TAG}_cfgs.err
+      timeout 600 python bench.py --workload two_galaxies --bodies 524288 --source-bits 16 --cpu-seconds 4 --no-general-masses > $O/${TAG}_bench_cfg5_1gpu.json 2>> $O/${TAG}_cfgs.err
       timeout 600 python bench.py --workload two_galaxies --bodies 524288 --no-traffic --no-cpu-baseline > $O/${TAG}_bench_cfg5_1gpu_fp32.json 2>> $O/${TAG}_cfgs.err
       timeout 600 python bench.py --dim 2 --no-traffic --no-cpu-baseline > $O/${TAG}_bench_n1_dim2.json 2>> $O/${TAG}_cfgs.err
       for m in strict; do for nb in 10000 65536 262144; do timeout 600 python bench.py --mode $m --bodies $nb --no-traffic --no-cpu-baseline >> $O/${TAG}_bench_strict.jsonl 2>> $O/${TAG}_cfgs.err; done; done
@@ -119,6 +119,14 @@ PY
       if [ "$(python -c 'import rust_exp_amd as r; print(r.device_count())' 2>/dev/null)" -ge 8 ]; then X=""; else X="NBX_GROUP_EXCHANGE=copy"; fi
       env $X timeout 900 python bench.py --gpus 8 --verify --no-cpu-baseline > $O/${TAG}_bench_group8_verify.json 2> $O/${TAG}_bench_group8_verify.err; echo "verify8 rc=$?"; cut -c1-800 $O/${TAG}_bench_group8_verify.json
       env $X NBX_GROUP_ENQUEUE=threads timeout 900 python bench.py --gpus 8 --verify --no-cpu-baseline > $O/${TAG}_bench_group8_verify_threads.json 2>> $O/${TAG}_bench_group8_verify.err; echo "verify8 threads rc=$?" ;;
+    fold)   # device quadtree with the reference fold vs exact sums vs host tree: bit-equality + ms per step by size; kernel trace
+      timeout 900 python tools/bh_fold_probe.py 0.85 > $O/${TAG}_bh_fold_probe.jsonl 2> $O/${TAG}_bh_fold_probe.err; cut -c1-60,130-420 $O/${TAG}_bh_fold_probe.jsonl
+      bash tools/prof_bh_fold.sh > /dev/null 2>&1
+      for n in 10000 65536; do cp $O/prof_fold_$n/p_kernel_stats.csv $O/${TAG}_bh_fold_kernel_stats_$n.csv; done ;;
+    frames) # the reference's frame loop through the six nb_* symbols (defaults; host tree + host draw; exact-sum device tree)
+      timeout 600 python tools/frame_loop.py > $O/${TAG}_frame_loop_level1.txt 2>&1; cat $O/${TAG}_frame_loop_level1.txt
+      NB_BH_TREE=host NB_DRAW=host timeout 600 python tools/frame_loop.py > $O/${TAG}_frame_loop_level1_host_tree_host_draw.txt 2>&1
+      NB_BH_FOLD=exact timeout 600 python tools/frame_loop.py > $O/${TAG}_frame_loop_level1_exact_fold.txt 2>&1; cat $O/${TAG}_frame_loop_level1_exact_fold.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
