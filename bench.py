@@ -214,6 +214,8 @@ def parse_args():
     ap.add_argument("--workload", default="plummer", choices=["plummer", "two_galaxies", "bh"])
     ap.add_argument("--theta", type=float, default=0.5, help="--workload bh: opening angle")
     ap.add_argument("--bh-tree", default="default", choices=["default", "host", "device"])
+    ap.add_argument("--bh-walk-records", type=int, default=-1, choices=[-1, 16, 32],
+                    help="--workload bh, device tree: node record size the wave walk reads (16 = the compact copy: A/B of round 3, slower)")
     ap.add_argument("--source-bits", type=int, default=32, choices=[16, 32],
                     help="16 = fp16 source copy / fp32 accumulators (BASELINE config #5)")
     ap.add_argument("--host", default="auto", choices=["auto", "single", "group", "torch"])
@@ -386,6 +388,8 @@ class SingleHost:
         e.set_strict_kernel(args.strict_kernel)
         if args.bh_tree != "default":
             e.set_bh_tree(args.bh_tree)
+        if args.bh_walk_records > 0:
+            e.set_option(rx.engine.NBX_OPT_BH_WALK_RECORDS, args.bh_walk_records)
         if args.shard_of > 1:
             e.set_shard(0, args.shard_of)
         e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])

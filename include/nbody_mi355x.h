@@ -137,6 +137,11 @@ enum nbx_option {
                                     * build's verdict (node count, EPS clusters); walk and kick-drift check it on the device, the
                                     * host at the next call that needs the state (nbx_synchronize, get, draw, the next step) and
                                     * redoes the step on the host tree if the build had to refuse. 0: wait inside the step */
+    NBX_OPT_BH_WALK_RECORDS = 16,  /* wave walk of a device-built exact-sum tree: 16 = from a compact copy of the tree (16-byte
+                                    * decision records + a mass word per node, written next to the 32-byte records), 32 or -1
+                                    * (default) = from the 32-byte records. Bit-identical results; the compact copy moves 15 % fewer
+                                    * bytes and is 20-26 % SLOWER (its second scalar load per visit): kept as the measured A/B of
+                                    * round 3, profiles/r03_bh_walk_records_ab.jsonl */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };

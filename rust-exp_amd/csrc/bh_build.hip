@@ -444,11 +444,19 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
                                                 const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const Prefix pre,
                                                 const int n, const int node_cap, BhNode* __restrict__ out, const int fold,
                                                 int4* __restrict__ big, const int big_cap, int* __restrict__ counters,
-                                                const int root_aside)
+                                                const int root_aside, BhWalk16* __restrict__ walk16, float* __restrict__ wmass)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = pre.base[n];
-    if (k < total && total <= node_cap) emit_node(sb, keys, idx, box, pre, n, out, fold, big, big_cap, counters, root_aside, k);
+    if (k < total && total <= node_cap) {
+        emit_node(sb, keys, idx, box, pre, n, out, fold, big, big_cap, counters, root_aside, k);
+        if (walk16) {   // the compact copy for the wave-uniform walk (fold = 0: every record is final here)
+            const float4* src = reinterpret_cast<const float4*>(&out[k]);
+            const float4 a = src[0], c = src[1];
+            walk16[k] = BhWalk16{a.x, a.y, c.z, __float_as_int(c.x)};
+            wmass[k] = a.z;
+        }
+    }
 }
 
 __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
@@ -1074,8 +1082,9 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 //          (the caller should build on the host: the reference's multi-body merges are not reproduced here)
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters /* pinned, >= 4 ints */, const unsigned** perm_dev, hipStream_t stream, int fold,
-                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done)
+                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, BhWalk16* walk16, float* wmass)
 {
+    if (fold != 0) { walk16 = nullptr; wmass = nullptr; }   // (the fold kernels write centres and masses after k_emit)
     *perm_dev = nullptr;
     if (n <= 0) return hipSuccess;
     size_t sort_tmp = 0;
@@ -1107,7 +1116,7 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     // base[n] leave at once; the pool check is inside)
     const int eb = n <= 65536 ? 64 : kTile;   // spread a small system's few waves over the CUs
     hipLaunchKernelGGL(k_emit, dim3((unsigned)((node_cap + eb - 1) / eb)), dim3(eb), 0, stream, k.sb, mk, k.idx1, k.box, k.pre, n, node_cap, out,
-                       fold, k.big, n, k.counters, root_aside ? 1 : 0);
+                       fold, k.big, n, k.counters, root_aside ? 1 : 0, walk16, wmass);
     if (fold == 1) {
         // one pair of waves per queued node; the count lives on the device: enough workgroups for every plausible queue
         // (a uniform system queues ~n/5 nodes), they loop when there are more

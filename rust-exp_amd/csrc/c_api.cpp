@@ -109,6 +109,10 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
         case NBX_OPT_BH_ASYNC:
             e->bh_async = value ? 1 : 0;
             return NBX_OK;
+        case NBX_OPT_BH_WALK_RECORDS:
+            if (value != 16 && value != 32 && value != -1) return fail(NBX_ERR_INVALID, "walk records must be 16, 32 or -1 (by size)");
+            e->bh_walk_records = (int)value;
+            return NBX_OK;
         case NBX_OPT_BH_FOLD:
             if (value != 0 && value != 1 && value != -1) return fail(NBX_ERR_INVALID, "bh fold must be 0 (exact sums), 1 (reference fold) or -1 (by size)");
             e->bh_fold = (int)value;
@@ -146,6 +150,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_BH_WAVE: return e->bh_wave;
         case NBX_OPT_BH_FOLD: return e->bh_fold;
         case NBX_OPT_BH_ASYNC: return e->bh_async;
+        case NBX_OPT_BH_WALK_RECORDS: return e->bh_walk_records;
         case NBX_OPT_BH_FALLBACKS: return e->bh_fallbacks;
         case NBX_OPT_BH_LAST_TREE: return e->bh_last_tree_device;
         case NBX_OPT_DRAW_AMBIGUOUS: return e->draw_ambiguous;
@@ -158,7 +163,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
 int32_t nbx_query_option(const nbx_engine* e, int32_t option, int64_t* value)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
-    if (option < NBX_OPT_FORCE_MODE || option > NBX_OPT_BH_ASYNC) return fail(NBX_ERR_INVALID, "unknown option %d", option);
+    if (option < NBX_OPT_FORCE_MODE || option > NBX_OPT_BH_WALK_RECORDS) return fail(NBX_ERR_INVALID, "unknown option %d", option);
     if (value) *value = nbx_get_option(e, option);
     return NBX_OK;
 }

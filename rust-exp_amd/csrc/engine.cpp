@@ -539,10 +539,19 @@ int build_tree_on_device_begin(nbx_engine* e, int* host_counters)
         HIP_TRY(hipEventCreateWithFlags(&e->ev_side_go, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_side_done, hipEventDisableTiming));
     }
+    // compact copy for the wave walk: opt-in (measured slower, profiles/r03_bh_walk_records_ab.jsonl), exact-sum trees only (every
+    // record is final when k_emit writes it)
+    const bool want16 = fold == 0 && e->bh_wave && e->bh_walk_records == 16;
+    if (want16) {
+        int rc16 = grow(&e->d_walk16, &e->walk16_cap, (size_t)node_cap);
+        if (rc16 == NBX_OK) rc16 = grow(&e->d_wmass, &e->wmass_cap, (size_t)node_cap);
+        if (rc16 != NBX_OK) return rc16;
+    }
+    e->walk16_valid = want16;
     ProfScope ps(e, NBX_K_TREE_BUILD);
     HIP_TRY(nbx::device_tree_build_begin(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes,
                                          host_counters ? host_counters : e->h_counters, &e->d_perm, e->stream, fold, e->side_stream,
-                                         e->ev_side_go, e->ev_side_done));
+                                         e->ev_side_go, e->ev_side_done, want16 ? e->d_walk16 : nullptr, want16 ? e->d_wmass : nullptr));
     return NBX_OK;
 }
 
@@ -643,7 +652,9 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
         ProfScope ps(e, NBX_K_BH_EVAL);
         HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta,
                                     wave ? (e->force_mode == 0 ? 2 : 3) : e->force_mode, e->d_f2,
-                                    e->stream, perm, gate, node_cap, crowd_limit, queue_limit));
+                                    e->stream, perm, gate, node_cap, crowd_limit, queue_limit,
+                                    (on_device && wave && e->walk16_valid) ? e->d_walk16 : nullptr,
+                                    (on_device && wave && e->walk16_valid) ? e->d_wmass : nullptr));
     }
     {
         ProfScope ps(e, NBX_K_INTEGRATE);
@@ -844,6 +855,8 @@ void free_device(nbx_engine* e)
     if (e->d_f2) (void)hipFree(e->d_f2);
     if (e->d_out4) (void)hipFree(e->d_out4);
     if (e->d_nodes) (void)hipFree(e->d_nodes);
+    if (e->d_walk16) (void)hipFree(e->d_walk16);
+    if (e->d_wmass) (void)hipFree(e->d_wmass);
     if (e->d_guard) (void)hipFree(e->d_guard);
     if (e->d_exc_idx) (void)hipFree(e->d_exc_idx);
     if (e->d_src4) (void)hipFree(e->d_src4);

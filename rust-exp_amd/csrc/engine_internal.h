@@ -49,6 +49,11 @@ struct nbx_engine {
     size_t out4_cap = 0;
     nbx::BhNode* d_nodes = nullptr;
     size_t nodes_cap = 0;
+    nbx::BhWalk16* d_walk16 = nullptr;   // compact copy of the device-built tree for the wave walk (NBX_OPT_BH_WALK_RECORDS)
+    float* d_wmass = nullptr;
+    size_t walk16_cap = 0, wmass_cap = 0;
+    int bh_walk_records = -1;            // 16 = the wave walk reads the compact copy (A/B'd in round 3: slower; opt-in), else the 32-byte records
+    bool walk16_valid = false;           // the compact copy describes the tree in d_nodes
     unsigned* d_guard = nullptr;   // max|coord| word for the batched-reciprocal kernel
     size_t guard_cap = 0;
     void* d_tree_ws = nullptr;     // device tree build workspace (NBX_OPT_BH_TREE = 1)

@@ -19,6 +19,17 @@ struct BhNode {
 };
 inline __host__ __device__ float bh_node_q(float s, bool interior) { return interior ? s * s : -1.0f; }
 
+// Compact copy of the tree for the wave-uniform fast walk (round 3): what a visit DECIDES on -- centre, opening threshold, skip --
+// in 16 bytes, the mass (needed only by the lanes that take the node, and not before the next record has been requested) in a
+// separate word array.  Fewer bytes per visited node (the ~13 % of a million-body tree that an XCD's walks touch are 7.9 MB of
+// 32-byte records, profiles/r03_bh_walk_lines_model.json, against a 4 MB L2).  MEASURED (profiles/r03_bh_walk_records_ab.jsonl):
+// 15 % less HBM traffic, 20-26 % MORE time -- the walk is bound by its dependent scalar loads, and this adds one per visit.
+// Opt-in (NBX_OPT_BH_WALK_RECORDS = 16); written by k_emit next to the BhNode array.
+struct BhWalk16 {
+    float px, py, q;
+    int32_t skip;
+};
+
 struct ForceLaunch {
     int grid, block, jsplit, bpt, dim, variant;
 };
@@ -111,10 +122,11 @@ hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel,
 // perm (optional): thread t evaluates body perm[t] -- a GLOBAL body index inside the slab
 // [lo, lo + n_targets) -- instead of body lo + t (spatial order => coherent waves); force_out is indexed by body - lo
 // gate_* (fast walks only): as launch_integrate_f2; n_nodes is then read from gate_counters[0] on the device
+// walk16 / wmass (mode 2 only): the compact copy of the tree (BhWalk16 + masses); same results, bit for bit
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
                           int mode, float2* force_out, hipStream_t stream, const unsigned* perm = nullptr,
                           int* gate_counters = nullptr, int gate_node_cap = 0, int gate_crowd_limit = 0,
-                          int gate_queue_limit = 0);
+                          int gate_queue_limit = 0, const BhWalk16* walk16 = nullptr, const float* wmass = nullptr);
 
 // planar (x, y) of posm[0..n) into device-visible pinned host arrays (input of the host quadtree build)
 hipError_t launch_split_xy(const float4* posm, int n, float* xs_host_pinned, float* ys_host_pinned, hipStream_t stream);
@@ -147,7 +159,8 @@ constexpr int kFoldFaithfulMax = 65536;   // default: faithful fold up to this m
 // on `side` from the start of the build, beside everything else (it is the longest chain and needs only the bodies)
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters, const unsigned** perm_dev, hipStream_t stream, int fold = 0,
-                                   hipStream_t side = nullptr, hipEvent_t ev_go = nullptr, hipEvent_t ev_done = nullptr);
+                                   hipStream_t side = nullptr, hipEvent_t ev_go = nullptr, hipEvent_t ev_done = nullptr,
+                                   BhWalk16* walk16 = nullptr, float* wmass = nullptr);
 hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status,
                                  hipStream_t stream, int fold = 0);
 // the device-side view of the same verdict: where the build's counters live (for launch_bh_eval / launch_integrate_f2 gates)

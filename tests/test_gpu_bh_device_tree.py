@@ -542,3 +542,23 @@ def test_steps_enqueued_without_waiting_for_the_build_verdict(rx, ob, fold):
     a, b = ref.get_particles(), d.get_particles()
     for k in ("px", "py", "vx", "vy"):
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+
+
+def test_compact_walk_records_are_bit_identical(rx, ob):
+    """NBX_OPT_BH_WALK_RECORDS = 16 (the round-3 A/B of the wave walk: 16-byte decision records + mass words, mass used one visit
+    late): every body's force and a step, bit for bit those of the 32-byte walk."""
+    from rust_exp_amd.engine import NBX_OPT_BH_WALK_RECORDS
+
+    st = rx.plummer_sphere(100000, dim=2)
+    res = []
+    for rec in (32, 16):
+        e = rx.NBodyEngine()
+        e.set_bh_fold("exact")
+        e.set_option(NBX_OPT_BH_WALK_RECORDS, rec)
+        e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+        for _ in range(3):
+            e.step_barnes_hut(0.5, 0.01, 1)
+        res.append(e.get_particles())
+    for k in ("px", "py", "vx", "vy"):
+        assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
+    assert np.abs(res[0]["px"] - st["px"]).max() > 0
