@@ -211,7 +211,8 @@ def parse_args():
                     help="bit-exact mode: 0 = by size; 16 / 8 = waves per 64-target workgroup; 1 = one thread per body")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="plummer", choices=["plummer", "two_galaxies", "bh"])
+    ap.add_argument("--workload", default="plummer", choices=["plummer", "two_galaxies", "stable_orbits", "bh"],
+                    help="stable_orbits = the reference's own preset (nb_stable_orbits n 0.5 30, seed 1; 2-D: unit planets + a 1000-mass sun)")
     ap.add_argument("--theta", type=float, default=0.5, help="--workload bh: opening angle")
     ap.add_argument("--bh-tree", default="default", choices=["default", "host", "device"])
     ap.add_argument("--bh-walk-records", type=int, default=-1, choices=[-1, 16, 32],
@@ -245,6 +246,9 @@ def make_state(args, rx):
         e.plummer_sphere(args.n, dim=2)   # the reference (and its quadtree) is 2-D
     elif args.workload == "plummer":
         e.plummer_sphere(args.n, dim=args.dim)
+    elif args.workload == "stable_orbits":
+        e.seed(1)
+        e.stable_orbits(args.n, 0.5, 30.0)
     else:
         e.two_galaxies(args.n)
     st = e.get_particles()
@@ -717,7 +721,7 @@ def main():
                 "metric": f"body-pair interactions/s at N={n} (brute-force O(N^2) step)",
                 "value": value, "unit": "interactions/s",
                 "dtype": "f32" if args.source_bits == 32 else "f32 (fp16 source copy)",
-                "config": {"workload": f"{'plummer_sphere' if args.workload == 'plummer' else 'two_galaxies'}_N{n}_brute_force_dim{launch['dim']}_dt{DT}"
+                "config": {"workload": f"{ {'plummer': 'plummer_sphere'}.get(args.workload, args.workload) }_N{n}_brute_force_dim{launch['dim']}_dt{DT}"
                                        + ("_fp16sources" if args.source_bits == 16 else "")
                                        + (f"_rank0_of_{args.shard_of}_slab_only" if args.shard_of > 1 else ""),
                            "bodies": n, "seed": "0x5EED0001", "force_mode": args.mode, "host": host_kind,

@@ -93,10 +93,11 @@ PY
       timeout 600 python bench.py --workload two_galaxies --bodies 524288 --source-bits 16 --cpu-seconds 4 --no-general-masses > $O/${TAG}_bench_cfg5_1gpu.json 2>> $O/${TAG}_cfgs.err
       timeout 600 python bench.py --workload two_galaxies --bodies 524288 --no-traffic --no-cpu-baseline > $O/${TAG}_bench_cfg5_1gpu_fp32.json 2>> $O/${TAG}_cfgs.err
       timeout 600 python bench.py --dim 2 --no-traffic --no-cpu-baseline > $O/${TAG}_bench_n1_dim2.json 2>> $O/${TAG}_cfgs.err
+      timeout 600 python bench.py --workload stable_orbits --no-traffic --no-cpu-baseline > $O/${TAG}_bench_stable_orbits_262144.json 2>> $O/${TAG}_cfgs.err
       for m in strict; do for nb in 10000 65536 262144; do timeout 600 python bench.py --mode $m --bodies $nb --no-traffic --no-cpu-baseline >> $O/${TAG}_bench_strict.jsonl 2>> $O/${TAG}_cfgs.err; done; done
       python - <<'PY'
 import json,glob
-for f in sorted(glob.glob("gpurun_out/*_bench_cfg*.json")+glob.glob("gpurun_out/*_bench_n1_dim2.json")):
+for f in sorted(glob.glob("gpurun_out/*_bench_cfg*.json")+glob.glob("gpurun_out/*_bench_n1_dim2.json")+glob.glob("gpurun_out/*_bench_stable_orbits_*.json")):
     d=json.load(open(f)); print(f.split("/")[-1], d["config"]["workload"], "%.3e"%d["value"], "frac %.4f"%d["roofline"]["frac"], d["config"]["launch"])
 for ln in open(glob.glob("gpurun_out/*_bench_strict.jsonl")[0]):
     d=json.loads(ln); print("strict", d["config"]["bodies"], "%.3e"%d["value"], "frac %.4f"%d["roofline"]["frac"], d["config"]["launch"])
