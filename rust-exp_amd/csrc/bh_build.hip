@@ -261,6 +261,116 @@ __global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict_
     close[j] = out;
 }
 
+// ---- 3c. what the pairs-only, neighbours-only merge above cannot see (reference fold only: that class promises the reference's
+// tree node for node or a hand-over to the host build) -------------------------------------------------------------------------
+// k_merge_links examines NEIGHBOURING entities of the key order.  Two bodies within EPS need not be neighbours (a cell boundary
+// between them puts other bodies in between), and the reference still merges them when every body between them arrived later;
+// and a body within EPS of a blob's centre is within 2 EPS of its members.  So: every entity looks at ALL entities within 2 EPS
+// (both axes) of it -- they sit in the 3 x 3 block of quadtree cells, at the deepest level whose cells are >= 2.5 EPS wide,
+// around its own cell, and every such cell is a contiguous range of the sorted keys (found by binary search) --
+//   * two or more of them: an EPS cluster the pairs-only merge may not reproduce  -> counted, host build
+//   * exactly one, within EPS, NOT a neighbour in key order: would the reference merge them (no earlier-arrived body shares
+//     their common cell)?  then the device tree misses a merge                  -> counted, host build
+//   * exactly one, a neighbour: k_merge_links' business (and k_emit checks the blob's path)
+// More than kCloseScanCap candidates in the block (a collinear or collapsed system): counted as well.
+constexpr int kCloseScanCap = 512;
+constexpr int kSideStreamsFrom = 4096;
+
+__device__ __forceinline__ int lower_bound_key(const unsigned long long* __restrict__ keys, const int n, const unsigned long long v)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kTile) void k_close_scan(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
+                                                      const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const int n,
+                                                      int* __restrict__ crowded)
+{
+    const int j = blockIdx.x * kTile + threadIdx.x;
+    if (j >= n) return;
+    const unsigned long long k = keys[j];
+    if (j > 0 && keys[j - 1] == k) return;            // the first body of an entity speaks for it
+    // grid level: cells at least 2.5 EPS wide in both axes (widths halve per level; the f32 midpoints move them by rounding only)
+    float wx = dec_f32(box[2]) - dec_f32(box[0]), wy = dec_f32(box[3]) - dec_f32(box[1]);
+    int D = 0;
+    while (D < kLevels && wx * 0.5f >= 2.5f * kEps && wy * 0.5f >= 2.5f * kEps) { wx *= 0.5f; wy *= 0.5f; D++; }
+    unsigned ix = 0, iy = 0;                          // this entity's cell: one bit per level (x: right = 1; y: lower = 1)
+    for (int l = 0; l < D; l++) {
+        const unsigned q = (unsigned)(k >> (2 * (kLevels - 1 - l))) & 3u;
+        ix = (ix << 1) | (q & 1u);
+        iy = (iy << 1) | (q >> 1);
+    }
+    const int sh = 2 * (kLevels - D);
+    const float4 p = sb[j];
+    int n2 = 0, nb = -1, seen = 0;
+    const unsigned lim = D == 0 ? 1u : (D >= 32 ? 0xFFFFFFFFu : (1u << D));
+    // the nine cells' key ranges: eighteen lower bounds found IN LOCKSTEP (one bisection step of all of them per iteration, so
+    // their loads overlap: a chain of ~log2(n) dependent loads instead of eighteen times that)
+    unsigned long long bound[18];
+    int pos[18];
+    bool cell_ok[9];
+#pragma unroll
+    for (int c9 = 0; c9 < 9; c9++) {
+        const long long cx = (long long)ix + (c9 % 3 - 1), cy = (long long)iy + (c9 / 3 - 1);
+        cell_ok[c9] = !(cx < 0 || cy < 0 || cx >= (long long)lim || cy >= (long long)lim);
+        unsigned long long prefix = 0;
+        for (int l = 0; l < D; l++) {
+            const unsigned bx = (unsigned)(cx >> (D - 1 - l)) & 1u, by = (unsigned)(cy >> (D - 1 - l)) & 1u;
+            prefix = (prefix << 2) | (unsigned long long)((by << 1) | bx);
+        }
+        bound[2 * c9] = D == 0 ? 0ull : prefix << sh;
+        bound[2 * c9 + 1] = D == 0 ? ~0ull : (prefix + 1ull) << sh;   // (keys use 62 bits: ~0 is above all of them)
+        pos[2 * c9] = 0; pos[2 * c9 + 1] = 0;
+    }
+    int top = 1;
+    while (top <= n / 2) top <<= 1;                                   // largest power of two <= n
+    for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+        for (int b = 0; b < 18; b++)
+            if (pos[b] + step <= n && keys[pos[b] + step - 1] < bound[b]) pos[b] += step;   // pos = number of keys below the bound
+    }
+#pragma unroll
+    for (int c9 = 0; c9 < 9; c9++) {
+        if (!cell_ok[c9]) continue;
+        for (int t = pos[2 * c9]; t < pos[2 * c9 + 1]; t++) {
+            if (keys[t] == k) continue;                          // this entity itself
+            if (t > 0 && keys[t - 1] == keys[t]) continue;       // only the first body of the other entity
+            if (++seen > kCloseScanCap) { atomicAdd(crowded, 1); return; }
+            const float4 q = sb[t];
+            if (fabsf(__fsub_rn(p.x, q.x)) < 2.0f * kEps && fabsf(__fsub_rn(p.y, q.y)) < 2.0f * kEps) { n2++; nb = t; }
+        }
+    }
+    if (n2 == 0) return;
+    if (n2 >= 2) { atomicAdd(crowded, 1); return; }
+    const float4 q = sb[nb];
+    if (!(fabsf(__fsub_rn(p.x, q.x)) < kEps && fabsf(__fsub_rn(p.y, q.y)) < kEps)) return;   // nbody.rs:249: not too close
+    if (run_end(keys, j, n) == nb || run_end(keys, nb, n) == j) return;                       // neighbours: k_merge_links decides
+    if (nb < j) return;                                                                       // the pair is judged once, by its left member
+    // would the reference merge them?  (as in k_merge_links, with everything between them among the rivals)
+    const int c = common_digits(k, keys[nb]);
+    const unsigned ia = idx[j], ib = idx[nb];
+    const unsigned second = ia > ib ? ia : ib;
+    const unsigned long long kf = ia < ib ? k : keys[nb];
+    bool rival = false;
+    int steps = 0;
+    for (int x = j - 1; x >= 0 && !rival; x--) {
+        if (common_digits(kf, keys[x]) < c) break;
+        if (++steps > kMergeScanCap) { atomicAdd(crowded, 1); return; }
+        rival = idx[x] < second;
+    }
+    for (int x = j + 1; x < n && !rival; x++) {
+        if (keys[x] == k || keys[x] == keys[nb]) continue;           // later arrivals of the two entities themselves
+        if (common_digits(kf, keys[x]) < c) break;
+        if (++steps > kMergeScanCap) { atomicAdd(crowded, 1); return; }
+        rival = idx[x] < second;
+    }
+    if (!rival) atomicAdd(crowded, 1);                               // a merge the neighbours-only logic cannot represent
+}
+
 // Pairs of entities only: of a chain of close boundaries every other one is dropped by the local rule "a boundary merges iff
 // the boundary at the start of its left entity does not" (deterministic, no scan, merges stay disjoint).  All members of a
 // merged pair of entities take the key of the entity that arrived first; the array stays sorted (the new key lies between the
@@ -520,6 +630,7 @@ __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const u
         o.px = p.x; o.py = p.y; o.m = 0.0f;
         if (b - a <= kFoldSmall) {
             // the node's bodies in index order: pick the smallest index above the last one, b - a times
+            // (requesting all <= 8 indices and records up front was tried: k_emit 18 -> 24 us at 10 000 bodies)
             float px = 0.0f, py = 0.0f, m = 0.0f;
             unsigned last = 0;
             for (int t = 0; t < b - a; t++) {
@@ -807,16 +918,9 @@ __global__ __launch_bounds__(128) void k_fold_root(const float4* __restrict__ po
 
 __global__ __launch_bounds__(128) void k_fold_big(const float4* __restrict__ posm, const float4* __restrict__ sb,
                                                   const unsigned* __restrict__ idx, const int4* __restrict__ big, const int big_cap,
-                                                  const int* __restrict__ counters, const int n, BhNode* __restrict__ out,
-                                                  int* __restrict__ host_counters)
+                                                  const int* __restrict__ counters, const int n, BhNode* __restrict__ out)
 {
     __shared__ FoldShared sh;
-    // the build's counters (node count, left-behind bodies, queued folds) are final when this kernel starts: workgroup 0 hands
-    // them to the host through pinned memory (no copy command of its own behind the build)
-    if (blockIdx.x == 0 && threadIdx.x < 3) {
-        host_counters[threadIdx.x] = counters[threadIdx.x];
-        __threadfence_system();
-    }
     int count = counters[2];
     if (count > big_cap) count = big_cap;
     for (int w = blockIdx.x; w < count; w += gridDim.x) {
@@ -1081,8 +1185,10 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 //          nodes (nothing usable was written), 2 when more than max(16, n/2000) bodies sit in clusters of >= 3 within EPS
 //          (the caller should build on the host: the reference's multi-body merges are not reproduced here)
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
-                                   int* host_counters /* pinned, >= 4 ints */, const unsigned** perm_dev, hipStream_t stream, int fold,
-                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, BhWalk16* walk16, float* wmass)
+                                   int* host_counters /* pinned, >= 4 ints; null: the caller's gated kick-drift publishes them */,
+                                   const unsigned** perm_dev, hipStream_t stream, int fold,
+                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, BhWalk16* walk16, float* wmass,
+                                   hipStream_t side2, hipEvent_t ev_sorted, hipEvent_t ev_scanned)
 {
     if (fold != 0) { walk16 = nullptr; wmass = nullptr; }   // (the fold kernels write centres and masses after k_emit)
     *perm_dev = nullptr;
@@ -1090,7 +1196,10 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     size_t sort_tmp = 0;
     if (device_tree_workspace_bytes(n, node_cap, &sort_tmp) > workspace_bytes) return hipErrorInvalidValue;
     const Workspace k = carve(workspace, n, sort_tmp);
-    const bool root_aside = fold == 1 && side && ev_go && ev_done && n > kFoldSmall;
+    // side streams pay from a few thousand bodies on: a join costs ~10 us, the root's chain 16 ns per body
+    // (NBX_SIDE_STREAMS_FROM overrides the measured crossover: profiles/r03_bh_side_stream_crossover.txt)
+    static const int side_from = [] { const char* v = std::getenv("NBX_SIDE_STREAMS_FROM"); return v ? std::atoi(v) : kSideStreamsFrom; }();
+    const bool root_aside = fold == 1 && side && ev_go && ev_done && n >= side_from;
     hipError_t e;
     if (root_aside) {
         // the root's fold -- n serial steps, needs only the bodies in index order -- starts NOW on the side stream, beside
@@ -1108,6 +1217,17 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     // EPS merge (pairs): links from the sorted keys + arrival order (this kernel also gathers the bodies into sorted order), then
     // both members of a pair share one key (keys0 is free again after the sort); everything below works on the merged keys
     hipLaunchKernelGGL(k_merge_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link);
+    const bool scan_aside = fold == 1 && side2 && ev_sorted && ev_scanned && n >= side_from;
+    if (fold == 1) {
+        // everything within 2 EPS of every entity: what the neighbours-only merge cannot see goes to the host build.  A
+        // latency-bound kernel (35-47 us) that only feeds the verdict: on a stream of its own beside merge, scan, emit and folds
+        if (scan_aside) {
+            if ((e = hipEventRecord(ev_sorted, stream)) != hipSuccess) return e;   // sorted keys + sorted bodies are final
+            if ((e = hipStreamWaitEvent(side2, ev_sorted, 0)) != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k_close_scan, dim3(nb), dim3(kTile), 0, scan_aside ? side2 : stream, k.sb, k.keys1, k.idx1, k.box, n, k.counters + 1);
+        if (scan_aside && (e = hipEventRecord(ev_scanned, side2)) != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(k_merge_keys, dim3(nb), dim3(kTile), 0, stream, k.keys1, k.idx1, k.link, n, k.keys0, k.counters + 1);
     const unsigned long long* mk = k.keys0;
     hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, k.sb, mk, n, k.block_sums, k.counters + 3);
@@ -1121,12 +1241,11 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
         // one pair of waves per queued node; the count lives on the device: enough workgroups for every plausible queue
         // (a uniform system queues ~n/5 nodes), they loop when there are more
         const int fb = n / 4 + 64;
-        hipLaunchKernelGGL(k_fold_big, dim3((unsigned)(fb < 8192 ? fb : 8192)), dim3(128), 0, stream, posm, k.sb, k.idx1, k.big, n, k.counters, n, out,
-                           host_counters);
+        hipLaunchKernelGGL(k_fold_big, dim3((unsigned)(fb < 8192 ? fb : 8192)), dim3(128), 0, stream, posm, k.sb, k.idx1, k.big, n, k.counters, n, out);
         if (root_aside && (e = hipStreamWaitEvent(stream, ev_done, 0)) != hipSuccess) return e;   // the tree is complete on `stream` from here
-    } else if ((e = hipMemcpyAsync(host_counters, k.counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) {
-        return e;
+        if (scan_aside && (e = hipStreamWaitEvent(stream, ev_scanned, 0)) != hipSuccess) return e;   // ... and so is the verdict
     }
+    if (host_counters && (e = hipMemcpyAsync(host_counters, k.counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -36,10 +36,15 @@ constexpr int kMaxFrames = 56;
 struct BuildGate {
     int* counters;
     int node_cap, crowd_limit, queue_limit;
+    int* host_out;    // pinned: the kick-drift's first thread hands the counters to the host (no copy command behind the build)
 };
 __device__ __forceinline__ bool gate_open(const BuildGate g, int& n_nodes, const bool mark = false)
 {
     if (!g.counters) return true;
+    if (mark && g.host_out) {
+        g.host_out[0] = g.counters[0]; g.host_out[1] = g.counters[1]; g.host_out[2] = g.counters[2];
+        __threadfence_system();
+    }
     if (g.counters[kTreePoisonWord] != 0) return false;
     const int nn = g.counters[0];
     if (nn > g.node_cap || g.counters[1] > g.crowd_limit || g.counters[2] > g.queue_limit) {
@@ -514,7 +519,7 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
                           int gate_node_cap, int gate_crowd_limit, int gate_queue_limit, const BhWalk16* walk16, const float* wmass)
 {
     if (n_targets <= 0) return hipSuccess;
-    const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit};
+    const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit, nullptr};
     if (gate_counters && !(mode == 0 || (mode == 2 && perm))) return hipErrorInvalidValue;   // only the fast walks are gated
     // per-lane walks: one wave per workgroup while the system is too small to fill the chip (spreads the waves over the CUs)
     const int block = n_targets <= 65536 ? 64 : kTile;
@@ -568,12 +573,12 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
 
 hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel, const float2* force, float dt,
                                int is_accel, int killbox, hipStream_t stream, int* gate_counters, int gate_node_cap,
-                               int gate_crowd_limit, int gate_queue_limit)
+                               int gate_crowd_limit, int gate_queue_limit, int* gate_host_out)
 {
     if (n_targets <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_integrate_f2, dim3((n_targets + kTile - 1) / kTile), dim3(kTile), 0, stream, posm, lo,
                        n_targets, vel, force, dt, is_accel, killbox,
-                       BuildGate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit});
+                       BuildGate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit, gate_host_out});
     return hipGetLastError();
 }
 

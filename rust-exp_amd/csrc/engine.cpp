@@ -515,7 +515,7 @@ static constexpr int kDeviceTreeMaxBodies = 1 << 25;
 // quadtree on the device (bh_build.hip), in two halves so that a group can start every device's build before it waits
 // for any: begin enqueues the build, end waits for it. *done = false when the node pool overflowed (the caller falls
 // back to the host build).
-int build_tree_on_device_begin(nbx_engine* e, int* host_counters)
+int build_tree_on_device_begin(nbx_engine* e, int* host_counters, bool publish_by_kernel)
 {
     HIP_TRY(hipSetDevice(e->device));
     e->tree_t0 = std::chrono::steady_clock::now();
@@ -538,6 +538,9 @@ int build_tree_on_device_begin(nbx_engine* e, int* host_counters)
         HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_side_go, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_side_done, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&e->side2_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_sorted, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_scanned, hipEventDisableTiming));
     }
     // compact copy for the wave walk: opt-in (measured slower, profiles/r03_bh_walk_records_ab.jsonl), exact-sum trees only (every
     // record is final when k_emit writes it)
@@ -550,8 +553,10 @@ int build_tree_on_device_begin(nbx_engine* e, int* host_counters)
     e->walk16_valid = want16;
     ProfScope ps(e, NBX_K_TREE_BUILD);
     HIP_TRY(nbx::device_tree_build_begin(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes,
-                                         host_counters ? host_counters : e->h_counters, &e->d_perm, e->stream, fold, e->side_stream,
-                                         e->ev_side_go, e->ev_side_done, want16 ? e->d_walk16 : nullptr, want16 ? e->d_wmass : nullptr));
+                                         publish_by_kernel ? nullptr : (host_counters ? host_counters : e->h_counters), &e->d_perm,
+                                         e->stream, fold, e->side_stream, e->ev_side_go, e->ev_side_done,
+                                         want16 ? e->d_walk16 : nullptr, want16 ? e->d_wmass : nullptr, e->side2_stream, e->ev_sorted,
+                                         e->ev_scanned));
     return NBX_OK;
 }
 
@@ -622,7 +627,7 @@ int slab_order(nbx_engine* e)
 }
 
 // traversal + kick-drift of this engine's slab against the node array it holds (e->d_nodes, e->n_flat)
-int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm, bool gated)
+int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm, bool gated, int* gate_host_out)
 {
     HIP_TRY(hipSetDevice(e->device));
     int* gate = nullptr;
@@ -659,7 +664,7 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
     {
         ProfScope ps(e, NBX_K_INTEGRATE);
         HIP_TRY(nbx::launch_integrate_f2(e->d_posm, e->lo, slab, e->d_vel, e->d_f2, dt, e->force_mode == 0 ? 1 : 0, 1,
-                                         e->stream, gate, node_cap, crowd_limit, queue_limit));
+                                         e->stream, gate, node_cap, crowd_limit, queue_limit, gated ? gate_host_out : nullptr));
     }
     if (e->source_half && !gated) {
         rc = refresh_half_sources(e, e->lo, slab);
@@ -747,12 +752,12 @@ static int step_bh_async(nbx_engine* e, float theta, float dt)
     const int slot = e->pend_next;
     int rc = resolve_slot(e, slot);                 // the slot must be free (only the case when two steps are already in flight)
     if (rc != NBX_OK) return rc;
-    rc = build_tree_on_device_begin(e, e->h_verdict[slot]);
+    rc = build_tree_on_device_begin(e, e->h_verdict[slot], /*publish_by_kernel=*/true);   // the gated kick-drift hands the counters over
     if (rc != NBX_OK) return rc;
     e->pending[slot].theta = theta; e->pending[slot].dt = dt;
     e->pending[slot].node_cap = 4 * e->n + 1024;
     e->pending[slot].fold = e->effective_fold();
-    rc = bh_eval_and_integrate(e, theta, dt, true, true, /*gated=*/true);
+    rc = bh_eval_and_integrate(e, theta, dt, true, true, /*gated=*/true, e->h_verdict[slot]);
     if (rc != NBX_OK) return rc;
     HIP_TRY(hipEventRecord(e->ev_step[slot], e->stream));
     e->pending[slot].active = true;
@@ -867,6 +872,9 @@ void free_device(nbx_engine* e)
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
     if (e->ev_side_go) (void)hipEventDestroy(e->ev_side_go);
     if (e->ev_side_done) (void)hipEventDestroy(e->ev_side_done);
+    if (e->side2_stream) { (void)hipStreamSynchronize(e->side2_stream); (void)hipStreamDestroy(e->side2_stream); }
+    if (e->ev_sorted) (void)hipEventDestroy(e->ev_sorted);
+    if (e->ev_scanned) (void)hipEventDestroy(e->ev_scanned);
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_fb) (void)hipFree(e->d_fb);
     if (e->h_fb) (void)hipHostFree(e->h_fb);

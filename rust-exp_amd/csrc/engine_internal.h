@@ -60,6 +60,8 @@ struct nbx_engine {
     size_t tree_ws_bytes = 0;
     hipStream_t side_stream = nullptr;   // device tree build: the root's fold runs here beside the rest (NBX_OPT_BH_FOLD = 1)
     hipEvent_t ev_side_go = nullptr, ev_side_done = nullptr;
+    hipStream_t side2_stream = nullptr;  // ... and the EPS-neighbourhood scan here
+    hipEvent_t ev_sorted = nullptr, ev_scanned = nullptr;
     int* h_counters = nullptr;     // pinned: per-level node counters of the device build
     const unsigned* d_perm = nullptr;   // spatial body order produced by the device build
     const unsigned* d_slab_perm = nullptr;  // d_perm restricted to this engine's slab (world > 1)
@@ -272,10 +274,11 @@ nbx::MassExceptions exceptions_of(const nbx_engine* e);
 nbx::SelfImage self_image_of(const nbx_engine* e);
 int step_brute(nbx_engine* e, float dt);
 int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also = nullptr, int n_also = 0, bool order_bodies = false);
-int build_tree_on_device_begin(nbx_engine* e, int* host_counters = nullptr);
+int build_tree_on_device_begin(nbx_engine* e, int* host_counters = nullptr, bool publish_by_kernel = false);
 int build_tree_on_device_end(nbx_engine* e, bool* done);
 int build_tree_on_device(nbx_engine* e, bool* done);
-int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm, bool gated = false);
+int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm, bool gated = false,
+                          int* gate_host_out = nullptr);
 int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt);
 int spatial_order(nbx_engine* e);
 int slab_order(nbx_engine* e);

@@ -113,7 +113,7 @@ hipError_t launch_max_coord(const float4* posm, int n_records, unsigned* guard, 
 // produced a usable tree -- for steps enqueued before the host has read the build's outcome
 hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel, const float2* force, float dt,
                                int is_accel, int killbox, hipStream_t stream, int* gate_counters = nullptr,
-                               int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0);
+                               int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0, int* gate_host_out = nullptr);
 
 // K3: Barnes-Hut traversal. mode 0 = fast (sequential pre-order accumulation, rcp),
 // mode 1 = strict (hierarchical summation order of nbody.rs:354-360 via an explicit frame stack,
@@ -156,11 +156,15 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 // cannot reproduce then reports status 2 (caller builds on the host).
 constexpr int kFoldFaithfulMax = 65536;   // default: faithful fold up to this many bodies (the root's chain is n serial steps)
 // side / ev_go / ev_done (optional, fold = 1): a second stream and two events of the same device -- the root's fold then runs
-// on `side` from the start of the build, beside everything else (it is the longest chain and needs only the bodies)
+// on `side` from the start of the build, beside everything else (it is the longest chain and needs only the bodies);
+// side2 / ev_sorted / ev_scanned: a third stream for the EPS-neighbourhood scan (feeds only the verdict).
+// host_counters: pinned words the build's counters are copied to at the end; null = the caller's gated kick-drift
+// (launch_integrate_f2 gate_host_out) hands them over instead, no copy command
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters, const unsigned** perm_dev, hipStream_t stream, int fold = 0,
                                    hipStream_t side = nullptr, hipEvent_t ev_go = nullptr, hipEvent_t ev_done = nullptr,
-                                   BhWalk16* walk16 = nullptr, float* wmass = nullptr);
+                                   BhWalk16* walk16 = nullptr, float* wmass = nullptr,
+                                   hipStream_t side2 = nullptr, hipEvent_t ev_sorted = nullptr, hipEvent_t ev_scanned = nullptr);
 hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status,
                                  hipStream_t stream, int fold = 0);
 // the device-side view of the same verdict: where the build's counters live (for launch_bh_eval / launch_integrate_f2 gates)
