@@ -34,9 +34,9 @@
 //     62-bit keys are identical -- the same level-31 cell, 4.7e-8 of the box -- always share one leaf, any number of them);
 //     more than max(16, n/2000) such bodies send the step to the host build;
 //   * no depth-50 panic (nbody.rs:230-232): keys stop at level 31.
-// Known hole of BOTH classes: a pair within EPS whose members are not neighbours in key order (they straddle a cell boundary
-// high up) merges in the reference only if every body between them in key order arrived later -- i.e. the pair are the first
-// bodies of a big cell; only neighbouring entities are examined here.
+// A pair within EPS whose members are not neighbours in key order (a third body of their common cell between them) merges in the
+// reference when every body between them arrived later: the neighbours-only merge misses it.  fold = 1 finds every such case
+// (k_close_scan, step 3c) and hands the step to the host build; fold = 0 lives with it (its own tolerance class).
 #include <cstring>   // rocPRIM's texture_cache_iterator.hpp calls memset() without including it
 
 #include <rocprim/device/device_radix_sort.hpp>

@@ -562,3 +562,37 @@ def test_compact_walk_records_are_bit_identical(rx, ob):
     for k in ("px", "py", "vx", "vy"):
         assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
     assert np.abs(res[0]["px"] - st["px"]).max() > 0
+
+
+def test_reference_fold_detects_merges_between_non_neighbouring_entities(rx, ob):
+    """Found by tests/fuzz_fast.py (seed 5214): 1 000 bodies within 0.03 of the origin, a fifth of them copies 1e-5 away from
+    another body.  Two bodies within EPS need not be neighbours in key order -- a third body of their common cell can sit
+    between them -- and the reference still merges them when that third body arrived later; the neighbours-only merge of the
+    device build misses it (10 nodes too many).  The reference-fold class must notice (k_close_scan: every entity looks at all
+    entities within 2 EPS) and hand the step to the host build; the exact-sum class keeps its looser contract."""
+    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+
+    rng = np.random.default_rng(5214)
+    n = int(rng.choice([2, 3, 17, 255, 256, 257, 1000, 4097, 9000, 20000, 70000, 150000]))
+    scale = float(rng.choice([1e-2, 1.0, 30.0, 3e3]))
+    assert (n, scale) == (1000, 0.01)
+    x = (rng.normal(0, 1, n) * scale).astype(np.float32)
+    y = (rng.normal(0, 1, n) * scale).astype(np.float32)
+    assert rng.random() < 0.5
+    k = n // 5
+    x[:k] = x[k:2 * k] + (rng.normal(0, 1e-3, k) * scale).astype(np.float32)
+    y[:k] = y[k:2 * k] + (rng.normal(0, 1e-3, k) * scale).astype(np.float32)
+    p = ob.particles(x, y, np.zeros(n), np.zeros(n), np.full(n, 0.37))
+    h = engines(rx, p); h.set_bh_tree("host")
+    d = engines(rx, p)                                  # default: device tree, reference fold
+    fx, fy, _ = h.forces(0.85)
+    gx, gy, _ = d.forces(0.85)
+    assert d.get_option(NBX_OPT_BH_FALLBACKS) == 1 and d.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
+    with pytest.raises(rx.NBodyError):
+        d.bh_flat_dump("device")
+    # a step through the pipelined path lands on the host tree too
+    d.step_barnes_hut(0.85, 0.01, 1); h.step_barnes_hut(0.85, 0.01, 1)
+    a, b = h.get_particles(), d.get_particles()
+    for kk in ("px", "py", "vx", "vy"):
+        assert np.array_equal(a[kk].view(np.uint32), b[kk].view(np.uint32)), kk
