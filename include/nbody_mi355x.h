@@ -121,8 +121,11 @@ enum nbx_option {
     NBX_OPT_BH_WAVE = 9,           /* 1 (default): with the device-built tree, walk the tree once per WAVE (node
                                     * records through the scalar cache, lanes park on accepted subtrees); 0: one
                                     * independent walk per lane. Bit-identical results either way */
-    NBX_OPT_BH_FALLBACKS = 10,     /* read only (nbx_get_option): device tree builds that ran out of node pool and were
-                                    * redone on the host since the engine was created */
+    NBX_OPT_BH_FALLBACKS = 10,     /* read only (nbx_get_option): Barnes-Hut evaluations since the engine was created that the
+                                    * device tree was selected for but the host tree served: builds the device refused (node
+                                    * pool exhausted; EPS clusters it cannot reproduce under NBX_OPT_BH_FOLD = 1) plus the steps
+                                    * sent straight to the host build after refusals in a row (2, 4 .. 32 steps, then the
+                                    * device is tried again; env NBX_BH_BACKOFF_MAX = longest run, 0 = always try the device) */
     NBX_OPT_BH_LAST_TREE = 11,     /* read only: where the tree of the last Barnes-Hut evaluation was built: 0 host, 1 device */
     NBX_OPT_DRAW_AMBIGUOUS = 12,   /* read only: tails the last device draw left to the host; -1 = the last draw ran on the host */
     NBX_OPT_STRICT_KERNEL = 13,    /* bit-exact all-pairs kernel: 0 = by targets per GPU (default), 16 or 8 = workgroups of that

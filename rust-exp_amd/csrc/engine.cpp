@@ -511,6 +511,7 @@ int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also, int n_also, bo
 
 // node slots are 32-bit and a body can own up to 32 nodes: beyond this size the host build is used
 static constexpr int kDeviceTreeMaxBodies = 1 << 25;
+static constexpr int kBackoffMaxSteps = 32;   // see nbx_engine::note_refusal
 
 // quadtree on the device (bh_build.hip), in two halves so that a group can start every device's build before it waits
 // for any: begin enqueues the build, end waits for it. *done = false when the node pool overflowed (the caller falls
@@ -560,6 +561,17 @@ int build_tree_on_device_begin(nbx_engine* e, int* host_counters, bool publish_b
     return NBX_OK;
 }
 
+// longest run of steps a back-off sends straight to the host build (engine_internal.h); NBX_BH_BACKOFF_MAX=0 turns it off
+static int backoff_max_steps()
+{
+    static const int v = [] {
+        const char* s = std::getenv("NBX_BH_BACKOFF_MAX");
+        const int x = s ? std::atoi(s) : kBackoffMaxSteps;
+        return x < 0 ? 0 : x;
+    }();
+    return v;
+}
+
 int build_tree_on_device_end(nbx_engine* e, bool* done)
 {
     *done = false;
@@ -569,6 +581,7 @@ int build_tree_on_device_end(nbx_engine* e, bool* done)
     HIP_TRY(nbx::device_tree_build_end(e->n, node_cap, e->h_counters, &n_nodes, &status, e->stream, e->effective_fold()));
     if (status != 0) {
         e->bh_fallbacks++;
+        e->note_refusal(backoff_max_steps());
         e->d_perm = nullptr;
         if (std::getenv("NBX_LOG"))
             std::fprintf(stderr, "[nbx] device tree build of %d bodies handed over to the host build: status %d (1 = pool / queue overflow, 2 = EPS "
@@ -576,6 +589,7 @@ int build_tree_on_device_end(nbx_engine* e, bool* done)
                          e->h_counters[1], e->h_counters[2]);
         return NBX_OK;   // caller takes the host path
     }
+    e->note_accepted();
     e->n_flat = (size_t)n_nodes;
     e->host_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - e->tree_t0).count();
     e->host_steps++;
@@ -706,6 +720,7 @@ static int resolve_slot(nbx_engine* e, int slot)
     e->pending[slot].active = false;
     const int status = verdict_of(e, slot);
     if (status == 0) {
+        e->note_accepted();
         e->n_flat = (size_t)e->h_verdict[slot][0];
         e->bh_last_tree_device = 1;
         e->host_steps++;
@@ -713,6 +728,7 @@ static int resolve_slot(nbx_engine* e, int slot)
     }
     // refused: this step's gated kernels did nothing and poisoned the step behind it (if one is in flight)
     e->bh_fallbacks++;
+    e->note_refusal(backoff_max_steps());
     e->d_perm = nullptr;
     const int other = slot ^ 1;
     const bool redo_later = e->pending[other].active;
@@ -768,7 +784,17 @@ static int step_bh_async(nbx_engine* e, float theta, float dt)
 int step_bh(nbx_engine* e, float theta, float dt)
 {
     int rc = NBX_OK;
-    const bool async_ok = e->bh_async && e->world == 1 && !e->source_half && e->n <= kDeviceTreeMaxBodies && e->use_device_tree();
+    if (e->any_pending() && e->bh_refusal_streak > 0) {   // a verdict that may start a back-off: read it before choosing the path
+        rc = resolve_pending(e);
+        if (rc != NBX_OK) return rc;
+    }
+    bool device_tree = e->use_device_tree() && e->n <= kDeviceTreeMaxBodies;
+    if (device_tree && e->bh_host_steps_left > 0) {       // back-off after refusals in a row (engine_internal.h)
+        e->bh_host_steps_left--;
+        e->bh_fallbacks++;
+        device_tree = false;
+    }
+    const bool async_ok = e->bh_async && e->world == 1 && !e->source_half && device_tree;
     if (!(async_ok && e->dev_ready && e->dev_valid && e->n > 0)) {   // (a live device state needs no upload, and no verdict read)
         rc = upload(e);
         if (rc != NBX_OK) return rc;
@@ -776,7 +802,7 @@ int step_bh(nbx_engine* e, float theta, float dt)
     if (e->n == 0) return NBX_OK;
     if (async_ok) return step_bh_async(e, theta, dt);
     bool on_device = false;
-    if (e->use_device_tree()) {
+    if (device_tree) {
         rc = build_tree_on_device(e, &on_device);
         if (rc != NBX_OK) return rc;
     }
@@ -906,6 +932,7 @@ void after_host_state_change(nbx_engine* e)
         e->pending[0].active = e->pending[1].active = false;
     }
     e->n = e->host.n();
+    e->bh_refusal_streak = e->bh_host_steps_left = 0;
     compute_slab(e);
     e->host_pos_valid = e->host_vel_valid = true;
     e->dev_valid = false;

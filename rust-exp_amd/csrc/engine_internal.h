@@ -98,7 +98,19 @@ struct nbx_engine {
     bool any_pending() const { return pending[0].active || pending[1].active; }
     int bh_async = 1;
     int bh_last_tree_device = 0;   // where the last evaluated tree was built
-    int bh_fallbacks = 0;          // device builds that fell back to the host (node pool exhausted)
+    int bh_fallbacks = 0;          // steps / evaluations the device tree was selected for but the host tree served
+    // Consecutive refused device builds (a dense core keeps its EPS clusters for many steps): from the second refusal in a row
+    // the next 2, 4, .. kBackoffMaxSteps steps go straight to the host build -- counted in bh_fallbacks like the refusals -- and
+    // then ONE step tries the device again.  Any replaced state (after_host_state_change) and any accepted build reset it.
+    int bh_refusal_streak = 0, bh_host_steps_left = 0;
+    void note_refusal(int max_steps)
+    {
+        if (++bh_refusal_streak >= 2 && max_steps > 0) {
+            const int k = bh_refusal_streak - 1;
+            bh_host_steps_left = k >= 30 || (1 << k) > max_steps ? max_steps : (1 << k);
+        }
+    }
+    void note_accepted() { bh_refusal_streak = 0; }
     void* d_counts = nullptr;      // device draw: uint2 hit counters per pixel
     size_t counts_cap = 0;         // pixels
     unsigned* d_fb = nullptr;

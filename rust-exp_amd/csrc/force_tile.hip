@@ -419,6 +419,11 @@ __global__ __launch_bounds__(kTile) void k_force_smem_pk(const float4* __restric
 // the per-interaction v_pk_mul (m_j * inv) leaves the loop -- 9 packed ops + 2 rcp per 2 interactions instead of 10 + 2 --
 // and the common mass multiplies the finished sums.  Sources are then weightless, so the zero-mass padding records cannot be
 // swept: the source loop ends at the true body count.
+// (Round 3, rejected: ONE v_rcp_f32 for a lane's four interactions with a source -- r = 1/(abcd) from two multiplies, the four
+//  inverses back with three packed multiplies: 18 packed + 4 packed + 1 mul + 1 rcp = 100 issue cycles instead of 104.  Measured
+//  2 % fewer cycles per step, but the extra packed multiplies cost more power than the three v_rcp_f32 they replace: at the same
+//  1.3 kW the clock settles at 2 178 MHz instead of 2 312 and the step takes 12.92 ms instead of 12.42
+//  (profiles/r03_k1_grouped_rcp_ab.txt).  The sweep is power-limited: fewer joules per interaction, not fewer issue slots.)
 // K4 (fp16 sources): `src` is not posm but the widened fp16 copy of it, so a target's own source record is NOT at the target's
 // fp32 position and its term is no exact zero: K2 / the force readout recompute it with the sweep's arithmetic and take it out
 // (SelfImage) -- the sweep itself is the same kernel, instruction for instruction.

@@ -596,3 +596,42 @@ def test_reference_fold_detects_merges_between_non_neighbouring_entities(rx, ob)
     a, b = h.get_particles(), d.get_particles()
     for kk in ("px", "py", "vx", "vy"):
         assert np.array_equal(a[kk].view(np.uint32), b[kk].view(np.uint32)), kk
+
+
+def test_refusals_in_a_row_back_off_to_the_host_build(rx, ob):
+    """A dense core keeps its EPS clusters for many steps: after the second refused device build in a row the next 2, 4, 8 ..
+    steps go straight to the host build, then one step tries the device again (engine_internal.h note_refusal).  Every step is
+    the host-tree step, bit for bit; the number of device builds attempted is read from the profile; a new state resets it."""
+    from rust_exp_amd.engine import NBX_K_TREE_BUILD, NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+
+    rng = np.random.default_rng(77)
+    n0 = 6000
+    x = rng.uniform(-20, 20, n0).astype(np.float32); y = rng.uniform(-20, 20, n0).astype(np.float32)
+    x2 = np.concatenate([x, x[:5] + np.float32(3e-5), x[:5] - np.float32(2e-5)])      # five EPS triples, at rest
+    y2 = np.concatenate([y, y[:5] + np.float32(1e-5), y[:5] + np.float32(4e-5)])
+    n = len(x2)
+    q = ob.particles(x2, y2, np.zeros(n), np.zeros(n), np.full(n, 1e-6))
+    from rust_exp_amd.engine import NBX_OPT_BH_ASYNC
+    h = engines(rx, q); h.set_bh_tree("host")
+    steps = 12
+    for _ in range(steps):
+        h.step_barnes_hut(0.85, 1e-4, 1)
+    a = h.get_particles()
+    for async_ in (1, 0):
+        d = engines(rx, q)
+        d.set_option(NBX_OPT_BH_ASYNC, async_)
+        d.profile(True)
+        for _ in range(steps):
+            d.step_barnes_hut(0.85, 1e-4, 1)
+        b = d.get_particles()
+        for k in ("px", "py", "vx", "vy"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+        assert d.get_option(NBX_OPT_BH_FALLBACKS) == steps and d.get_option(NBX_OPT_BH_LAST_TREE) == 0
+        # attempts: steps 1, 2 (refused twice -> 2 host steps), 5 (-> 4 host steps), 10 (-> 8 host steps); the pipelined form had
+        # step 2's build in flight when step 1's verdict arrived (poisoned, enqueued again): one build more
+        assert d.profile_read(NBX_K_TREE_BUILD)[1] == (5 if async_ else 4)
+    # a new state starts afresh: the device tree serves it at once
+    p = ob.stable_orbits(6000, 0.5, 30.0, 3)
+    d.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    d.step_barnes_hut(0.85, 0.01, 1)
+    assert d.get_option(NBX_OPT_BH_LAST_TREE) == 1 and d.get_option(NBX_OPT_BH_FALLBACKS) == steps

@@ -11,7 +11,10 @@ sys.path.insert(0, ROOT)
 import rust_exp_amd as rx  # noqa: E402
 from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS  # noqa: E402
 
-for scene, n in (("stable_orbits", 10000), ("random_disk", 10000), ("random_disk", 2000), ("stable_orbits", 65536), ("random_disk", 65536)):
+CASES = (("stable_orbits", 10000), ("random_disk", 10000), ("random_disk", 2000), ("stable_orbits", 65536), ("random_disk", 65536))
+if len(sys.argv) > 1:   # e.g. random_disk:65536
+    CASES = tuple((a.split(":")[0], int(a.split(":")[1])) for a in sys.argv[1:])
+for scene, n in CASES:
     e = rx.NBodyEngine()
     e.seed(11)
     if scene == "stable_orbits":
