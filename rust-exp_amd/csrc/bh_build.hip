@@ -9,7 +9,9 @@
 //      reference's own f32 midpoint arithmetic (cx = (x1+x2)*0.5, nbody.rs:289-290, :324-331) for 31 levels
 //      -> 62-bit key, 2 bits per level, quadrant order [UL,UR,LL,LR] = 0..3 like the reference's child array
 //   3. radix sort (rocPRIM) of (key, body index)
-//   3b. the reference's EPS merge of close PAIRS, decided from the sorted keys and the arrival order (see there)
+//   3b. the reference's EPS merge (nbody.rs:249-260) -- reference fold: whole clusters of close bodies replayed in arrival order
+//       (k_cells / k_blobs / k_place, section 3c); exact-sum class: close PAIRS decided from the sorted keys and the arrival
+//       order (k_merge_links / k_merge_keys, section 3b)
 //   4. nodes straight from the sorted keys: every node is (first body a, depth l); how many nodes start at each body
 //      follows from the digits it shares with its two neighbours, an exclusive scan of those counts gives every node's
 //      PRE-ORDER slot, and a node's skip pointer is the slot of the first node after its bodies (see "the tree from
@@ -18,8 +20,9 @@
 //      fold = 1 (default up to 65 536 bodies): the reference's f32 running fold over the node's bodies in ARRIVAL order
 //               (nbody.rs:303-320) -- small nodes in k_emit, the others in k_fold_big (one pair of waves per node: m chain, IEEE
 //               reciprocals, p chain), the root on a side stream from the start of the build.  The flattened tree then equals the
-//               host tree BIT FOR BIT; whatever the pairs-only merge cannot reproduce node for node (a third body within EPS,
-//               a blob whose centre leaves its first member's cell) is detected and the step goes to the host build.
+//               host tree BIT FOR BIT; what the cluster replay cannot reproduce node for node (a blob whose centre leaves its
+//               first member's path above its leaf, a merge that hinges on another cluster, ...: 3c) is detected and the step
+//               goes to the host build.
 //      fold = 0 (above 65 536 bodies): deterministic fp64 prefix sums over the sorted bodies, one rounding to f32 per node.
 //      Node sizes: the first body's path replayed with the reference's f32 midpoints.
 //
@@ -35,8 +38,8 @@
 //     more than max(16, n/2000) such bodies send the step to the host build;
 //   * no depth-50 panic (nbody.rs:230-232): keys stop at level 31.
 // A pair within EPS whose members are not neighbours in key order (a third body of their common cell between them) merges in the
-// reference when every body between them arrived later: the neighbours-only merge misses it.  fold = 1 finds every such case
-// (k_close_scan, step 3c) and hands the step to the host build; fold = 0 lives with it (its own tolerance class).
+// reference when every body between them arrived later: the neighbours-only merge misses it.  fold = 1 replays it like every
+// other cluster (3c); fold = 0 lives with it (its own tolerance class).
 #include <cstring>   // rocPRIM's texture_cache_iterator.hpp calls memset() without including it
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -124,13 +127,44 @@ __device__ __forceinline__ int descend(float& x1, float& y1, float& x2, float& y
     return q;
 }
 
+__device__ __forceinline__ void fold_mass(float& px, float& py, float& m, const float qx, const float qy, const float qm)
+{
+    if (m == 0.0f) { px = qx; py = qy; m = qm; return; }                 // nbody.rs:305-311
+    const float inv = 1.0f / __fadd_rn(m, qm);                            // :315
+    px = __fmul_rn(__fadd_rn(__fmul_rn(px, m), __fmul_rn(qx, qm)), inv);  // :316
+    py = __fmul_rn(__fadd_rn(__fmul_rn(py, m), __fmul_rn(qy, qm)), inv);  // :317
+    m = __fadd_rn(m, qm);                                                 // :318
+}
+
+// one level down by a recorded quadrant choice: the child's AABB as create_children makes it (nbody.rs:289-300)
+__device__ __forceinline__ void descend_digit(float& x1, float& y1, float& x2, float& y2, const int q)
+{
+    const float cx = __fmul_rn(__fadd_rn(x1, x2), 0.5f);
+    const float cy = __fmul_rn(__fadd_rn(y1, y2), 0.5f);
+    if (q & 2) y2 = cy; else y1 = cy;
+    if (q & 1) x1 = cx; else x2 = cx;
+}
+
+// the path of an arbitrary point (a blob's centre): the same 31 quadrant choices k_keys records for a body
+__device__ __forceinline__ unsigned long long path_key(const unsigned* __restrict__ box, const float x, const float y)
+{
+    float x1 = dec_f32(box[0]), y1 = dec_f32(box[1]), x2 = dec_f32(box[2]), y2 = dec_f32(box[3]);
+    unsigned long long key = 0;
+#pragma unroll 1
+    for (int l = 0; l < kLevels; l++) key = (key << 2) | (unsigned long long)descend(x1, y1, x2, y2, x, y);
+    return key;
+}
+
 __global__ __launch_bounds__(kTile) void k_keys(const float4* __restrict__ posm, const int n,
                                                 const unsigned* __restrict__ box, unsigned long long* __restrict__ keys,
-                                                unsigned* __restrict__ idx, int* __restrict__ counters)
+                                                unsigned* __restrict__ idx, int* __restrict__ counters,
+                                                unsigned long long* __restrict__ cell_table, const int cell_slots)
 {
     const int i = blockIdx.x * kTile + threadIdx.x;
     // this build's counters and tickets (see Workspace): cleared here instead of by a memset of their own
-    if (i < 4) counters[i] = 0;
+    if (i < 8) counters[i] = 0;
+    // ... and the table of occupied grid cells that k_cells fills after the sort (reference fold only; at most 4 slots per body)
+    for (int t = i; t < cell_slots; t += (int)gridDim.x * kTile) cell_table[t] = 0ull;
     if (i >= n) return;
     float x1 = dec_f32(box[0]), y1 = dec_f32(box[1]), x2 = dec_f32(box[2]), y2 = dec_f32(box[3]);
     const float4 p = posm[i];
@@ -261,114 +295,411 @@ __global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict_
     close[j] = out;
 }
 
-// ---- 3c. what the pairs-only, neighbours-only merge above cannot see (reference fold only: that class promises the reference's
-// tree node for node or a hand-over to the host build) -------------------------------------------------------------------------
-// k_merge_links examines NEIGHBOURING entities of the key order.  Two bodies within EPS need not be neighbours (a cell boundary
-// between them puts other bodies in between), and the reference still merges them when every body between them arrived later;
-// and a body within EPS of a blob's centre is within 2 EPS of its members.  So: every entity looks at ALL entities within 2 EPS
-// (both axes) of it -- they sit in the 3 x 3 block of quadtree cells, at the deepest level whose cells are >= 2.5 EPS wide,
-// around its own cell, and every such cell is a contiguous range of the sorted keys (found by binary search) --
-//   * two or more of them: an EPS cluster the pairs-only merge may not reproduce  -> counted, host build
-//   * exactly one, within EPS, NOT a neighbour in key order: would the reference merge them (no earlier-arrived body shares
-//     their common cell)?  then the device tree misses a merge                  -> counted, host build
-//   * exactly one, a neighbour: k_merge_links' business (and k_emit checks the blob's path)
-// More than kCloseScanCap candidates in the block (a collinear or collapsed system): counted as well.
-constexpr int kCloseScanCap = 512;
+// ---- 3c. the reference's EPS merge in full (reference fold: that class promises the reference's tree node for node) ---------
+//
+// Sequential insertion (nbody.rs:226-284) decides a body B's fate when it ARRIVES: among the entities in the tree at that moment
+// -- single bodies and blobs of merged bodies -- B walks down to the leaf of the one entity A that shares the most leading path
+// digits with it (a tie, or none: B opens a leaf of its own); if A's current centre is closer than EPS in both axes B is folded
+// into A (add_mass), else the leaf splits and B becomes an entity.  A blob's centre moves with every member, later arrivals are
+// tested against the moved centre, and the blob travels down by its centre whenever its leaf splits (nbody.rs:271-281).
+// All of this involves only bodies within 2 EPS of one another: B within EPS of a centre is within 2 EPS of one of the members.
+// So:
+//   * k_cells   a hash table of the occupied cells of a grid (the quadtree level whose cells are >= 2.5 EPS wide; a cell is a
+//               contiguous range of the sorted keys) -> "who is within 2 EPS of this point" is nine probes, not a search;
+//   * k_blobs   every entity-by-key (a run of identical keys; usually one body) looks around; one with company that arrived
+//               before all of its neighbours collects its connected component (chains of < 2 EPS links; usually 2-5 bodies) and,
+//               if it is the component's first arrival, REPLAYS the component's arrivals in index order, by the rule above:
+//               entities in LDS, exact f32 folds, the nearest-entity rule from the keys, outside bodies that arrived earlier and
+//               share the cell taken into account (k_merge_links' rival scan).  Members that end in another entity's blob take
+//               that entity's key ("ghosts": listed for k_place);
+//   * k_place   the bodies in the order of their ENTITY keys (a ghost moves next to its entity: usually by a slot or two, but by
+//               any distance when a coarse cell boundary runs between the two) -- keys, indices, records, out of place.
+// The tree files a blob under the key of its FIRST member.  What that, or the replay, cannot reproduce soundly is not guessed:
+// the step then goes to the host build (counted in counters[1], the reasons in counters[5]):
+//   * a blob centre whose path leaves the path of the blob's first member above the blob's final leaf (the reference would
+//     have sent the blob down another branch at some split; k_emit compares pmin with the leaf depth).  Following the centres
+//     exactly -- a path made of stretches, one per centre -- was built too: every entity's depth over time then hinges on its
+//     nearest earlier-arrived neighbours in key order, and in the dense cores where blobs form those are members of OTHER
+//     components more often than not (the 10 000-body nb_random_disk: 695 of 1 000 steps refused, against 1 like this);
+//   * a body of ANOTHER component among the rivals of a merge (its entity may sit elsewhere),
+//   * any body outside the component within EPS of any centre a blob ever had (the 2 EPS argument holds for exact arithmetic;
+//     this checks the computed centres),
+//   * two entities in one level-31 cell that do not merge (the reference goes deeper than the keys do),
+//   * components of more than kBlobRuns entities / kBlobBodies bodies, more than kGhostCap ghosts, crowded neighbourhoods.
+constexpr int kCloseScanCap = 512;     // entities looked at around one point
 constexpr int kSideStreamsFrom = 4096;
+constexpr int kBlobRuns = 48;
+constexpr int kBlobBodies = 96;
+constexpr int kGhostCap = 2048;
+constexpr int kRivalScanCap = 1024;
 
-__device__ __forceinline__ int lower_bound_key(const unsigned long long* __restrict__ keys, const int n, const unsigned long long v)
+// why a build of the reference-fold class refused: counters[1] counts, counters[5] collects these bits (NBX_LOG prints them)
+enum : int {
+    kWhyCrowdedScan = 1,      // more than kCloseScanCap entities around one point
+    kWhyBigComponent = 4,     // more than kBlobRuns entities / kBlobBodies bodies in one component
+    kWhyRival = 8,            // a merge hinges on a body of another component (or on too long a scan)
+    kWhyOutsider = 16,        // somebody outside the component within EPS of a blob's centre
+    kWhyLevel31 = 32,         // two entities in one level-31 cell that do not merge
+    kWhyGhosts = 64,          // more than kGhostCap bodies to move
+    kWhyCentrePath = 128,     // a blob's centre left the path of its first member above the blob's leaf
+    kWhyBigLeaf = 256,        // a leaf of more bodies than the leaf fold orders
+};
+__device__ __forceinline__ void refuse(int* __restrict__ counters, const int why)
 {
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (keys[mid] < v) lo = mid + 1; else hi = mid;
-    }
-    return lo;
+    atomicAdd(&counters[1], 1);
+    atomicOr(&counters[5], why);
 }
 
-__global__ __launch_bounds__(kTile) void k_close_scan(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
-                                                      const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const int n,
-                                                      int* __restrict__ crowded)
+struct CellGrid {
+    int D, sh;                         // D digits of a key name a grid cell; key >> sh = the cell's prefix
+    const unsigned long long* hk;      // open addressing: prefix + 1 (0 = free) ...
+    const int* hv;                     // ... -> the first sorted slot of the cell
+    unsigned mask;
+};
+
+__device__ __forceinline__ CellGrid make_grid(const unsigned* __restrict__ box, const unsigned long long* hk, const int* hv,
+                                              const unsigned mask)
 {
-    const int j = blockIdx.x * kTile + threadIdx.x;
-    if (j >= n) return;
-    const unsigned long long k = keys[j];
-    if (j > 0 && keys[j - 1] == k) return;            // the first body of an entity speaks for it
-    // grid level: cells at least 2.5 EPS wide in both axes (widths halve per level; the f32 midpoints move them by rounding only)
+    // cells at least 2.5 EPS wide in both axes (widths halve per level; the f32 midpoints move them by rounding only)
     float wx = dec_f32(box[2]) - dec_f32(box[0]), wy = dec_f32(box[3]) - dec_f32(box[1]);
     int D = 0;
     while (D < kLevels && wx * 0.5f >= 2.5f * kEps && wy * 0.5f >= 2.5f * kEps) { wx *= 0.5f; wy *= 0.5f; D++; }
-    unsigned ix = 0, iy = 0;                          // this entity's cell: one bit per level (x: right = 1; y: lower = 1)
-    for (int l = 0; l < D; l++) {
-        const unsigned q = (unsigned)(k >> (2 * (kLevels - 1 - l))) & 3u;
+    return CellGrid{D, 2 * (kLevels - D), hk, hv, mask};
+}
+
+__device__ __forceinline__ unsigned hash_cell(unsigned long long c)
+{
+    c ^= c >> 33; c *= 0xff51afd7ed558ccdull;
+    c ^= c >> 33; c *= 0xc4ceb9fe1a85ec53ull;
+    c ^= c >> 33;
+    return (unsigned)c;
+}
+
+// Gathers the bodies into sorted order (sb[j] = posm[idx[j]]), starts every body as its own entity, and enters the first body
+// of every grid cell into the table.
+__global__ __launch_bounds__(kTile) void k_cells(const float4* __restrict__ posm, float4* __restrict__ sb,
+                                                 const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
+                                                 const unsigned* __restrict__ box, const int n, unsigned long long* __restrict__ hk,
+                                                 int* __restrict__ hv, const unsigned mask, unsigned long long* __restrict__ ekey,
+                                                 unsigned char* __restrict__ pmin)
+{
+    const int j = blockIdx.x * kTile + threadIdx.x;
+    if (j >= n) return;
+    sb[j] = posm[idx[j]];
+    const unsigned long long k = keys[j];
+    ekey[j] = k;
+    pmin[j] = (unsigned char)kLevels;
+    const CellGrid g = make_grid(box, hk, hv, mask);
+    const unsigned long long prefix = k >> g.sh;
+    if (j > 0 && (keys[j - 1] >> g.sh) == prefix) return;
+    unsigned h = hash_cell(prefix) & mask;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&hk[h], 0ull, prefix + 1ull);   // (a prefix is entered once: by its first slot)
+        if (old == 0ull) { hv[h] = j; return; }
+        h = (h + 1u) & mask;
+    }
+}
+
+__device__ __forceinline__ int cell_start(const CellGrid& g, const unsigned long long prefix)
+{
+    unsigned h = hash_cell(prefix) & g.mask;
+    for (;;) {
+        const unsigned long long kk = g.hk[h];
+        if (kk == 0ull) return -1;
+        if (kk == prefix + 1ull) return g.hv[h];
+        h = (h + 1u) & g.mask;
+    }
+}
+
+// f(first slot of an entity-by-key) for every one in the 3 x 3 block of grid cells around the cell of `at` (a path key), until f
+// returns false.  0: all visited; 1: stopped by f; 2: more than kCloseScanCap of them (a collinear or collapsed system)
+template <class F>
+__device__ __forceinline__ int visit_entities_near(const CellGrid& g, const unsigned long long at,
+                                                   const unsigned long long* __restrict__ keys, const int n, F&& f)
+{
+    unsigned ix = 0, iy = 0;                          // one bit per level (x: right = 1; y: lower = 1)
+    for (int l = 0; l < g.D; l++) {
+        const unsigned q = (unsigned)(at >> (2 * (kLevels - 1 - l))) & 3u;
         ix = (ix << 1) | (q & 1u);
         iy = (iy << 1) | (q >> 1);
     }
-    const int sh = 2 * (kLevels - D);
-    const float4 p = sb[j];
-    int n2 = 0, nb = -1, seen = 0;
-    const unsigned lim = D == 0 ? 1u : (D >= 32 ? 0xFFFFFFFFu : (1u << D));
-    // the nine cells' key ranges: eighteen lower bounds found IN LOCKSTEP (one bisection step of all of them per iteration, so
-    // their loads overlap: a chain of ~log2(n) dependent loads instead of eighteen times that)
-    unsigned long long bound[18];
-    int pos[18];
-    bool cell_ok[9];
-#pragma unroll
+    const long long lim = 1ll << g.D;
+    int seen = 0;
     for (int c9 = 0; c9 < 9; c9++) {
         const long long cx = (long long)ix + (c9 % 3 - 1), cy = (long long)iy + (c9 / 3 - 1);
-        cell_ok[c9] = !(cx < 0 || cy < 0 || cx >= (long long)lim || cy >= (long long)lim);
+        if (cx < 0 || cy < 0 || cx >= lim || cy >= lim) continue;
         unsigned long long prefix = 0;
-        for (int l = 0; l < D; l++) {
-            const unsigned bx = (unsigned)(cx >> (D - 1 - l)) & 1u, by = (unsigned)(cy >> (D - 1 - l)) & 1u;
+        for (int l = 0; l < g.D; l++) {
+            const unsigned bx = (unsigned)(cx >> (g.D - 1 - l)) & 1u, by = (unsigned)(cy >> (g.D - 1 - l)) & 1u;
             prefix = (prefix << 2) | (unsigned long long)((by << 1) | bx);
         }
-        bound[2 * c9] = D == 0 ? 0ull : prefix << sh;
-        bound[2 * c9 + 1] = D == 0 ? ~0ull : (prefix + 1ull) << sh;   // (keys use 62 bits: ~0 is above all of them)
-        pos[2 * c9] = 0; pos[2 * c9 + 1] = 0;
-    }
-    int top = 1;
-    while (top <= n / 2) top <<= 1;                                   // largest power of two <= n
-    for (int step = top; step > 0; step >>= 1) {
-#pragma unroll
-        for (int b = 0; b < 18; b++)
-            if (pos[b] + step <= n && keys[pos[b] + step - 1] < bound[b]) pos[b] += step;   // pos = number of keys below the bound
-    }
-#pragma unroll
-    for (int c9 = 0; c9 < 9; c9++) {
-        if (!cell_ok[c9]) continue;
-        for (int t = pos[2 * c9]; t < pos[2 * c9 + 1]; t++) {
-            if (keys[t] == k) continue;                          // this entity itself
-            if (t > 0 && keys[t - 1] == keys[t]) continue;       // only the first body of the other entity
-            if (++seen > kCloseScanCap) { atomicAdd(crowded, 1); return; }
-            const float4 q = sb[t];
-            if (fabsf(__fsub_rn(p.x, q.x)) < 2.0f * kEps && fabsf(__fsub_rn(p.y, q.y)) < 2.0f * kEps) { n2++; nb = t; }
+        int t = cell_start(g, prefix);
+        if (t < 0) continue;
+        while (t < n && (keys[t] >> g.sh) == prefix) {
+            if (++seen > kCloseScanCap) return 2;
+            if (!f(t)) return 1;
+            t = run_end(keys, t, n);
         }
     }
-    if (n2 == 0) return;
-    if (n2 >= 2) { atomicAdd(crowded, 1); return; }
-    const float4 q = sb[nb];
-    if (!(fabsf(__fsub_rn(p.x, q.x)) < kEps && fabsf(__fsub_rn(p.y, q.y)) < kEps)) return;   // nbody.rs:249: not too close
-    if (run_end(keys, j, n) == nb || run_end(keys, nb, n) == j) return;                       // neighbours: k_merge_links decides
-    if (nb < j) return;                                                                       // the pair is judged once, by its left member
-    // would the reference merge them?  (as in k_merge_links, with everything between them among the rivals)
-    const int c = common_digits(k, keys[nb]);
-    const unsigned ia = idx[j], ib = idx[nb];
-    const unsigned second = ia > ib ? ia : ib;
-    const unsigned long long kf = ia < ib ? k : keys[nb];
-    bool rival = false;
+    return 0;
+}
+
+__device__ __forceinline__ bool within(const float4 a, const float4 b, const float r)
+{
+    return fabsf(__fsub_rn(a.x, b.x)) < r && fabsf(__fsub_rn(a.y, b.y)) < r;
+}
+
+struct BlobShared {
+    int run_first[kBlobRuns], run_last[kBlobRuns];   // the component: entities by key, as ranges of sorted slots
+    int mem_slot[kBlobBodies];                       // its bodies in arrival order ...
+    unsigned mem_idx[kBlobBodies];
+    unsigned char mem_ent[kBlobBodies];              // ... and the entity each of them ended in
+    unsigned char ent_pmin[kBlobBodies];             // entities of the replay: fewest digits any of its centres shared with its key
+    unsigned long long ent_key[kBlobBodies];         //   the key of the body that opened it
+    float ent_x[kBlobBodies], ent_y[kBlobBodies], ent_m[kBlobBodies];
+    int ent_first[kBlobBodies];                      //   that body's sorted slot
+};
+
+__device__ __forceinline__ bool in_component(const BlobShared& s, const int nruns, const int slot)
+{
+    for (int u = 0; u < nruns; u++)
+        if (slot >= s.run_first[u] && slot < s.run_last[u]) return true;
+    return false;
+}
+
+struct ReplayView {
+    const CellGrid& g;
+    const float4* __restrict__ sb;
+    const unsigned long long* __restrict__ keys;
+    const unsigned* __restrict__ idx;
+    const unsigned* __restrict__ box;
+    int n;
+};
+
+// Is a body that does not belong to the component, arrived before body (slot, ib) and shares at least c digits with it in the
+// tree when that body arrives?  0 no, 1 yes (the body then never reaches the component's entity), 2 cannot tell -> host build
+__device__ __forceinline__ int outside_rival(const BlobShared& s, const int nruns, const ReplayView& v, const int slot,
+                                             const unsigned long long kb, const unsigned ib, const int c)
+{
     int steps = 0;
-    for (int x = j - 1; x >= 0 && !rival; x--) {
-        if (common_digits(kf, keys[x]) < c) break;
-        if (++steps > kMergeScanCap) { atomicAdd(crowded, 1); return; }
-        rival = idx[x] < second;
+    for (int dir = -1; dir <= 1; dir += 2) {
+        for (int x = slot + dir; x >= 0 && x < v.n; x += dir) {
+            if (common_digits(kb, v.keys[x]) < c) break;
+            if (++steps > kRivalScanCap) return 2;
+            if (v.idx[x] >= ib || in_component(s, nruns, x)) continue;   // arrives later / the replay knows it
+            // an outsider that was there first.  It is an entity under its own key unless it belongs to a component of its own
+            // (then its entity may carry another member's key): anybody within 2 EPS of it?
+            const float4 px = v.sb[x];
+            const unsigned long long kx = v.keys[x];
+            bool company = false;
+            const int st = visit_entities_near(v.g, kx, v.keys, v.n, [&](const int t) {
+                if (v.keys[t] == kx) return true;
+                if (within(px, v.sb[t], 2.0f * kEps)) { company = true; return false; }
+                return true;
+            });
+            return (st == 2 || company) ? 2 : 1;
+        }
     }
-    for (int x = j + 1; x < n && !rival; x++) {
-        if (keys[x] == k || keys[x] == keys[nb]) continue;           // later arrivals of the two entities themselves
-        if (common_digits(kf, keys[x]) < c) break;
-        if (++steps > kMergeScanCap) { atomicAdd(crowded, 1); return; }
-        rival = idx[x] < second;
+    return 0;
+}
+
+// The component's arrivals replayed in index order by ONE lane.  0, or why the host build has to do this step.
+__device__ int replay_component(BlobShared& s, const int nruns, const ReplayView& v, unsigned long long* __restrict__ ekey,
+                                unsigned char* __restrict__ pmin, int* __restrict__ ghosts, int* __restrict__ counters)
+{
+    int k = 0;
+    for (int r = 0; r < nruns; r++)
+        for (int slot = s.run_first[r]; slot < s.run_last[r]; slot++) {   // (the caller made sure they fit)
+            const unsigned a = v.idx[slot];
+            int pos = k++;
+            while (pos > 0 && s.mem_idx[pos - 1] > a) { s.mem_idx[pos] = s.mem_idx[pos - 1]; s.mem_slot[pos] = s.mem_slot[pos - 1]; pos--; }
+            s.mem_idx[pos] = a;
+            s.mem_slot[pos] = slot;
+        }
+    int ne = 0;
+    for (int t = 0; t < k; t++) {
+        const int slot = s.mem_slot[t];
+        const unsigned long long kb = v.keys[slot];
+        const float4 pb = v.sb[slot];
+        int best = -1, cbest = -1;
+        bool tie = false;
+        for (int e = 0; e < ne; e++) {
+            const int c = common_digits(kb, s.ent_key[e]);
+            if (c > cbest) { cbest = c; best = e; tie = false; }
+            else if (c == cbest) tie = true;
+        }
+        bool fresh = best < 0 || tie;   // no entity of the component yet / two equally near: a leaf of its own (nbody.rs:234-240)
+        if (!fresh) {
+            const int st = outside_rival(s, nruns, v, slot, kb, s.mem_idx[t], cbest);
+            if (st == 2) return kWhyRival;
+            fresh = st == 1;
+        }
+        if (!fresh) {
+            // arrives at entity `best`'s leaf (nbody.rs:249-260)
+            if (fabsf(__fsub_rn(s.ent_x[best], pb.x)) < kEps && fabsf(__fsub_rn(s.ent_y[best], pb.y)) < kEps) {
+                float x = s.ent_x[best], y = s.ent_y[best], m = s.ent_m[best];
+                fold_mass(x, y, m, pb.x, pb.y, pb.w);
+                s.ent_x[best] = x; s.ent_y[best] = y; s.ent_m[best] = m;
+                s.mem_ent[t] = (unsigned char)best;
+                const unsigned long long kc = path_key(v.box, x, y);
+                const int c = common_digits(kc, s.ent_key[best]);
+                if (c < (int)s.ent_pmin[best]) s.ent_pmin[best] = (unsigned char)c;
+                // nobody outside the component may ever be within EPS of this centre
+                const float4 centre = make_float4(x, y, 0.0f, 0.0f);
+                const int st = visit_entities_near(v.g, kc, v.keys, v.n, [&](const int u) {
+                    return !within(centre, v.sb[u], kEps) || in_component(s, nruns, u);
+                });
+                if (st != 0) return kWhyOutsider;
+                continue;
+            }
+            if (cbest >= kLevels) return kWhyLevel31;   // the same level-31 cell and not close: the reference splits deeper than the keys go
+        }
+        s.ent_key[ne] = kb;
+        s.ent_x[ne] = pb.x; s.ent_y[ne] = pb.y; s.ent_m[ne] = pb.w;
+        s.ent_first[ne] = slot;
+        s.ent_pmin[ne] = (unsigned char)kLevels;
+        s.mem_ent[t] = (unsigned char)ne;
+        ne++;
     }
-    if (!rival) atomicAdd(crowded, 1);                               // a merge the neighbours-only logic cannot represent
+    int why = 0;
+    for (int t = 0; t < k; t++) {
+        const int slot = s.mem_slot[t];
+        const unsigned long long ke = s.ent_key[s.mem_ent[t]];
+        if (ke == v.keys[slot]) continue;
+        ekey[slot] = ke;                                     // a ghost: filed under its entity's key
+        const int gi = atomicAdd(&counters[4], 1);
+        if (gi < kGhostCap) ghosts[gi] = slot; else why = kWhyGhosts;
+    }
+    for (int e = 0; e < ne; e++) pmin[s.ent_first[e]] = s.ent_pmin[e];
+    return why;
+}
+
+__global__ __launch_bounds__(kTile) void k_blobs(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
+                                                 const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const int n,
+                                                 const unsigned long long* __restrict__ hk, const int* __restrict__ hv,
+                                                 const unsigned mask, unsigned long long* __restrict__ ekey,
+                                                 unsigned char* __restrict__ pmin, int* __restrict__ ghosts, int* __restrict__ counters)
+{
+    __shared__ BlobShared bs[kTile / 64];             // one component at a time per wave
+    const int j = blockIdx.x * kTile + threadIdx.x;
+    const CellGrid g = make_grid(box, hk, hv, mask);
+    bool root = false;
+    unsigned mine = 0;
+    if (j < n && !(j > 0 && keys[j - 1] == keys[j])) {   // the first body of an entity-by-key speaks for it
+        const unsigned long long kj = keys[j];
+        const float4 p = sb[j];
+        mine = idx[j];
+        bool company = false, later = true;
+        const int st = visit_entities_near(g, kj, keys, n, [&](const int t) {
+            if (keys[t] == kj || !within(p, sb[t], 2.0f * kEps)) return true;
+            company = true;
+            if (idx[t] < mine) later = false;
+            return true;
+        });
+        if (st == 2) refuse(counters, kWhyCrowdedScan);
+        // alone, or a neighbour arrived first (the component's first arrival replays it): nothing to do
+        root = st != 2 && company && later;
+        const int last = run_end(keys, j, n);
+        if (st != 2 && !company && last - j > 1) {
+            // Several bodies of one level-31 cell and nobody else around: one leaf -- as long as every arrival is within EPS of the
+            // centre the earlier ones have folded to.  Where an ulp of the coordinates is no longer small against EPS (|x| in the
+            // thousands) the folded centre of even IDENTICAL positions can sit more than EPS away (nbody.rs:315-317 round three
+            // times): the reference then splits, 31 levels are not enough, and the host build has to do it.
+            float cx = 0.0f, cy = 0.0f, cm = 0.0f;
+            bool one_leaf = true;
+            for (int t = j; t < last && one_leaf; t++) {          // (the stable sort left them in index order)
+                const float4 q = sb[t];
+                if (t > j && !(fabsf(__fsub_rn(cx, q.x)) < kEps && fabsf(__fsub_rn(cy, q.y)) < kEps)) one_leaf = false;
+                fold_mass(cx, cy, cm, q.x, q.y, q.w);
+            }
+            if (!one_leaf) refuse(counters, kWhyLevel31);
+        }
+    }
+    // the wave's candidates one after the other (they share the wave's LDS record; a lane cannot wait for another lane)
+    BlobShared& s = bs[threadIdx.x >> 6];
+    unsigned long long todo = __ballot(root);
+    while (todo) {
+        const int lane = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        if ((int)(threadIdx.x & 63) != lane) continue;
+        int nruns = 1;
+        s.run_first[0] = j;
+        s.run_last[0] = run_end(keys, j, n);
+        int bodies = s.run_last[0] - j;
+        bool first = true, fits = bodies <= kBlobBodies;
+        for (int r = 0; r < nruns && first && fits; r++) {
+            const int fr = s.run_first[r];
+            const float4 pr = sb[fr];
+            const unsigned long long kr = keys[fr];
+            const int st = visit_entities_near(g, kr, keys, n, [&](const int t) {
+                if (keys[t] == kr || !within(pr, sb[t], 2.0f * kEps)) return true;
+                for (int u = 0; u < nruns; u++)
+                    if (s.run_first[u] == t) return true;
+                if (idx[t] < mine) { first = false; return false; }
+                const int e = run_end(keys, t, n);
+                bodies += e - t;
+                if (nruns == kBlobRuns || bodies > kBlobBodies) { fits = false; return false; }
+                s.run_first[nruns] = t; s.run_last[nruns] = e;
+                nruns++;
+                return true;
+            });
+            if (st == 2) fits = false;
+        }
+        if (first) {
+            const ReplayView v{g, sb, keys, idx, box, n};
+            const int why = fits ? replay_component(s, nruns, v, ekey, pmin, ghosts, counters) : kWhyBigComponent;
+            if (why) refuse(counters, why);
+        }
+    }
+}
+
+// The bodies in the order of their entity keys.  Everybody but the ghosts keeps its relative order (their keys are sorted); a
+// ghost goes behind the bodies that carry its entity's key themselves.  Keys, indices, records and pmin, out of place.
+__global__ __launch_bounds__(kTile) void k_place(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ ekey,
+                                                 const unsigned* __restrict__ idx, const float4* __restrict__ sb,
+                                                 const unsigned char* __restrict__ pmin, const int* __restrict__ ghosts,
+                                                 const int* __restrict__ counters, const int n, unsigned long long* __restrict__ keys2,
+                                                 unsigned* __restrict__ idx2, float4* __restrict__ sb2, unsigned char* __restrict__ pmin2)
+{
+    __shared__ int gslot[kGhostCap];
+    __shared__ unsigned long long gkey[kGhostCap];
+    int G = counters[4];
+    const bool overflow = G > kGhostCap;              // the step is refused then: everybody stays where it is, under its own
+    if (overflow) G = 0;                              // key (the arrays below must hold a permutation whatever happens)
+    for (int t = threadIdx.x; t < G; t += kTile) {
+        const int sl = ghosts[t];
+        gslot[t] = sl;
+        gkey[t] = ekey[sl];
+    }
+    __syncthreads();
+    const int j = blockIdx.x * kTile + threadIdx.x;
+    if (j >= n) return;
+    const unsigned long long own = keys[j], ek = overflow ? own : ekey[j];
+    int pos = j;
+    if (G > 0) {
+        if (ek == own) {
+            int before = 0, ahead = 0;
+            for (int t = 0; t < G; t++) { before += gslot[t] < j ? 1 : 0; ahead += gkey[t] < own ? 1 : 0; }
+            pos = j - before + ahead;
+        } else {
+            int lo = 0, hi = n;                       // first slot whose key is above the entity's
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (keys[mid] <= ek) lo = mid + 1; else hi = mid;
+            }
+            int before = 0, ahead = 0;
+            for (int t = 0; t < G; t++) {
+                before += gslot[t] < lo ? 1 : 0;
+                ahead += (gkey[t] < ek || (gkey[t] == ek && gslot[t] < j)) ? 1 : 0;
+            }
+            pos = lo - before + ahead;
+        }
+    }
+    if (pos < 0 || pos >= n) return;
+    keys2[pos] = ek;
+    idx2[pos] = idx[j];
+    sb2[pos] = sb[j];
+    pmin2[pos] = pmin[j];
 }
 
 // Pairs of entities only: of a chain of close boundaries every other one is dropped by the local rule "a boundary merges iff
@@ -508,15 +839,6 @@ __global__ __launch_bounds__(kTile) void k_scan_write(const float4* __restrict__
     }
 }
 
-__device__ __forceinline__ void fold_mass(float& px, float& py, float& m, const float qx, const float qy, const float qm)
-{
-    if (m == 0.0f) { px = qx; py = qy; m = qm; return; }                 // nbody.rs:305-311
-    const float inv = 1.0f / __fadd_rn(m, qm);                            // :315
-    px = __fmul_rn(__fadd_rn(__fmul_rn(px, m), __fmul_rn(qx, qm)), inv);  // :316
-    py = __fmul_rn(__fadd_rn(__fmul_rn(py, m), __fmul_rn(qy, qm)), inv);  // :317
-    m = __fadd_rn(m, qm);                                                 // :318
-}
-
 // first body j >= b that does NOT share its first `level` digits with body a (bodies [a, b) are known to)
 __device__ __forceinline__ int group_end(const unsigned long long* __restrict__ keys, const unsigned long long ka, int b,
                                          const int n, const int level)
@@ -541,7 +863,8 @@ __device__ __forceinline__ int group_end(const unsigned long long* __restrict__ 
 __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
                                           const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const Prefix pre,
                                           const int n, BhNode* __restrict__ out, const int fold, int4* __restrict__ big,
-                                          const int big_cap, int* __restrict__ counters, const int root_aside, const int k);
+                                          const int big_cap, int* __restrict__ counters, const int root_aside, const int k,
+                                          const unsigned char* __restrict__ pmin);
 //
 // fold (round 3): how an interior node's mass and centre are obtained.
 //   0 = exact: fp64 sums over the node's bodies, rounded once (round 2; systems above kFoldFaithfulMax bodies)
@@ -554,12 +877,13 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
                                                 const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const Prefix pre,
                                                 const int n, const int node_cap, BhNode* __restrict__ out, const int fold,
                                                 int4* __restrict__ big, const int big_cap, int* __restrict__ counters,
-                                                const int root_aside, BhWalk16* __restrict__ walk16, float* __restrict__ wmass)
+                                                const int root_aside, BhWalk16* __restrict__ walk16, float* __restrict__ wmass,
+                                                const unsigned char* __restrict__ pmin)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = pre.base[n];
     if (k < total && total <= node_cap) {
-        emit_node(sb, keys, idx, box, pre, n, out, fold, big, big_cap, counters, root_aside, k);
+        emit_node(sb, keys, idx, box, pre, n, out, fold, big, big_cap, counters, root_aside, k, pmin);
         if (walk16) {   // the compact copy for the wave-uniform walk (fold = 0: every record is final here)
             const float4* src = reinterpret_cast<const float4*>(&out[k]);
             const float4 a = src[0], c = src[1];
@@ -572,7 +896,8 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
 __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
                                           const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const Prefix pre,
                                           const int n, BhNode* __restrict__ out, const int fold, int4* __restrict__ big,
-                                          const int big_cap, int* __restrict__ counters, const int root_aside, const int k)
+                                          const int big_cap, int* __restrict__ counters, const int root_aside, const int k,
+                                          const unsigned char* __restrict__ pmin)
 {
     int a = 0;
     {
@@ -589,10 +914,11 @@ __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const u
     const int leaf = top + count - 1;
     const int l = top + (k - first);
     const float4 p = sb[a];
-    // node size: replay the body's path with the reference's f32 midpoints (nbody.rs:289-300)
+    // node size: the path replayed with the reference's f32 midpoints (nbody.rs:289-300), by the key's digits -- the quadrant
+    // choices of the body that opened the entity
     float x1 = dec_f32(box[0]), y1 = dec_f32(box[1]), x2 = dec_f32(box[2]), y2 = dec_f32(box[3]);
 #pragma unroll 1
-    for (int d = 0; d < l; d++) descend(x1, y1, x2, y2, p.x, p.y);
+    for (int d = 0; d < l; d++) descend_digit(x1, y1, x2, y2, (int)(ka >> (2 * (kLevels - 1 - d))) & 3);
     BhNode o;
     o.s = __fsub_rn(x2, x1);                        // nbody.rs:341
     o.pad1 = 0;
@@ -601,27 +927,51 @@ __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const u
         // ARRIVAL order like the reference's add_mass (nbody.rs:303-320).  Equal keys come out of the stable sort in index order;
         // a merged pair of entities is two such ascending segments back to back: fold them as a two-way merge by index.
         const int b = run_end(keys, a, n);
-        int split = b;                              // start of the second ascending segment, if any
+        int split = b, segments = 1;                // start of the second ascending segment, if any
         for (int j = a + 1; j < b; j++)
-            if (idx[j] < idx[j - 1]) { split = j; break; }
-        int u = a, v = split;
+            if (idx[j] < idx[j - 1]) {
+                if (segments == 1) split = j;
+                segments++;
+            }
         float px = 0.0f, py = 0.0f, m = 0.0f;
-        while (u < split || v < b) {
-            const bool take_u = v >= b || (u < split && idx[u] < idx[v]);
-            const float4 q = sb[take_u ? u : v];
-            if (take_u) u++; else v++;
-            fold_mass(px, py, m, q.x, q.y, q.w);    // the first one is copied exactly (m == 0 branch)
+        if (segments <= 2) {
+            int u = a, v = split;
+            while (u < split || v < b) {
+                const bool take_u = v >= b || (u < split && idx[u] < idx[v]);
+                const float4 q = sb[take_u ? u : v];
+                if (take_u) u++; else v++;
+                fold_mass(px, py, m, q.x, q.y, q.w);    // the first one is copied exactly (m == 0 branch)
+            }
+        } else if (b - a <= kBlobBodies) {
+            // a blob of several entities (k_place files the ghosts behind the entity's own run, in slot order): the next
+            // smallest index, b - a times
+            unsigned last = 0;
+            for (int t = 0; t < b - a; t++) {
+                unsigned best = 0xFFFFFFFFu;
+                int bj = a;
+                for (int j = a; j < b; j++) {
+                    const unsigned v = idx[j];
+                    if ((t == 0 || v > last) && v < best) { best = v; bj = j; }
+                }
+                const float4 q = sb[bj];
+                fold_mass(px, py, m, q.x, q.y, q.w);
+                last = best;
+            }
+        } else {
+            refuse(counters, kWhyBigLeaf);          // (the replay admits no blob this big)
         }
         o.px = px; o.py = py; o.m = m;
         o.skip = first + count;
         o.interior = 0; o.q = -1.0f;
+        // a blob's centres must have travelled down the path of its first member as far as this leaf (k_blobs)
+        if (pmin && (int)pmin[a] < l) refuse(counters, kWhyCentrePath);
         if (fold == 1 && b - a > 1 && (px != p.x || py != p.y)) {
             // A merged blob travels by its OWN centre in the reference (the split re-inserts (px, py), nbody.rs:271-281); this
             // leaf sits on the path of the blob's first member.  The same leaf unless the centre left the member's cell:
             float u1 = dec_f32(box[0]), v1 = dec_f32(box[1]), u2 = dec_f32(box[2]), v2 = dec_f32(box[3]);
 #pragma unroll 1
             for (int d = 0; d < l; d++) descend(u1, v1, u2, v2, px, py);
-            if (u1 != x1 || v1 != y1 || u2 != x2 || v2 != y2) atomicAdd(&counters[1], 1);   // counted as "crowded": host build
+            if (u1 != x1 || v1 != y1 || u2 != x2 || v2 != y2) refuse(counters, kWhyCentrePath);   // counted as "crowded": host build
         }
     } else if (fold == 1) {
         const int b = group_end(keys, ka, a + 1, n, l);
@@ -937,6 +1287,14 @@ __global__ __launch_bounds__(128) void k_fold_big(const float4* __restrict__ pos
 // [12..15] the root box (encoded); then 256 float4 partial boxes of k_bbox.
 constexpr size_t kHeaderBytes = 256 + 256 * sizeof(float4);
 
+// slots of the grid-cell table: a power of two, at least two per body (one cell per body at most)
+static size_t cell_table_slots(int n)
+{
+    size_t h = 1024;
+    while (h < 2 * (size_t)n) h <<= 1;
+    return h;
+}
+
 size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
 {
     (void)node_cap;   // the build needs no per-node scratch: nodes are written straight into the caller's array
@@ -955,8 +1313,14 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     add(sizeof(double) * ((size_t)n + 1) * 3);         // prefix sums m, m*x, m*y
     add(sizeof(int) * ((size_t)n + 1));                // pre-order base
     add(sizeof(ScanItem) * (nb + 1));                  // block sums
-    add((size_t)n);                                    // EPS-merge links
+    add((size_t)n);                                    // EPS-merge links / pmin
     add(sizeof(int4) * (size_t)n);                     // nodes queued for k_fold_big (more than n of them -> host build)
+    // reference fold: the EPS blobs (k_cells / k_blobs / k_place)
+    add(sizeof(float4) * (size_t)n);                   // bodies in entity order
+    add(sizeof(unsigned long long) * (size_t)n);       // entity keys
+    add((size_t)n);                                    // pmin in entity order
+    add((sizeof(unsigned long long) + sizeof(int)) * cell_table_slots(n));
+    add(sizeof(int) * kGhostCap);
     return bytes;
 }
 
@@ -979,6 +1343,13 @@ struct Workspace {
     ScanItem* block_sums;
     unsigned char* link;
     int4* big;
+    float4* sb2;
+    unsigned long long* ekey;
+    unsigned char* pmin2;
+    unsigned long long* hk;
+    int* hv;
+    unsigned hmask;
+    int* ghosts;
 };
 Workspace carve(void* workspace, int n, size_t sort_tmp)
 {
@@ -1002,15 +1373,25 @@ Workspace carve(void* workspace, int n, size_t sort_tmp)
     k.block_sums = reinterpret_cast<ScanItem*>(take(sizeof(ScanItem) * (nb + 1)));
     k.link = reinterpret_cast<unsigned char*>(take((size_t)n));
     k.big = reinterpret_cast<int4*>(take(sizeof(int4) * (size_t)n));
+    k.sb2 = reinterpret_cast<float4*>(take(sizeof(float4) * (size_t)n));
+    k.ekey = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * (size_t)n));
+    k.pmin2 = reinterpret_cast<unsigned char*>(take((size_t)n));
+    const size_t slots = cell_table_slots(n);
+    char* table = take((sizeof(unsigned long long) + sizeof(int)) * slots);
+    k.hk = reinterpret_cast<unsigned long long*>(table);
+    k.hv = reinterpret_cast<int*>(table + sizeof(unsigned long long) * slots);
+    k.hmask = (unsigned)(slots - 1);
+    k.ghosts = reinterpret_cast<int*>(take(sizeof(int) * kGhostCap));
     return k;
 }
 
 // root AABB -> path keys -> sorted (key, body) pairs in keys1 / idx1
-hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sort_tmp, hipStream_t stream)
+hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sort_tmp, hipStream_t stream, bool cell_table = false)
 {
     const int nb = (n + kTile - 1) / kTile;
     hipLaunchKernelGGL(k_bbox, dim3(nb < 256 ? nb : 256), dim3(kTile), 0, stream, posm, n, k.box, k.part, k.counters + 8);
-    hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, k.box, k.keys0, k.idx0, k.counters);
+    hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, k.box, k.keys0, k.idx0, k.counters, k.hk,
+                       cell_table ? (int)(k.hmask + 1u) : 0);
     return rocprim::radix_sort_pairs(k.sort_tmp, sort_tmp, k.keys0, k.keys1, k.idx0, k.idx1, (size_t)n, 0, 2 * kLevels, stream);
 }
 }  // namespace
@@ -1193,6 +1574,7 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
                                    hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, BhWalk16* walk16, float* wmass,
                                    hipStream_t side2, hipEvent_t ev_sorted, hipEvent_t ev_scanned)
 {
+    (void)side2; (void)ev_sorted; (void)ev_scanned;   // (round 3's neighbourhood scan ran beside the build; the replay is part of it)
     if (fold != 0) { walk16 = nullptr; wmass = nullptr; }   // (the fold kernels write centres and masses after k_emit)
     *perm_dev = nullptr;
     if (n <= 0) return hipSuccess;
@@ -1212,43 +1594,46 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
         hipLaunchKernelGGL(k_fold_root, dim3(1), dim3(128), 0, side, posm, n, out);
         if ((e = hipEventRecord(ev_done, side)) != hipSuccess) return e;
     }
-    e = sort_bodies(posm, n, k, sort_tmp, stream);
+    e = sort_bodies(posm, n, k, sort_tmp, stream, fold == 1);
     if (e != hipSuccess) return e;
     *perm_dev = k.idx1;
     const int nb = (n + kTile - 1) / kTile;
     const int sb = (n + kScanBlock - 1) / kScanBlock;
-    // EPS merge (pairs): links from the sorted keys + arrival order (this kernel also gathers the bodies into sorted order), then
-    // both members of a pair share one key (keys0 is free again after the sort); everything below works on the merged keys
-    hipLaunchKernelGGL(k_merge_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link);
-    const bool scan_aside = fold == 1 && side2 && ev_sorted && ev_scanned && n >= side_from;
+    // the bodies in sorted order and the reference's EPS merge; everything below works on ENTITY keys (every member of a
+    // blob carries the key of the blob's first arrival), the bodies' indices and records in that order
+    const unsigned long long* mk = k.keys0;      // (keys0 / idx0 are free again after the sort)
+    const unsigned* mi = k.idx1;
+    const float4* ms = k.sb;
+    const unsigned char* pmin = nullptr;
     if (fold == 1) {
-        // everything within 2 EPS of every entity: what the neighbours-only merge cannot see goes to the host build.  A
-        // latency-bound kernel (35-47 us) that only feeds the verdict: on a stream of its own beside merge, scan, emit and folds
-        if (scan_aside) {
-            if ((e = hipEventRecord(ev_sorted, stream)) != hipSuccess) return e;   // sorted keys + sorted bodies are final
-            if ((e = hipStreamWaitEvent(side2, ev_sorted, 0)) != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(k_close_scan, dim3(nb), dim3(kTile), 0, scan_aside ? side2 : stream, k.sb, k.keys1, k.idx1, k.box, n, k.counters + 1);
-        if (scan_aside && (e = hipEventRecord(ev_scanned, side2)) != hipSuccess) return e;
+        // blobs of any size, replayed (3c): the tree is then the reference's, node for node -- or the step is refused
+        hipLaunchKernelGGL(k_cells, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, k.box, n, k.hk, k.hv, k.hmask, k.ekey, k.link);
+        hipLaunchKernelGGL(k_blobs, dim3(nb), dim3(kTile), 0, stream, k.sb, k.keys1, k.idx1, k.box, n, k.hk, k.hv, k.hmask, k.ekey, k.link,
+                           k.ghosts, k.counters);
+        hipLaunchKernelGGL(k_place, dim3(nb), dim3(kTile), 0, stream, k.keys1, k.ekey, k.idx1, k.sb, k.link, k.ghosts, k.counters, n,
+                           k.keys0, k.idx0, k.sb2, k.pmin2);
+        mi = k.idx0; ms = k.sb2; pmin = k.pmin2;
+    } else {
+        // pairs of neighbouring entities only (3b): links from the sorted keys + arrival order (this kernel also gathers the
+        // bodies into sorted order), then both members of a pair share one key
+        hipLaunchKernelGGL(k_merge_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link);
+        hipLaunchKernelGGL(k_merge_keys, dim3(nb), dim3(kTile), 0, stream, k.keys1, k.idx1, k.link, n, k.keys0, k.counters + 1);
     }
-    hipLaunchKernelGGL(k_merge_keys, dim3(nb), dim3(kTile), 0, stream, k.keys1, k.idx1, k.link, n, k.keys0, k.counters + 1);
-    const unsigned long long* mk = k.keys0;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, k.sb, mk, n, k.block_sums, k.counters + 3);
-    hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, k.sb, mk, n, k.block_sums, k.pre, k.counters);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.counters + 3);
+    hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.pre, k.counters);
     // one thread per node; the node count is only known on the device, so the grid covers the whole pool (threads beyond
     // base[n] leave at once; the pool check is inside)
     const int eb = n <= 65536 ? 64 : kTile;   // spread a small system's few waves over the CUs
-    hipLaunchKernelGGL(k_emit, dim3((unsigned)((node_cap + eb - 1) / eb)), dim3(eb), 0, stream, k.sb, mk, k.idx1, k.box, k.pre, n, node_cap, out,
-                       fold, k.big, n, k.counters, root_aside ? 1 : 0, walk16, wmass);
+    hipLaunchKernelGGL(k_emit, dim3((unsigned)((node_cap + eb - 1) / eb)), dim3(eb), 0, stream, ms, mk, mi, k.box, k.pre, n, node_cap, out,
+                       fold, k.big, n, k.counters, root_aside ? 1 : 0, walk16, wmass, pmin);
     if (fold == 1) {
         // one pair of waves per queued node; the count lives on the device: enough workgroups for every plausible queue
         // (a uniform system queues ~n/5 nodes), they loop when there are more
         const int fb = n / 4 + 64;
-        hipLaunchKernelGGL(k_fold_big, dim3((unsigned)(fb < 8192 ? fb : 8192)), dim3(128), 0, stream, posm, k.sb, k.idx1, k.big, n, k.counters, n, out);
+        hipLaunchKernelGGL(k_fold_big, dim3((unsigned)(fb < 8192 ? fb : 8192)), dim3(128), 0, stream, posm, ms, mi, k.big, n, k.counters, n, out);
         if (root_aside && (e = hipStreamWaitEvent(stream, ev_done, 0)) != hipSuccess) return e;   // the tree is complete on `stream` from here
-        if (scan_aside && (e = hipStreamWaitEvent(stream, ev_scanned, 0)) != hipSuccess) return e;   // ... and so is the verdict
     }
-    if (host_counters && (e = hipMemcpyAsync(host_counters, k.counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if (host_counters && (e = hipMemcpyAsync(host_counters, k.counters, 8 * sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -43,6 +43,7 @@ __device__ __forceinline__ bool gate_open(const BuildGate g, int& n_nodes, const
     if (!g.counters) return true;
     if (mark && g.host_out) {
         g.host_out[0] = g.counters[0]; g.host_out[1] = g.counters[1]; g.host_out[2] = g.counters[2];
+        g.host_out[5] = g.counters[5];   // why the build refused, if it did (bh_build.hip kWhy..)
         __threadfence_system();
     }
     if (g.counters[kTreePoisonWord] != 0) return false;

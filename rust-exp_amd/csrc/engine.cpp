@@ -585,8 +585,8 @@ int build_tree_on_device_end(nbx_engine* e, bool* done)
         e->d_perm = nullptr;
         if (std::getenv("NBX_LOG"))
             std::fprintf(stderr, "[nbx] device tree build of %d bodies handed over to the host build: status %d (1 = pool / queue overflow, 2 = EPS "
-                                 "clusters), nodes %d of %d, left-behind bodies %d, queued folds %d\n", e->n, status, e->h_counters[0], node_cap,
-                         e->h_counters[1], e->h_counters[2]);
+                                 "clusters), nodes %d of %d, left-behind bodies %d (why 0x%x), queued folds %d\n", e->n, status, e->h_counters[0], node_cap,
+                         e->h_counters[1], (unsigned)e->h_counters[5], e->h_counters[2]);
         return NBX_OK;   // caller takes the host path
     }
     e->note_accepted();
@@ -736,9 +736,9 @@ static int resolve_slot(nbx_engine* e, int slot)
     e->pending[other].active = false;
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (std::getenv("NBX_LOG"))
-        std::fprintf(stderr, "[nbx] device tree build of %d bodies refused (status %d: nodes %d of %d, left-behind bodies %d, queued folds %d): "
+        std::fprintf(stderr, "[nbx] device tree build of %d bodies refused (status %d: nodes %d of %d, left-behind bodies %d (why 0x%x), queued folds %d): "
                              "step redone on the host tree%s\n", e->n, status, e->h_verdict[slot][0], p.node_cap, e->h_verdict[slot][1],
-                     e->h_verdict[slot][2], redo_later ? ", the step behind it enqueued again" : "");
+                     (unsigned)e->h_verdict[slot][5], e->h_verdict[slot][2], redo_later ? ", the step behind it enqueued again" : "");
     HIP_TRY(hipMemsetAsync(nbx::device_tree_counters(e->d_tree_ws) + nbx::kTreePoisonWord, 0, sizeof(int), e->stream));
     const bool want_order = e->bh_wave && e->n >= 65536;
     int rc = build_and_upload_tree(e, nullptr, 0, want_order);

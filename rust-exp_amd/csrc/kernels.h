@@ -152,12 +152,12 @@ size_t device_slab_order_workspace_bytes(int n);
 hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* workspace, size_t workspace_bytes,
                              const unsigned** slab_perm, hipStream_t stream);
 // fold: 0 = interior masses / centres are roundings of exact fp64 sums (own tolerance class); 1 = the reference's f32 running
-// fold in arrival order (nbody.rs:303-320): the host tree's interior records bit for bit; any cluster the pairs-only EPS merge
-// cannot reproduce then reports status 2 (caller builds on the host).
+// fold in arrival order (nbody.rs:303-320), EPS clusters of any size replayed in arrival order: the host tree bit for bit; what
+// the replay cannot reproduce reports status 2 (caller builds on the host; the reasons are in the build's counter word 5).
 constexpr int kFoldFaithfulMax = 65536;   // default: faithful fold up to this many bodies (the root's chain is n serial steps)
 // side / ev_go / ev_done (optional, fold = 1): a second stream and two events of the same device -- the root's fold then runs
 // on `side` from the start of the build, beside everything else (it is the longest chain and needs only the bodies);
-// side2 / ev_sorted / ev_scanned: a third stream for the EPS-neighbourhood scan (feeds only the verdict).
+// side2 / ev_sorted / ev_scanned: unused (round 3's neighbourhood scan ran on a third stream; the cluster replay is part of the build).
 // host_counters: pinned words the build's counters are copied to at the end; null = the caller's gated kick-drift
 // (launch_integrate_f2 gate_host_out) hands them over instead, no copy command
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,

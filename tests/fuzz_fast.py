@@ -9,7 +9,9 @@ the device's sums are exact -- and a handful of opening decisions flip), everyon
 Round 3: a third of the cases have ONE common mass plus 0 / 1 / 5 / 30 exceptions (the unit-mass sweep + K2 correction from
 16 384 bodies on); up to 65 536 bodies the device tree carries the reference's running fold, so whenever it is kept (no EPS
 cluster handed to the host build) its forces must equal the host tree's BIT FOR BIT; and four Barnes-Hut steps enqueued back to
-back (the two-slot pipeline without a host wait) must leave the state of four waited-for steps, bit for bit."""
+back (the two-slot pipeline without a host wait) must leave the state of four waited-for steps, bit for bit.
+Late round 3: 40 % of the cases get 5 / 50 / 300 clusters of 2 .. 6 bodies around EPS wide in shuffled arrival order (the device
+build replays whole clusters: k_blobs)."""
 import os
 import sys
 import time
@@ -21,31 +23,54 @@ sys.path.insert(0, ROOT)
 import rust_exp_amd as rx  # noqa: E402
 
 
+def make_case(seed):
+    """The case of one seed: positions, velocities, masses, theta, number of clusters added."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([2, 3, 17, 255, 256, 257, 1000, 4097, 9000, 20000, 70000, 150000]))
+    scale = float(rng.choice([1e-2, 1.0, 30.0, 3e3]))
+    x = (rng.normal(0, 1, n) * scale).astype(np.float32)
+    y = (rng.normal(0, 1, n) * scale).astype(np.float32)
+    if rng.random() < 0.5 and n > 50:
+        k = n // 5
+        x[:k] = x[k:2 * k] + (rng.normal(0, 1e-3, k) * scale).astype(np.float32)
+        y[:k] = y[k:2 * k] + (rng.normal(0, 1e-3, k) * scale).astype(np.float32)
+    clumps = 0
+    if rng.random() < 0.4 and n > 50:
+        # clusters of 2 .. 6 bodies around EPS wide (absolute: the reference's EPS is 1e-4 whatever the scale), arrival order
+        # shuffled: blobs of several members, blobs with unmerged neighbours, merges across cell boundaries (k_blobs / k_place)
+        clumps = int(rng.choice([5, 50, 300]))
+        spread = float(rng.choice([1e-5, 3e-5, 6e-5, 1.5e-4]))
+        xs, ys = [x], [y]
+        for c in rng.choice(n, min(clumps, n), replace=False):
+            kk = int(rng.integers(1, 6))
+            xs.append((x[c] + rng.normal(0, spread, kk)).astype(np.float32))
+            ys.append((y[c] + rng.normal(0, spread, kk)).astype(np.float32))
+        x, y = np.concatenate(xs), np.concatenate(ys)
+        perm = rng.permutation(len(x))
+        x, y = x[perm], y[perm]
+        n = len(x)
+    mk = rng.choice(["unit", "wide", "common"])
+    if mk == "common":
+        m = np.full(n, rng.choice([0.37, 1.0, 2.5e-3]), np.float32)
+        k_exc = int(rng.choice([0, 1, 5, 30]))
+        if k_exc and n > 2 * k_exc:
+            m[rng.choice(n, k_exc, replace=False)] = (10.0 ** rng.uniform(-2, 3, k_exc)).astype(np.float32)
+    else:
+        m = {"unit": rng.uniform(0.5, 2.0, n), "wide": 10.0 ** rng.uniform(-3, 3, n)}[mk].astype(np.float32)
+    vx = rng.normal(0, 1, n).astype(np.float32); vy = rng.normal(0, 1, n).astype(np.float32)
+    theta = float(rng.choice([0.3, 0.5, 0.85]))
+    return x, y, vx, vy, m, theta, mk, clumps, scale
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     bad = 0
+    kept = [[0, 0], [0, 0]]     # [clumps added?][device tree kept?]
     t0 = time.time()
     for seed in range(first, first + count):
-        rng = np.random.default_rng(seed)
-        n = int(rng.choice([2, 3, 17, 255, 256, 257, 1000, 4097, 9000, 20000, 70000, 150000]))
-        scale = float(rng.choice([1e-2, 1.0, 30.0, 3e3]))
-        x = (rng.normal(0, 1, n) * scale).astype(np.float32)
-        y = (rng.normal(0, 1, n) * scale).astype(np.float32)
-        if rng.random() < 0.5 and n > 50:
-            k = n // 5
-            x[:k] = x[k:2 * k] + (rng.normal(0, 1e-3, k) * scale).astype(np.float32)
-            y[:k] = y[k:2 * k] + (rng.normal(0, 1e-3, k) * scale).astype(np.float32)
-        mk = rng.choice(["unit", "wide", "common"])
-        if mk == "common":
-            m = np.full(n, rng.choice([0.37, 1.0, 2.5e-3]), np.float32)
-            k_exc = int(rng.choice([0, 1, 5, 30]))
-            if k_exc and n > 2 * k_exc:
-                m[rng.choice(n, k_exc, replace=False)] = (10.0 ** rng.uniform(-2, 3, k_exc)).astype(np.float32)
-        else:
-            m = {"unit": rng.uniform(0.5, 2.0, n), "wide": 10.0 ** rng.uniform(-3, 3, n)}[mk].astype(np.float32)
-        vx = rng.normal(0, 1, n).astype(np.float32); vy = rng.normal(0, 1, n).astype(np.float32)
-        theta = float(rng.choice([0.3, 0.5, 0.85]))
+        x, y, vx, vy, m, theta, mk, clumps, scale = make_case(seed)
+        n = len(x)
         why = []
         try:
             def eng(mode, tree=0):
@@ -78,9 +103,12 @@ def main():
                 err = np.maximum(np.abs(dx_ - bfx), np.abs(dy_ - bfy)) / bsc
                 if not np.isfinite(dx_).all():
                     why.append("device tree not finite")
-                elif np.percentile(err, 99.9) > 2e-4 or err.max() > 5e-3:
+                elif np.percentile(err, 99.9) > 2e-4 or (err.max() > 5e-3 and not (clumps and n > 65536)):
+                    # (above 65 536 bodies the default is the exact-sum class: pairs only, a few bodies of bigger clusters
+                    #  left unmerged by contract -- their own forces are then off by O(1); only the 99.9 % bound applies)
                     why.append("device tree p99.9 %.2e max %.2e" % (np.percentile(err, 99.9), err.max()))
                 from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_OPT_BH_LAST_TREE
+                kept[int(clumps > 0)][int(fd.get_option(NBX_OPT_BH_LAST_TREE) == 1)] += 1
                 if 512 <= n <= 65536 and fd.get_option(NBX_OPT_BH_LAST_TREE) == 1:   # reference fold kept: the host tree, bit for bit
                     if not (np.array_equal(dx_.view(np.uint32), bfx.view(np.uint32)) and np.array_equal(dy_.view(np.uint32), bfy.view(np.uint32))):
                         why.append("reference-fold device tree != host tree (%d words)" % int((dx_.view(np.uint32) != bfx.view(np.uint32)).sum()))
@@ -102,7 +130,8 @@ def main():
         if why:
             bad += 1
             print("FAIL seed", seed, "n", n, "scale", scale, "masses", mk, "theta", theta, why)
-    print("fuzz fast: %d cases, %d failures, %.1f s" % (count, bad, time.time() - t0))
+    print("fuzz fast: %d cases, %d failures, %.1f s; device tree kept / handed over: %d / %d without added clusters, %d / %d with"
+          % (count, bad, time.time() - t0, kept[0][1], kept[0][0], kept[1][1], kept[1][0]))
 
 
 if __name__ == "__main__":

@@ -66,10 +66,11 @@ def test_device_tree_with_the_reference_fold_equals_the_host_tree_bit_for_bit(rx
             assert rc == 0 and np.abs(gx - ofx).max() <= 2e-5 * scale and np.abs(gy - ofy).max() <= 2e-5 * scale
 
 
-def test_device_tree_reference_fold_hands_eps_clusters_to_the_host_build(rx, ob):
-    """What the pairs-only EPS merge cannot reproduce node for node (a third body within EPS, a blob whose centre leaves its
-    first member's cell) is DETECTED in the reference-fold class, however few bodies it concerns, and the step runs on the host
-    tree: the result is then the host-tree result bit for bit.  (The exact-sum class tolerates up to max(16, n/2000) such bodies.)"""
+def test_device_tree_reference_fold_replays_eps_clusters(rx, ob):
+    """Blobs of three bodies within EPS (nbody.rs:249-260: arrivals folded into a blob while they stay within EPS of its
+    moving centre): the reference-fold class replays every connected cluster's arrivals in index order on the device (k_blobs)
+    and the flattened tree is the host tree, bit for bit -- no hand-over.  (The exact-sum class merges pairs only and tolerates
+    up to max(16, n/2000) bodies left behind.)"""
     from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
 
     rng = np.random.default_rng(17)
@@ -85,13 +86,60 @@ def test_device_tree_reference_fold_hands_eps_clusters_to_the_host_build(rx, ob)
     fx, fy, _ = a.forces(0.5)
     gx, gy, _ = b.forces(0.5)
     hx, hy, _ = c.forces(0.5)
-    assert b.get_option(NBX_OPT_BH_FALLBACKS) == 1 and b.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    assert b.get_option(NBX_OPT_BH_FALLBACKS) == 0 and b.get_option(NBX_OPT_BH_LAST_TREE) == 1
     assert c.get_option(NBX_OPT_BH_FALLBACKS) == 0 and c.get_option(NBX_OPT_BH_LAST_TREE) == 1
     assert np.array_equal(gx.view(np.uint32), fx.view(np.uint32)) and np.array_equal(gy.view(np.uint32), fy.view(np.uint32))
-    with pytest.raises(rx.NBodyError):
-        b.bh_flat_dump("device")                         # the dump refuses too: there is no faithful device tree for this system
+    host, dev = b.bh_flat_dump(False), b.bh_flat_dump("device")
+    _bit_equal_trees(host, dev)
+    assert int((host["interior"] == 0).sum()) == 6000    # three bodies per blob, one leaf each
     scale = max(np.abs(fx).max(), np.abs(fy).max())
     assert np.abs(hx - fx).max() <= 2e-3 * scale
+
+
+def _clumps(rng, n_base, n_clumps, spread, box=20.0, masses=(0.5, 2.0), max_members=6):
+    x = rng.uniform(-box, box, n_base).astype(np.float32); y = rng.uniform(-box, box, n_base).astype(np.float32)
+    xs, ys = [x], [y]
+    for c in range(n_clumps):
+        k = int(rng.integers(1, max_members))
+        xs.append((x[c] + rng.normal(0, spread, k)).astype(np.float32))
+        ys.append((y[c] + rng.normal(0, spread, k)).astype(np.float32))
+    x, y = np.concatenate(xs), np.concatenate(ys)
+    perm = rng.permutation(len(x))
+    x, y = x[perm], y[perm]
+    return x, y, rng.uniform(masses[0], masses[1], len(x)).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed,n_base,n_clumps,spread,on_device", [
+    (1, 4000, 300, 1.5e-5, True), (2, 20000, 600, 1e-5, True), (3, 600, 150, 2e-5, True), (4, 60000, 500, 1.5e-5, True),
+    (5, 4000, 300, 4e-5, None), (6, 4000, 300, 1e-4, None), (7, 20000, 2000, 7e-5, None), (8, 600, 200, 2e-4, None),
+    (9, 3000, 3000, 6e-5, False)])
+def test_device_tree_reference_fold_clusters_in_random_arrival_order(rx, ob, seed, n_base, n_clumps, spread, on_device):
+    """Hundreds of clusters of 2 .. 6 bodies, everything arriving in random order (members of a cluster interleaved with thousands
+    of other bodies; clusters that straddle cell boundaries of every level).  Tight clusters (every member within EPS of the
+    moving centre) the device build replays and files under their first member: the host tree bit for bit.  Looser ones leave
+    unmerged bodies a fraction of EPS beside a blob, its leaf is then ~18 levels deep and the blob's centre often sits in another
+    cell than its first member at that depth: the build says so (NBX_LOG: why 0x80) and the step runs on the host tree.  Either
+    way the forces are the host tree's, bit for bit; a system made of nothing but clusters (the last case: more bodies to move
+    than the build lists, more nodes than its pool holds) goes to the host build as a whole."""
+    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+
+    rng = np.random.default_rng(1000 + seed)
+    x, y, m = _clumps(rng, n_base, n_clumps, spread)
+    n = len(x)
+    p = ob.particles(x, y, np.zeros(n), np.zeros(n), m)
+    h = engines(rx, p); h.set_bh_tree("host")
+    d = engines(rx, p)
+    fx, fy, _ = h.forces(0.85)
+    gx, gy, _ = d.forces(0.85)
+    assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
+    device = d.get_option(NBX_OPT_BH_LAST_TREE) == 1
+    assert d.get_option(NBX_OPT_BH_FALLBACKS) == (0 if device else 1)
+    if on_device is not None:
+        assert device == on_device
+    if device:
+        host, dev = d.bh_flat_dump(False), d.bh_flat_dump("device")
+        _bit_equal_trees(host, dev)
+        assert int((host["interior"] == 0).sum()) < n - n_clumps // 4     # blobs did form
 
 
 @pytest.mark.parametrize("make,n", [("disk", 5000), ("orbits", 20000), ("plummer", 100000), ("tiny", 2), ("one", 1)])
@@ -564,12 +612,12 @@ def test_compact_walk_records_are_bit_identical(rx, ob):
     assert np.abs(res[0]["px"] - st["px"]).max() > 0
 
 
-def test_reference_fold_detects_merges_between_non_neighbouring_entities(rx, ob):
+def test_reference_fold_merges_between_non_neighbouring_entities(rx, ob):
     """Found by tests/fuzz_fast.py (seed 5214): 1 000 bodies within 0.03 of the origin, a fifth of them copies 1e-5 away from
     another body.  Two bodies within EPS need not be neighbours in key order -- a third body of their common cell can sit
-    between them -- and the reference still merges them when that third body arrived later; the neighbours-only merge of the
-    device build misses it (10 nodes too many).  The reference-fold class must notice (k_close_scan: every entity looks at all
-    entities within 2 EPS) and hand the step to the host build; the exact-sum class keeps its looser contract."""
+    between them -- and the reference still merges them when that third body arrived later; a neighbours-only merge misses it
+    (10 nodes too many: the exact-sum class keeps that looser contract).  The reference-fold class must reproduce it (k_blobs
+    replays the cluster, k_place moves the merged body next to its entity) or hand the step to the host build."""
     from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
 
     rng = np.random.default_rng(5214)
@@ -587,11 +635,12 @@ def test_reference_fold_detects_merges_between_non_neighbouring_entities(rx, ob)
     d = engines(rx, p)                                  # default: device tree, reference fold
     fx, fy, _ = h.forces(0.85)
     gx, gy, _ = d.forces(0.85)
-    assert d.get_option(NBX_OPT_BH_FALLBACKS) == 1 and d.get_option(NBX_OPT_BH_LAST_TREE) == 0
     assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
-    with pytest.raises(rx.NBodyError):
-        d.bh_flat_dump("device")
-    # a step through the pipelined path lands on the host tree too
+    if d.get_option(NBX_OPT_BH_LAST_TREE) == 1:          # since the replay of whole clusters (k_blobs): the device tree itself
+        _bit_equal_trees(d.bh_flat_dump(False), d.bh_flat_dump("device"))
+    else:
+        assert d.get_option(NBX_OPT_BH_FALLBACKS) == 1
+    # a step through the pipelined path gives the host-tree step too
     d.step_barnes_hut(0.85, 0.01, 1); h.step_barnes_hut(0.85, 0.01, 1)
     a, b = h.get_particles(), d.get_particles()
     for kk in ("px", "py", "vx", "vy"):
@@ -599,16 +648,16 @@ def test_reference_fold_detects_merges_between_non_neighbouring_entities(rx, ob)
 
 
 def test_refusals_in_a_row_back_off_to_the_host_build(rx, ob):
-    """A dense core keeps its EPS clusters for many steps: after the second refused device build in a row the next 2, 4, 8 ..
+    """A system the device build refuses tends to stay that way for many steps: after the second refused build in a row the next 2, 4, 8 ..
     steps go straight to the host build, then one step tries the device again (engine_internal.h note_refusal).  Every step is
     the host-tree step, bit for bit; the number of device builds attempted is read from the profile; a new state resets it."""
     from rust_exp_amd.engine import NBX_K_TREE_BUILD, NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
 
     rng = np.random.default_rng(77)
-    n0 = 6000
+    n0 = 4000
     x = rng.uniform(-20, 20, n0).astype(np.float32); y = rng.uniform(-20, 20, n0).astype(np.float32)
-    x2 = np.concatenate([x, x[:5] + np.float32(3e-5), x[:5] - np.float32(2e-5)])      # five EPS triples, at rest
-    y2 = np.concatenate([y, y[:5] + np.float32(1e-5), y[:5] + np.float32(4e-5)])
+    x2 = np.concatenate([x, x + np.float32(2e-4)])      # thousands of pairs 2e-4 apart, at rest: ~18-level chains, the node
+    y2 = np.concatenate([y, y])                         # pool overflows at every step
     n = len(x2)
     q = ob.particles(x2, y2, np.zeros(n), np.zeros(n), np.full(n, 1e-6))
     from rust_exp_amd.engine import NBX_OPT_BH_ASYNC
