@@ -132,8 +132,9 @@ enum nbx_option {
                                     * many waves per 64 targets (term producers + one summing wave), 1 = one thread per body.
                                     * Bit-identical results whichever runs */
     NBX_OPT_BH_FOLD = 14,          /* device-built tree, interior nodes: 1 = the reference's own f32 running fold of masses and
-                                    * centres in ARRIVAL order (nbody.rs:303-320) -- the host tree's records bit for bit; systems
-                                    * with EPS clusters the device merge cannot reproduce node for node go to the host build;
+                                    * centres in ARRIVAL order (nbody.rs:303-320) and its EPS merge (nbody.rs:249-260: blobs of any
+                                    * size, grown in arrival order) replayed on the device -- the host tree's records bit for bit;
+                                    * systems the replay cannot reproduce node for node go to the host build (NBX_LOG says why);
                                     * 0 = roundings of the exact sums (own tolerance class);
                                     * -1 (default) = 1 up to 65 536 bodies (the root's fold is n serial steps), 0 above */
     NBX_OPT_BH_ASYNC = 15,         /* 1 (default): a Barnes-Hut step on the device-built tree is enqueued without waiting for the

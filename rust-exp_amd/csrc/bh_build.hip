@@ -400,42 +400,75 @@ __global__ __launch_bounds__(kTile) void k_cells(const float4* __restrict__ posm
     }
 }
 
-__device__ __forceinline__ int cell_start(const CellGrid& g, const unsigned long long prefix)
+// every second bit of a word: bit b of v -> bit 2b (and back)
+__device__ __forceinline__ unsigned long long spread_bits(const unsigned v)
 {
-    unsigned h = hash_cell(prefix) & g.mask;
-    for (;;) {
-        const unsigned long long kk = g.hk[h];
-        if (kk == 0ull) return -1;
-        if (kk == prefix + 1ull) return g.hv[h];
-        h = (h + 1u) & g.mask;
-    }
+    unsigned long long x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+__device__ __forceinline__ unsigned compact_bits(unsigned long long x)
+{
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return (unsigned)x;
 }
 
 // f(first slot of an entity-by-key) for every one in the 3 x 3 block of grid cells around the cell of `at` (a path key), until f
-// returns false.  0: all visited; 1: stopped by f; 2: more than kCloseScanCap of them (a collinear or collapsed system)
+// returns false.  0: all visited; 1: stopped by f; 2: more than kCloseScanCap of them (a collinear or collapsed system).
+// own >= 0: `at` is the key of the body in sorted slot `own` -- its own cell is then found by walking left from that slot (the
+// neighbouring keys are in the cache of the wave's coalesced loads) instead of through the table.  The table probes of the other
+// cells are issued together, then the hits' slots, before anything is looked at: one round trip each instead of nine in a row
+// (nearly every probe finds an empty cell).
 template <class F>
 __device__ __forceinline__ int visit_entities_near(const CellGrid& g, const unsigned long long at,
-                                                   const unsigned long long* __restrict__ keys, const int n, F&& f)
+                                                   const unsigned long long* __restrict__ keys, const int n, const int own, F&& f)
 {
-    unsigned ix = 0, iy = 0;                          // one bit per level (x: right = 1; y: lower = 1)
-    for (int l = 0; l < g.D; l++) {
-        const unsigned q = (unsigned)(at >> (2 * (kLevels - 1 - l))) & 3u;
-        ix = (ix << 1) | (q & 1u);
-        iy = (iy << 1) | (q >> 1);
-    }
+    const unsigned long long centre = at >> g.sh;     // digit = (lower << 1) | right, one per level
+    const unsigned ix = compact_bits(centre), iy = compact_bits(centre >> 1);
     const long long lim = 1ll << g.D;
-    int seen = 0;
+    unsigned long long prefix[9], found[9];
+    unsigned h[9];
+#pragma unroll
     for (int c9 = 0; c9 < 9; c9++) {
         const long long cx = (long long)ix + (c9 % 3 - 1), cy = (long long)iy + (c9 / 3 - 1);
-        if (cx < 0 || cy < 0 || cx >= lim || cy >= lim) continue;
-        unsigned long long prefix = 0;
-        for (int l = 0; l < g.D; l++) {
-            const unsigned bx = (unsigned)(cx >> (g.D - 1 - l)) & 1u, by = (unsigned)(cy >> (g.D - 1 - l)) & 1u;
-            prefix = (prefix << 2) | (unsigned long long)((by << 1) | bx);
+        const bool inside = !(cx < 0 || cy < 0 || cx >= lim || cy >= lim);
+        const unsigned long long p = (spread_bits((unsigned)cy) << 1) | spread_bits((unsigned)cx);
+        prefix[c9] = p;
+        h[c9] = hash_cell(p) & g.mask;
+        found[c9] = !inside ? 0ull : (c9 == 4 && own >= 0) ? p + 1ull : g.hk[h[c9]];
+    }
+    int start[9];
+#pragma unroll
+    for (int c9 = 0; c9 < 9; c9++) start[c9] = (found[c9] == prefix[c9] + 1ull && !(c9 == 4 && own >= 0)) ? g.hv[h[c9]] : -1;
+    if (own >= 0) {
+        int t = own, steps = 0;
+        while (t > 0 && (keys[t - 1] >> g.sh) == centre && ++steps <= 64) t--;
+        start[4] = steps > 64 ? g.hv[h[4]] : t;       // (a crowded cell: the table knows where it starts -- it holds every cell)
+        if (steps > 64) found[4] = g.hk[h[4]];
+    }
+    int seen = 0;
+#pragma unroll 1
+    for (int c9 = 0; c9 < 9; c9++) {
+        if (found[c9] == 0ull) continue;              // outside the grid, or nobody there
+        int t = start[c9];
+        if (found[c9] != prefix[c9] + 1ull) {         // the slot held another cell: probe on
+            unsigned hh = h[c9];
+            unsigned long long kk = found[c9];
+            while (kk != 0ull && kk != prefix[c9] + 1ull) { hh = (hh + 1u) & g.mask; kk = g.hk[hh]; }
+            if (kk == 0ull) continue;
+            t = g.hv[hh];
         }
-        int t = cell_start(g, prefix);
-        if (t < 0) continue;
-        while (t < n && (keys[t] >> g.sh) == prefix) {
+        const unsigned long long pc = prefix[c9];
+        while (t < n && (keys[t] >> g.sh) == pc) {
             if (++seen > kCloseScanCap) return 2;
             if (!f(t)) return 1;
             t = run_end(keys, t, n);
@@ -492,7 +525,7 @@ __device__ __forceinline__ int outside_rival(const BlobShared& s, const int nrun
             const float4 px = v.sb[x];
             const unsigned long long kx = v.keys[x];
             bool company = false;
-            const int st = visit_entities_near(v.g, kx, v.keys, v.n, [&](const int t) {
+            const int st = visit_entities_near(v.g, kx, v.keys, v.n, x, [&](const int t) {
                 if (v.keys[t] == kx) return true;
                 if (within(px, v.sb[t], 2.0f * kEps)) { company = true; return false; }
                 return true;
@@ -546,7 +579,7 @@ __device__ int replay_component(BlobShared& s, const int nruns, const ReplayView
                 if (c < (int)s.ent_pmin[best]) s.ent_pmin[best] = (unsigned char)c;
                 // nobody outside the component may ever be within EPS of this centre
                 const float4 centre = make_float4(x, y, 0.0f, 0.0f);
-                const int st = visit_entities_near(v.g, kc, v.keys, v.n, [&](const int u) {
+                const int st = visit_entities_near(v.g, kc, v.keys, v.n, -1, [&](const int u) {
                     return !within(centre, v.sb[u], kEps) || in_component(s, nruns, u);
                 });
                 if (st != 0) return kWhyOutsider;
@@ -590,7 +623,7 @@ __global__ __launch_bounds__(kTile) void k_blobs(const float4* __restrict__ sb, 
         const float4 p = sb[j];
         mine = idx[j];
         bool company = false, later = true;
-        const int st = visit_entities_near(g, kj, keys, n, [&](const int t) {
+        const int st = visit_entities_near(g, kj, keys, n, j, [&](const int t) {
             if (keys[t] == kj || !within(p, sb[t], 2.0f * kEps)) return true;
             company = true;
             if (idx[t] < mine) later = false;
@@ -631,7 +664,7 @@ __global__ __launch_bounds__(kTile) void k_blobs(const float4* __restrict__ sb, 
             const int fr = s.run_first[r];
             const float4 pr = sb[fr];
             const unsigned long long kr = keys[fr];
-            const int st = visit_entities_near(g, kr, keys, n, [&](const int t) {
+            const int st = visit_entities_near(g, kr, keys, n, fr, [&](const int t) {
                 if (keys[t] == kr || !within(pr, sb[t], 2.0f * kEps)) return true;
                 for (int u = 0; u < nruns; u++)
                     if (s.run_first[u] == t) return true;
