@@ -35,7 +35,7 @@
 //   * clusters of three or more bodies within EPS: the reference folds arrivals into one blob while each stays within EPS
 //     of the blob's current centre; here only the first two of a run of mutually-close sorted neighbours merge (bodies whose
 //     62-bit keys are identical -- the same level-31 cell, 4.7e-8 of the box -- always share one leaf, any number of them);
-//     more than max(16, n/2000) such bodies send the step to the host build;
+//     more than max(16, n/8000) such bodies send the step to the host build;
 //   * no depth-50 panic (nbody.rs:230-232): keys stop at level 31.
 // A pair within EPS whose members are not neighbours in key order (a third body of their common cell between them) merges in the
 // reference when every body between them arrived later: the neighbours-only merge misses it.  fold = 1 replays it like every
@@ -262,13 +262,27 @@ __device__ __forceinline__ int run_start(const unsigned long long* __restrict__ 
 __global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict__ posm, float4* __restrict__ sb,
                                                        const unsigned long long* __restrict__ keys,
                                                        const unsigned* __restrict__ idx, const int n,
-                                                       unsigned char* __restrict__ close)
+                                                       unsigned char* __restrict__ close, int* __restrict__ crowded)
 {
     const int j = blockIdx.x * kTile + threadIdx.x;
     if (j >= n) return;
     const float4 b = posm[idx[j]];
     sb[j] = b;
     unsigned char out = 0;
+    if (j + 1 < n && keys[j + 1] == keys[j] && !(j > 0 && keys[j - 1] == keys[j])) {
+        // The first of several bodies of one level-31 cell: one leaf as long as every arrival is within EPS of the centre the
+        // earlier ones have folded to.  Where an ulp of the coordinates is no longer small against EPS (|x| in the thousands) the
+        // folded centre of even identical positions can sit more than EPS away (nbody.rs:315-317 round three times) and the
+        // reference splits: such bodies are counted as left behind.
+        float cx = 0.0f, cy = 0.0f, cm = 0.0f;
+        int left = 0;
+        for (int t = j; t < n && keys[t] == keys[j]; t++) {        // (the stable sort left them in index order)
+            const float4 q = posm[idx[t]];
+            if (t > j && !(fabsf(__fsub_rn(cx, q.x)) < kEps && fabsf(__fsub_rn(cy, q.y)) < kEps)) left++;
+            fold_mass(cx, cy, cm, q.x, q.y, q.w);
+        }
+        if (left) atomicAdd(crowded, left);
+    }
     if (j > 0 && keys[j - 1] != keys[j]) {
         // the entity's position is its first arrival's (later arrivals of the same cell are < 5e-8 of the box away)
         const int r = run_start(keys, j - 1);
@@ -1599,7 +1613,7 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 //   begin: enqueues everything on `stream`, including the copy of the node count into the pinned host_counters;
 //          *perm_dev = the sorted body order (device pointer inside the workspace: thread t handles body perm[t])
 //   end:   waits for the stream; *n_nodes_host = node count; *status = 1 when the tree needs more than node_cap
-//          nodes (nothing usable was written), 2 when more than max(16, n/2000) bodies sit in clusters of >= 3 within EPS
+//          nodes (nothing usable was written), 2 when more than max(16, n/8000) bodies sit in clusters of >= 3 within EPS
 //          (the caller should build on the host: the reference's multi-body merges are not reproduced here)
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters /* pinned, >= 4 ints; null: the caller's gated kick-drift publishes them */,
@@ -1649,7 +1663,7 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     } else {
         // pairs of neighbouring entities only (3b): links from the sorted keys + arrival order (this kernel also gathers the
         // bodies into sorted order), then both members of a pair share one key
-        hipLaunchKernelGGL(k_merge_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link);
+        hipLaunchKernelGGL(k_merge_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link, k.counters + 1);
         hipLaunchKernelGGL(k_merge_keys, dim3(nb), dim3(kTile), 0, stream, k.keys1, k.idx1, k.link, n, k.keys0, k.counters + 1);
     }
     hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.counters + 3);
@@ -1676,7 +1690,7 @@ void device_tree_limits(int n, int fold, int* crowd_limit, int* queue_limit)
 {
     // fold = 1 promises the reference's tree node for node: ANY body the pairs-only merge left behind (or a blob whose centre
     // left its first member's cell) sends the step to the host build; fold = 0 tolerates a few (its own tolerance class)
-    *crowd_limit = fold == 1 ? 0 : (n / 2000 > 16 ? n / 2000 : 16);
+    *crowd_limit = fold == 1 ? 0 : (n / 8000 > 16 ? n / 8000 : 16);
     *queue_limit = fold == 1 ? n : 0x7FFFFFFF;
 }
 

