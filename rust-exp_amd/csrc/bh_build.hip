@@ -35,7 +35,7 @@
 //   * clusters of three or more bodies within EPS: the reference folds arrivals into one blob while each stays within EPS
 //     of the blob's current centre; here only the first two of a run of mutually-close sorted neighbours merge (bodies whose
 //     62-bit keys are identical -- the same level-31 cell, 4.7e-8 of the box -- always share one leaf, any number of them);
-//     more than max(16, n/8000) such bodies send the step to the host build;
+//     more than max(16, n/2000) such bodies send the step to the host build;
 //   * no depth-50 panic (nbody.rs:230-232): keys stop at level 31.
 // A pair within EPS whose members are not neighbours in key order (a third body of their common cell between them) merges in the
 // reference when every body between them arrived later: the neighbours-only merge misses it.  fold = 1 replays it like every
@@ -1613,7 +1613,7 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 //   begin: enqueues everything on `stream`, including the copy of the node count into the pinned host_counters;
 //          *perm_dev = the sorted body order (device pointer inside the workspace: thread t handles body perm[t])
 //   end:   waits for the stream; *n_nodes_host = node count; *status = 1 when the tree needs more than node_cap
-//          nodes (nothing usable was written), 2 when more than max(16, n/8000) bodies sit in clusters of >= 3 within EPS
+//          nodes (nothing usable was written), 2 when more than max(16, n/2000) bodies sit in clusters of >= 3 within EPS
 //          (the caller should build on the host: the reference's multi-body merges are not reproduced here)
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters /* pinned, >= 4 ints; null: the caller's gated kick-drift publishes them */,
@@ -1690,7 +1690,7 @@ void device_tree_limits(int n, int fold, int* crowd_limit, int* queue_limit)
 {
     // fold = 1 promises the reference's tree node for node: ANY body the pairs-only merge left behind (or a blob whose centre
     // left its first member's cell) sends the step to the host build; fold = 0 tolerates a few (its own tolerance class)
-    *crowd_limit = fold == 1 ? 0 : (n / 8000 > 16 ? n / 8000 : 16);
+    *crowd_limit = fold == 1 ? 0 : (n / 2000 > 16 ? n / 2000 : 16);
     *queue_limit = fold == 1 ? n : 0x7FFFFFFF;
 }
 

@@ -70,7 +70,7 @@ def test_device_tree_reference_fold_replays_eps_clusters(rx, ob):
     """Blobs of three bodies within EPS (nbody.rs:249-260: arrivals folded into a blob while they stay within EPS of its
     moving centre): the reference-fold class replays every connected cluster's arrivals in index order on the device (k_blobs)
     and the flattened tree is the host tree, bit for bit -- no hand-over.  (The exact-sum class merges pairs only and tolerates
-    up to max(16, n/8000) bodies left behind.)"""
+    up to max(16, n/2000) bodies left behind.)"""
     from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
 
     rng = np.random.default_rng(17)
@@ -270,7 +270,7 @@ def test_device_tree_duplicates_with_partners_and_crowded_clusters(rx, ob):
     """Bodies of one level-31 cell (exact duplicates) are one entity: they share a leaf in arrival order, and a close
     partner merges with the whole entity exactly like the reference does (nbody.rs:249-260) -- same tree as the host's.
     Clusters of three or more DISTINCT positions within EPS are another matter: the reference grows multi-body blobs in arrival
-    order, which the pairs-only merge does not reproduce.  A few such bodies (<= max(16, n/8000)) are tolerated; a system
+    order, which the pairs-only merge does not reproduce.  A few such bodies (<= max(16, n/2000)) are tolerated; a system
     full of them -- dense clumps -- is detected by the device build and redone on the host: the host-tree result bit for bit."""
     from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
 

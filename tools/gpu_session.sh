@@ -15,6 +15,8 @@
 #   fuzz    the four hand-run fuzz campaigns (tests/fuzz_*.py)
 #   ubench  instruction-issue microbenchmarks
 #   strict  bit-exact all-pairs kernels: kernel sweep by size + PMC summaries
+#   xlat / verify8 / fold / frames / fallback   exchange floor + scaling bound; the self-validating 8-engine line; device tree with the
+#           reference fold (bit-equality, ms per step, kernel trace); the level-1 frame loop; hand-over rate of long runs
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG="${TAG:-r03}"
 O=gpurun_out
@@ -128,6 +130,10 @@ PY
       timeout 600 python tools/frame_loop.py > $O/${TAG}_frame_loop_level1.txt 2>&1; cat $O/${TAG}_frame_loop_level1.txt
       NB_BH_TREE=host NB_DRAW=host timeout 600 python tools/frame_loop.py > $O/${TAG}_frame_loop_level1_host_tree_host_draw.txt 2>&1
       NB_BH_FOLD=exact timeout 600 python tools/frame_loop.py > $O/${TAG}_frame_loop_level1_exact_fold.txt 2>&1; cat $O/${TAG}_frame_loop_level1_exact_fold.txt ;;
+    fallback) # how often the reference-fold device tree hands a step to the host build over long runs of the reference's own scenes
+      timeout 1500 python tools/bh_fallback_rate.py stable_orbits:10000 random_disk:10000 random_disk:2000 random_disk:20000 random_disk:30000 stable_orbits:65536 random_disk:65536 > $O/${TAG}_bh_fallback_rate.jsonl 2> $O/${TAG}_bh_fallback_rate.err
+      NBX_BH_BACKOFF_MAX=0 timeout 600 python tools/bh_fallback_rate.py random_disk:65536 | sed 's/^{/{"note": "NBX_BH_BACKOFF_MAX=0: every step tries the device first", /' >> $O/${TAG}_bh_fallback_rate.jsonl
+      cut -c1-200 $O/${TAG}_bh_fallback_rate.jsonl ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
