@@ -1627,10 +1627,8 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters /* pinned, >= 4 ints; null: the caller's gated kick-drift publishes them */,
                                    const unsigned** perm_dev, hipStream_t stream, int fold,
-                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, BhWalk16* walk16, float* wmass,
-                                   hipStream_t side2, hipEvent_t ev_sorted, hipEvent_t ev_scanned)
+                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, BhWalk16* walk16, float* wmass)
 {
-    (void)side2; (void)ev_sorted; (void)ev_scanned;   // (round 3's neighbourhood scan ran beside the build; the replay is part of it)
     if (fold != 0) { walk16 = nullptr; wmass = nullptr; }   // (the fold kernels write centres and masses after k_emit)
     *perm_dev = nullptr;
     if (n <= 0) return hipSuccess;

@@ -539,9 +539,6 @@ int build_tree_on_device_begin(nbx_engine* e, int* host_counters, bool publish_b
         HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_side_go, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_side_done, hipEventDisableTiming));
-        HIP_TRY(hipStreamCreateWithFlags(&e->side2_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_sorted, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_scanned, hipEventDisableTiming));
     }
     // compact copy for the wave walk: opt-in (measured slower, profiles/r03_bh_walk_records_ab.jsonl), exact-sum trees only (every
     // record is final when k_emit writes it)
@@ -556,8 +553,7 @@ int build_tree_on_device_begin(nbx_engine* e, int* host_counters, bool publish_b
     HIP_TRY(nbx::device_tree_build_begin(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes,
                                          publish_by_kernel ? nullptr : (host_counters ? host_counters : e->h_counters), &e->d_perm,
                                          e->stream, fold, e->side_stream, e->ev_side_go, e->ev_side_done,
-                                         want16 ? e->d_walk16 : nullptr, want16 ? e->d_wmass : nullptr, e->side2_stream, e->ev_sorted,
-                                         e->ev_scanned));
+                                         want16 ? e->d_walk16 : nullptr, want16 ? e->d_wmass : nullptr));
     return NBX_OK;
 }
 
@@ -898,9 +894,6 @@ void free_device(nbx_engine* e)
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
     if (e->ev_side_go) (void)hipEventDestroy(e->ev_side_go);
     if (e->ev_side_done) (void)hipEventDestroy(e->ev_side_done);
-    if (e->side2_stream) { (void)hipStreamSynchronize(e->side2_stream); (void)hipStreamDestroy(e->side2_stream); }
-    if (e->ev_sorted) (void)hipEventDestroy(e->ev_sorted);
-    if (e->ev_scanned) (void)hipEventDestroy(e->ev_scanned);
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_fb) (void)hipFree(e->d_fb);
     if (e->h_fb) (void)hipHostFree(e->h_fb);

@@ -60,8 +60,6 @@ struct nbx_engine {
     size_t tree_ws_bytes = 0;
     hipStream_t side_stream = nullptr;   // device tree build: the root's fold runs here beside the rest (NBX_OPT_BH_FOLD = 1)
     hipEvent_t ev_side_go = nullptr, ev_side_done = nullptr;
-    hipStream_t side2_stream = nullptr;  // ... and the EPS-neighbourhood scan here
-    hipEvent_t ev_sorted = nullptr, ev_scanned = nullptr;
     int* h_counters = nullptr;     // pinned: per-level node counters of the device build
     const unsigned* d_perm = nullptr;   // spatial body order produced by the device build
     const unsigned* d_slab_perm = nullptr;  // d_perm restricted to this engine's slab (world > 1)

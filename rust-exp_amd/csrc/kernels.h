@@ -157,14 +157,12 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 constexpr int kFoldFaithfulMax = 65536;   // default: faithful fold up to this many bodies (the root's chain is n serial steps)
 // side / ev_go / ev_done (optional, fold = 1): a second stream and two events of the same device -- the root's fold then runs
 // on `side` from the start of the build, beside everything else (it is the longest chain and needs only the bodies);
-// side2 / ev_sorted / ev_scanned: unused (round 3's neighbourhood scan ran on a third stream; the cluster replay is part of the build).
 // host_counters: pinned words the build's counters are copied to at the end; null = the caller's gated kick-drift
 // (launch_integrate_f2 gate_host_out) hands them over instead, no copy command
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters, const unsigned** perm_dev, hipStream_t stream, int fold = 0,
                                    hipStream_t side = nullptr, hipEvent_t ev_go = nullptr, hipEvent_t ev_done = nullptr,
-                                   BhWalk16* walk16 = nullptr, float* wmass = nullptr,
-                                   hipStream_t side2 = nullptr, hipEvent_t ev_sorted = nullptr, hipEvent_t ev_scanned = nullptr);
+                                   BhWalk16* walk16 = nullptr, float* wmass = nullptr);
 hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status,
                                  hipStream_t stream, int fold = 0);
 // the device-side view of the same verdict: where the build's counters live (for launch_bh_eval / launch_integrate_f2 gates)

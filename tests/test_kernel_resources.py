@@ -79,3 +79,20 @@ def test_fold_kernels_of_the_device_tree_build(tmp_path):
     for v in folds:
         assert v["private_segment_fixed_size"] <= 16 and v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0, v
         assert 8 * v["group_segment_fixed_size"] <= 160 * 1024 and v["vgpr_count"] <= 256, v
+
+
+def test_cluster_replay_kernels_of_the_device_tree_build(tmp_path):
+    """k_cells / k_blobs / k_place (reference fold: EPS clusters replayed on the device).  k_blobs is the one every body runs
+    through with the whole replay inlined behind a branch almost nobody takes: it must not spill, must keep its per-wave replay
+    record in LDS (four records per workgroup) and leave at least four waves per SIMD; out of line the replay cost the kernel
+    191 VGPRs and a scratch frame (measured slower)."""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    strict = re.search(r"^STRICT\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    k = _metadata(tmp_path, "bh_build.hip", strict)
+    blobs = next(v for n, v in k.items() if "k_blobs" in n)
+    # (a few SGPRs spill into VGPR lanes -- no memory traffic; nothing goes to scratch beyond the lambda bookkeeping)
+    assert blobs["vgpr_spill_count"] == 0 and blobs["sgpr_spill_count"] <= 32 and blobs["private_segment_fixed_size"] <= 16, blobs
+    assert blobs["vgpr_count"] <= 128 and 3000 * 4 <= blobs["group_segment_fixed_size"] <= 16 * 1024, blobs
+    for name in ("k_cells", "k_place"):
+        v = next(v for n, v in k.items() if name in n)
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 and v["vgpr_count"] <= 64, (name, v)
