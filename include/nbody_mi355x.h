@@ -41,7 +41,8 @@ extern "C" {
 /* source copy for the all-pairs sweep, BASELINE config #5; default 32).                          */
 /* Both levels: NBX_HOST_THREADS (workers of the host quadtree build / flatten / draw; default   */
 /* min(hardware threads, 32)), NBX_GROUP_EXCHANGE=copy (see nbx_group_*), NBX_LOG=1 (one stderr   */
-/* line per step), NBX_TIMING=1 (host tree-build phases).                                         */
+/* line per step; a device tree build that hands its step to the host build says why),            */
+/* NBX_TIMING=1 (host tree-build phases), NBX_BH_BACKOFF_MAX (see NBX_OPT_BH_FALLBACKS).          */
 
 /* replaces nbody.rs:34-37   pub extern fn nb_num_particles() -> i32 */
 int32_t nb_num_particles(void);
