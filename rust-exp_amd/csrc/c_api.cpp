@@ -153,6 +153,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_BH_WALK_RECORDS: return e->bh_walk_records;
         case NBX_OPT_BH_FALLBACKS: return e->bh_fallbacks;
         case NBX_OPT_BH_LAST_TREE: return e->bh_last_tree_device;
+        case NBX_OPT_BH_REFUSAL: return e->bh_last_refusal;
         case NBX_OPT_DRAW_AMBIGUOUS: return e->draw_ambiguous;
         default: return NBX_ERR_INVALID;
     }
@@ -163,7 +164,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
 int32_t nbx_query_option(const nbx_engine* e, int32_t option, int64_t* value)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
-    if (option < NBX_OPT_FORCE_MODE || option > NBX_OPT_BH_WALK_RECORDS) return fail(NBX_ERR_INVALID, "unknown option %d", option);
+    if (option < NBX_OPT_FORCE_MODE || option > NBX_OPT_BH_REFUSAL) return fail(NBX_ERR_INVALID, "unknown option %d", option);
     if (value) *value = nbx_get_option(e, option);
     return NBX_OK;
 }

@@ -578,6 +578,7 @@ int build_tree_on_device_end(nbx_engine* e, bool* done)
     if (status != 0) {
         e->bh_fallbacks++;
         e->note_refusal(backoff_max_steps());
+        e->note_why(status, e->h_counters[5]);
         e->d_perm = nullptr;
         if (std::getenv("NBX_LOG"))
             std::fprintf(stderr, "[nbx] device tree build of %d bodies handed over to the host build: status %d (1 = pool / queue overflow, 2 = EPS "
@@ -725,6 +726,7 @@ static int resolve_slot(nbx_engine* e, int slot)
     // refused: this step's gated kernels did nothing and poisoned the step behind it (if one is in flight)
     e->bh_fallbacks++;
     e->note_refusal(backoff_max_steps());
+    e->note_why(status, e->h_verdict[slot][5]);
     e->d_perm = nullptr;
     const int other = slot ^ 1;
     const bool redo_later = e->pending[other].active;

@@ -101,6 +101,8 @@ struct nbx_engine {
     // the next 2, 4, .. kBackoffMaxSteps steps go straight to the host build -- counted in bh_fallbacks like the refusals -- and
     // then ONE step tries the device again.  Any replaced state (after_host_state_change) and any accepted build reset it.
     int bh_refusal_streak = 0, bh_host_steps_left = 0;
+    int bh_last_refusal = 0;       // NBX_OPT_BH_REFUSAL: reasons of the last refused device build (status and counter word 5)
+    void note_why(int status, int why) { bh_last_refusal = status == 1 ? 0x10000 : (why ? why : 0x20000); }
     void note_refusal(int max_steps)
     {
         if (++bh_refusal_streak >= 2 && max_steps > 0) {

@@ -442,6 +442,10 @@ def test_group_info_threads_and_option_queries_without_device(rx, monkeypatch):
     assert e.query_option(NBX_OPT_DRAW_DEVICE) == -1 and e.query_option(NBX_OPT_DRAW_AMBIGUOUS) == 0
     with pytest.raises(rx.NBodyError):
         e.query_option(99)
+    from rust_exp_amd.engine import NBX_OPT_BH_REFUSAL
+    assert e.query_option(NBX_OPT_BH_REFUSAL) == 0          # read only: no device build has refused anything yet
+    with pytest.raises(rx.NBodyError):
+        e.set_option(NBX_OPT_BH_REFUSAL, 1)
 
 
 def test_host_worker_pool_serves_concurrent_builds(rx, ob):

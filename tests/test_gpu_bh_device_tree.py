@@ -134,6 +134,9 @@ def test_device_tree_reference_fold_clusters_in_random_arrival_order(rx, ob, see
     assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
     device = d.get_option(NBX_OPT_BH_LAST_TREE) == 1
     assert d.get_option(NBX_OPT_BH_FALLBACKS) == (0 if device else 1)
+    from rust_exp_amd.engine import NBX_OPT_BH_REFUSAL
+    why = d.get_option(NBX_OPT_BH_REFUSAL)                  # the build says why it handed the system over
+    assert (why == 0) == device and (device or why & (0x10000 | 8 | 16 | 32 | 64 | 128))
     if on_device is not None:
         assert device == on_device
     if device:
@@ -401,6 +404,8 @@ def test_device_tree_node_pool_overflow_falls_back_to_host_build(rx, ob):
     assert a.get_option(NBX_OPT_BH_LAST_TREE) == 0 and a.get_option(NBX_OPT_BH_FALLBACKS) == 0
     gx, gy, _ = b.forces(0.5)
     assert b.get_option(NBX_OPT_BH_FALLBACKS) == 1 and b.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    from rust_exp_amd.engine import NBX_OPT_BH_REFUSAL
+    assert b.get_option(NBX_OPT_BH_REFUSAL) == 0x10000      # "the node pool overflowed"
     assert b.bh_host_timing()["nodes"] == a.bh_host_timing()["nodes"] > 4 * n
     assert np.array_equal(gx.view(np.uint32), fx.view(np.uint32)) and np.array_equal(gy.view(np.uint32), fy.view(np.uint32))
     b.step_barnes_hut(0.5, 0.01, 1)
