@@ -152,8 +152,8 @@ enum nbx_option {
                                     * cluster replay (NBX_OPT_BH_FOLD = 1): 1 more than 512 entities around one point, 4 a cluster
                                     * of more than 48 entities / 96 bodies, 8 a merge hinges on another cluster, 16 an outsider
                                     * within EPS of a blob's centre, 32 two entities in one level-31 cell that do not merge,
-                                    * 64 more than 2 048 bodies to move, 128 a blob's centre left its first member's path above
-                                    * its leaf, 256 a leaf of more bodies than the leaf fold orders; exact-sum class: 0x20000 = more
+                                    * 64 more than 4 096 bodies to move, 128 a blob's successive centres part ways above its
+                                    * leaf, 256 a leaf of more bodies than the leaf fold orders; exact-sum class: 0x20000 = more
                                     * bodies left unmerged than it tolerates */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */

@@ -20,9 +20,9 @@
 //      fold = 1 (default up to 65 536 bodies): the reference's f32 running fold over the node's bodies in ARRIVAL order
 //               (nbody.rs:303-320) -- small nodes in k_emit, the others in k_fold_big (one pair of waves per node: m chain, IEEE
 //               reciprocals, p chain), the root on a side stream from the start of the build.  The flattened tree then equals the
-//               host tree BIT FOR BIT; what the cluster replay cannot reproduce node for node (a blob whose centre leaves its
-//               first member's path above its leaf, a merge that hinges on another cluster, ...: 3c) is detected and the step
-//               goes to the host build.
+//               host tree BIT FOR BIT; what the cluster replay cannot reproduce node for node (a blob whose successive centres
+//               part ways above its leaf, a merge that hinges on another cluster, ...: 3c) is detected and the step goes to the
+//               host build.
 //      fold = 0 (above 65 536 bodies): deterministic fp64 prefix sums over the sorted bodies, one rounding to f32 per node.
 //      Node sizes: the first body's path replayed with the reference's f32 midpoints.
 //
@@ -324,17 +324,21 @@ __global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict_
 //               before all of its neighbours collects its connected component (chains of < 2 EPS links; usually 2-5 bodies) and,
 //               if it is the component's first arrival, REPLAYS the component's arrivals in index order, by the rule above:
 //               entities in LDS, exact f32 folds, the nearest-entity rule from the keys, outside bodies that arrived earlier and
-//               share the cell taken into account (k_merge_links' rival scan).  Members that end in another entity's blob take
-//               that entity's key ("ghosts": listed for k_place);
+//               share the cell taken into account (k_merge_links' rival scan).  A blob's path is its centre's; its members take
+//               the path of its last centre as their key ("ghosts" when that is not their own: listed for k_place);
 //   * k_place   the bodies in the order of their ENTITY keys (a ghost moves next to its entity: usually by a slot or two, but by
 //               any distance when a coarse cell boundary runs between the two) -- keys, indices, records, out of place.
-// The tree files a blob under the key of its FIRST member.  What that, or the replay, cannot reproduce soundly is not guessed:
-// the step then goes to the host build (counted in counters[1], the reasons in counters[5]):
-//   * a blob centre whose path leaves the path of the blob's first member above the blob's final leaf (the reference would
-//     have sent the blob down another branch at some split; k_emit compares pmin with the leaf depth).  Following the centres
-//     exactly -- a path made of stretches, one per centre -- was built too: every entity's depth over time then hinges on its
-//     nearest earlier-arrived neighbours in key order, and in the dense cores where blobs form those are members of OTHER
-//     components more often than not (the 10 000-body nb_random_disk: 695 of 1 000 steps refused, against 1 like this);
+// The tree files a blob under the path of its LAST centre.  In the reference the path is made of stretches, each laid down by the
+// centre the blob had while its leaf went from one depth to the next (the first by the opener's own position); the last centre's
+// path is that path down to the blob's final leaf iff every centre the blob ever had shares it that far, and the opener's
+// position shares it as far as the opener's leaf went before it took in its first body (at most the digits those two share).
+// What that, or the replay, cannot reproduce soundly is not guessed: the step then goes to the host build (counted in
+// counters[1], the reasons in counters[5]):
+//   * a blob whose successive centres do not share one path down to its final leaf (k_emit compares pmin with the leaf depth;
+//     blobs of three or more bodies with an unmerged body a fraction of EPS away, mostly).  Telling WHICH centre laid down which
+//     stretch was built too: every entity's depth over time then hinges on its nearest earlier-arrived neighbours in key order,
+//     and in the dense cores where blobs form those are members of OTHER components more often than not (the 10 000-body
+//     nb_random_disk: 695 of 1 000 steps refused, against none like this);
 //   * a body of ANOTHER component among the rivals of a merge (its entity may sit elsewhere),
 //   * any body outside the component within EPS of any centre a blob ever had (the 2 EPS argument holds for exact arithmetic;
 //     this checks the computed centres),
@@ -344,7 +348,7 @@ constexpr int kCloseScanCap = 512;     // entities looked at around one point
 constexpr int kSideStreamsFrom = 4096;
 constexpr int kBlobRuns = 48;
 constexpr int kBlobBodies = 96;
-constexpr int kGhostCap = 2048;
+constexpr int kGhostCap = 4096;
 constexpr int kRivalScanCap = 1024;
 
 // why a build of the reference-fold class refused: counters[1] counts, counters[5] collects these bits (NBX_LOG prints them)
@@ -355,7 +359,7 @@ enum : int {
     kWhyOutsider = 16,        // somebody outside the component within EPS of a blob's centre
     kWhyLevel31 = 32,         // two entities in one level-31 cell that do not merge
     kWhyGhosts = 64,          // more than kGhostCap bodies to move
-    kWhyCentrePath = 128,     // a blob's centre left the path of its first member above the blob's leaf
+    kWhyCentrePath = 128,     // a blob's centres do not share one path down to the blob's leaf
     kWhyBigLeaf = 256,        // a leaf of more bodies than the leaf fold orders
 };
 __device__ __forceinline__ void refuse(int* __restrict__ counters, const int why)
@@ -501,10 +505,11 @@ struct BlobShared {
     int mem_slot[kBlobBodies];                       // its bodies in arrival order ...
     unsigned mem_idx[kBlobBodies];
     unsigned char mem_ent[kBlobBodies];              // ... and the entity each of them ended in
-    unsigned char ent_pmin[kBlobBodies];             // entities of the replay: fewest digits any of its centres shared with its key
-    unsigned long long ent_key[kBlobBodies];         //   the key of the body that opened it
+    unsigned char ent_pmin[kBlobBodies];             // entities of the replay: fewest digits two successive centres' paths shared
+    unsigned char ent_c1[kBlobBodies];               //   digits the opener shared with the first body it took in (kLevels + 1: none yet)
+    unsigned long long ent_key[kBlobBodies];         //   path: the opener's key, then the path of the current centre
     float ent_x[kBlobBodies], ent_y[kBlobBodies], ent_m[kBlobBodies];
-    int ent_first[kBlobBodies];                      //   that body's sorted slot
+    int ent_first[kBlobBodies];                      //   the opener's sorted slot
 };
 
 __device__ __forceinline__ bool in_component(const BlobShared& s, const int nruns, const int slot)
@@ -588,9 +593,14 @@ __device__ int replay_component(BlobShared& s, const int nruns, const ReplayView
                 fold_mass(x, y, m, pb.x, pb.y, pb.w);
                 s.ent_x[best] = x; s.ent_y[best] = y; s.ent_m[best] = m;
                 s.mem_ent[t] = (unsigned char)best;
+                // the blob's path from here on is its centre's (nbody.rs:271-281: a split re-inserts it by its position)
                 const unsigned long long kc = path_key(v.box, x, y);
-                const int c = common_digits(kc, s.ent_key[best]);
-                if (c < (int)s.ent_pmin[best]) s.ent_pmin[best] = (unsigned char)c;
+                if ((int)s.ent_c1[best] > kLevels) s.ent_c1[best] = (unsigned char)cbest;   // the leaf was at most this deep
+                else {
+                    const int c = common_digits(kc, s.ent_key[best]);
+                    if (c < (int)s.ent_pmin[best]) s.ent_pmin[best] = (unsigned char)c;
+                }
+                s.ent_key[best] = kc;
                 // nobody outside the component may ever be within EPS of this centre
                 const float4 centre = make_float4(x, y, 0.0f, 0.0f);
                 const int st = visit_entities_near(v.g, kc, v.keys, v.n, -1, [&](const int u) {
@@ -605,19 +615,33 @@ __device__ int replay_component(BlobShared& s, const int nruns, const ReplayView
         s.ent_x[ne] = pb.x; s.ent_y[ne] = pb.y; s.ent_m[ne] = pb.w;
         s.ent_first[ne] = slot;
         s.ent_pmin[ne] = (unsigned char)kLevels;
+        s.ent_c1[ne] = (unsigned char)(kLevels + 1);
         s.mem_ent[t] = (unsigned char)ne;
         ne++;
+    }
+    // A blob is filed under the path of its LAST centre.  That is its path in the reference's tree down to its final leaf iff
+    // every centre it ever had shares that path that far (each stretch of the path was laid down by the centre of its time; the
+    // fewest digits two successive centres share is the fewest any shares with the last) and the opener's own position shares
+    // it down to the depth its leaf had when it took in its first body -- at most the digits the two shared.  k_emit knows the
+    // final leaf depth and compares (pmin); two entities that end on one 62-bit path would need a deeper tree than the keys hold.
+    for (int e = 0; e < ne; e++) {
+        if ((int)s.ent_c1[e] > kLevels) continue;            // never took anybody in: its own key, nothing to check
+        const int ca = common_digits(v.keys[s.ent_first[e]], s.ent_key[e]);
+        if (ca < (int)s.ent_c1[e] && ca < (int)s.ent_pmin[e]) s.ent_pmin[e] = (unsigned char)ca;
+        for (int o = 0; o < ne; o++)
+            if (o != e && s.ent_key[o] == s.ent_key[e]) return kWhyLevel31;
     }
     int why = 0;
     for (int t = 0; t < k; t++) {
         const int slot = s.mem_slot[t];
-        const unsigned long long ke = s.ent_key[s.mem_ent[t]];
+        const int e = s.mem_ent[t];
+        pmin[slot] = s.ent_pmin[e];
+        const unsigned long long ke = s.ent_key[e];
         if (ke == v.keys[slot]) continue;
-        ekey[slot] = ke;                                     // a ghost: filed under its entity's key
+        ekey[slot] = ke;                                     // a ghost: filed under its entity's path
         const int gi = atomicAdd(&counters[4], 1);
         if (gi < kGhostCap) ghosts[gi] = slot; else why = kWhyGhosts;
     }
-    for (int e = 0; e < ne; e++) pmin[s.ent_first[e]] = s.ent_pmin[e];
     return why;
 }
 
@@ -1010,11 +1034,12 @@ __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const u
         o.px = px; o.py = py; o.m = m;
         o.skip = first + count;
         o.interior = 0; o.q = -1.0f;
-        // a blob's centres must have travelled down the path of its first member as far as this leaf (k_blobs)
+        // a blob's centres must all have travelled down the path it is filed under as far as this leaf (k_blobs)
         if (pmin && (int)pmin[a] < l) refuse(counters, kWhyCentrePath);
-        if (fold == 1 && b - a > 1 && (px != p.x || py != p.y)) {
-            // A merged blob travels by its OWN centre in the reference (the split re-inserts (px, py), nbody.rs:271-281); this
-            // leaf sits on the path of the blob's first member.  The same leaf unless the centre left the member's cell:
+        if (fold == 1 && b - a > 1 && (px != p.x || py != p.y) && keys[a] == path_key(box, p.x, p.y)) {
+            // A merged blob travels by its OWN centre in the reference (the split re-inserts (px, py), nbody.rs:271-281).  The
+            // replay files a blob under its centre's path; one it never saw -- bodies of ONE level-31 cell without company --
+            // sits on the path of its first member.  The same leaf unless the centre left that cell:
             float u1 = dec_f32(box[0]), v1 = dec_f32(box[1]), u2 = dec_f32(box[2]), v2 = dec_f32(box[3]);
 #pragma unroll 1
             for (int d = 0; d < l; d++) descend(u1, v1, u2, v2, px, py);

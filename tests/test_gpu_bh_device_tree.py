@@ -111,14 +111,14 @@ def _clumps(rng, n_base, n_clumps, spread, box=20.0, masses=(0.5, 2.0), max_memb
 
 @pytest.mark.parametrize("seed,n_base,n_clumps,spread,on_device", [
     (1, 4000, 300, 1.5e-5, True), (2, 20000, 600, 1e-5, True), (3, 600, 150, 2e-5, True), (4, 60000, 500, 1.5e-5, True),
-    (5, 4000, 300, 4e-5, None), (6, 4000, 300, 1e-4, None), (7, 20000, 2000, 7e-5, None), (8, 600, 200, 2e-4, None),
-    (9, 3000, 3000, 6e-5, False)])
+    (12, 8000, 800, 3e-5, True), (5, 4000, 300, 4e-5, None), (6, 4000, 300, 1e-4, None), (7, 20000, 2000, 7e-5, None),
+    (8, 600, 200, 2e-4, None), (9, 3000, 3000, 6e-5, False)])
 def test_device_tree_reference_fold_clusters_in_random_arrival_order(rx, ob, seed, n_base, n_clumps, spread, on_device):
     """Hundreds of clusters of 2 .. 6 bodies, everything arriving in random order (members of a cluster interleaved with thousands
     of other bodies; clusters that straddle cell boundaries of every level).  Tight clusters (every member within EPS of the
-    moving centre) the device build replays and files under their first member: the host tree bit for bit.  Looser ones leave
-    unmerged bodies a fraction of EPS beside a blob, its leaf is then ~18 levels deep and the blob's centre often sits in another
-    cell than its first member at that depth: the build says so (NBX_LOG: why 0x80) and the step runs on the host tree.  Either
+    moving centre) the device build replays and files under their centre's path: the host tree bit for bit.  Looser ones leave
+    unmerged bodies a fraction of EPS beside a blob of several bodies, its leaf is then ~18 levels deep and the blob's successive
+    centres often sit in different cells at that depth: the build says so (NBX_OPT_BH_REFUSAL: 0x80) and the step runs on the host tree.  Either
     way the forces are the host tree's, bit for bit; a system made of nothing but clusters (the last case: more bodies to move
     than the build lists, more nodes than its pool holds) goes to the host build as a whole."""
     from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
