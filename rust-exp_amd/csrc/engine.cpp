@@ -411,7 +411,7 @@ int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also, int n_also, bo
         if (rc != NBX_OK) return rc;
     }
     const auto t1 = clk::now();
-    // big systems: the routing of the bodies to the top tree's buckets and their stable scatter run on the device
+    // bigger systems: the routing of the bodies to the top tree's buckets and their stable scatter run on the device
     // (bh_build.hip) while the host threads fold; any device-side problem just leaves both to the host
     nbx::QuadTree::RouteFn route = [e](const nbx::QuadTree::TopView& v, int warm, int rest, int* pbucket,
                                        nbx::QuadTree::Event* sorted, size_t* offset) -> bool {
@@ -455,7 +455,9 @@ int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also, int n_also, bo
         for (int b = 0; b <= v.nb; b++) offset[b] = (size_t)off_host[b];
         return true;
     };
-    const bool device_routes = e->dev_valid && e->n >= 262144;
+    // (from 16 384 bodies on: the host's own routing + scatter is 0.9 of the build's 2.0 ms at 65 536 bodies -- host-tree step
+    //  3.1 -> 2.2 ms there, 1.27 -> 1.10 at 20 000, 0.84 -> 0.89 at 10 000; round 2 used it from 262 144 bodies only)
+    const bool device_routes = e->dev_valid && e->n >= 16384;
     rc = e->tree.build(bx, by, e->host.m.data(), e->n, /*preflatten=*/true, device_routes ? &route : nullptr);
     if (rc == NBX_ERR_TREE_DEPTH) return fail(rc, "quadtree depth > 50 (the reference panics here, nbody.rs:230-232)");
     if (rc != NBX_OK) return fail(rc, "quadtree build hit a reference assert (nbody.rs:267/:293/:304)");
