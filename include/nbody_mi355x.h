@@ -114,11 +114,14 @@ enum nbx_option {
                                     * few tails whose octant sits within 1e-5 of a step of the reference's f32 expression
                                     * (diagonal or near-diagonal velocities) are decided by the host's own atan2f.
                                     * Default (-1): host below 4096 bodies or while the state is not on the GPU, device otherwise */
-    NBX_OPT_BH_TREE = 8,           /* Barnes-Hut tree: 0 = built on the host exactly like the reference (always used by
-                                    * the bit-exact mode), 1 = built on the device (bh_build.hip: same node set and leaf
-                                    * records incl. the reference's EPS merge of close pairs; interior centres of mass are
-                                    * the reference's running f32 fold up to 65 536 bodies, roundings of the exact mean above:
-                                    * NBX_OPT_BH_FOLD), -1 (default) = device in the fast mode from 512 bodies on, else host */
+    NBX_OPT_BH_TREE = 8,           /* Barnes-Hut tree: 0 = built on the host exactly like the reference (the bit-exact mode's
+                                    * default), 1 = built on the device (bh_build.hip: same node set and leaf records incl. the
+                                    * reference's EPS merge; interior centres of mass are the reference's running f32 fold up to
+                                    * 65 536 bodies, roundings of the exact mean above: NBX_OPT_BH_FOLD).  The bit-exact mode
+                                    * honours 1 only while the device tree carries the reference fold (that tree IS the host
+                                    * tree bit for bit, or the build refuses and the host builds: the same results at a third of
+                                    * the step time at 10 000 bodies).  -1 (default) = device in the fast mode from 512 bodies on,
+                                    * else host */
     NBX_OPT_BH_WAVE = 9,           /* 1 (default): with the device-built tree, walk the tree once per WAVE (node
                                     * records through the scalar cache, lanes park on accepted subtrees); 0: one
                                     * independent walk per lane. Bit-identical results either way */

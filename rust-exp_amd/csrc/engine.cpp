@@ -794,7 +794,7 @@ int step_bh(nbx_engine* e, float theta, float dt)
         e->bh_fallbacks++;
         device_tree = false;
     }
-    const bool async_ok = e->bh_async && e->world == 1 && !e->source_half && device_tree;
+    const bool async_ok = e->bh_async && e->world == 1 && !e->source_half && device_tree && e->force_mode == 0;
     if (!(async_ok && e->dev_ready && e->dev_valid && e->n > 0)) {   // (a live device state needs no upload, and no verdict read)
         rc = upload(e);
         if (rc != NBX_OK) return rc;

@@ -3,7 +3,7 @@
 suite's randomized tests use fixed seeds):   python tests/fuzz_strict.py [first_seed] [count]
 Random sizes 2 .. 70 000, coordinate scales 1e-3 .. 2e5, mass ranges inside and outside the short-division guard, clumps,
 near-duplicates and exact duplicates; one brute-force step and one Barnes-Hut step, positions and velocities compared bit
-for bit (a tree the oracle refuses must be refused by the library too)."""
+for bit (a tree the oracle refuses must be refused by the library too).  Half of the cases ask for the device-built tree."""
 import os
 import sys
 import time
@@ -41,6 +41,8 @@ def main():
         e = rx.NBodyEngine(mode="strict")
         kernel = int(rng.choice([0, 1, 8, 16]))    # NBX_OPT_STRICT_KERNEL: every all-pairs kernel must give the same bits
         e.set_strict_kernel(kernel)
+        tree = str(rng.choice(["host", "device"]))   # late round 3: the bit-exact mode on the device-built tree (reference fold,
+        e.set_bh_tree(tree)                          # on request only): the same bits, or a refusal that ends in the host build
         e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
         q = p.copy()
         ok = True
@@ -65,7 +67,7 @@ def main():
             print("seed", seed, "exception", repr(ex))
         if not ok:
             bad += 1
-            print("MISMATCH seed", seed, "n", n, "scale", scale, "masses", mk, "theta", theta, "kernel", kernel)
+            print("MISMATCH seed", seed, "n", n, "scale", scale, "masses", mk, "theta", theta, "kernel", kernel, "tree", tree)
     print("fuzz: %d cases, %d mismatches, %.1f s" % (count, bad, time.time() - t0))
 
 

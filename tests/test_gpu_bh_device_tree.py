@@ -360,7 +360,10 @@ def test_tree_choice_by_mode_and_size(rx, ob):
         e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
         e.step_barnes_hut(0.5, 0.01, 1)
         assert e.get_option(NBX_OPT_BH_LAST_TREE) == want, (n, mode)
-    e.set_bh_tree("device")                  # strict keeps the host build whatever the option says
+    e.set_bh_tree("device")                  # strict takes the device build only on request, and only with the reference fold
+    e.step_barnes_hut(0.5, 0.01, 1)
+    assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1
+    e.set_bh_fold("exact")
     e.step_barnes_hut(0.5, 0.01, 1)
     assert e.get_option(NBX_OPT_BH_LAST_TREE) == 0
     f = rx.NBodyEngine()
@@ -370,17 +373,47 @@ def test_tree_choice_by_mode_and_size(rx, ob):
     assert f.get_option(NBX_OPT_BH_LAST_TREE) == 0
 
 
-def test_strict_mode_ignores_the_device_tree(rx, ob):
-    """Bit-exact mode keeps the reference-faithful host build even when the device build is selected."""
-    p = ob.random_disk(3000, 45)
+@pytest.mark.parametrize("make,n", [("disk", 3000), ("orbits", 10000), ("clusters", 4892), ("plummer", 40000)])
+def test_strict_mode_on_the_device_tree_is_still_the_oracle(rx, ob, make, n):
+    """The bit-exact mode keeps the reference-faithful host build unless the caller selects the device build; with the reference
+    fold that tree is the host tree bit for bit (or refused and built on the host), so three bit-exact steps on it are the
+    oracle's three steps, bit for bit -- clusters of bodies within EPS included.  With exactly summed nodes (NBX_OPT_BH_FOLD = 0)
+    the request is ignored: that tree is not the reference's."""
+    from rust_exp_amd.engine import NBX_OPT_BH_LAST_TREE
+
+    if make == "disk":
+        p = ob.random_disk(n, 45)
+    elif make == "orbits":
+        p = ob.stable_orbits(n, 0.5, 30.0, 46)
+    elif make == "clusters":
+        x, y, m = _clumps(np.random.default_rng(1001), 4000, 300, 1.5e-5)
+        assert len(x) == n
+        p = ob.particles(x, y, np.zeros(n), np.zeros(n), m)
+    else:
+        st = rx.plummer_sphere(n, dim=2)
+        p = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
     e = rx.NBodyEngine(mode="strict")
     e.set_bh_tree("device")
     e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
-    e.step_barnes_hut(0.6, 0.01, 1)
-    q = p.copy(); ob.step_barnes_hut(q, 0.6, 0.01, 1)
+    q = p.copy()
+    for k in range(3):
+        e.step_barnes_hut(0.6, 0.01, 1)
+        # (the clusters fall in on themselves: a later step may be one the device build hands to the host build)
+        assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1 or (make == "clusters" and k > 0)
+        ob.step_barnes_hut(q, 0.6, 0.01, 1)
     st = e.get_particles()
     for k in ("px", "py", "vx", "vy"):
-        assert np.array_equal(st[k].view(np.uint32), q[k].view(np.uint32))
+        assert np.array_equal(st[k].view(np.uint32), q[k].view(np.uint32)), k
+    fx, fy, _ = e.forces(0.6)
+    rc, ofx, ofy = ob.bh_forces(q, 0.6, nthreads=8)
+    assert rc == 0 and np.array_equal(fx.view(np.uint32), ofx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), ofy.view(np.uint32))
+    e.set_bh_fold("exact")
+    e.step_barnes_hut(0.6, 0.01, 1)
+    assert e.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    f = rx.NBodyEngine(mode="strict")        # default tree choice: the host build
+    f.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    f.step_barnes_hut(0.6, 0.01, 1)
+    assert f.get_option(NBX_OPT_BH_LAST_TREE) == 0
 
 
 def test_device_tree_node_pool_overflow_falls_back_to_host_build(rx, ob):
