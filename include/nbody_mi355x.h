@@ -120,7 +120,7 @@ enum nbx_option {
                                     * 65 536 bodies, roundings of the exact mean above: NBX_OPT_BH_FOLD).  The bit-exact mode
                                     * honours 1 only while the device tree carries the reference fold (that tree IS the host
                                     * tree bit for bit, or the build refuses and the host builds: the same results at a third of
-                                    * the step time at 10 000 bodies).  -1 (default) = device in the fast mode from 512 bodies on,
+                                    * the step time at 10 000 bodies).  -1 (default) = device in the fast mode from 1 024 bodies on (512 with NBX_OPT_BH_FOLD = 0),
                                     * else host */
     NBX_OPT_BH_WAVE = 9,           /* 1 (default): with the device-built tree, walk the tree once per WAVE (node
                                     * records through the scalar cache, lanes park on accepted subtrees); 0: one

@@ -1,5 +1,5 @@
-// bh_build.hip -- quadtree build ON THE DEVICE.  The fast mode's DEFAULT from 512 bodies on
-// (NBX_OPT_BH_TREE); the bit-exact mode always builds on the host.
+// bh_build.hip -- quadtree build ON THE DEVICE.  The fast mode's DEFAULT from 1 024 bodies on
+// (NBX_OPT_BH_TREE; 512 with exactly summed nodes); the bit-exact mode builds on the host unless asked (reference fold only).
 //
 // The host build (host_ops.cpp) inserts the bodies one by one exactly as the reference does (nbody.rs:388-415); at 1 M bodies that
 // is 13-16 ms per step, at the reference's 10 000 bodies 0.5 ms.  This file builds the SAME flattened tree without leaving the GPU:

@@ -65,7 +65,7 @@ struct nbx_engine {
     const unsigned* d_slab_perm = nullptr;  // d_perm restricted to this engine's slab (world > 1)
     void* d_slab_ws = nullptr;
     size_t slab_ws_bytes = 0;
-    // NBX_OPT_BH_TREE: 0 host, 1 device, -1 (default) device in fast mode from 512 bodies on (measured crossover: a step with the
+    // NBX_OPT_BH_TREE: 0 host, 1 device, -1 (default) device in fast mode from 512 (exact sums) / 1 024 (reference fold) bodies on (measured crossover: a step with the
     // host build costs 0.141 / 0.208 / 0.303 / 0.509 ms at 512 / 1000 / 2000 / 4000 bodies, with the device build 0.124 / 0.135 /
     // 0.144 / 0.145 ms; below ~400 bodies the host build's few microseconds win: profiles/r02_bh_tree_crossover.txt)
     int bh_tree_device = -1;
@@ -80,7 +80,9 @@ struct nbx_engine {
     {
         if (!(mass_min > 0.0f)) return false;
         if (force_mode != 0) return bh_tree_device == 1 && effective_fold() == 1;
-        return bh_tree_device == 1 || (bh_tree_device < 0 && n >= kDeviceTreeFrom);
+        // (by size: the exact-sum build pays from ~400 bodies on, the reference fold -- the root's chain -- from ~1 000:
+        //  profiles/r02_bh_tree_crossover.txt, r03_bh_tree_crossover_reference_fold.txt)
+        return bh_tree_device == 1 || (bh_tree_device < 0 && n >= (effective_fold() == 1 ? 2 * kDeviceTreeFrom : kDeviceTreeFrom));
     }
     // NBX_OPT_BH_FOLD: interior nodes of the DEVICE-built tree: 1 = the reference's f32 running fold in arrival order (the host
     // tree's records bit for bit), 0 = roundings of exact sums (round 2), -1 (default) = faithful up to kFoldFaithfulMax bodies

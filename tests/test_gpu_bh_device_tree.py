@@ -1,4 +1,4 @@
-"""GPU: quadtree built ON THE DEVICE (bh_build.hip; the fast mode's default from 512 bodies on) against the host build,
+"""GPU: quadtree built ON THE DEVICE (bh_build.hip; the fast mode's default from 1 024 bodies on) against the host build,
 which is node-for-node the oracle's tree.  Two classes (NBX_OPT_BH_FOLD):
   * fold = reference (round 3; the default up to 65 536 bodies): interior masses and centres are the reference's own f32 running
     fold in arrival order (nbody.rs:303-320) -> the flattened tree equals the host tree BIT FOR BIT, or the build reports EPS
@@ -349,11 +349,11 @@ def test_device_tree_exact_sums_are_at_least_as_close_to_exact_arithmetic_as_the
 
 
 def test_tree_choice_by_mode_and_size(rx, ob):
-    """NBX_OPT_BH_TREE = -1 (default): device build in the fast mode from 512 bodies on, host build below and always in the
-    bit-exact mode; 0 / 1 force one or the other."""
+    """NBX_OPT_BH_TREE = -1 (default): device build in the fast mode from 1 024 bodies on (512 with exactly summed nodes), host
+    build below and in the bit-exact mode; 0 / 1 force one or the other."""
     from rust_exp_amd.engine import NBX_OPT_BH_LAST_TREE, NBX_OPT_BH_TREE
 
-    for n, mode, want in ((4096, "fast", 1), (512, "fast", 1), (511, "fast", 0), (20000, "strict", 0)):
+    for n, mode, want in ((4096, "fast", 1), (1024, "fast", 1), (1023, "fast", 0), (20000, "strict", 0)):
         p = ob.random_disk(n, 3)
         e = rx.NBodyEngine(mode=mode)
         assert e.get_option(NBX_OPT_BH_TREE) == -1
@@ -371,6 +371,11 @@ def test_tree_choice_by_mode_and_size(rx, ob):
     f.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     f.step_barnes_hut(0.5, 0.01, 1)
     assert f.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    for n, want in ((512, 1), (511, 0)):     # exactly summed nodes: no root chain, the device build pays earlier
+        p = ob.random_disk(n, 3)
+        g = engines(rx, p, fold="exact")
+        g.step_barnes_hut(0.5, 0.01, 1)
+        assert g.get_option(NBX_OPT_BH_LAST_TREE) == want, n
 
 
 @pytest.mark.parametrize("make,n", [("disk", 3000), ("orbits", 10000), ("clusters", 4892), ("plummer", 40000)])
@@ -670,7 +675,7 @@ def test_reference_fold_merges_between_non_neighbouring_entities(rx, ob):
     y[:k] = y[k:2 * k] + (rng.normal(0, 1e-3, k) * scale).astype(np.float32)
     p = ob.particles(x, y, np.zeros(n), np.zeros(n), np.full(n, 0.37))
     h = engines(rx, p); h.set_bh_tree("host")
-    d = engines(rx, p)                                  # default: device tree, reference fold
+    d = engines(rx, p); d.set_bh_tree("device")         # device tree, reference fold (below 1 024 bodies the default is the host build)
     fx, fy, _ = h.forces(0.85)
     gx, gy, _ = d.forces(0.85)
     assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
