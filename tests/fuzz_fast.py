@@ -118,19 +118,25 @@ def main():
                 if 512 <= n <= 65536 and fd.get_option(NBX_OPT_BH_LAST_TREE) == 1:   # reference fold kept: the host tree, bit for bit
                     if not (np.array_equal(dx_.view(np.uint32), bfx.view(np.uint32)) and np.array_equal(dy_.view(np.uint32), bfy.view(np.uint32))):
                         why.append("reference-fold device tree != host tree (%d words)" % int((dx_.view(np.uint32) != bfx.view(np.uint32)).sum()))
-                if n >= 512:
-                    pa, pb = eng("fast", 1), eng("fast", 1)
-                    pb.set_option(NBX_OPT_BH_ASYNC, 0)
-                    for _ in range(4):
-                        pa.step_barnes_hut(theta, 0.01, 1); pb.step_barnes_hut(theta, 0.01, 1)
-                    sa, sb = pa.get_particles(), pb.get_particles()
-                    if any(not np.array_equal(sa[k].view(np.uint32), sb[k].view(np.uint32)) for k in ("px", "py", "vx", "vy")):
-                        why.append("pipelined steps != waited-for steps")
-                for e in (ff, fd):
-                    e.step_barnes_hut(theta, 0.01, 1); e.step_brute_force(0.01)
-                    st = e.get_particles()
-                    if not (np.isfinite(st["px"]).all() and np.isfinite(st["vx"]).all()):
-                        why.append("state not finite")
+                # (once the bodies have moved a tree may be one the reference panics on -- two bodies an ulp apart at |x| ~ 3000
+                #  need cells no f32 midpoint can make: the library then reports the reference's panic, seed 91685 -- not a failure)
+                try:
+                    if n >= 512:
+                        pa, pb = eng("fast", 1), eng("fast", 1)
+                        pb.set_option(NBX_OPT_BH_ASYNC, 0)
+                        for _ in range(4):
+                            pa.step_barnes_hut(theta, 0.01, 1); pb.step_barnes_hut(theta, 0.01, 1)
+                        sa, sb = pa.get_particles(), pb.get_particles()
+                        if any(not np.array_equal(sa[k].view(np.uint32), sb[k].view(np.uint32)) for k in ("px", "py", "vx", "vy")):
+                            why.append("pipelined steps != waited-for steps")
+                    for e in (ff, fd):
+                        e.step_barnes_hut(theta, 0.01, 1); e.step_brute_force(0.01)
+                        st = e.get_particles()
+                        if not (np.isfinite(st["px"]).all() and np.isfinite(st["vx"]).all()):
+                            why.append("state not finite")
+                except rx.NBodyError as ex:
+                    if ex.code not in (-4, -5):      # NBX_ERR_TREE_DEPTH, NBX_ERR_TREE: the reference's own panics
+                        raise
         except Exception as ex:   # noqa: BLE001
             why.append("exception " + repr(ex))
         if why:
