@@ -623,10 +623,10 @@ int QuadTree::build(const float* px, const float* py, const float* m, int n, boo
     const auto tp0 = std::chrono::steady_clock::now();
     // bucket level, sequential warm-up and worker count by size (measured on the target host, profiles/README.md):
     // small systems want few workers (waking 31 threads for 10 000 bodies costs more than it buys) and a short warm-up
-    const int limit = n >= 262144 ? 7 : (n >= 16384 ? 5 : 4);   // 7: ~3000 buckets at 1 M bodies
+    const int limit = n >= 262144 ? 8 : (n >= 16384 ? 5 : 4);   // 8 levels under a 2 048-body warm-up: ~4 000 buckets at 1 M bodies
     // (the warm-up is sequential: with the routing on the device from 16 384 bodies on, 1 024 bodies of it instead of 2 048 / 8 192
     //  are 5-15 % of a host-tree step at 30 000 .. 131 072 bodies -- discs, orbits, Plummer spheres, a collapsed core alike)
-    const int warm = std::min(n, n >= 262144 ? 8192 : 1024);
+    const int warm = std::min(n, n >= 262144 ? 2048 : 1024);   // (262 144-body Plummer disc: 6.4-7.5 ms per host-tree step with 8 192 / 7 levels, 5.0-5.6 like this)
     std::vector<Node>& top = nodes;
     std::vector<uint8_t> level;
     bucket_of.clear();
