@@ -540,9 +540,9 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
         hipLaunchKernelGGL(k_bh_eval_strict, grid, dim3(block), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
                            force_out, perm);
     else if (mode == 2 && perm) {
-        // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 8 and 64 bodies each
+        // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 4 and 64 bodies each
         int bpw = 64;
-        while (bpw > 8 && (n_targets + bpw - 1) / bpw < 4096) bpw >>= 1;
+        while (bpw > 4 && (n_targets + bpw - 1) / bpw < 4096) bpw >>= 1;   // (4 instead of 8 from 16 384 bodies down: 0.123 -> 0.120 ms per step at 10 000, 0.098 -> 0.094 at 2 000; 2 adds nothing)
         // XCD-aware block order (see the kernel): eval 0.634 -> 0.620 ms at 1 M bodies, 0.295 -> 0.252 at 262 144, 0.117 -> 0.111 at 10 000
         const int xcd_order = 1;
         const int nblk = (n_targets + bpw - 1) / bpw;
@@ -564,7 +564,8 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
         else if (bpw == 64) go(k_bh_eval_fast_wave<64>);
         else if (bpw == 32) go(k_bh_eval_fast_wave<32>);
         else if (bpw == 16) go(k_bh_eval_fast_wave<16>);
-        else go(k_bh_eval_fast_wave<8>);
+        else if (bpw == 8) go(k_bh_eval_fast_wave<8>);
+        else go(k_bh_eval_fast_wave<4>);
     }
     else
         hipLaunchKernelGGL(k_bh_eval_fast, grid, dim3(block), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta,
