@@ -156,7 +156,7 @@ enum nbx_option {
                                     * of more than 48 entities / 96 bodies, 8 a merge hinges on another cluster, 16 an outsider
                                     * within EPS of a blob's centre, 32 two entities in one level-31 cell that do not merge,
                                     * 64 more than 4 096 bodies to move, 128 a blob's successive centres part ways above its
-                                    * leaf, 256 a leaf of more bodies than the leaf fold orders; exact-sum class: 0x20000 = more
+                                    * leaf, 512 (bit-exact mode) a leaf deeper than 25 levels, where the reference may panic, 256 a leaf of more bodies than the leaf fold orders; exact-sum class: 0x20000 = more
                                     * bodies left unmerged than it tolerates */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */

@@ -361,6 +361,7 @@ enum : int {
     kWhyGhosts = 64,          // more than kGhostCap bodies to move
     kWhyCentrePath = 128,     // a blob's centres do not share one path down to the blob's leaf
     kWhyBigLeaf = 256,        // a leaf of more bodies than the leaf fold orders
+    kWhyDepthPanic = 512,     // (bit-exact mode only) a leaf deeper than 25 levels: the reference may panic on its depth counter
 };
 __device__ __forceinline__ void refuse(int* __restrict__ counters, const int why)
 {
@@ -1036,6 +1037,12 @@ __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const u
         o.px = px; o.py = py; o.m = m;
         o.skip = first + count;
         o.interior = 0; o.q = -1.0f;
+        // The reference panics when its depth COUNTER passes 50 (nbody.rs:230-232), and that counter grows by two per level while
+        // a leaf is being split down (the re-insert of nbody.rs:278-281 starts one above the node it descends from): a body that
+        // ends at level d can have driven it to 2 d.  No leaf deeper than 25 levels -> no panic; deeper ones (two bodies a few
+        // 1e-6 of the box apart) are left to the host build, which counts like the reference -- asked for by the bit-exact
+        // mode, whose contract includes the panics (the fast mode documents that it has none).
+        if ((root_aside & 2) && l > 25) refuse(counters, kWhyDepthPanic);
         // a blob's centres must all have travelled down the path it is filed under as far as this leaf (k_blobs)
         if (pmin && (int)pmin[a] < l) refuse(counters, kWhyCentrePath);
         if (fold == 1 && b - a > 1 && (px != p.x || py != p.y) && keys[a] == path_key(box, p.x, p.y)) {
@@ -1069,7 +1076,7 @@ __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const u
                 last = best;
             }
             o.px = px; o.py = py; o.m = m;
-        } else if (k == 0 && root_aside) {
+        } else if (k == 0 && (root_aside & 1)) {
             // the root's fold runs on the side stream (k_fold_root) and writes (px, py, m) of this record itself
             float4* dst = reinterpret_cast<float4*>(&out[0]);
             reinterpret_cast<float*>(dst)[3] = o.s;
@@ -1654,7 +1661,7 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters /* pinned, >= 4 ints; null: the caller's gated kick-drift publishes them */,
                                    const unsigned** perm_dev, hipStream_t stream, int fold,
-                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, BhWalk16* walk16, float* wmass)
+                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, BhWalk16* walk16, float* wmass, bool depth_panic_guard)
 {
     if (fold != 0) { walk16 = nullptr; wmass = nullptr; }   // (the fold kernels write centres and masses after k_emit)
     *perm_dev = nullptr;
@@ -1706,7 +1713,7 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     // base[n] leave at once; the pool check is inside)
     const int eb = n <= 65536 ? 64 : kTile;   // spread a small system's few waves over the CUs
     hipLaunchKernelGGL(k_emit, dim3((unsigned)((node_cap + eb - 1) / eb)), dim3(eb), 0, stream, ms, mk, mi, k.box, k.pre, n, node_cap, out,
-                       fold, k.big, n, k.counters, root_aside ? 1 : 0, walk16, wmass, pmin);
+                       fold, k.big, n, k.counters, (root_aside ? 1 : 0) | (depth_panic_guard ? 2 : 0), walk16, wmass, pmin);
     if (fold == 1) {
         // one pair of waves per queued node; the count lives on the device: enough workgroups for every plausible queue
         // (a uniform system queues ~n/5 nodes), they loop when there are more

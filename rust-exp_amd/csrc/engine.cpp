@@ -555,7 +555,8 @@ int build_tree_on_device_begin(nbx_engine* e, int* host_counters, bool publish_b
     HIP_TRY(nbx::device_tree_build_begin(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes,
                                          publish_by_kernel ? nullptr : (host_counters ? host_counters : e->h_counters), &e->d_perm,
                                          e->stream, fold, e->side_stream, e->ev_side_go, e->ev_side_done,
-                                         want16 ? e->d_walk16 : nullptr, want16 ? e->d_wmass : nullptr));
+                                         want16 ? e->d_walk16 : nullptr, want16 ? e->d_wmass : nullptr,
+                                         /*depth_panic_guard=*/e->force_mode != 0));
     return NBX_OK;
 }
 

@@ -162,7 +162,7 @@ constexpr int kFoldFaithfulMax = 65536;   // default: faithful fold up to this m
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters, const unsigned** perm_dev, hipStream_t stream, int fold = 0,
                                    hipStream_t side = nullptr, hipEvent_t ev_go = nullptr, hipEvent_t ev_done = nullptr,
-                                   BhWalk16* walk16 = nullptr, float* wmass = nullptr);
+                                   BhWalk16* walk16 = nullptr, float* wmass = nullptr, bool depth_panic_guard = false);
 hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status,
                                  hipStream_t stream, int fold = 0);
 // the device-side view of the same verdict: where the build's counters live (for launch_bh_eval / launch_integrate_f2 gates)

@@ -727,3 +727,31 @@ def test_refusals_in_a_row_back_off_to_the_host_build(rx, ob):
     d.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     d.step_barnes_hut(0.85, 0.01, 1)
     assert d.get_option(NBX_OPT_BH_LAST_TREE) == 1 and d.get_option(NBX_OPT_BH_FALLBACKS) == steps
+
+
+def test_strict_mode_on_the_device_tree_keeps_the_references_depth_panic(rx, ob):
+    """The reference panics when its depth COUNTER passes 50 (nbody.rs:230-232) -- and the counter grows by two per level while a
+    leaf is split down, so two bodies 1.5e-4 apart (not "too close") in a box 4e4 wide, 28 levels to separate, trip it although no
+    node is deeper than 29.  The device build has no such counter: in the bit-exact mode it therefore leaves every tree with a
+    leaf below level 25 to the host build, which counts like the reference (NBX_OPT_BH_REFUSAL 0x200), and the caller gets the
+    reference's panic as NBX_ERR_TREE_DEPTH; found by tests/fuzz_strict.py seed 20206.  The fast mode documents that it has no
+    depth panic and builds the tree."""
+    from rust_exp_amd.engine import NBX_OPT_BH_LAST_TREE, NBX_OPT_BH_REFUSAL
+
+    rng = np.random.default_rng(5)
+    n0 = 1500
+    x = np.concatenate([[1.0, 1.0 + 1.5e-4], rng.uniform(-2e4, 2e4, n0)]).astype(np.float32)
+    y = np.concatenate([[1.0, 1.0], rng.uniform(-2e4, 2e4, n0)]).astype(np.float32)
+    n = len(x)
+    p = ob.particles(x, y, np.zeros(n), np.zeros(n), np.ones(n))
+    rc, _, _ = ob.bh_forces(p, 0.5, nthreads=1)
+    assert rc != 0                                      # the oracle (= the reference) panics on this system
+    e = rx.NBodyEngine(mode="strict")
+    e.set_bh_tree("device")
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    with pytest.raises(rx.NBodyError) as err:
+        e.forces(0.5)
+    assert err.value.code == -4 and e.get_option(NBX_OPT_BH_REFUSAL) == 0x200
+    f = engines(rx, p); f.set_bh_tree("device")
+    fx, fy, _ = f.forces(0.5)
+    assert f.get_option(NBX_OPT_BH_LAST_TREE) == 1 and np.isfinite(fx).all() and np.isfinite(fy).all()
