@@ -5,6 +5,11 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 T=${TAG:-r02}
 bash tools/gpu_session.sh smoke tests bench bh prof pmc power k1ab k1sweep cfgs shapes ubench strict fuzz
+# round 3: the self-validating 8-engine line, the exchange floor + scaling bound, the reference-fold device tree (probe, kernel
+# stats), the level-1 frame loops, the hand-over rates of long runs; then the soak and the crossover tables
+bash tools/gpu_session.sh verify8 xlat fold frames fallback
+python tools/soak.py 100000 > gpurun_out/${T}_soak.txt 2>&1
+bash tools/bh_side_stream_crossover.sh > gpurun_out/${T}_bh_side_stream_crossover.txt 2>&1
 bash tools/bh_walk_pmc.sh > /dev/null
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/nbx_bh_stats -o p --output-format csv -- python $OLDPWD/bench.py --workload bh --no-cpu-baseline --no-traffic --steps 10 > /dev/null 2>&1); find /tmp/nbx_bh_stats -name '*kernel_stats.csv' -exec cp {} gpurun_out/${T}_bh_kernel_stats.csv \;
 python tools/bh_device_tree_probe.py > gpurun_out/${T}_bh_device_tree_probe.log 2>&1; cp gpurun_out/bh_device_tree_probe.json gpurun_out/${T}_bh_device_tree_probe.json
