@@ -206,3 +206,46 @@ def test_draw_truncation_and_bounds(ob):
     fb = ob.draw(p, 100, 100)
     assert fb[50, 0] == 2 * 0x0027404C      # -50.5 -> x=-0.5 -> column 0 ; -49.5 -> 0.5 -> column 0
     assert (fb != 0).sum() == 5 + 1 + 1     # cross + body pixel + tail pixel (N octant: one row up, y-1)
+
+
+def test_bh_depth_panic_counts_two_per_level_of_a_split_chain(ob):
+    """nbody.rs:230-232 tests a COUNTER, not the level of a node: the re-insert of a split (nbody.rs:278-281) starts one above the
+    node it descends from, so the counter grows by two per level while a leaf is split down.  A body that arrives at a leaf at
+    level d0 and ends at level d1 drives it to d0 + 2 (d1 - d0) <= 2 d1: a tree whose leaves are all at level <= 25 cannot panic,
+    deeper ones can although no node is anywhere near level 50.  (The device build has no such counter: in the bit-exact mode it
+    hands every tree with a leaf below level 25 to the host build -- bh_build.hip kWhyDepthPanic.)"""
+    rng = np.random.default_rng(12)
+    panics_seen = 0
+    for case in range(60):
+        half = float(rng.choice([50.0, 2e3, 2e4, 1e6]))
+        gap = float(rng.choice([1.5e-4, 4e-4, 3e-3, 0.05]))
+        n0 = 200
+        x = np.concatenate([[1.0, 1.0 + gap], rng.uniform(-half, half, n0)]).astype(np.float32)
+        y = np.concatenate([[1.0, 1.0], rng.uniform(-half, half, n0)]).astype(np.float32)
+        n = len(x)
+        order = rng.permutation(n)
+        p = ob.particles(x[order], y[order], np.zeros(n), np.zeros(n), np.ones(n))
+        rc, st = ob.bh_tree_stats(p)
+        # level at which the two close bodies part: the descent of nbody.rs:289-300 / :324-331 in f32
+        f = np.float32
+        x1, y1, x2, y2 = f(x.min()), f(y.min()), f(x.max()), f(y.max())
+        level = 0
+        while level < 60:
+            cx, cy = f((x1 + x2) * f(0.5)), f((y1 + y2) * f(0.5))
+            qa = (2 if y[0] < cy else 0) + (0 if x[0] < cx else 1)
+            qb = (2 if y[1] < cy else 0) + (0 if x[1] < cx else 1)
+            if qa != qb:
+                break
+            if y[0] < cy: y2 = cy
+            else: y1 = cy
+            if x[0] < cx: x2 = cx
+            else: x1 = cx
+            level += 1
+        leaf_level = level + 1
+        if rc != 0:
+            panics_seen += 1
+            assert leaf_level > 25, (half, gap, leaf_level)          # a panic needs a leaf below level 25 ...
+            assert leaf_level < 50                                    # ... and none anywhere near level 50
+        else:
+            assert st["depth"] >= leaf_level - 1
+    assert panics_seen >= 3
