@@ -217,6 +217,9 @@ def parse_args():
     ap.add_argument("--bh-tree", default="default", choices=["default", "host", "device"])
     ap.add_argument("--bh-walk-records", type=int, default=-1, choices=[-1, 16, 32],
                     help="--workload bh, device tree: node record size the wave walk reads (16 = the compact copy: A/B of round 3, slower)")
+    ap.add_argument("--bh-walk", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="--workload bh, fast mode: 1 = walk over child groups, hand-scheduled (round 4, default), 2 = the same walk "
+                         "compiled, 0 = node walk of rounds 1-3")
     ap.add_argument("--source-bits", type=int, default=32, choices=[16, 32],
                     help="16 = fp16 source copy / fp32 accumulators (BASELINE config #5)")
     ap.add_argument("--host", default="auto", choices=["auto", "single", "group", "torch"])
@@ -394,6 +397,8 @@ class SingleHost:
             e.set_bh_tree(args.bh_tree)
         if args.bh_walk_records > 0:
             e.set_option(rx.engine.NBX_OPT_BH_WALK_RECORDS, args.bh_walk_records)
+        if args.bh_walk >= 0:
+            e.set_option(rx.engine.NBX_OPT_BH_WALK, args.bh_walk)
         if args.shard_of > 1:
             e.set_shard(0, args.shard_of)
         e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"], st["pz"], st["vz"])

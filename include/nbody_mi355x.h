@@ -158,6 +158,15 @@ enum nbx_option {
                                     * 64 more than 4 096 bodies to move, 128 a blob's successive centres part ways above its
                                     * leaf, 512 (bit-exact mode) a leaf deeper than 25 levels, where the reference may panic, 256 a leaf of more bodies than the leaf fold orders; exact-sum class: 0x20000 = more
                                     * bodies left unmerged than it tolerates */
+    NBX_OPT_BH_WALK = 18,          /* fast-mode Barnes-Hut traversal: 1 (default) = over CHILD GROUPS (round 4, bh_walk.hip): the tree is
+                                    * re-laid every step as one record per opened node -- its children's (x, y, m, T), T = the
+                                    * reference's opening test s/sqrt(d^2) < theta turned into one exact threshold on d^2
+                                    * (bh_threshold.h) -- so a walk loads once per OPENED node, decides with one compare per child
+                                    * and keeps who-is-inside as a scalar lane mask; the loop is hand-scheduled gfx950 assembly.
+                                    * 2 = the same walk as the compiler schedules it (bit-identical results; the A/B of DESIGN.md
+                                    * K3).  0 = the node-by-node walk of rounds 1-3 (bh_eval.hip).  All make the reference's
+                                    * decision for every body and node; 0 differs from 1 / 2 in the order the terms are added
+                                    * (the fast mode's stated tolerance) */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };
@@ -334,6 +343,15 @@ int32_t nbx_bh_host_timing(nbx_engine *e, double *ms4, int32_t *steps, int32_t *
 /* Work of one Barnes-Hut evaluation on the current state: tree nodes visited and pair laws evaluated, summed
  * over this engine's slab (for roofline accounting; runs a counting traversal, no state change). */
 int32_t nbx_bh_work(nbx_engine *e, float theta, uint64_t *node_visits, uint64_t *pair_evals);
+/* The same counting traversal in more detail: out4 = { node visits, pair laws evaluated (nbody.rs:164-184: 12 flops each in 2-D),
+ * opening tests = visits of INTERIOR nodes (nbody.rs:341-345: 2 sub, 2 mul, 1 add, 1 sqrt, 1 div = 7 flops each as written),
+ * child groups loaded per body summed over the slab (NBX_OPT_BH_WALK = 1; 0 for the node walk) }. */
+int32_t nbx_bh_work_detail(nbx_engine *e, float theta, uint64_t *out4);
+/* The opening threshold of bh_threshold.h: the float T with  (s / sqrt(d2) < theta, nbody.rs:344-345)  <=>  d2 > T  for every
+ * float d2 >= 0.  Host evaluation; nbx_bh_take_thresholds_device evaluates count of them on the engine's GPU (test hook: the walk
+ * relies on host and device agreeing with the reference's own arithmetic). */
+float nbx_bh_take_threshold(float s, float theta);
+int32_t nbx_bh_take_thresholds_device(nbx_engine *e, int32_t count, const float *s, const float *theta, float *out);
 /* launch geometry the last force launch used (for DESIGN/bench reporting); any pointer may be NULL.
  * Bit-exact kernel: jsplit = 1 (the source loop is never split), bodies_per_thread = 1 and
  * variant = -(NBX_OPT_STRICT_KERNEL actually used): -16 / -8 = waves per workgroup of 64 targets, -1 = one thread per body. */

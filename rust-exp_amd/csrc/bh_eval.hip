@@ -22,39 +22,11 @@
 // (see there) -- used whenever a spatial order of the bodies is available (device-built tree, or host tree with
 // n >= 65536); results are bit-identical to the per-lane walk.  Tree nodes are read-only 32-B records.
 #include "kernels.h"
+#include "bh_gate.h"
 
 namespace nbx {
 
 constexpr int kMaxFrames = 56;
-
-// Device-side gate of a step enqueued BEHIND a device tree build whose outcome the host has not read yet (engine.cpp,
-// speculative step): counters = the build's {node count, left-behind bodies, queued folds}; the walk and the kick-drift run
-// only if the build produced a usable tree, exactly the test device_tree_build_end makes on the host -- otherwise they leave the
-// state untouched and the host redoes the step on the host tree.  counters == nullptr: no gate (n_nodes comes from the host).
-// counters[kTreePoisonWord]: an EARLIER gated step was refused and the host has not redone it yet -- nothing may run on the
-// state until it has.  The kick-drift of a refused step raises it (mark = true).
-struct BuildGate {
-    int* counters;
-    int node_cap, crowd_limit, queue_limit;
-    int* host_out;    // pinned: the kick-drift's first thread hands the counters to the host (no copy command behind the build)
-};
-__device__ __forceinline__ bool gate_open(const BuildGate g, int& n_nodes, const bool mark = false)
-{
-    if (!g.counters) return true;
-    if (mark && g.host_out) {
-        g.host_out[0] = g.counters[0]; g.host_out[1] = g.counters[1]; g.host_out[2] = g.counters[2];
-        g.host_out[5] = g.counters[5];   // why the build refused, if it did (bh_build.hip kWhy..)
-        __threadfence_system();
-    }
-    if (g.counters[kTreePoisonWord] != 0) return false;
-    const int nn = g.counters[0];
-    if (nn > g.node_cap || g.counters[1] > g.crowd_limit || g.counters[2] > g.queue_limit) {
-        if (mark) g.counters[kTreePoisonWord] = 1;
-        return false;
-    }
-    n_nodes = nn;
-    return true;
-}
 
 // The fast kernels decide "take or open" without the square root and without a node-type branch:
 //     take = q < theta^2 * d^2,   q = s*s (interior)  or  -1 (leaf)            (BhNode::q, set when the tree is flattened)
@@ -458,7 +430,7 @@ __global__ __launch_bounds__(kTile) void k_bh_count(const float4* __restrict__ p
                                                     unsigned long long* __restrict__ totals)
 {
     const int it = blockIdx.x * kTile + threadIdx.x;
-    unsigned visits = 0, pairs = 0;
+    unsigned visits = 0, pairs = 0, tests = 0;
     if (it < n_targets) {
         const float4 pi = posm[lo + it];
         const float th2 = theta > 0.0f ? theta * theta : 0.0f;
@@ -471,18 +443,21 @@ __global__ __launch_bounds__(kTile) void k_bh_count(const float4* __restrict__ p
             const bool take = take_node(c.z, a.w, d2, dx, dy, th2 * (1.0f - 1.0e-5f), th2 * (1.0f + 1.0e-5f), theta);
             visits++;
             pairs += take ? 1u : 0u;
+            tests += c.z >= 0.0f ? 1u : 0u;   // interior (q = s*s; a leaf has q = -1): the reference's opening test runs
             i = take ? __float_as_int(c.x) : i + 1;
         }
     }
-    unsigned long long v = visits, q = pairs;
+    unsigned long long v = visits, q = pairs, w = tests;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         v += __shfl_xor(v, off);
         q += __shfl_xor(q, off);
+        w += __shfl_xor(w, off);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&totals[0], v);
         atomicAdd(&totals[1], q);
+        atomicAdd(&totals[2], w);
     }
 }
 

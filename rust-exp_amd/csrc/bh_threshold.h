@@ -1,0 +1,78 @@
+// bh_threshold.h -- the reference's opening test (nbody.rs:341-345) as ONE exact comparison per node.
+//
+//   reference:   s = x2 - x1 ;  dist_sq = dx*dx + dy*dy ;  accept  <=>  fl( s / fl(sqrt(dist_sq)) ) < theta
+//
+// sqrt and divide are correctly rounded, hence monotone: for a node of size s >= 0 the left-hand side never grows when dist_sq
+// grows.  So for every (s, theta) there is one float T with
+//
+//                accept  <=>  dist_sq > T                      (dist_sq any float >= 0, +inf included; NaN -> not accepted)
+//
+// bh_take_threshold(s, theta) finds that T by evaluating the reference's own expression on neighbouring floats (a guess from
+// (s/theta)^2, then a bisection over the float bit patterns, which order like the floats they encode).  A walk that compares
+// the reference's dist_sq (unfused: fl(fl(dx*dx) + fl(dy*dy))) with T makes the reference's decision for EVERY body and node --
+// no band around the boundary, no second test -- at the price of one v_cmp.  Rounds 1-3 compared q = s*s with theta^2 * d^2
+// and re-made decisions inside a 1e-5 band with the reference's arithmetic: 2 multiplies, 2 compares and a mask test per visit.
+//
+// T >= 0 always (dist_sq = 0 gives s/0 = +inf or NaN: never accepted, nbody.rs:345);  theta <= 0, NaN theta or NaN s: nothing
+// is accepted, T = +inf.  Host and device compute the same T: it is a property of (s, theta), not of the search.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+namespace nbx {
+
+__host__ __device__ inline float bh_bits_to_float(uint32_t u)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+__host__ __device__ inline uint32_t bh_float_to_bits(float f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+#endif
+}
+
+// the reference's test, in the reference's arithmetic (nbody.rs:344-345); translation units that include this header are
+// compiled with -ffp-contract=off, and hipcc's sqrtf and '/' are correctly rounded (its default, like Rust's f32::sqrt and '/')
+__host__ __device__ inline bool bh_reference_accepts(float s, float dist_sq, float theta)
+{
+    return s / sqrtf(dist_sq) < theta;
+}
+
+__host__ __device__ inline float bh_take_threshold(float s, float theta)
+{
+    const uint32_t kInf = 0x7F800000u;
+    if (!bh_reference_accepts(s, bh_bits_to_float(kInf), theta)) return bh_bits_to_float(kInf);   // nothing is ever accepted
+    // invariant of the bisection: !accepts(lo) && accepts(hi)   (accepts(0) is always false)
+    uint32_t lo = 0u, hi = kInf;
+    {
+        const double r = (double)s / (double)theta;
+        const double g = r * r;
+        const float gf = g < 3.0e38 ? (float)g : 3.0e38f;
+        const uint32_t ug = bh_float_to_bits(gf);            // gf >= 0: a valid position on the pattern axis
+        const uint32_t a = ug > 8u ? ug - 8u : 0u;
+        const uint32_t b = ug + 8u < kInf ? ug + 8u : kInf;
+        if (!bh_reference_accepts(s, bh_bits_to_float(a), theta)) lo = a;
+        if (bh_reference_accepts(s, bh_bits_to_float(b), theta)) hi = b;
+    }
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (bh_reference_accepts(s, bh_bits_to_float(mid), theta)) hi = mid;
+        else lo = mid;
+    }
+    return bh_bits_to_float(lo);                             // the largest dist_sq the reference does NOT accept
+}
+
+}  // namespace nbx

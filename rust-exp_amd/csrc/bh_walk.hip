@@ -1,0 +1,468 @@
+// bh_walk.hip -- K3, round 4: the fast Barnes-Hut walk over CHILD GROUPS.  COMPILED WITH -ffp-contract=off.
+//
+// Replaces Node::compute_force (nbody.rs:333-377) for the fast mode, like bh_eval.hip's node walk did in rounds 1-3, and makes
+// the same decisions -- the reference's, for every body and node.  What bounded that walk, measured
+// (profiles/r04_bh_walk_pmc_n1048576.json): one wave-visit = 13.3 VALU + 12.8 SALU + 4.8 branch + 1 SMEM instructions, and a
+// SIMD issues at most ONE scalar-side instruction (SALU, branch, SMEM) every 4 cycles: 18.7 x 4 = 75 of the 96 cycles a visit
+// took.  The walk was bound by SCALAR issue (0.58 busy) and VALU issue (0.59 busy) together, behind a dependent load per visit.
+// This file is organised around cutting both:
+//
+//  * the unit of the walk is an OPENED node, not a visited one.  When a node is opened all (<= 4) children are needed
+//    (nbody.rs:354-360), so the tree is re-laid as one record per interior node holding its children's (x, y, m, T) -- one
+//    s_load_dwordx16, one scalar-cache line -- plus four child words: 950 visits per wave at a million bodies, 287 loads.
+//  * the opening test is ONE compare: dist_sq > T with the per-node threshold of bh_threshold.h (the reference's
+//    s/sqrt(dist_sq) < theta, exactly): no theta^2 d^2 products, no band, no second compare, no mask test.
+//  * (x, y) arithmetic is packed: d = (nx,ny) - (px,py) is one v_pk_add_f32 with the record's SGPR pair as operand,
+//    (dx^2, dy^2) one v_pk_mul_f32, the accumulation one v_pk_fma_f32.  dist_sq = dx^2 + dy^2 unfused, as the reference.
+//  * who is inside a subtree is a 64-bit scalar mask M that travels with the walk: EXEC = M for the whole group, the compare is a
+//    v_cmpx (EXEC = the lanes that take the child: the pair law runs under it, no select), M & ~EXEC = the lanes that want the
+//    child opened, and the SCC that s_andn2 leaves says whether anybody does.  Opened children go on a wave-level stack
+//    (lanes of three VGPRs: group, mask lo, mask hi).
+//  * the loop is written in assembly (k_bh_walk_groups): 8 VALU + 3 scalar instructions per child, ~12 scalar per group.  The
+//    compiler's version of the same walk (NBX_OPT_BH_WALK = 2, walk_groups_compiled below; also what a wave falls back to if
+//    its stack outgrows the 64 lanes) spends 49 SALU + 20 branches per group on the same work: 0.55 ms against the node walk's
+//    0.62 at a million bodies -- scalar-issue bound like its predecessor.
+//
+// Order of accumulation (all three forms: assembly, compiled, per-lane): a group's present children in DESCENDING slot order,
+// every child's pair law added in the lanes that take it; then the subtrees of the opened children in ASCENDING slot order,
+// depth first.  A lane adds the terms of exactly the groups it is inside, in that order, whichever bodies share its wave:
+// bit-identical results.  (Rounds 1-3 accumulated in pre-order of the nodes; the fast mode never promised a summation order --
+// the bit-exact mode keeps the reference's hierarchical sums in bh_eval.hip.)
+#include "bh_gate.h"
+#include "bh_threshold.h"
+#include "kernels.h"
+
+namespace nbx {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+// ---- tree -> groups ------------------------------------------------------------------------------------------------------
+// Group k + 1 = the children of node k (pre-order index) if node k is interior; group 0 = the root alone (the reference tests
+// the root like any other node, nbody.rs:338-345: a tall root box can be accepted from its far ends).  Indexing the groups by
+// node keeps this a map without a scan; the slots of exterior nodes are never touched.
+// kid[c]: BYTE offset of child c's own group record (interior child), kGroupLeaf, or kGroupAbsent (present children first).
+constexpr int kGroupLeaf = -1, kGroupAbsent = -2;
+
+__device__ __forceinline__ void group_slot(const BhNode nd, const int index, const float theta, float4& rec, int& kid)
+{
+    if (nd.interior) {
+        rec = make_float4(nd.px, nd.py, nd.m, bh_take_threshold(nd.s, theta));
+        kid = (index + 1) * (int)sizeof(BhGroup);
+    } else {
+        // a leaf is always evaluated (nbody.rs:371); the body's own leaf adds m * 0 / (0 + EPS) = exactly 0 (nbody.rs:365)
+        rec = make_float4(nd.px, nd.py, nd.m, -1.0f);
+        kid = kGroupLeaf;
+    }
+}
+
+__global__ __launch_bounds__(kTile) void k_bh_groups(const BhNode* __restrict__ nodes, int n_nodes, const float theta,
+                                                     BhGroup* __restrict__ groups, const BuildGate gate)
+{
+    if (!gate_open(gate, n_nodes)) return;
+    const int k = blockIdx.x * kTile + threadIdx.x;
+    const float4 none = make_float4(0.0f, 0.0f, 0.0f, __builtin_inff());   // never taken (and never visited: its kid says absent)
+    if (k == 0) {
+        // an empty tree: one massless leaf, so that the walk has something harmless to evaluate
+        float4 r0 = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+        int kid0 = kGroupLeaf;
+        if (n_nodes > 0) group_slot(nodes[0], 0, theta, r0, kid0);
+        groups[0].c[0] = r0; groups[0].c[1] = none; groups[0].c[2] = none; groups[0].c[3] = none;
+        groups[0].kid = make_int4(kid0, kGroupAbsent, kGroupAbsent, kGroupAbsent);
+    }
+    if (k >= n_nodes) return;
+    const int2 hdr = *reinterpret_cast<const int2*>(&nodes[k].skip);   // skip, interior
+    if (!hdr.y) return;
+    float4 rec[4] = {none, none, none, none};
+    int kid[4] = {kGroupAbsent, kGroupAbsent, kGroupAbsent, kGroupAbsent};
+    int c = k + 1;
+#pragma unroll
+    for (int slot = 0; slot < 4; slot++) {
+        if (c < hdr.x) {
+            const BhNode nd = nodes[c];
+            group_slot(nd, c, theta, rec[slot], kid[slot]);
+            c = nd.skip;
+        }
+    }
+    BhGroup* g = &groups[k + 1];
+    g->c[0] = rec[0]; g->c[1] = rec[1]; g->c[2] = rec[2]; g->c[3] = rec[3];
+    g->kid = make_int4(kid[0], kid[1], kid[2], kid[3]);
+}
+
+// ---- the shared walk, compiler-generated form ------------------------------------------------------------------------------
+// Wave-level stack of pending groups: entry e lives in lane e of three VGPRs (group offset, mask lo, mask hi); entries beyond
+// the 64th go to LDS.  Every opened child is pushed (last slot first, so the first slot's subtree is walked first); at most 4
+// per level are pending, 52 levels at most (the builds refuse deeper trees like the reference's panic, nbody.rs:230).
+constexpr int kSpill = 4 * 52 - 64;
+
+__device__ __forceinline__ int writelane(const int value, const int lane, int reg)
+{
+    // (VOP3 takes one SGPR: the lane select goes through m0)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(value), "s"(lane) : "m0");
+    return reg;
+}
+
+struct WaveStack {
+    int g = 0, lo = 0, hi = 0;   // lanes = entries
+    int sp = 0;                  // wave-uniform
+    __device__ __forceinline__ void push(const int group, const u64 mask, volatile int* spill)
+    {
+        if (sp < 64) {
+            g = writelane(group, sp, g);
+            lo = writelane((int)(unsigned)mask, sp, lo);
+            hi = writelane((int)(unsigned)(mask >> 32), sp, hi);
+        } else if (sp - 64 < kSpill) {
+            if (threadIdx.x == 0) {
+                spill[3 * (sp - 64) + 0] = group;
+                spill[3 * (sp - 64) + 1] = (int)(unsigned)mask;
+                spill[3 * (sp - 64) + 2] = (int)(unsigned)(mask >> 32);
+            }
+        }
+        sp++;
+    }
+    __device__ __forceinline__ void pop(int& group, u64& mask, volatile int* spill)
+    {
+        sp--;
+        int a, b, c;
+        if (sp < 64) {
+            a = __builtin_amdgcn_readlane(g, sp);
+            b = __builtin_amdgcn_readlane(lo, sp);
+            c = __builtin_amdgcn_readlane(hi, sp);
+        } else if (sp - 64 < kSpill) {
+            a = __builtin_amdgcn_readfirstlane(spill[3 * (sp - 64) + 0]);
+            b = __builtin_amdgcn_readfirstlane(spill[3 * (sp - 64) + 1]);
+            c = __builtin_amdgcn_readfirstlane(spill[3 * (sp - 64) + 2]);
+        } else {   // unreachable (see kSpill): an empty mask -- the group is loaded and nobody is inside
+            a = 0; b = 0; c = 0;
+        }
+        group = a;
+        mask = (u64)(unsigned)b | ((u64)(unsigned)c << 32);
+    }
+};
+
+// One child of the group in (G, K): d = (nx,ny) - p, dist_sq as the reference forms it (nbody.rs:342-344); the lanes of M with
+// "not (dist_sq <= T)" take it -- a NaN takes (and poisons the sum, as a NaN does in the reference) instead of opening, so a leaf
+// (T = -1) is taken by ALL of M and never opened, without a test of its kind; the pair law a += m d / (dist_sq + EPS)
+// (nbody.rs:174-183, rcp for /) runs under the exec mask of the takers (the empty asm keeps the block a branch: if-converted it
+// costs two v_cndmask per child); the other lanes of M open the child: its group goes on the stack with their mask.
+#define NBX_GROUP_CHILD(c)                                                                 \
+    {                                                                                      \
+        const v2f nxy = {G[4 * (c) + 0], G[4 * (c) + 1]};                                  \
+        const v2f d = nxy - p;                                                             \
+        const v2f sq = d * d;                                                              \
+        const float d2 = sq.x + sq.y;                                                      \
+        const u64 tm = __ballot(!(d2 <= G[4 * (c) + 3])) & M;                              \
+        if (__builtin_amdgcn_inverse_ballot_w64(tm)) {                                     \
+            asm volatile("");                                                              \
+            const float s = G[4 * (c) + 2] * __builtin_amdgcn_rcpf(d2 + kEps);             \
+            const v2f ss = {s, s};                                                         \
+            acc = __builtin_elementwise_fma(ss, d, acc);                                   \
+        }                                                                                  \
+        const u64 om = M & ~tm;                                                            \
+        if (om != 0ull) st.push(K[c], om, spill);                                          \
+    }
+
+__device__ __forceinline__ v2f walk_groups_compiled(const BhGroup* __restrict__ groups, const v2f p, u64 M, volatile int* spill)
+{
+    v2f acc = {0.0f, 0.0f};
+    WaveStack st;
+    unsigned g = 0u;   // byte offset of the group record
+    for (;;) {
+        // (constant address space: a uniform load from it is a scalar load whatever else the kernel does -- the records were written
+        //  by an earlier kernel)
+        typedef const v16f __attribute__((address_space(4))) * rec16_t;
+        typedef const v4i __attribute__((address_space(4))) * rec4_t;
+        const uintptr_t rec = reinterpret_cast<uintptr_t>(groups) + (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)g);
+        const v16f G = *reinterpret_cast<rec16_t>(rec);
+        const v4i K = *reinterpret_cast<rec4_t>(rec + 64);
+        if (K[2] != kGroupAbsent) {
+            if (K[3] != kGroupAbsent) NBX_GROUP_CHILD(3)
+            NBX_GROUP_CHILD(2)
+            NBX_GROUP_CHILD(1)
+        } else if (K[1] != kGroupAbsent) {
+            NBX_GROUP_CHILD(1)
+        }
+        NBX_GROUP_CHILD(0)
+        if (st.sp == 0) break;
+        int ng;
+        st.pop(ng, M, spill);
+        g = (unsigned)ng;
+    }
+    return acc;
+}
+
+// ---- the shared walk, hand-scheduled ---------------------------------------------------------------------------------------
+// The same walk with the scalar side written by hand.  Registers (fixed; bound through the asm constraints):
+//   s[36:51] group record (x,y,m,T) x 4    s[52:55] child words        s[56:57] M        s[58:59] lanes that open the child
+//   s60 stack pointer   s61 byte offset of the group   s[62:63] EXEC at entry   s[64:65] groups   s[66:67] groups + 64   s68 overflow
+//   v[10:11] p   v[12:13] sum   v[14:15] d   v[16:17] (dx^2, dy^2)   v18 dist_sq   v[20:21] m/(dist_sq+EPS)   v22 v23 v24 stack
+// Per child: 8 VALU (v_pk_add, v_pk_mul, v_add, v_cmpx, v_add, v_rcp, v_mul, v_pk_fma) + s_andn2 + s_mov exec + s_cbranch.
+// The s_nop 0 after each packed op and the scalar instruction between v_rcp and its use are the wait states gfx950 asks for
+// (packed-result forwarding; transcendental result).  A wave whose stack would pass 64 entries leaves with s68 = 1 and redoes its
+// walk in the compiled form (LDS spill) -- the same sums in the same order.
+#define NBX_ASM_CHILD(x, m, T, K, c)                                                                       \
+    "Lc" #c "_%=:\n"                                                                                       \
+    " v_pk_add_f32 v[14:15], " x ", v[10:11] neg_lo:[0,1] neg_hi:[0,1]\n"                                  \
+    " s_nop 0\n"                                                                                           \
+    " v_pk_mul_f32 v[16:17], v[14:15], v[14:15]\n"                                                         \
+    " s_nop 0\n"                                                                                           \
+    " v_add_f32 v18, v16, v17\n"                                                                           \
+    " v_cmpx_nge_f32 vcc, " T ", v18\n"               /* EXEC = lanes of M with not (T >= dist_sq): they take the child */ \
+    " v_add_f32 v20, 0x38d1b717, v18\n"               /* dist_sq + EPS (nbody.rs:180) */                   \
+    " v_rcp_f32 v20, v20\n"                                                                                \
+    " s_andn2_b64 s[58:59], s[56:57], exec\n"         /* the lanes of M that open it; SCC = anybody */      \
+    " v_mul_f32 v20, " m ", v20\n"                                                                         \
+    " v_pk_fma_f32 v[12:13], v[20:21], v[14:15], v[12:13] op_sel_hi:[0,1,1]\n"                             \
+    " s_mov_b64 exec, s[56:57]\n"                                                                          \
+    " s_cbranch_scc1 Lpush" #c "_%=\n"                                                                     \
+    "Lback" #c "_%=:\n"
+#define NBX_ASM_PUSH(K, c)                                                                                 \
+    "Lpush" #c "_%=:\n"                                                                                    \
+    " s_cmp_ge_u32 s60, 64\n"                                                                              \
+    " s_cbranch_scc1 Lovf_%=\n"                                                                            \
+    " s_mov_b32 m0, s60\n"                                                                                 \
+    " s_add_u32 s60, s60, 1\n"                                                                             \
+    " v_writelane_b32 v22, " K ", m0\n"                                                                    \
+    " v_writelane_b32 v23, s58, m0\n"                                                                      \
+    " v_writelane_b32 v24, s59, m0\n"                                                                      \
+    " s_branch Lback" #c "_%=\n"
+
+__device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ groups, const v2f p, u64 M, int& overflow)
+{
+    v2f acc = {0.0f, 0.0f};
+    const char* base = reinterpret_cast<const char*>(groups);
+    asm volatile(
+        " s_mov_b64 s[62:63], exec\n"
+        " s_mov_b32 s60, 0\n"
+        " s_mov_b32 s61, 0\n"
+        " s_mov_b32 s68, 0\n"
+        " s_branch Lload_%=\n"
+        "Lpop_%=:\n"
+        " s_cmp_eq_u32 s60, 0\n"
+        " s_cbranch_scc1 Ldone_%=\n"
+        " s_add_u32 s60, s60, -1\n"
+        " v_readlane_b32 s61, v22, s60\n"
+        " v_readlane_b32 s56, v23, s60\n"
+        " v_readlane_b32 s57, v24, s60\n"
+        "Lload_%=:\n"
+        " s_load_dwordx16 s[36:51], s[64:65], s61\n"
+        " s_load_dwordx4 s[52:55], s[66:67], s61\n"
+        " s_mov_b64 exec, s[56:57]\n"
+        " s_waitcnt lgkmcnt(0)\n"
+        " s_cmp_eq_u32 s54, -2\n"                 // slot 2 absent: one or two children
+        " s_cbranch_scc1 Lle2_%=\n"
+        " s_cmp_eq_u32 s55, -2\n"
+        " s_cbranch_scc1 Lc2_%=\n"
+        NBX_ASM_CHILD("s[48:49]", "s50", "s51", "s55", 3)
+        NBX_ASM_CHILD("s[44:45]", "s46", "s47", "s54", 2)
+        NBX_ASM_CHILD("s[40:41]", "s42", "s43", "s53", 1)
+        NBX_ASM_CHILD("s[36:37]", "s38", "s39", "s52", 0)
+        " s_branch Lpop_%=\n"
+        "Lle2_%=:\n"
+        " s_cmp_eq_u32 s53, -2\n"
+        " s_cbranch_scc0 Lc1_%=\n"
+        " s_branch Lc0_%=\n"
+        NBX_ASM_PUSH("s55", 3)
+        NBX_ASM_PUSH("s54", 2)
+        NBX_ASM_PUSH("s53", 1)
+        NBX_ASM_PUSH("s52", 0)
+        "Lovf_%=:\n"
+        " s_mov_b32 s68, 1\n"
+        "Ldone_%=:\n"
+        " s_mov_b64 exec, s[62:63]\n"
+        : "+{v[12:13]}"(acc), "={s68}"(overflow), "+{s[56:57]}"(M)
+        : "{s[64:65]}"(base), "{s[66:67]}"(base + 64), "{v[10:11]}"(p)
+        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
+          "s54", "s55", "s58", "s59", "s60", "s61", "s62", "s63", "v14", "v15", "v16", "v17", "v18", "v20", "v21", "v22", "v23", "v24",
+          "vcc", "scc", "m0");
+    return acc;
+}
+
+template <int BPW, bool ASM>
+__global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* __restrict__ posm, const int lo, const int n_targets,
+                                                       const BhGroup* __restrict__ groups, float2* __restrict__ out,
+                                                       const unsigned* __restrict__ perm, const int xcd_order, const BuildGate gate)
+{
+    __shared__ int spill_mem[3 * kSpill];
+    int n_nodes_unused = 0;
+    if (!gate_open(gate, n_nodes_unused)) return;
+    // XCD-aware order (as the node walk, bh_eval.hip): XCD k walks the k-th contiguous eighth of the Morton-ordered bodies
+    const int blk = xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int t = blk * BPW + threadIdx.x;
+    const bool valid = (int)threadIdx.x < BPW && t < n_targets;
+    const u64 M = __ballot(valid);
+    if (M == 0ull) return;
+    const int it = valid ? (perm ? (int)perm[t] - lo : t) : 0;
+    const float4 pi = posm[lo + it];
+    const v2f p = {pi.x, pi.y};
+    v2f acc;
+    int overflow = ASM ? 0 : 1;
+    if (ASM) acc = walk_groups_asm(groups, p, M, overflow);
+    if (__builtin_amdgcn_readfirstlane(overflow)) acc = walk_groups_compiled(groups, p, M, spill_mem);   // (uniform: the asm's output is an SGPR)
+    if (valid) out[it] = make_float2(acc.x, acc.y);
+}
+
+// ---- the same walk, private to a lane (bodies in particle-index order: host tree below 65 536 bodies, NBX_OPT_BH_WAVE = 0) ---
+constexpr int kLaneStack = 4 * 52;
+
+__global__ __launch_bounds__(kTile) void k_bh_walk_groups_lane(const float4* __restrict__ posm, const int lo, const int n_targets,
+                                                               const BhGroup* __restrict__ groups, float2* __restrict__ out,
+                                                               const unsigned* __restrict__ perm, const BuildGate gate)
+{
+    int n_nodes_unused = 0;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_targets || !gate_open(gate, n_nodes_unused)) return;
+    const int it = perm ? (int)perm[t] - lo : t;
+    const float4 pi = posm[lo + it];
+    const v2f p = {pi.x, pi.y};
+    v2f acc = {0.0f, 0.0f};
+    int stack[kLaneStack];
+    int sp = 0;
+    unsigned g = 0u;
+    for (;;) {
+        const BhGroup G = *reinterpret_cast<const BhGroup*>(reinterpret_cast<const char*>(groups) + g);
+        const int K[4] = {G.kid.x, G.kid.y, G.kid.z, G.kid.w};
+#pragma unroll
+        for (int c = 3; c >= 0; c--) {
+            if (K[c] == kGroupAbsent) continue;
+            const v2f nxy = {G.c[c].x, G.c[c].y};
+            const v2f d = nxy - p;
+            const v2f sq = d * d;
+            const float d2 = sq.x + sq.y;
+            if (!(d2 <= G.c[c].w)) {
+                const float s = G.c[c].z * __builtin_amdgcn_rcpf(d2 + kEps);
+                const v2f ss = {s, s};
+                acc = __builtin_elementwise_fma(ss, d, acc);
+            } else if (sp < kLaneStack) {
+                stack[sp++] = K[c];
+            }
+        }
+        if (sp == 0) break;
+        g = (unsigned)stack[--sp];
+    }
+    out[it] = make_float2(acc.x, acc.y);
+}
+
+// Work counter over the groups (nbx_bh_work with NBX_OPT_BH_WALK != 0): children visited, pair laws evaluated, opening tests and
+// groups loaded, per launch.  The same visits / pair laws / tests as bh_eval.hip's k_bh_count over the nodes if -- and only if --
+// both walks make the same decisions.
+__global__ __launch_bounds__(kTile) void k_bh_count_groups(const float4* __restrict__ posm, const int lo, const int n_targets,
+                                                           const BhGroup* __restrict__ groups, unsigned long long* __restrict__ totals)
+{
+    const int it = blockIdx.x * kTile + threadIdx.x;
+    unsigned visits = 0, pairs = 0, tests = 0, loads = 0;
+    if (it < n_targets) {
+        const float4 pi = posm[lo + it];
+        const v2f p = {pi.x, pi.y};
+        int stack[kLaneStack];
+        int sp = 0;
+        unsigned g = 0u;
+        for (;;) {
+            const BhGroup G = *reinterpret_cast<const BhGroup*>(reinterpret_cast<const char*>(groups) + g);
+            const int K[4] = {G.kid.x, G.kid.y, G.kid.z, G.kid.w};
+            loads++;
+#pragma unroll
+            for (int c = 3; c >= 0; c--) {
+                if (K[c] == kGroupAbsent) continue;
+                const v2f nxy = {G.c[c].x, G.c[c].y};
+                const v2f d = nxy - p;
+                const v2f sq = d * d;
+                const float d2 = sq.x + sq.y;
+                visits++;
+                if (K[c] >= 0) tests++;   // an interior node: the reference runs its opening test (nbody.rs:338-345)
+                if (!(d2 <= G.c[c].w)) pairs++;
+                else if (sp < kLaneStack) stack[sp++] = K[c];
+            }
+            if (sp == 0) break;
+            g = (unsigned)stack[--sp];
+        }
+    }
+    unsigned long long v = visits, q = pairs, w = tests, l = loads;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_xor(v, off);
+        q += __shfl_xor(q, off);
+        w += __shfl_xor(w, off);
+        l += __shfl_xor(l, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&totals[0], v);
+        atomicAdd(&totals[1], q);
+        atomicAdd(&totals[2], w);
+        atomicAdd(&totals[3], l);
+    }
+}
+
+hipError_t launch_bh_count_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, unsigned long long* totals,
+                                  hipStream_t stream)
+{
+    if (n_targets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bh_count_groups, dim3((unsigned)((n_targets + kTile - 1) / kTile)), dim3(kTile), 0, stream, posm, lo, n_targets,
+                       groups, totals);
+    return hipGetLastError();
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------------------
+size_t bh_groups_count(int node_cap) { return (size_t)node_cap + 1; }
+bool bh_groups_addressable(int node_cap) { return ((size_t)node_cap + 1) * sizeof(BhGroup) < ((size_t)1 << 31); }
+
+hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta, BhGroup* groups, hipStream_t stream,
+                            int* gate_counters, int gate_node_cap, int gate_crowd_limit, int gate_queue_limit)
+{
+    const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit, nullptr};
+    const int threads = n_nodes_or_cap > 0 ? n_nodes_or_cap : 1;   // an empty tree still gets its group 0
+    hipLaunchKernelGGL(k_bh_groups, dim3((unsigned)((threads + kTile - 1) / kTile)), dim3(kTile), 0, stream, nodes, n_nodes_or_cap,
+                       theta, groups, gate);
+    return hipGetLastError();
+}
+
+template <bool ASM>
+static void launch_wave_walk(int bpw, dim3 g, hipStream_t stream, const float4* posm, int lo, int n_targets, const BhGroup* groups,
+                             float2* out, const unsigned* perm, BuildGate gate)
+{
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, g, dim3(64), 0, stream, posm, lo, n_targets, groups, out, perm, 1, gate); };
+    if (bpw == 64) go(k_bh_walk_groups<64, ASM>);
+    else if (bpw == 32) go(k_bh_walk_groups<32, ASM>);
+    else if (bpw == 16) go(k_bh_walk_groups<16, ASM>);
+    else if (bpw == 8) go(k_bh_walk_groups<8, ASM>);
+    else go(k_bh_walk_groups<4, ASM>);
+}
+
+hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, float2* out, hipStream_t stream,
+                                 const unsigned* perm, bool wave, bool hand_scheduled, int* gate_counters, int gate_node_cap,
+                                 int gate_crowd_limit, int gate_queue_limit)
+{
+    if (n_targets <= 0) return hipSuccess;
+    const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit, nullptr};
+    if (wave && perm) {
+        // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 4 and 64 bodies each (as the node walk)
+        int bpw = 64;
+        while (bpw > 4 && (n_targets + bpw - 1) / bpw < 4096) bpw >>= 1;
+        const int nblk = (n_targets + bpw - 1) / bpw;
+        const dim3 g((unsigned)((nblk + 7) / 8 * 8));
+        if (hand_scheduled) launch_wave_walk<true>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate);
+        else launch_wave_walk<false>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate);
+    } else {
+        const int block = n_targets <= 65536 ? 64 : kTile;
+        hipLaunchKernelGGL(k_bh_walk_groups_lane, dim3((unsigned)((n_targets + block - 1) / block)), dim3(block), 0, stream, posm, lo,
+                           n_targets, groups, out, perm, gate);
+    }
+    return hipGetLastError();
+}
+
+// test hook: T of bh_threshold.h evaluated on the device
+__global__ void k_bh_thresholds(const float* __restrict__ s, const float* __restrict__ theta, float* __restrict__ out, const int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = bh_take_threshold(s[i], theta[i]);
+}
+hipError_t launch_bh_thresholds(const float* s, const float* theta, float* out, int count, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bh_thresholds, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, s, theta, out, count);
+    return hipGetLastError();
+}
+
+}  // namespace nbx

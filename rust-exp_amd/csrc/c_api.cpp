@@ -4,6 +4,7 @@
 #include <new>
 
 #include "engine_internal.h"
+#include "bh_threshold.h"
 
 using namespace nbxi;
 
@@ -61,6 +62,16 @@ void nbx_destroy(nbx_engine* e)
 int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    switch (option) {   // a step that is still in flight was issued under the CURRENT options: settle it (and redo it, if its device
+                        // build was refused) before any option that shapes a step changes
+        case NBX_OPT_FORCE_MODE: case NBX_OPT_BH_TREE: case NBX_OPT_BH_FOLD: case NBX_OPT_BH_WAVE: case NBX_OPT_BH_ASYNC:
+        case NBX_OPT_SOURCE_PRECISION: case NBX_OPT_BH_WALK: case NBX_OPT_BH_WALK_RECORDS: {
+            const int rc = resolve_pending(e);
+            if (rc != NBX_OK) return rc;
+            break;
+        }
+        default: break;
+    }
     switch (option) {
         case NBX_OPT_FORCE_MODE:
             if (value != 0 && value != 1) return fail(NBX_ERR_INVALID, "force mode must be 0 (fast) or 1 (strict)");
@@ -90,6 +101,9 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
             }
             return NBX_OK;
         case NBX_OPT_KERNEL_VARIANT:
+            // (17 / 18 are what the engine REPORTS for the fp16-source sweeps; K2 and the force readout key off them, so a caller
+            //  must not be able to set them)
+            if (value < -1 || value > 7) return fail(NBX_ERR_INVALID, "kernel variant must be -1 (auto) or 0..7");
             e->variant = (int)value;
             return NBX_OK;
         case NBX_OPT_STRICT_KERNEL:
@@ -108,6 +122,11 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
             return NBX_OK;
         case NBX_OPT_BH_ASYNC:
             e->bh_async = value ? 1 : 0;
+            return NBX_OK;
+        case NBX_OPT_BH_WALK:
+            if (value != 0 && value != 1 && value != 2)
+                return fail(NBX_ERR_INVALID, "bh walk must be 1 (child groups), 2 (child groups, compiled loop) or 0 (node walk)");
+            e->bh_walk = (int)value;
             return NBX_OK;
         case NBX_OPT_BH_WALK_RECORDS:
             if (value != 16 && value != 32 && value != -1) return fail(NBX_ERR_INVALID, "walk records must be 16, 32 or -1 (by size)");
@@ -151,6 +170,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_BH_FOLD: return e->bh_fold;
         case NBX_OPT_BH_ASYNC: return e->bh_async;
         case NBX_OPT_BH_WALK_RECORDS: return e->bh_walk_records;
+        case NBX_OPT_BH_WALK: return e->bh_walk;
         case NBX_OPT_BH_FALLBACKS: return e->bh_fallbacks;
         case NBX_OPT_BH_LAST_TREE: return e->bh_last_tree_device;
         case NBX_OPT_BH_REFUSAL: return e->bh_last_refusal;
@@ -369,10 +389,14 @@ int32_t nbx_forces(nbx_engine* e, float theta, int32_t cap, float* fx, float* fy
             if (rc != NBX_OK) return rc;
         }
         e->bh_last_tree_device = on_device ? 1 : 0;
-        ProfScope ps(e, NBX_K_BH_EVAL);
         const unsigned* perm = (on_device && e->world == 1) ? e->d_perm : nullptr;
-        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta,
-                                    (e->force_mode == 0 && perm && e->bh_wave) ? 2 : e->force_mode, e->d_f2, e->stream, perm));
+        if (e->force_mode == 0) {
+            rc = launch_fast_walk(e, theta, perm, perm && e->bh_wave, on_device, nullptr, 0, 0, 0);
+            if (rc != NBX_OK) return rc;
+        } else {
+            ProfScope ps(e, NBX_K_BH_EVAL);
+            HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, e->force_mode, e->d_f2, e->stream, perm));
+        }
         is_accel = e->force_mode == 0;
     }
     std::vector<float2> tmp((size_t)slab);
@@ -666,7 +690,17 @@ int32_t nbx_profile_read(nbx_engine* e, int32_t kernel_id, double* total_ms, int
 
 int32_t nbx_bh_work(nbx_engine* e, float theta, uint64_t* node_visits, uint64_t* pair_evals)
 {
-    if (!e) return fail(NBX_ERR_INVALID, "null engine");
+    uint64_t out[4] = {0, 0, 0, 0};
+    const int32_t rc = nbx_bh_work_detail(e, theta, out);
+    if (rc != NBX_OK) return rc;
+    if (node_visits) *node_visits = out[0];
+    if (pair_evals) *pair_evals = out[1];
+    return NBX_OK;
+}
+
+int32_t nbx_bh_work_detail(nbx_engine* e, float theta, uint64_t* out4)
+{
+    if (!e || !out4) return fail(NBX_ERR_INVALID, "null argument");
     int rc = upload(e);
     if (rc != NBX_OK) return rc;
     bool on_device = false;
@@ -679,15 +713,43 @@ int32_t nbx_bh_work(nbx_engine* e, float theta, uint64_t* node_visits, uint64_t*
         if (rc != NBX_OK) return rc;
     }
     unsigned long long* d_tot = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tot), 16));
-    HIP_TRY(hipMemsetAsync(d_tot, 0, 16, e->stream));
-    HIP_TRY(nbx::launch_bh_count(e->d_posm, e->lo, e->slab(), e->d_nodes, (int)e->n_flat, theta, d_tot, e->stream));
-    unsigned long long h[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h, d_tot, 16, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tot), 32));
+    HIP_TRY(hipMemsetAsync(d_tot, 0, 32, e->stream));
+    if (e->bh_walk != 0 && e->force_mode == 0 && nbx::bh_groups_addressable((int)e->n_flat)) {   // counted over the structure the selected walk uses
+        rc = grow(&e->d_groups, &e->groups_cap, nbx::bh_groups_count((int)e->n_flat));
+        if (rc != NBX_OK) { (void)hipFree(d_tot); return rc; }
+        HIP_TRY(nbx::launch_bh_groups(e->d_nodes, (int)e->n_flat, theta, e->d_groups, e->stream));
+        HIP_TRY(nbx::launch_bh_count_groups(e->d_posm, e->lo, e->slab(), e->d_groups, d_tot, e->stream));
+    } else {
+        HIP_TRY(nbx::launch_bh_count(e->d_posm, e->lo, e->slab(), e->d_nodes, (int)e->n_flat, theta, d_tot, e->stream));
+    }
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, d_tot, 32, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipFree(d_tot));
-    if (node_visits) *node_visits = h[0];
-    if (pair_evals) *pair_evals = h[1];
+    for (int i = 0; i < 4; i++) out4[i] = h[i];
+    return NBX_OK;
+}
+
+float nbx_bh_take_threshold(float s, float theta) { return nbx::bh_take_threshold(s, theta); }
+
+int32_t nbx_bh_take_thresholds_device(nbx_engine* e, int32_t count, const float* s, const float* theta, float* out)
+{
+    if (!e || count < 0 || (count > 0 && (!s || !theta || !out))) return fail(NBX_ERR_INVALID, "bad arguments");
+    if (count == 0) return NBX_OK;
+    int rc = ensure_device(e);
+    if (rc != NBX_OK) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    float* d = nullptr;
+    const size_t bytes = sizeof(float) * (size_t)count;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), 3 * bytes));
+    hipError_t err = hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, e->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(d + count, theta, bytes, hipMemcpyHostToDevice, e->stream);
+    if (err == hipSuccess) err = nbx::launch_bh_thresholds(d, d + count, d + 2 * (size_t)count, count, e->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(out, d + 2 * (size_t)count, bytes, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    (void)hipFree(d);
+    HIP_TRY(err);
     return NBX_OK;
 }
 

@@ -640,6 +640,32 @@ int slab_order(nbx_engine* e)
     return NBX_OK;
 }
 
+// Fast-mode traversal of the node array this engine holds (e->d_nodes, e->n_flat -- or, gated, the count the device build left in
+// its counters) for the slab's bodies, accelerations into e->d_f2.  NBX_OPT_BH_WALK = 1 (default) / 2: the tree is first re-laid as
+// child groups with the step's theta (k_bh_groups), then walked group by group (bh_walk.hip: hand-scheduled / compiled loop);
+// 0 (or a tree too large for 31-bit record offsets: beyond ~4 M bodies): the node walk of rounds 1-3.
+int launch_fast_walk(nbx_engine* e, float theta, const unsigned* perm, bool wave, bool on_device, int* gate, int gate_node_cap,
+                     int gate_crowd_limit, int gate_queue_limit)
+{
+    const int slab = e->slab();
+    ProfScope ps(e, NBX_K_BH_EVAL);
+    const int nodes_or_cap = gate ? gate_node_cap : (int)e->n_flat;
+    if (e->bh_walk != 0 && nbx::bh_groups_addressable(nodes_or_cap)) {
+        const int rc = grow(&e->d_groups, &e->groups_cap, nbx::bh_groups_count(nodes_or_cap));
+        if (rc != NBX_OK) return rc;
+        HIP_TRY(nbx::launch_bh_groups(e->d_nodes, nodes_or_cap, theta, e->d_groups, e->stream, gate, gate_node_cap, gate_crowd_limit,
+                                      gate_queue_limit));
+        HIP_TRY(nbx::launch_bh_walk_groups(e->d_posm, e->lo, slab, e->d_groups, e->d_f2, e->stream, perm, wave, e->bh_walk == 1, gate,
+                                           gate_node_cap, gate_crowd_limit, gate_queue_limit));
+        return NBX_OK;
+    }
+    const bool w16 = on_device && wave && e->walk16_valid;
+    HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, wave ? 2 : 0, e->d_f2, e->stream, perm, gate,
+                                gate_node_cap, gate_crowd_limit, gate_queue_limit, w16 ? e->d_walk16 : nullptr,
+                                w16 ? e->d_wmass : nullptr));
+    return NBX_OK;
+}
+
 // traversal + kick-drift of this engine's slab against the node array it holds (e->d_nodes, e->n_flat)
 int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm, bool gated, int* gate_host_out)
 {
@@ -667,13 +693,13 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
     }
     e->bh_last_tree_device = on_device ? 1 : 0;
     const bool wave = perm != nullptr && e->bh_wave;   // shared walk per wave, in both modes (same results as the per-lane walks)
-    {
+    if (e->force_mode == 0) {
+        rc = launch_fast_walk(e, theta, perm, wave, on_device, gate, node_cap, crowd_limit, queue_limit);
+        if (rc != NBX_OK) return rc;
+    } else {
         ProfScope ps(e, NBX_K_BH_EVAL);
-        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta,
-                                    wave ? (e->force_mode == 0 ? 2 : 3) : e->force_mode, e->d_f2,
-                                    e->stream, perm, gate, node_cap, crowd_limit, queue_limit,
-                                    (on_device && wave && e->walk16_valid) ? e->d_walk16 : nullptr,
-                                    (on_device && wave && e->walk16_valid) ? e->d_wmass : nullptr));
+        HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, wave ? 3 : e->force_mode, e->d_f2,
+                                    e->stream, perm));
     }
     {
         ProfScope ps(e, NBX_K_INTEGRATE);
@@ -887,6 +913,7 @@ void free_device(nbx_engine* e)
     if (e->d_f2) (void)hipFree(e->d_f2);
     if (e->d_out4) (void)hipFree(e->d_out4);
     if (e->d_nodes) (void)hipFree(e->d_nodes);
+    if (e->d_groups) (void)hipFree(e->d_groups);
     if (e->d_walk16) (void)hipFree(e->d_walk16);
     if (e->d_wmass) (void)hipFree(e->d_wmass);
     if (e->d_guard) (void)hipFree(e->d_guard);

@@ -54,6 +54,12 @@ struct nbx_engine {
     size_t walk16_cap = 0, wmass_cap = 0;
     int bh_walk_records = -1;            // 16 = the wave walk reads the compact copy (A/B'd in round 3: slower; opt-in), else the 32-byte records
     bool walk16_valid = false;           // the compact copy describes the tree in d_nodes
+    // round 4: the fast walk's copy of the tree, one record of (x, y, m, T) x 4 + child words per opened node (bh_walk.hip);
+    // rebuilt from d_nodes by every fast Barnes-Hut evaluation (T depends on the step's theta)
+    nbx::BhGroup* d_groups = nullptr;
+    size_t groups_cap = 0;
+    int bh_walk = 1;                     // NBX_OPT_BH_WALK: 1 = child groups, hand-scheduled loop (default), 2 = child groups, compiled
+                                         // loop, 0 = the node walk of rounds 1-3 (bh_eval.hip)
     unsigned* d_guard = nullptr;   // max|coord| word for the batched-reciprocal kernel
     size_t guard_cap = 0;
     void* d_tree_ws = nullptr;     // device tree build workspace (NBX_OPT_BH_TREE = 1)
@@ -299,6 +305,9 @@ int build_tree_on_device_end(nbx_engine* e, bool* done);
 int build_tree_on_device(nbx_engine* e, bool* done);
 int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm, bool gated = false,
                           int* gate_host_out = nullptr);
+// the fast traversal of e->d_nodes for this engine's slab into e->d_f2 (accelerations): child-group walk or node walk (NBX_OPT_BH_WALK)
+int launch_fast_walk(nbx_engine* e, float theta, const unsigned* perm, bool wave, bool on_device, int* gate, int gate_node_cap,
+                     int gate_crowd_limit, int gate_queue_limit);
 int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt);
 int spatial_order(nbx_engine* e);
 int slab_order(nbx_engine* e);

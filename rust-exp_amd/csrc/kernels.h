@@ -30,6 +30,33 @@ struct BhWalk16 {
     int32_t skip;
 };
 
+// Round 4: the fast walk's copy of the tree (bh_walk.hip).  One record per OPENED node: the (x, y, m, T) of its up to four
+// children -- 64 bytes, one scalar-cache line, one s_load_dwordx16 -- present ones first, in the reference's child order
+// (nbody.rs:295-300), then four child words.  T = the opening threshold of bh_threshold.h for an interior child (take <=>
+// dist_sq > T: the reference's s/sqrt(dist_sq) < theta exactly), -1 for a leaf (always evaluated), +inf for an absent slot.
+// kid = BYTE offset of that child's own record (>= 0), -1 = leaf, -2 = absent.  Record 0 holds the root; record k + 1 the
+// children of pre-order node k.
+struct alignas(128) BhGroup {
+    float4 c[4];
+    int4 kid;
+    int4 unused[3];
+};
+size_t bh_groups_count(int node_cap);        // records a tree of node_cap nodes needs
+bool bh_groups_addressable(int node_cap);    // their byte offsets fit the 31 bits a child word has
+// records from the flattened tree, with the step's theta.  n_nodes_or_cap = the node count, or (gated: the count is still on the
+// device, bh_gate.h) the capacity of the node array -- the kernel then reads the count itself
+hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta, BhGroup* groups, hipStream_t stream,
+                            int* gate_counters = nullptr, int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0);
+// accelerations of the slab's bodies (fast mode).  wave && perm: one walk per wave (bodies in the spatial order perm; hand_scheduled:
+// the assembly loop, else the compiler's), else one per lane; bit-identical results whichever runs
+hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, float2* out, hipStream_t stream,
+                                 const unsigned* perm, bool wave, bool hand_scheduled, int* gate_counters = nullptr,
+                                 int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0);
+hipError_t launch_bh_count_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, unsigned long long* totals,
+                                  hipStream_t stream);   // totals[0] children visited, [1] pair laws, [2] opening tests (visits of
+                                                         // interior nodes), [3] groups loaded (per body)
+hipError_t launch_bh_thresholds(const float* s, const float* theta, float* out, int count, hipStream_t stream);   // test hook
+
 struct ForceLaunch {
     int grid, block, jsplit, bpt, dim, variant;
 };

@@ -42,6 +42,7 @@ NBX_OPT_BH_FOLD = 14
 NBX_OPT_BH_ASYNC = 15
 NBX_OPT_BH_WALK_RECORDS = 16
 NBX_OPT_BH_REFUSAL = 17
+NBX_OPT_BH_WALK = 18
 
 NBX_GROUP_INFO_EXCHANGE = 0
 NBX_GROUP_INFO_RCCL_RANKS = 1
@@ -250,6 +251,12 @@ def lib():
     L.nbx_profile_read.restype = i32
     L.nbx_bh_work.argtypes = [E, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.nbx_bh_work.restype = i32
+    L.nbx_bh_work_detail.argtypes = [E, C.c_float, C.POINTER(C.c_uint64)]
+    L.nbx_bh_work_detail.restype = i32
+    L.nbx_bh_take_threshold.argtypes = [C.c_float, C.c_float]
+    L.nbx_bh_take_threshold.restype = C.c_float
+    L.nbx_bh_take_thresholds_device.argtypes = [E, i32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.nbx_bh_take_thresholds_device.restype = i32
     L.nbx_bh_host_timing.argtypes = [E, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(i32)]
     L.nbx_bh_host_timing.restype = i32
     L.nbx_last_launch.argtypes = [E] + [C.POINTER(i32)] * 6
@@ -531,6 +538,19 @@ class NBodyEngine:
         v, q = C.c_uint64(), C.c_uint64()
         _check(self._L.nbx_bh_work(self._h, theta, C.byref(v), C.byref(q)))
         return {"node_visits": v.value, "pair_evals": q.value}
+
+    def bh_work_detail(self, theta):
+        out = (C.c_uint64 * 4)()
+        _check(self._L.nbx_bh_work_detail(self._h, theta, out))
+        return {"node_visits": out[0], "pair_evals": out[1], "opening_tests": out[2], "group_loads": out[3]}
+
+    def bh_take_thresholds(self, s, theta):
+        """bh_threshold.h's T for every (s[i], theta[i]), evaluated on this engine's GPU (test hook)."""
+        s = np.ascontiguousarray(s, dtype=np.float32)
+        theta = np.ascontiguousarray(theta, dtype=np.float32)
+        out = np.empty_like(s)
+        _check(self._L.nbx_bh_take_thresholds_device(self._h, s.size, s.ctypes.data, theta.ctypes.data, out.ctypes.data))
+        return out
 
     def bh_host_timing(self):
         ms = (C.c_double * 4)()

@@ -456,17 +456,20 @@ def test_device_tree_node_pool_overflow_falls_back_to_host_build(rx, ob):
     assert b.get_option(NBX_OPT_BH_LAST_TREE) == 1 and b.get_option(NBX_OPT_BH_FALLBACKS) == 2
 
 
+@pytest.mark.parametrize("walk", [1, 2, 0])
 @pytest.mark.parametrize("n,theta", [(1, 0.5), (70, 0.5), (5000, 0.3), (100000, 0.85)])
-def test_wave_uniform_walk_is_bit_identical_to_the_per_lane_walk(rx, ob, n, theta):
-    """NBX_OPT_BH_WAVE: one walk per wave (scalar node loads, lanes parked on accepted subtrees) must make every
-    body's decisions and sums exactly as the per-lane walk does."""
-    from rust_exp_amd.engine import NBX_OPT_BH_WAVE
+def test_wave_uniform_walk_is_bit_identical_to_the_per_lane_walk(rx, ob, n, theta, walk):
+    """NBX_OPT_BH_WAVE: one walk per wave (scalar record loads; lanes inside a subtree kept as a scalar mask -- child-group walk,
+    walk = 1 -- or parked on accepted subtrees -- node walk of rounds 1-3, walk = 0) must make every body's decisions and sums
+    exactly as the per-lane walk of the same kind does."""
+    from rust_exp_amd.engine import NBX_OPT_BH_WALK, NBX_OPT_BH_WAVE
 
     p = ob.stable_orbits(n, 0.5, 30.0, 61) if n > 1 else ob.random_disk(1, 61)
     res = []
     for wave in (0, 1):
         e = engines(rx, p)
         e.set_bh_tree("device")
+        e.set_option(NBX_OPT_BH_WALK, walk)
         e.set_option(NBX_OPT_BH_WAVE, wave)
         fx, fy, _ = e.forces(theta)
         e.step_barnes_hut(theta, 0.01, 1)
@@ -476,13 +479,14 @@ def test_wave_uniform_walk_is_bit_identical_to_the_per_lane_walk(rx, ob, n, thet
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+@pytest.mark.parametrize("walk", [1, 2, 0])
 @pytest.mark.parametrize("theta", [0.5, 0.25, 1.0])
-def test_wave_uniform_walk_on_a_lattice_takes_the_exact_test_path(rx, ob, theta):
+def test_wave_uniform_walk_on_a_lattice_takes_the_exact_test_path(rx, ob, theta, walk):
     """Bodies on a power-of-two lattice put many node centres at distances where s/d equals theta exactly or to within the
-    1e-5 band: those visits take the reference's own sqrt-and-divide test (take_node's exact path). Decisions and sums
-    must still be the per-lane walk's, bit for bit, and the forces must agree with the oracle's Barnes-Hut to the fast-mode
-    tolerance."""
-    from rust_exp_amd.engine import NBX_OPT_BH_WAVE
+    1e-5 band: those visits take the reference's own sqrt-and-divide test (node walk: take_node's exact path; child-group walk:
+    the exact threshold of bh_threshold.h sits right there). Decisions and sums must still be the per-lane walk's, bit for bit,
+    and the forces must agree with the oracle's Barnes-Hut to the fast-mode tolerance."""
+    from rust_exp_amd.engine import NBX_OPT_BH_WALK, NBX_OPT_BH_WAVE
 
     side = 64
     gx, gy = np.meshgrid(np.arange(side, dtype=np.float32), np.arange(side, dtype=np.float32))
@@ -496,6 +500,7 @@ def test_wave_uniform_walk_on_a_lattice_takes_the_exact_test_path(rx, ob, theta)
     for wave in (0, 1):
         e = engines(rx, p, fold="exact")
         e.set_bh_tree("device")
+        e.set_option(NBX_OPT_BH_WALK, walk)
         e.set_option(NBX_OPT_BH_WAVE, wave)
         fx, fy, _ = e.forces(theta)
         res.append((fx, fy))
@@ -638,13 +643,14 @@ def test_steps_enqueued_without_waiting_for_the_build_verdict(rx, ob, fold):
 def test_compact_walk_records_are_bit_identical(rx, ob):
     """NBX_OPT_BH_WALK_RECORDS = 16 (the round-3 A/B of the wave walk: 16-byte decision records + mass words, mass used one visit
     late): every body's force and a step, bit for bit those of the 32-byte walk."""
-    from rust_exp_amd.engine import NBX_OPT_BH_WALK_RECORDS
+    from rust_exp_amd.engine import NBX_OPT_BH_WALK, NBX_OPT_BH_WALK_RECORDS
 
     st = rx.plummer_sphere(100000, dim=2)
     res = []
     for rec in (32, 16):
         e = rx.NBodyEngine()
         e.set_bh_fold("exact")
+        e.set_option(NBX_OPT_BH_WALK, 0)   # the record size is a property of the node walk
         e.set_option(NBX_OPT_BH_WALK_RECORDS, rec)
         e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
         for _ in range(3):

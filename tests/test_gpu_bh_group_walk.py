@@ -1,0 +1,172 @@
+"""GPU: the round-4 fast Barnes-Hut walk over child groups (bh_walk.hip, NBX_OPT_BH_WALK = 1, the default) against
+  * the oracle's traversal (oracle/nbody_oracle.c, nbody.rs:333-377) -- forces to the fast mode's tolerance,
+  * the node walk of rounds 1-3 (NBX_OPT_BH_WALK = 0) -- same decisions (equal work counters), forces to rounding,
+  * its own per-lane form -- bit for bit (tests/test_gpu_bh_device_tree.py parametrises those over both walks),
+and the threshold it decides with (bh_threshold.h) against the reference's own sqrt-and-divide test, float by float."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(rx, p, walk, tree=None, fold=None, wave=None):
+    from rust_exp_amd.engine import NBX_OPT_BH_WALK, NBX_OPT_BH_WAVE
+
+    e = rx.NBodyEngine()
+    if fold:
+        e.set_bh_fold(fold)
+    if tree:
+        e.set_bh_tree(tree)
+    e.set_option(NBX_OPT_BH_WALK, walk)
+    if wave is not None:
+        e.set_option(NBX_OPT_BH_WAVE, wave)
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    return e
+
+
+def _reference_accepts(s, x, theta):
+    """nbody.rs:344-345 in numpy float32 (correctly rounded sqrt and divide): s / sqrt(dist_sq) < theta."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (np.float32(s) / np.sqrt(np.float32(x), dtype=np.float32)) < np.float32(theta)
+
+
+def _threshold_cases():
+    rng = np.random.default_rng(11)
+    s = np.concatenate([
+        np.exp(rng.uniform(np.log(1e-6), np.log(2e2), 4000)),            # node sizes of real trees, and far beyond
+        [0.0, 1e-38, 1e-45, 1.0, 100.0, 3e38, np.inf, 0.5, 0.25, 64.0, 1e-20, 1e20],
+        2.0 ** rng.integers(-20, 8, 500),                                  # lattice-like sizes: exact ties with power-of-two distances
+    ]).astype(np.float32)
+    theta = np.concatenate([
+        rng.choice([0.05, 0.1, 0.25, 0.3, 0.5, 0.85, 0.95, 1.0, 2.0], 4000),
+        [0.5, 0.5, 0.5, 0.0, -1.0, 0.5, 0.5, np.nan, 1e-30, 1e30, 0.5, 0.5],
+        rng.choice([0.25, 0.5, 1.0], 500),
+    ]).astype(np.float32)
+    return s, theta
+
+
+def test_take_threshold_is_the_references_test_on_host_and_device(rx):
+    """T = bh_take_threshold(s, theta) must satisfy, in the reference's own f32 arithmetic: the reference does NOT accept
+    dist_sq = T and DOES accept the next float above it (so, the test being monotone, accept <=> dist_sq > T everywhere);
+    T = +inf where nothing is accepted.  Host (nbx_bh_take_threshold) and device (k_bh_thresholds) must agree bit for bit."""
+    s, theta = _threshold_cases()
+    L = rx.lib()
+    host = np.array([L.nbx_bh_take_threshold(float(a), float(b)) for a, b in zip(s, theta)], dtype=np.float32)
+    e = rx.NBodyEngine()
+    dev = e.bh_take_thresholds(s, theta)
+    assert np.array_equal(host.view(np.uint32), dev.view(np.uint32))
+    T = host
+    assert np.all(T >= 0)
+    never = ~_reference_accepts(s, np.float32(np.inf), theta)
+    assert np.all(np.isinf(T[never]))
+    ok = ~never
+    assert not np.any(_reference_accepts(s[ok], T[ok], theta[ok]))
+    up = np.nextafter(T[ok], np.float32(np.inf), dtype=np.float32)
+    assert np.all(_reference_accepts(s[ok], up, theta[ok]))
+    # and on a window of floats around T: the decision is "dist_sq > T", float by float
+    for k in (-3, -2, -1, 1, 2, 3, 50):
+        x = (T[ok].view(np.uint32).astype(np.int64) + k)
+        good = (x >= 0) & (x <= 0x7F800000)
+        xf = x[good].astype(np.uint32).view(np.float32)
+        assert np.array_equal(_reference_accepts(s[ok][good], xf, theta[ok][good]), xf > T[ok][good]), k
+
+
+@pytest.mark.parametrize("make,n,theta", [("orbits", 3, 0.5), ("disk", 100, 0.85), ("orbits", 10000, 0.85), ("disk", 10000, 0.5),
+                                          ("plummer", 65536, 0.5), ("plummer", 200000, 0.3), ("orbits", 300000, 1.0)])
+def test_group_walk_makes_the_node_walks_decisions_and_the_oracles_forces(rx, ob, make, n, theta):
+    if make == "plummer":
+        st = rx.plummer_sphere(n, dim=2)
+        p = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    else:
+        p = ob.stable_orbits(n, 0.5, 30.0, 3) if make == "orbits" else ob.random_disk(n, 3)
+    tree = "host" if n < 1000 else "device"      # both builds; the host tree below 65 536 bodies is walked lane by lane
+    eg = _engine(rx, p, 1, tree=tree, fold="reference" if n <= 65536 else "exact")
+    en = _engine(rx, p, 0, tree=tree, fold="reference" if n <= 65536 else "exact")
+    wg, wn = eg.bh_work(theta), en.bh_work(theta)
+    assert wg == wn, (wg, wn)                    # same children tested, same pair laws: the same decisions
+    gx, gy, _ = eg.forces(theta)
+    nx, ny, _ = en.forces(theta)
+    ec = _engine(rx, p, 2, tree=tree, fold="reference" if n <= 65536 else "exact")   # the compiled form of the group walk
+    cx, cy, _ = ec.forces(theta)
+    assert np.array_equal(gx.view(np.uint32), cx.view(np.uint32)) and np.array_equal(gy.view(np.uint32), cy.view(np.uint32))
+    scale = max(np.abs(nx).max(), np.abs(ny).max())
+    # same terms; they differ by the order of the additions and by d^2 being formed with or without an FMA: a few ulps of the
+    # largest partial sum (the sun of nb_stable_orbits sums 10^4 terms of alternating sign: 1.4e-5 of its force)
+    assert max(np.abs(gx - nx).max(), np.abs(gy - ny).max()) <= 2e-5 * scale
+    if n <= 65536:                                # the tree is the oracle's, node for node: the oracle's own traversal applies
+        rc, ofx, ofy = ob.bh_forces(p, theta, nthreads=8)
+        assert rc == 0
+        oscale = max(np.abs(ofx).max(), np.abs(ofy).max())
+        err = np.maximum(np.abs(gx - ofx), np.abs(gy - ofy)) / oscale
+        assert err.max() <= 2e-5 and np.percentile(err, 99) <= 1e-5, (err.max(), np.percentile(err, 99))
+
+
+@pytest.mark.parametrize("n", [2000, 70000])
+def test_group_walk_steps_like_the_node_walk(rx, ob, n):
+    """Ten steps, device tree (gated, asynchronous steps included): positions and velocities of the two walks stay within the
+    fast mode's per-step tolerance of each other, and the group walk's first step within it of the oracle's."""
+    from conftest import fast_tolerances
+
+    p = ob.stable_orbits(n, 0.5, 30.0, 8)
+    tol_dp, tol_dv = fast_tolerances(ob, p, 0.01, steps=1) if n <= 4096 else (2e-4, 2e-2)
+    eg, en = _engine(rx, p, 1), _engine(rx, p, 0)
+    eg.step_barnes_hut(0.85, 0.01, 1)
+    en.step_barnes_hut(0.85, 0.01, 1)
+    a, b = eg.get_particles(), en.get_particles()
+    assert np.abs(a["px"] - b["px"]).max() <= tol_dp and np.abs(a["vx"] - b["vx"]).max() <= tol_dv
+    o = p.copy()
+    assert ob.step_barnes_hut(o, 0.85, 0.01, 8) == 0
+    assert np.abs(a["px"] - o["px"]).max() <= tol_dp and np.abs(a["py"] - o["py"]).max() <= tol_dp
+    assert np.abs(a["vx"] - o["vx"]).max() <= tol_dv and np.abs(a["vy"] - o["vy"]).max() <= tol_dv
+    for _ in range(9):
+        eg.step_barnes_hut(0.85, 0.01, 1)
+    eg.synchronize()
+    c = eg.get_particles()
+    assert np.all(np.isfinite(c["px"])) and np.abs(c["px"] - a["px"]).max() > 0
+
+
+def test_group_walk_on_a_deep_tree_spills_its_stack_correctly(rx, ob):
+    """Two tight clumps far apart plus a sparse halo: the leaves under one wave sit ~24 levels down, so the wave's stack of
+    pending sibling groups passes its 64 register-resident entries and uses the LDS spill.  Wave walk == lane walk, bit for bit,
+    and both within tolerance of the oracle."""
+    from rust_exp_amd.engine import NBX_OPT_BH_WAVE
+
+    rng = np.random.default_rng(4)
+    pts = []
+    for cx, cy, scale in ((-40.0, -40.0, 1e-3), (40.0, 40.0, 2e-4), (0.0, 0.0, 30.0)):
+        m = 1500
+        pts.append(np.stack([cx + scale * rng.standard_normal(m), cy + scale * rng.standard_normal(m)], 1))
+    xy = np.concatenate(pts).astype(np.float32)
+    xy = xy[rng.permutation(len(xy))]
+    n = len(xy)
+    p = ob.particles(xy[:, 0], xy[:, 1], np.zeros(n), np.zeros(n), rng.uniform(0.1, 1.5, n))
+    res = []
+    for wave in (0, 1):
+        e = _engine(rx, p, 1, tree="device", fold="exact", wave=wave)
+        res.append(e.forces(0.3)[:2])
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    rc, ofx, ofy = ob.bh_forces(p, 0.3, nthreads=8)
+    assert rc == 0
+    scale = max(np.abs(ofx).max(), np.abs(ofy).max())
+    err = np.maximum(np.abs(res[1][0] - ofx), np.abs(res[1][1] - ofy)) / scale
+    assert np.percentile(err, 99.9) <= 2e-5 and err.max() <= 2e-3, (np.percentile(err, 99.9), err.max())
+
+
+def test_group_walk_degenerate_trees(rx, ob):
+    """One body (the root is a leaf), two coincident bodies (merged leaf), bodies on a vertical line (root box of zero width:
+    s = 0 everywhere), theta at and below zero (nothing is ever accepted: every leaf is reached)."""
+    cases = {
+        "one": ob.particles([1.0], [2.0], [0.0], [0.0], [1.0]),
+        "coincident": ob.particles([1.0, 1.0], [2.0, 2.0], [0, 0], [0, 0], [1.0, 2.0]),
+        "vertical": ob.particles(np.zeros(300), np.linspace(-20, 20, 300), np.zeros(300), np.zeros(300), np.ones(300)),
+    }
+    for name, p in cases.items():
+        for theta in (0.5, 1e-6, -0.25):
+            for tree in ("host", "device"):
+                e = _engine(rx, p, 1, tree=tree)
+                gx, gy, _ = e.forces(theta)
+                rc, ofx, ofy = ob.bh_forces(p, theta)
+                assert rc == 0
+                scale = max(np.abs(ofx).max(), np.abs(ofy).max(), 1e-30)
+                assert max(np.abs(gx - ofx).max(), np.abs(gy - ofy).max()) <= 1e-5 * scale, (name, theta, tree)
