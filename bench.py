@@ -139,19 +139,27 @@ def measure_traffic(argv_tail, kernel_substr, timeout=120):
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
             if r.returncode != 0:
                 return None
-            vals = []
+            subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
+            per = {k: [] for k in subs}     # several kernels (e.g. conversion + walk of one traversal): per-launch means are summed
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                        vals.append(float(row["Counter_Value"]))
-            if not vals:
+                    if row["Counter_Name"] != counter:
+                        continue
+                    for k in subs:
+                        if k in row["Kernel_Name"]:
+                            per[k].append(float(row["Counter_Value"]))
+                            break
+            if not per[subs[0]]:
                 return None
-            out[counter] = float(np.mean(vals))
-            out[counter + "_launches"] = len(vals)
+            out[counter] = float(sum(np.mean(v) for v in per.values() if v))
+            out[counter + "_launches"] = len(per[subs[0]])
+            out[counter + "_by_kernel"] = {k: float(np.mean(v)) for k, v in per.items() if v}
         read_b = 2.0 * out["FETCH_SIZE"] * 1024.0
         write_b = out["WRITE_SIZE"] * 1024.0
         return {"bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_bytes": write_b,
                 "launches_sampled": out["FETCH_SIZE_launches"],
+                "read_bytes_by_kernel": {k: 2048.0 * v for k, v in out["FETCH_SIZE_by_kernel"].items()},
+                "write_bytes_by_kernel": {k: 1024.0 * v for k, v in out["WRITE_SIZE_by_kernel"].items()},
                 "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) on a 3-step child run of this "
                        "command, this box, this run; KiB -> B, FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM)"}
     except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
@@ -771,55 +779,74 @@ def main():
         else:
             value = float(n) * args.steps / elapsed
             ht = engine.bh_host_timing()
-            wk = engine.bh_work(args.theta)
-            ev_s = max(per[0]["bh_eval_ms"], 1e-9) * 1e-3
-            lane_ops_per_visit = 8.4   # modelled (round 2): 4 VALU lane-ops for the opening test + 6 for the pair law on ~74 % of the visits
-            valu_peak = info["compute_units"] * 4 * info["clock_khz"] * 1e3 * 32.0   # lane-ops/s: 32 lanes per cycle per SIMD
-            visits_per_s = wk["node_visits"] / ev_s
+            wk = engine.bh_work_detail(args.theta)
+            ev_s = max(per[0]["bh_eval_ms"], 1e-9) * 1e-3     # HIP events around the traversal: (tree -> child groups) + walk
+            walk_kind = engine.get_option(rx.engine.NBX_OPT_BH_WALK) if args.mode == "fast" else 0
+            # the kernels of one traversal, by name: the walk, and (child-group walks) the conversion of the tree before it
+            walk_kernel = "k_bh_walk_groups" if walk_kind else "k_bh_eval"
+            trav_kernels = (walk_kernel, "k_bh_groups(") if walk_kind else (walk_kernel,)
+            # ALGORITHMIC flops of one evaluation, counted from the reference as written (2-D, div and sqrt = 1 flop each):
+            #   pair law  nbody.rs:164-184 + :358    2 sub, 2 mul + 1 add, 1 add eps, 1 mul, 1 div, 2 mul, 2 add          = 12
+            #   opening test nbody.rs:341-345        2 sub, 2 mul + 1 add, 1 sqrt, 1 div (the compare is not counted)      =  7
+            # pair laws and opening tests (= visits of interior nodes) are counted by a counting traversal of this state
+            flops = 12.0 * wk["pair_evals"] + 7.0 * wk["opening_tests"]
+            achieved = flops / ev_s / 1e12
             bh_traffic, bh_traffic_info, issue = None, None, None
-            if world == 1 and not args.no_traffic:   # HBM bytes of the traversal kernel, measured now (see measure_traffic)
+            if world == 1 and not args.no_traffic:   # HBM bytes of the traversal kernels, measured now (see measure_traffic)
                 tail = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
-                bh_traffic_info = measure_traffic(tail + ["--no-cpu-baseline", "--no-traffic"], "k_bh_eval")
+                bh_traffic_info = measure_traffic(tail + ["--no-cpu-baseline", "--no-traffic"], trav_kernels)
                 if bh_traffic_info:
                     bh_traffic = bh_traffic_info["bytes_per_launch"]
-                # ... and its instruction issue, from counters of this run instead of a modelled constant (VERDICT r02 next #5b)
-                pm = measure_counters(tail + ["--no-cpu-baseline", "--no-traffic"], "k_bh_eval",
-                                      ["SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVES", "GRBM_GUI_ACTIVE"])
+                # ... and the walk kernel's instruction issue, from counters of this run
+                pm = measure_counters(tail + ["--no-cpu-baseline", "--no-traffic"], walk_kernel,
+                                      ["SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA",
+                                       "GRBM_GUI_ACTIVE"])
                 if pm and pm.get("GRBM_GUI_ACTIVE") and pm.get("SQ_ACTIVE_INST_VALU") and pm.get("SQ_INSTS_SMEM"):
                     n_simd = info["compute_units"] * 4
                     cyc = pm["GRBM_GUI_ACTIVE"] / 8.0                # the counter is summed over the 8 XCDs
+                    loads = pm["SQ_INSTS_SMEM"] / (2.0 if walk_kind else 1.0)   # a group turn issues two scalar loads, a node visit one
                     issue = {"valu_busy_frac": 4.0 * pm["SQ_ACTIVE_INST_VALU"] / n_simd / cyc,   # SQ_ACTIVE_INST_* count quad-cycles
-                             "valu_issue_frac": 4.0 * pm["SQ_INSTS_VALU"] / n_simd / cyc,       # a wave64 VALU instruction holds its SIMD 4 cycles
-                             "valu_insts_per_wave_visit": pm["SQ_INSTS_VALU"] / pm["SQ_INSTS_SMEM"],   # one scalar node load per visit
-                             "salu_insts_per_wave_visit": pm["SQ_INSTS_SALU"] / pm["SQ_INSTS_SMEM"],
-                             "wave_visits_per_launch": pm["SQ_INSTS_SMEM"], "waves": pm.get("SQ_WAVES"),
+                             "scalar_busy_frac": 4.0 * pm.get("SQ_ACTIVE_INST_SCA", 0.0) / n_simd / cyc,
+                             "wave_slots_occupied_frac": 4.0 * pm.get("SQ_WAVE_CYCLES", 0.0) / (8.0 * n_simd) / cyc,
+                             "valu_insts_per_wave_turn": pm["SQ_INSTS_VALU"] / loads,
+                             "salu_insts_per_wave_turn": pm["SQ_INSTS_SALU"] / loads,
+                             "branch_insts_per_wave_turn": pm.get("SQ_INSTS_BRANCH", 0.0) / loads,
+                             "wave_turns_per_launch": loads, "waves": pm.get("SQ_WAVES"),
+                             "turn": "one child group loaded (two scalar loads)" if walk_kind else "one node visited (one scalar load)",
                              "kernel_cycles": cyc, "launches_sampled": pm.get("SQ_INSTS_VALU_launches"),
                              "how": "rocprofv3 --kernel-trace --pmc, two passes (SQ_*; GRBM_GUI_ACTIVE) on a 3-step child run of this "
-                                    "command; GRBM_GUI_ACTIVE / 8 = kernel cycles, 1024 SIMDs"}
+                                    "command; GRBM_GUI_ACTIVE / 8 = kernel cycles, 1024 SIMDs x 8 wave slots"}
+            groups_bytes = 80.0 * ht["nodes"]   # upper bound: an 80-byte record per node (interior ones have one), written once, read once
+            algorithmic = 32.0 * ht["nodes"] + 24.0 * n + (2.0 * groups_bytes if walk_kind else 0.0)
             out.update({
                 "metric": f"bodies/s through nb_step_barnes_hut (theta={args.theta}) at N={n}",
                 "value": value, "unit": "body-steps/s", "dtype": "f32",
                 "config": {"workload": f"plummer_disk_projection_N{n}_barnes_hut_theta{args.theta}_dt{DT}", "bodies": n,
                            "seed": "0x5EED0001", "force_mode": args.mode, "host": host_kind, "sharding": sharding,
-                           "tree": {0: "host (reference-faithful insertion build)", 1: "device (bh_build.hip)"}[engine.get_option(rx.engine.NBX_OPT_BH_LAST_TREE)]},
+                           "tree": {0: "host (reference-faithful insertion build)", 1: "device (bh_build.hip)"}[engine.get_option(rx.engine.NBX_OPT_BH_LAST_TREE)],
+                           "walk": {0: "node by node (bh_eval.hip, rounds 1-3)", 1: "child groups, hand-scheduled loop (bh_walk.hip)",
+                                    2: "child groups, compiled loop (bh_walk.hip)"}[walk_kind]},
                 "ms_split": {"bh_eval_kernel": per[0]["bh_eval_ms"], "integrate_kernel": per[0]["integrate_ms"],
                              "host_download": ht["download_ms"],
                              # device tree: GPU time of the build, first launch to last (HIP events); host tree: host wall time
                              "tree_build": per[0]["device_tree_build_ms"] if per[0].get("device_tree_builds") else ht["build_ms"],
                              "flatten": ht["flatten_ms"],
                              "upload_wait": ht["upload_ms"], "tree_nodes": ht["nodes"]},
-                "roofline": {"bound": "valu_issue", "bound_contract_class": "neither hbm nor mfma: a serial per-wave tree walk, bounded by "
-                             "instruction issue (DESIGN.md K3)", "kernel": "k_bh_eval_*",
-                             "achieved": (issue["valu_busy_frac"] * valu_peak if issue else visits_per_s * lane_ops_per_visit) / 1e12,
-                             "peak": valu_peak / 1e12, "unit": "T lane-op/s",
-                             "frac": issue["valu_busy_frac"] if issue else visits_per_s * lane_ops_per_visit / valu_peak,
-                             "frac_source": "measured: VALU busy cycles of the traversal kernel (SQ_ACTIVE_INST_VALU) over its SIMD-cycles, this run"
-                                            if issue else "modelled: 8.4 lane-ops per body-visit (no rocprofv3 / --no-traffic)",
-                             "frac_modelled": visits_per_s * lane_ops_per_visit / valu_peak, "issue_counters": issue,
-                             "node_visits_per_body": wk["node_visits"] / n, "pair_evals_per_body": wk["pair_evals"] / n,
+                "roofline": {"bound": "valu_fp32",
+                             "bound_contract_class": "mfma (dense fp32 peak: the f32 MFMA rate equals the fp32 vector rate, 157.3 TFLOP/s; "
+                                                     "no MFMA is used): a tree walk is bound by instruction issue, not by HBM",
+                             "kernel": " + ".join(k.rstrip("(") for k in trav_kernels),
+                             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                             "frac_definition": "algorithmic flops of one evaluation (12 per pair law + 7 per opening test, the reference's "
+                                                "expressions as written, nbody.rs:164-184, :341-345) / traversal time (HIP events: tree -> "
+                                                "child groups + walk) / fp32 vector peak",
+                             "flops_per_launch": flops, "pair_evals_per_body": wk["pair_evals"] / n,
+                             "opening_tests_per_body": wk["opening_tests"] / n, "node_visits_per_body": wk["node_visits"] / n,
+                             "group_loads_per_body": wk["group_loads"] / n,
                              "kernel_avg_ms": per[0]["bh_eval_ms"],
-                             "hbm_algorithmic_bytes_per_launch": 32.0 * ht["nodes"] + 24.0 * n,
-                             "hbm_frac_of_8TBps": (32.0 * ht["nodes"] + 24.0 * n) / ev_s / 8e12, "traffic": bh_traffic,
+                             "valu_busy_frac": issue["valu_busy_frac"] if issue else None, "issue_counters": issue,
+                             "hbm_algorithmic_bytes_per_launch": algorithmic,
+                             "hbm_frac_of_8TBps": algorithmic / ev_s / 8e12, "traffic": bh_traffic,
                              "traffic_measurement": bh_traffic_info},
             })
         if world > 1 or host_kind != "single":

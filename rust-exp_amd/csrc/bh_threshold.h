@@ -8,7 +8,8 @@
 //                accept  <=>  dist_sq > T                      (dist_sq any float >= 0, +inf included; NaN -> not accepted)
 //
 // bh_take_threshold(s, theta) finds that T by evaluating the reference's own expression on neighbouring floats (a guess from
-// (s/theta)^2, then a bisection over the float bit patterns, which order like the floats they encode).  A walk that compares
+// (s/theta)^2, its neighbours one by one, and -- should the guess ever be far off -- a bisection over the float bit patterns,
+// which order like the floats they encode).  A walk that compares
 // the reference's dist_sq (unfused: fl(fl(dx*dx) + fl(dy*dy))) with T makes the reference's decision for EVERY body and node --
 // no band around the boundary, no second test -- at the price of one v_cmp.  Rounds 1-3 compared q = s*s with theta^2 * d^2
 // and re-made decisions inside a 1e-5 band with the reference's arithmetic: 2 multiplies, 2 compares and a mask test per visit.
@@ -54,25 +55,35 @@ __host__ __device__ inline bool bh_reference_accepts(float s, float dist_sq, flo
 __host__ __device__ inline float bh_take_threshold(float s, float theta)
 {
     const uint32_t kInf = 0x7F800000u;
-    if (!bh_reference_accepts(s, bh_bits_to_float(kInf), theta)) return bh_bits_to_float(kInf);   // nothing is ever accepted
-    // invariant of the bisection: !accepts(lo) && accepts(hi)   (accepts(0) is always false)
-    uint32_t lo = 0u, hi = kInf;
-    {
-        const double r = (double)s / (double)theta;
-        const double g = r * r;
-        const float gf = g < 3.0e38 ? (float)g : 3.0e38f;
-        const uint32_t ug = bh_float_to_bits(gf);            // gf >= 0: a valid position on the pattern axis
-        const uint32_t a = ug > 8u ? ug - 8u : 0u;
-        const uint32_t b = ug + 8u < kInf ? ug + 8u : kInf;
-        if (!bh_reference_accepts(s, bh_bits_to_float(a), theta)) lo = a;
-        if (bh_reference_accepts(s, bh_bits_to_float(b), theta)) hi = b;
+    // a guess from (s/theta)^2 in double, then its neighbours one by one: the threshold sits within a few floats of the guess
+    // (two roundings of 2^-24 each, the sqrt halving the first), so two or three evaluations of the reference's test settle it
+    const double r = (double)s / (double)theta;
+    const double g = r * r;
+    const float gf = g < 3.0e38 ? (float)g : 3.0e38f;            // (a NaN guess lands on 3e38 too)
+    const uint32_t ug = bh_float_to_bits(gf);                    // gf >= 0: a valid position on the pattern axis
+    uint32_t lo = 0u, hi = kInf;                                 // bisection bounds if the probing does not settle it
+    if (bh_reference_accepts(s, gf, theta)) {                    // T is below the guess
+        hi = ug;
+        for (uint32_t k = 1u; k <= 4u && k <= ug; k++) {
+            if (!bh_reference_accepts(s, bh_bits_to_float(ug - k), theta)) return bh_bits_to_float(ug - k);
+            hi = ug - k;
+        }
+        if (hi == 0u) return 0.0f;                               // (cannot happen: dist_sq = 0 is never accepted)
+    } else {                                                     // T is the guess or above it
+        lo = ug;
+        for (uint32_t k = 1u; k <= 4u && ug + k <= kInf; k++) {
+            if (bh_reference_accepts(s, bh_bits_to_float(ug + k), theta)) return bh_bits_to_float(ug + k - 1u);
+            lo = ug + k;
+        }
+        if (lo >= kInf || !bh_reference_accepts(s, bh_bits_to_float(kInf), theta)) return bh_bits_to_float(kInf);   // never accepted
     }
+    // invariant: !accepts(lo) && accepts(hi); the bit patterns of non-negative floats order like the floats
     while (hi - lo > 1u) {
         const uint32_t mid = lo + (hi - lo) / 2u;
         if (bh_reference_accepts(s, bh_bits_to_float(mid), theta)) hi = mid;
         else lo = mid;
     }
-    return bh_bits_to_float(lo);                             // the largest dist_sq the reference does NOT accept
+    return bh_bits_to_float(lo);                                 // the largest dist_sq the reference does NOT accept
 }
 
 }  // namespace nbx

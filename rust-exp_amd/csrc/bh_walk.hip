@@ -197,10 +197,11 @@ __device__ __forceinline__ v2f walk_groups_compiled(const BhGroup* __restrict__ 
 // The same walk with the scalar side written by hand.  Registers (fixed; bound through the asm constraints):
 //   s[36:51] group record (x,y,m,T) x 4    s[52:55] child words        s[56:57] M        s[58:59] lanes that open the child
 //   s60 stack pointer   s61 byte offset of the group   s[62:63] EXEC at entry   s[64:65] groups   s[66:67] groups + 64   s68 overflow
+//   s72, s[70:71] newest stack entry (group, mask; s72 < 0: none)
 //   v[10:11] p   v[12:13] sum   v[14:15] d   v[16:17] (dx^2, dy^2)   v18 dist_sq   v[20:21] m/(dist_sq+EPS)   v22 v23 v24 stack
-// Per child: 8 VALU (v_pk_add, v_pk_mul, v_add, v_cmpx, v_add, v_rcp, v_mul, v_pk_fma) + s_andn2 + s_mov exec + s_cbranch.
-// The s_nop 0 after each packed op and the scalar instruction between v_rcp and its use are the wait states gfx950 asks for
-// (packed-result forwarding; transcendental result).  A wave whose stack would pass 64 entries leaves with s68 = 1 and redoes its
+// Per child: 8 VALU (v_pk_add, v_pk_mul, v_add, v_cmpx, v_add, v_rcp, v_mul, v_pk_fma; the last three skipped when no lane takes
+// the child) + s_andn2 + s_mov exec + 2 branches.  The s_nop 0 after each packed op and after v_rcp are the wait states gfx950
+// asks for (packed-result forwarding; transcendental result).  A wave whose stack would pass 64 entries leaves with s68 = 1 and redoes its
 // walk in the compiled form (LDS spill) -- the same sums in the same order.
 #define NBX_ASM_CHILD(x, m, T, K, c)                                                                       \
     "Lc" #c "_%=:\n"                                                                                       \
@@ -211,22 +212,32 @@ __device__ __forceinline__ v2f walk_groups_compiled(const BhGroup* __restrict__ 
     " v_add_f32 v18, v16, v17\n"                                                                           \
     " v_cmpx_nge_f32 vcc, " T ", v18\n"               /* EXEC = lanes of M with not (T >= dist_sq): they take the child */ \
     " v_add_f32 v20, 0x38d1b717, v18\n"               /* dist_sq + EPS (nbody.rs:180) */                   \
-    " v_rcp_f32 v20, v20\n"                                                                                \
     " s_andn2_b64 s[58:59], s[56:57], exec\n"         /* the lanes of M that open it; SCC = anybody */      \
+    " s_cbranch_execz Lskip" #c "_%=\n"               /* nobody takes it (the top of every walk) */        \
+    " v_rcp_f32 v20, v20\n"                                                                                \
+    " s_nop 0\n"                                                                                           \
     " v_mul_f32 v20, " m ", v20\n"                                                                         \
     " v_pk_fma_f32 v[12:13], v[20:21], v[14:15], v[12:13] op_sel_hi:[0,1,1]\n"                             \
+    "Lskip" #c "_%=:\n"                                                                                    \
     " s_mov_b64 exec, s[56:57]\n"                                                                          \
     " s_cbranch_scc1 Lpush" #c "_%=\n"                                                                     \
     "Lback" #c "_%=:\n"
+// push (group K, mask s[58:59]): the newest entry stays in scalar registers (s72, s[70:71]; s72 < 0 = none) -- it is what the next
+// pop wants whenever this group opens anything -- and only an entry it displaces goes to lane s60 of the stack registers
 #define NBX_ASM_PUSH(K, c)                                                                                 \
     "Lpush" #c "_%=:\n"                                                                                    \
+    " s_cmp_lt_i32 s72, 0\n"                                                                               \
+    " s_cbranch_scc1 Lfill" #c "_%=\n"                                                                     \
     " s_cmp_ge_u32 s60, 64\n"                                                                              \
     " s_cbranch_scc1 Lovf_%=\n"                                                                            \
     " s_mov_b32 m0, s60\n"                                                                                 \
     " s_add_u32 s60, s60, 1\n"                                                                             \
-    " v_writelane_b32 v22, " K ", m0\n"                                                                    \
-    " v_writelane_b32 v23, s58, m0\n"                                                                      \
-    " v_writelane_b32 v24, s59, m0\n"                                                                      \
+    " v_writelane_b32 v22, s72, m0\n"                                                                      \
+    " v_writelane_b32 v23, s70, m0\n"                                                                      \
+    " v_writelane_b32 v24, s71, m0\n"                                                                      \
+    "Lfill" #c "_%=:\n"                                                                                    \
+    " s_mov_b32 s72, " K "\n"                                                                              \
+    " s_mov_b64 s[70:71], s[58:59]\n"                                                                      \
     " s_branch Lback" #c "_%=\n"
 
 __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ groups, const v2f p, u64 M, int& overflow)
@@ -238,8 +249,16 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
         " s_mov_b32 s60, 0\n"
         " s_mov_b32 s61, 0\n"
         " s_mov_b32 s68, 0\n"
+        " s_mov_b32 s72, -1\n"
         " s_branch Lload_%=\n"
         "Lpop_%=:\n"
+        " s_cmp_lt_i32 s72, 0\n"
+        " s_cbranch_scc1 Lpopv_%=\n"
+        " s_mov_b32 s61, s72\n"                   // the entry in scalar registers
+        " s_mov_b64 s[56:57], s[70:71]\n"
+        " s_mov_b32 s72, -1\n"
+        " s_branch Lload_%=\n"
+        "Lpopv_%=:\n"
         " s_cmp_eq_u32 s60, 0\n"
         " s_cbranch_scc1 Ldone_%=\n"
         " s_add_u32 s60, s60, -1\n"
@@ -275,7 +294,7 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
         : "+{v[12:13]}"(acc), "={s68}"(overflow), "+{s[56:57]}"(M)
         : "{s[64:65]}"(base), "{s[66:67]}"(base + 64), "{v[10:11]}"(p)
         : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
-          "s54", "s55", "s58", "s59", "s60", "s61", "s62", "s63", "v14", "v15", "v16", "v17", "v18", "v20", "v21", "v22", "v23", "v24",
+          "s54", "s55", "s58", "s59", "s60", "s61", "s62", "s63", "s70", "s71", "s72", "v14", "v15", "v16", "v17", "v18", "v20", "v21", "v22", "v23", "v24",
           "vcc", "scc", "m0");
     return acc;
 }
