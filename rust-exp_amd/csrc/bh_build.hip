@@ -259,13 +259,10 @@ __device__ __forceinline__ int run_start(const unsigned long long* __restrict__ 
 }
 
 // Also gathers the bodies into sorted order (sb[j] = posm[idx[j]]: round 2 had a kernel of its own for that).
-__global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict__ posm, float4* __restrict__ sb,
-                                                       const unsigned long long* __restrict__ keys,
-                                                       const unsigned* __restrict__ idx, const int n,
-                                                       unsigned char* __restrict__ close, int* __restrict__ crowded)
+__device__ __forceinline__ void merge_links_body(const int j, const float4* __restrict__ posm, float4* __restrict__ sb,
+                                                 const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
+                                                 const int n, unsigned char* __restrict__ close, int* __restrict__ crowded)
 {
-    const int j = blockIdx.x * kTile + threadIdx.x;
-    if (j >= n) return;
     const float4 b = posm[idx[j]];
     sb[j] = b;
     unsigned char out = 0;
@@ -307,6 +304,15 @@ __global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict_
         }
     }
     close[j] = out;
+}
+
+__global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict__ posm, float4* __restrict__ sb,
+                                                       const unsigned long long* __restrict__ keys,
+                                                       const unsigned* __restrict__ idx, const int n,
+                                                       unsigned char* __restrict__ close, int* __restrict__ crowded)
+{
+    const int j = blockIdx.x * kTile + threadIdx.x;
+    if (j < n) merge_links_body(j, posm, sb, keys, idx, n, close, crowded);
 }
 
 // ---- 3c. the reference's EPS merge in full (reference fold: that class promises the reference's tree node for node) ---------
@@ -781,12 +787,10 @@ __global__ __launch_bounds__(kTile) void k_place(const unsigned long long* __res
 // merged pair of entities take the key of the entity that arrived first; the array stays sorted (the new key lies between the
 // old ones).  Bodies left behind by the rule -- third and later entities of a chain, where the reference would have grown a
 // bigger blob -- are counted in *crowded.
-__global__ __launch_bounds__(kTile) void k_merge_keys(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
-                                                      const unsigned char* __restrict__ close, const int n,
-                                                      unsigned long long* __restrict__ out, int* __restrict__ crowded)
+__device__ __forceinline__ void merge_keys_body(const int j, const unsigned long long* __restrict__ keys,
+                                                const unsigned* __restrict__ idx, const unsigned char* __restrict__ close,
+                                                const int n, unsigned long long* __restrict__ out, int* __restrict__ crowded)
 {
-    const int j = blockIdx.x * kTile + threadIdx.x;
-    if (j >= n) return;
     const int r = run_start(keys, j);             // this body's entity is [r, e)
     const int e = run_end(keys, j, n);
     unsigned long long k = keys[j];
@@ -798,6 +802,14 @@ __global__ __launch_bounds__(kTile) void k_merge_keys(const unsigned long long* 
         k = idx[r] < idx[e] ? keys[r] : keys[e];  // the entity starting at e merges with this one (close[r] is 0 here)
     }
     out[j] = k;
+}
+
+__global__ __launch_bounds__(kTile) void k_merge_keys(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
+                                                      const unsigned char* __restrict__ close, const int n,
+                                                      unsigned long long* __restrict__ out, int* __restrict__ crowded)
+{
+    const int j = blockIdx.x * kTile + threadIdx.x;
+    if (j < n) merge_keys_body(j, keys, idx, close, n, out, crowded);
 }
 
 __device__ __forceinline__ ScanItem scan_item(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
@@ -1420,6 +1432,203 @@ hipError_t device_tree_workspace_init(void* workspace, hipStream_t stream)
     return hipMemsetAsync(workspace, 0, 256, stream);
 }
 
+// ---- small systems: box, keys and sort in two launches ---------------------------------------------------------------------
+// Up to kSmallFrontMax bodies (the reference's default scene has 10 000, RustNBodyExperiment.hs:42-47) the build is a chain of
+// short kernels and pays for every launch: k_bbox, k_keys and rocPRIM's radix sort (merge-sort path: 5 launches, 36 us at 10 000
+// bodies) are 7 of them.  Here:
+//   k_front_chunks  one workgroup per chunk of 256 bodies, a body per thread: the root AABB (every workgroup folds ALL positions
+//                   itself -- min and max are exact in any order, 160 KB of L2-resident reads cost less than a grid-wide hand-off),
+//                   the body's path key, and a bitonic sort of the chunk's (key, index) pairs IN REGISTERS: partners inside a
+//                   wave trade through ds_bpermute (33 of the 36 stages), across waves through LDS (3);
+//   k_front_rank    one thread per body: its place in the whole order = its place in its chunk + the number of smaller pairs in
+//                   every other chunk -- a 9-probe search each, over a copy of all chunk keys in LDS (8 bytes x n <= 128 KB of
+//                   gfx950's 160) -- written straight there.
+// (key, index) pairs are distinct and the order total: the result is exactly what the stable radix sort of the keys delivers.
+// (Tried first: ONE 1024-thread workgroup holding all pairs in LDS, 105 bitonic stages: 0.29 ms per build at 10 000 bodies against
+//  0.076 -- every stage moves all 147 KB through one CU's 128 B/clk of LDS; then chunks of 1 024 sorted in LDS and ranked by
+//  binary searches in global memory: 0.099 -- 100 dependent L2 round trips per body.)
+constexpr int kSmallFrontMax = 16384;
+constexpr int kChunk = kTile;          // bodies per workgroup of k_front_chunks = threads
+constexpr unsigned long long kPadKey = ~0ull;   // (real keys occupy 62 bits)
+
+__device__ __forceinline__ bool pair_less(const unsigned long long ka, const unsigned ia, const unsigned long long kb, const unsigned ib)
+{
+    return ka < kb || (ka == kb && ia < ib);
+}
+
+__global__ __launch_bounds__(kTile) void k_front_chunks(const float4* __restrict__ posm, const int n, unsigned* __restrict__ box,
+                                                        unsigned long long* __restrict__ keys_out, unsigned* __restrict__ idx_out,
+                                                        int* __restrict__ counters, unsigned long long* __restrict__ cell_table,
+                                                        const int cell_slots)
+{
+    __shared__ unsigned long long skey[kChunk];
+    __shared__ unsigned sidx[kChunk];
+    __shared__ float red[kTile / 64][4];
+    const int tid = threadIdx.x;
+    // this build's counters and tickets, and the table of occupied grid cells (reference fold), as k_keys clears them
+    if (blockIdx.x == 0 && tid < 8) counters[tid] = 0;
+    for (int t = blockIdx.x * kTile + tid; t < cell_slots; t += (int)gridDim.x * kTile) cell_table[t] = 0ull;
+    // 1. root AABB (nbody.rs:388-398); eight independent loads in flight per thread
+    float x1 = 3.40282347e+38f, y1 = 3.40282347e+38f, x2 = -3.40282347e+38f, y2 = -3.40282347e+38f;
+    for (int i0 = tid; i0 < n; i0 += 8 * kTile) {
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * kTile;
+            q[u] = posm[i < n ? i : i0];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            x1 = fminf(x1, q[u].x); y1 = fminf(y1, q[u].y); x2 = fmaxf(x2, q[u].x); y2 = fmaxf(y2, q[u].y);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x1 = fminf(x1, __shfl_xor(x1, off)); y1 = fminf(y1, __shfl_xor(y1, off));
+        x2 = fmaxf(x2, __shfl_xor(x2, off)); y2 = fmaxf(y2, __shfl_xor(y2, off));
+    }
+    if ((tid & 63) == 0) { red[tid >> 6][0] = x1; red[tid >> 6][1] = y1; red[tid >> 6][2] = x2; red[tid >> 6][3] = y2; }
+    __syncthreads();
+    x1 = red[0][0]; y1 = red[0][1]; x2 = red[0][2]; y2 = red[0][3];
+#pragma unroll
+    for (int w = 1; w < kTile / 64; w++) {
+        x1 = fminf(x1, red[w][0]); y1 = fminf(y1, red[w][1]); x2 = fmaxf(x2, red[w][2]); y2 = fmaxf(y2, red[w][3]);
+    }
+    if (blockIdx.x == 0 && tid == 0) { box[0] = enc_f32(x1); box[1] = enc_f32(y1); box[2] = enc_f32(x2); box[3] = enc_f32(y2); }
+    // 2. this thread's body: its path of quadrant choices (k_keys; the box goes through the same encode / decode as there)
+    const int body = blockIdx.x * kChunk + tid;
+    unsigned long long key = kPadKey;
+    unsigned id = 0xFFFFFFFFu;
+    if (body < n) {
+        float ax = dec_f32(enc_f32(x1)), ay = dec_f32(enc_f32(y1)), cx = dec_f32(enc_f32(x2)), cy = dec_f32(enc_f32(y2));
+        const float4 p = posm[body];
+        key = 0;
+#pragma unroll 1
+        for (int l = 0; l < kLevels; l++) key = (key << 2) | (unsigned long long)descend(ax, ay, cx, cy, p.x, p.y);
+        id = (unsigned)body;
+    }
+    // 3. bitonic sort of the chunk's 256 pairs, one per thread (padding pairs are larger than every real one)
+#pragma unroll 1
+    for (int k = 2; k <= kChunk; k <<= 1) {
+#pragma unroll 1
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            unsigned long long ok;
+            unsigned oi;
+            if (j < 64) {                         // the partner is a lane of this wave
+                ok = (unsigned long long)(unsigned)__shfl_xor((int)(unsigned)key, j) |
+                     ((unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(key >> 32), j) << 32);
+                oi = (unsigned)__shfl_xor((int)id, j);
+            } else {
+                __syncthreads();
+                skey[tid] = key; sidx[tid] = id;
+                __syncthreads();
+                ok = skey[tid ^ j]; oi = sidx[tid ^ j];
+            }
+            const bool up = (tid & k) == 0;       // this block of k sorts ascending
+            const bool lower = (tid & j) == 0;    // this thread holds the pair's lower position
+            const bool mine_less = pair_less(key, id, ok, oi);
+            if (mine_less != (up == lower)) { key = ok; id = oi; }
+        }
+    }
+    if (body < n) {                                // padding sorted to the end of the (last) chunk
+        keys_out[body] = key;
+        idx_out[body] = id;
+    }
+}
+
+constexpr int kRankThreads = kTile;
+__global__ __launch_bounds__(kRankThreads) void k_front_rank(const unsigned long long* __restrict__ ckeys, const unsigned* __restrict__ cidx,
+                                                      const int n, unsigned long long* __restrict__ keys_out,
+                                                      unsigned* __restrict__ idx_out)
+{
+    extern __shared__ unsigned long long rkeys[];          // every chunk's sorted keys, padded to whole chunks
+    const int chunks = (n + kChunk - 1) / kChunk;
+    {   // copy in: two keys per 16-byte load, sixteen loads in flight per thread (the chunks were written by the kernel before:
+        // every first touch goes past the L2, a microsecond or two each)
+        constexpr int kFlight = 16;
+        const int pairs = chunks * kChunk / 2;
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(ckeys);   // (the workspace arrays are 256-byte aligned)
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(rkeys);
+        for (int t0 = threadIdx.x; t0 < pairs; t0 += kFlight * kRankThreads) {
+            ulonglong2 q[kFlight];
+#pragma unroll
+            for (int u = 0; u < kFlight; u++) {
+                const int t = t0 + u * kRankThreads;
+                q[u] = make_ulonglong2(kPadKey, kPadKey);
+                if (2 * t + 1 < n) q[u] = src[t];
+                else if (2 * t < n) q[u].x = ckeys[2 * t];
+            }
+#pragma unroll
+            for (int u = 0; u < kFlight; u++) {
+                const int t = t0 + u * kRankThreads;
+                if (t < pairs) dst[t] = q[u];
+            }
+        }
+    }
+    __syncthreads();
+    const int j = blockIdx.x * kRankThreads + threadIdx.x;
+    if (j >= n) return;
+    const unsigned long long key = rkeys[j];
+    const unsigned id = cidx[j];
+    const int mine = j / kChunk;
+    int pos = j - mine * kChunk;
+    // pairs of chunk c smaller than mine: the keys below mine -- lower bound over the chunk's 256 keys, 8 halvings and a last
+    // probe, eight chunks abreast, no branch in sight -- plus, among keys EQUAL to mine (bodies of one level-31 cell that landed
+    // in different chunks: rare), those with a smaller index
+    constexpr int kAbreast = 8;
+    for (int c0 = 0; c0 < chunks; c0 += kAbreast) {
+        int lo[kAbreast];
+#pragma unroll
+        for (int u = 0; u < kAbreast; u++) lo[u] = 0;
+#pragma unroll
+        for (int step = kChunk / 2; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int u = 0; u < kAbreast; u++) {
+                const int c = c0 + u < chunks ? c0 + u : c0;
+                lo[u] += rkeys[c * kChunk + lo[u] + step - 1] < key ? step : 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kAbreast; u++) {
+            const int c = c0 + u < chunks ? c0 + u : c0;
+            const unsigned long long at = rkeys[c * kChunk + lo[u]];
+            lo[u] += at < key ? 1 : 0;
+            const bool counted = c0 + u < chunks && c != mine;
+            pos += counted ? lo[u] : 0;
+            if (counted && at == key) {           // (lo[u] did not move: it names the first key equal to mine)
+                for (int t = lo[u]; t < kChunk && rkeys[c * kChunk + t] == key; t++) pos += cidx[c * kChunk + t] < id ? 1 : 0;
+            }
+        }
+    }
+    keys_out[pos] = key;
+    idx_out[pos] = id;
+}
+
+bool small_front_enabled(int n)
+{
+    static const int limit = [] {
+        const char* v = std::getenv("NBX_SMALL_FRONT_MAX");   // 0 turns the two-launch front off (A/B against rocPRIM's sort)
+        const int x = v ? std::atoi(v) : kSmallFrontMax;
+        return x < 0 ? 0 : (x > kSmallFrontMax ? kSmallFrontMax : x);
+    }();
+    return n <= limit;
+}
+
+hipError_t launch_front_small(const float4* posm, int n, unsigned* box, unsigned long long* chunk_keys, unsigned* chunk_idx,
+                              unsigned long long* keys_out, unsigned* idx_out, int* counters, unsigned long long* cell_table,
+                              int cell_slots, hipStream_t stream)
+{
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_rank),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kSmallFrontMax);
+    if (attr != hipSuccess) return attr;
+    const int chunks = (n + kChunk - 1) / kChunk;
+    hipLaunchKernelGGL(k_front_chunks, dim3((unsigned)chunks), dim3(kTile), 0, stream, posm, n, box, chunk_keys, chunk_idx, counters,
+                       cell_table, cell_slots);
+    hipLaunchKernelGGL(k_front_rank, dim3((unsigned)((n + kRankThreads - 1) / kRankThreads)), dim3(kRankThreads),
+                       (size_t)8 * (size_t)chunks * kChunk, stream, chunk_keys, chunk_idx, n, keys_out, idx_out);
+    return hipGetLastError();
+}
+
 namespace {
 struct Workspace {
     int* counters;
@@ -1478,6 +1687,9 @@ Workspace carve(void* workspace, int n, size_t sort_tmp)
 // root AABB -> path keys -> sorted (key, body) pairs in keys1 / idx1
 hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sort_tmp, hipStream_t stream, bool cell_table = false)
 {
+    if (small_front_enabled(n))   // a small system (the reference's own 10 000 bodies): two launches instead of seven, no library sort
+        return launch_front_small(posm, n, k.box, k.keys0, k.idx0, k.keys1, k.idx1, k.counters, k.hk, cell_table ? (int)(k.hmask + 1u) : 0,
+                                  stream);
     const int nb = (n + kTile - 1) / kTile;
     hipLaunchKernelGGL(k_bbox, dim3(nb < 256 ? nb : 256), dim3(kTile), 0, stream, posm, n, k.box, k.part, k.counters + 8);
     hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, k.box, k.keys0, k.idx0, k.counters, k.hk,
@@ -1707,6 +1919,9 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
         hipLaunchKernelGGL(k_merge_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link, k.counters + 1);
         hipLaunchKernelGGL(k_merge_keys, dim3(nb), dim3(kTile), 0, stream, k.keys1, k.idx1, k.link, n, k.keys0, k.counters + 1);
     }
+    // (for small systems the pair merge and the scan were tried as phases of ONE 1024-thread workgroup: 90 us against 22 for the
+    //  four launches at 10 000 bodies -- per-body work here is chains of dependent loads that miss the L2 after every kernel
+    //  boundary, and one CU hides far less of that than forty)
     hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.counters + 3);
     hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.pre, k.counters);
     // one thread per node; the node count is only known on the device, so the grid covers the whole pool (threads beyond

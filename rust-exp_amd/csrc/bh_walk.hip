@@ -28,6 +28,8 @@
 // depth first.  A lane adds the terms of exactly the groups it is inside, in that order, whichever bodies share its wave:
 // bit-identical results.  (Rounds 1-3 accumulated in pre-order of the nodes; the fast mode never promised a summation order --
 // the bit-exact mode keeps the reference's hierarchical sums in bh_eval.hip.)
+#include <cstdlib>
+
 #include "bh_gate.h"
 #include "bh_threshold.h"
 #include "kernels.h"
@@ -459,6 +461,8 @@ hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, cons
         // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 4 and 64 bodies each (as the node walk)
         int bpw = 64;
         while (bpw > 4 && (n_targets + bpw - 1) / bpw < 4096) bpw >>= 1;
+        static const int forced = [] { const char* v = std::getenv("NBX_BH_BPW"); return v ? std::atoi(v) : 0; }();   // (A/B knob)
+        if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) bpw = forced;
         const int nblk = (n_targets + bpw - 1) / bpw;
         const dim3 g((unsigned)((nblk + 7) / 8 * 8));
         if (hand_scheduled) launch_wave_walk<true>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate);
