@@ -894,12 +894,17 @@ void free_device(nbx_engine* e)
 {
     if (!e->dev_ready) return;
     e->pending[0].active = e->pending[1].active = false;
+    // everything in flight first -- a gated kick-drift of an asynchronous Barnes-Hut step may still be about to write its
+    // verdict into h_verdict[], the root's fold may still run on the side stream -- THEN the buffers and events they use
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->side_stream) (void)hipStreamSynchronize(e->side_stream);
     for (int k = 0; k < 2; k++) {
         if (e->h_verdict[k]) (void)hipHostFree(e->h_verdict[k]);
         if (e->ev_step[k]) (void)hipEventDestroy(e->ev_step[k]);
+        e->h_verdict[k] = nullptr;
+        e->ev_step[k] = nullptr;
     }
-    (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& r : e->prof) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
@@ -923,7 +928,7 @@ void free_device(nbx_engine* e)
     if (e->d_tree_ws) (void)hipFree(e->d_tree_ws);
     if (e->d_slab_ws) (void)hipFree(e->d_slab_ws);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
-    if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
+    if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
     if (e->ev_side_go) (void)hipEventDestroy(e->ev_side_go);
     if (e->ev_side_done) (void)hipEventDestroy(e->ev_side_done);
     if (e->d_counts) (void)hipFree(e->d_counts);

@@ -26,6 +26,7 @@ struct RcclApi {
     void* so = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;   // optional: used to tear down a collective that only some ranks joined
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -44,6 +45,7 @@ RcclApi* rccl_api()
         if (so) {
             api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(so, "ncclCommInitAll"));
             api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(so, "ncclCommDestroy"));
+            api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(so, "ncclCommAbort"));
             api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(so, "ncclAllGather"));
             api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(so, "ncclBroadcast"));
             api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(so, "ncclGroupStart"));
@@ -187,12 +189,15 @@ int run_phases(nbx_group* g, const std::vector<std::function<int(int)>>& phases)
     return NBX_OK;
 }
 
-void group_destroy_comms(nbx_group* g)
+// abort = true: a collective may have been enqueued by only SOME ranks (one rank's enqueue failed after its peers' kernels
+// were launched: they spin waiting for it) -- ncclCommAbort tears those kernels down, where a stream synchronisation or
+// ncclCommDestroy would wait for them forever
+void group_destroy_comms(nbx_group* g, bool abort = false)
 {
     if (g->comms.empty()) return;
     if (RcclApi* api = rccl_api())
         for (ncclComm_t c : g->comms)
-            if (c) (void)api->CommDestroy(c);
+            if (c) (void)((abort && api->CommAbort) ? api->CommAbort(c) : api->CommDestroy(c));
     g->comms.clear();
     g->rccl_ranks = 0;
 }
@@ -372,7 +377,10 @@ int group_exchange_array(nbx_group* g, bool half)
         if (rc == NBX_OK) rc = group_exchange_rccl(g, half);
         if (rc != NBX_OK) {
             const std::string why = g_last_error;
-            for (nbx_engine* e : g->eng) {   // nothing of the failed attempt may still be in flight
+            // nothing of the failed attempt may still be in flight: the communicators are ABORTED first (ranks that did enqueue
+            // their share wait for the one that could not; no stream they run on would ever drain), then the streams drained
+            group_destroy_comms(g, /*abort=*/true);
+            for (nbx_engine* e : g->eng) {
                 (void)hipSetDevice(e->device);
                 (void)hipStreamSynchronize(e->stream);
             }

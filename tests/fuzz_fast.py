@@ -108,9 +108,15 @@ def main():
                     why.append("device tree not finite")
                 elif clumps and n > 65536:
                     # above 65 536 bodies the default is the exact-sum class: pairs only, up to max(16, n/2000) bodies of bigger
-                    # clusters left unmerged by contract -- they and their blob-mates then feel O(1) different forces (n/2000
-                    # bodies x up to 6 mates is more than the 0.1 % the percentile below allows): finiteness only
-                    pass
+                    # clusters left unmerged by contract -- they and their blob-mates (up to 7 each) then feel O(1) different
+                    # forces, more than the 0.1 % the percentile below allows.  Still quantitative: everybody else is
+                    # held to the unclustered bounds -- the 99th percentile instead of the 99.9th, and no more bodies beyond the
+                    # max-error bound than the contract's left-behind bodies and their mates
+                    allowed = 8 * max(16, n // 2000)
+                    beyond = int((err > (1e-2 if theta > 0.8 else 5e-3)).sum())
+                    if np.percentile(err, 99.0) > 4e-4 or beyond > allowed:
+                        why.append("device tree (clustered, exact sums) p99 %.2e, %d bodies beyond the max-error bound (%d allowed)"
+                                   % (np.percentile(err, 99.0), beyond, allowed))
                 elif np.percentile(err, 99.9) > (4e-4 if n > 100000 else 2e-4) or err.max() > (1e-2 if theta > 0.8 else 5e-3):
                     why.append("device tree p99.9 %.2e max %.2e" % (np.percentile(err, 99.9), err.max()))
                 from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_OPT_BH_LAST_TREE

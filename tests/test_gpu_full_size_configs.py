@@ -41,6 +41,24 @@ def _sample_targets(lo, hi, count=512):
     return lo + (np.arange(count, dtype=np.int64) * (hi - lo)) // count
 
 
+def _fp64_forces_fp16_sources(st, idx, chunk=16):
+    """F_i = m_i * sum_{j != i} m_j^h (p_j^h - p_i) / (|p_j^h - p_i|^2 + 1e-4) in float64, 2-D: the pair law of nbody.rs:174-183
+    with every SOURCE (position and mass) rounded to fp16 as config #5 stores it; targets keep their fp32 state.  [len(idx), 2]."""
+    P = np.stack([st["px"], st["py"]], 1).astype(np.float64)
+    Ph = np.stack([st["px"], st["py"]], 1).astype(np.float16).astype(np.float64)
+    mh = st["m"].astype(np.float16).astype(np.float64)
+    m = st["m"].astype(np.float64)
+    idx = np.asarray(idx)
+    out = np.zeros((len(idx), 2))
+    for a in range(0, len(idx), chunk):
+        ii = idx[a:a + chunk]
+        d = Ph[None, :, :] - P[ii, None, :]
+        w = mh[None, :] / ((d * d).sum(-1) + 1e-4)
+        w[np.arange(len(ii)), ii] = 0.0          # a body does not attract itself (the kernel takes its own image out again)
+        out[a:a + chunk] = (w[:, :, None] * d).sum(1) * m[ii, None]
+    return out
+
+
 @pytest.mark.parametrize("masses", ["equal", "random"])
 def test_headline_kernel_at_the_headline_shape_against_fp64(rx, masses):
     """The kernel bench.py times, at the shape it times it: N = 262 144, dim 3, DEFAULT launch =
@@ -184,6 +202,17 @@ def test_config5_two_galaxies_524288_fp16_sources(rx):
     b.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
     fx, fy, _ = a.forces()
     hx, hy, _ = b.forces()
+    # EXTERNAL check at full size, at the launch shape bench.py times for this config: the unit-mass sweep over
+    # the widened fp16 copy with its two exceptional sources, S = 4, 8 192 workgroups -- against a float64 sum that uses the SAME
+    # fp16-rounded sources (tests/test_gpu_half_sources.py's model, chunked), on 512 targets spread over the whole range plus both
+    # galaxy cores (exceptional sources AND targets), each against ALL 524 288 sources.  Bound: fp32 rounding, 1e-5 of max|F|.
+    ll = b.last_launch()
+    assert (ll["variant"], ll["jsplit"], ll["grid"], ll["block"], ll["dim"]) == (18, 4, 8192, 256, 2), ll
+    idx = np.unique(np.r_[_sample_targets(0, n), 0, n // 2])
+    F = _fp64_forces_fp16_sources(st, idx)
+    got = np.stack([hx[idx], hy[idx]], 1).astype(np.float64)
+    err = np.abs(got - F).max() / np.abs(F).max()
+    assert err <= 1e-5, err
     rel = np.hypot(hx - fx, hy - fy) / (np.hypot(fx, fy) + 1e-20)
     assert np.median(rel) < 5e-3
     # without the self-image correction every body would feel ~50*m of spurious self force: the galaxy cores
