@@ -245,6 +245,9 @@ def parse_args():
                          "steady_state block (clock and socket power from rocm-smi); 0 = skip")
     ap.add_argument("--no-general-masses", action="store_true",
                     help="skip the general_masses block (the same run on random masses: the kernel with the m_j multiply)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="first contact with a multi-GPU node: create the communicator, run ONE exchange of the real payload and ONE "
+                         "verified step, print what was found (rccl_ranks, exchange microseconds, per-rank kernel ms, verify) and exit")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -575,8 +578,115 @@ class TorchHost:
             self.dist.destroy_process_group()
 
 
+# ---- first contact with a multi-GPU node must say WHERE it failed -------------------------------------
+DIAG = {"stage": "start"}
+
+
+def stage(name, **facts):
+    """Where the run is; what is known so far. Printed (stderr, every rank; stdout line, rank 0) if the run dies."""
+    DIAG["stage"] = name
+    DIAG.update(facts)
+
+
+def multi_gpu_fields(per, host_kind, world, is_bh, group_info=None, backend="nccl"):
+    """The multi-GPU part of the JSON line from plain data (no GPU, no library): per = one dict per rank with its slab, the
+    average ms of its dominant kernel inside the timed loop and -- single-process group -- the all-gather as its stream saw it."""
+    kk = "bh_eval_ms" if is_bh else "force_ms"
+    out = {"per_gpu": per,
+           "rank_skew": {"kernel_ms_min": min(r[kk] for r in per), "kernel_ms_max": max(r[kk] for r in per),
+                         "note": "per-rank average of the dominant kernel inside the timed loop (HIP events on each rank's stream)"}}
+    if host_kind == "group":
+        xs = [r["exchange_us"] for r in per]
+        out["all_gather_us_per_step"] = float(np.mean(xs))
+        out["rank_skew"].update({"exchange_us_min": min(xs), "exchange_us_max": max(xs),
+                                 "exchange_note": "as seen from each rank's stream: includes the wait for the slowest peer"})
+        gi = group_info or {}
+        out["exchange"] = gi.get("exchange")
+        out["rccl_ranks"] = gi.get("rccl_ranks")
+        out["enqueue_threads"] = gi.get("enqueue_threads")
+        if gi.get("note"):
+            out["exchange_note"] = gi["note"]
+    elif host_kind == "torch":
+        out["exchange"] = "torch.distributed " + backend
+        out["rccl_ranks"] = world if backend == "nccl" else 0
+    return out
+
+
+def per_gpu_rows(host, rx, host_kind, world):
+    """Per-engine kernel times (HIP events on each engine's own stream) as plain rows; gathered over the ranks for the torch host."""
+    per = []
+    for e in host.engines:
+        k_ms, k_cnt = e.profile_read(rx.NBX_K_FORCE)
+        i_ms, i_cnt = e.profile_read(rx.NBX_K_INTEGRATE)
+        b_ms, b_cnt = e.profile_read(rx.NBX_K_BH_EVAL)
+        x_ms, x_cnt = e.profile_read(rx.NBX_K_EXCHANGE)
+        t_ms, t_cnt = e.profile_read(rx.NBX_K_TREE_BUILD)
+        lo, hi = e.slab()
+        per.append({"slab": [lo, hi], "force_ms": k_ms / max(k_cnt, 1), "force_launches": k_cnt,
+                    "integrate_ms": i_ms / max(i_cnt, 1), "bh_eval_ms": b_ms / max(b_cnt, 1), "bh_eval_launches": b_cnt,
+                    "exchange_us": 1e3 * x_ms / max(x_cnt, 1), "exchanges": x_cnt,
+                    "device_tree_build_ms": t_ms / max(t_cnt, 1), "device_tree_builds": t_cnt})
+        e.profile(False)
+    if host_kind == "torch" and world > 1:
+        rows = host.gather_floats([per[0]["slab"][0], per[0]["slab"][1], per[0]["force_ms"], per[0]["force_launches"],
+                                   per[0]["integrate_ms"], per[0]["bh_eval_ms"], per[0]["bh_eval_launches"]])
+        per = [{"slab": [int(r[0]), int(r[1])], "force_ms": r[2], "force_launches": int(r[3]), "integrate_ms": r[4],
+                "bh_eval_ms": r[5], "bh_eval_launches": int(r[6]), "exchange_us": None, "exchanges": 0} for r in rows]
+        per[0]["exchange_us"] = None   # torch's collective runs on ProcessGroupNCCL's own stream: see ms_per_step minus kernels
+    return per
+
+
+def dry_run(host, args, rx, step, is_bh, host_kind, real_stdout):
+    """--dry-run: the communicator exists (host construction), now ONE exchange of the real payload, ONE profiled step and ONE
+    verified step; one JSON line saying what was found. Exit code 0 = the multi-GPU path works on this node."""
+    stage("dry-run: first exchange (communicator already created)")
+    host.sync(); host.barrier()
+    t0 = time.perf_counter()
+    host.prepare(args.theta if is_bh else 0.0)
+    host.sync(); host.barrier()
+    first_exchange_ms = (time.perf_counter() - t0) * 1e3
+    stage("dry-run: one profiled step", first_exchange_ms=first_exchange_ms)
+    for e in host.engines:
+        e.profile(True); e.profile_reset()
+    t0 = time.perf_counter()
+    step()
+    host.sync(); host.barrier()
+    step_ms = host.reduce_max(time.perf_counter() - t0) * 1e3
+    per = per_gpu_rows(host, rx, host_kind, host.world)
+    stage("dry-run: one verified step", step_ms=step_ms)
+    args.verify_steps = 1
+    verify = verify_against_plain_engine(host, args, rx, step, is_bh, getattr(host, "local_rank", 0))
+    stage("dry-run: done")
+    if host.rank == 0:
+        out = {"dry_run": True, "n_gpus": host.world, "host": host_kind, "bodies": args.n, "workload": args.workload,
+               "first_exchange_ms_including_setup": first_exchange_ms, "one_step_ms": step_ms, "verify": verify}
+        out.update(multi_gpu_fields(per, host_kind, host.world, is_bh,
+                                    host.group.info() if host_kind == "group" else None, os.environ.get("NBX_DIST_BACKEND", "nccl")))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    host.close()
+    if verify is not None and not verify["ok"]:
+        sys.exit(3)
+
+
 def main():
     real_stdout = _claim_stdout()
+    rank = int(os.environ.get("RANK", "0"))
+    try:
+        run(real_stdout)
+    except SystemExit:
+        raise
+    except BaseException as ex:   # noqa: BLE001 -- whatever it is, say where
+        import traceback
+
+        diag = dict(DIAG, rank=rank, world_size=int(os.environ.get("WORLD_SIZE", "1")), error=repr(ex),
+                    traceback=traceback.format_exc().splitlines()[-6:])
+        sys.stderr.write("bench.py: FAILED at stage '%s' on rank %d: %s\n" % (DIAG["stage"], rank, json.dumps(diag)))
+        if rank == 0:   # still one JSON line on stdout: no value, but where it died and what was known by then
+            os.write(real_stdout, (json.dumps({"metric": None, "value": None, "error": repr(ex), "diagnostics": diag}) + "\n").encode())
+        sys.exit(4)
+
+
+def run(real_stdout):
     # multi-process GPU work on this stack needs dmabuf IPC (exported by the driver; harmless to restate)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse_args()
@@ -599,10 +709,17 @@ def main():
     import rust_exp_amd as rx
 
     n = args.n
+    stage("initial conditions", host=host_kind, gpus=args.gpus, bodies=n, workload=args.workload)
     st = make_state(args, rx)
+    stage("host construction: engines, communicator (ncclCommInitAll / init_process_group)")
     host = {"single": SingleHost, "group": GroupHost, "torch": TorchHost}[host_kind](args, rx, st)
     world, rank = host.world, host.rank
     is_bh = args.workload == "bh"
+    if host_kind == "group":
+        gi0 = host.group.info()
+        stage("host constructed", world=world, exchange=gi0["exchange"], rccl_ranks=gi0["rccl_ranks"], exchange_note=gi0["note"])
+    else:
+        stage("host constructed", world=world, backend=os.environ.get("NBX_DIST_BACKEND", "nccl") if host_kind == "torch" else None)
 
     def step():
         if is_bh:
@@ -610,9 +727,17 @@ def main():
         else:
             host.step_brute()
 
+    if args.dry_run:
+        return dry_run(host, args, rx, step, is_bh, host_kind, real_stdout)
     # inputs resident in HBM, every buffer allocated and the communicator created before anything is timed, whatever
     # --warmup says; the W warm-up steps follow
+    stage("first exchange (allocations, communicator warm-up)")
     host.prepare(args.theta if is_bh else 0.0)
+    if host_kind == "group":
+        gi0 = host.group.info()
+        stage("warm-up steps", exchange=gi0["exchange"], rccl_ranks=gi0["rccl_ranks"], exchange_note=gi0["note"])
+    else:
+        stage("warm-up steps")
     if args.traffic_child:
         for _ in range(3):
             step()
@@ -631,12 +756,14 @@ def main():
         e.profile_reset()
         e.bh_host_timing()
     host.barrier(); host.sync()
+    stage("timed steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     host.sync(); host.barrier()
     t1 = time.perf_counter()
     elapsed = host.reduce_max(t1 - t0)
+    stage("per-rank kernel times", ms_per_step=elapsed / args.steps * 1e3)
     if not profile_in_region:
         for e in host.engines:
             e.profile(True)
@@ -647,25 +774,8 @@ def main():
         host.sync(); host.barrier()
 
     # per-engine kernel times (HIP events on each engine's own stream, inside the timed region)
-    per = []
-    for e in host.engines:
-        k_ms, k_cnt = e.profile_read(rx.NBX_K_FORCE)
-        i_ms, i_cnt = e.profile_read(rx.NBX_K_INTEGRATE)
-        b_ms, b_cnt = e.profile_read(rx.NBX_K_BH_EVAL)
-        x_ms, x_cnt = e.profile_read(rx.NBX_K_EXCHANGE)
-        t_ms, t_cnt = e.profile_read(rx.NBX_K_TREE_BUILD)
-        lo, hi = e.slab()
-        per.append({"slab": [lo, hi], "force_ms": k_ms / max(k_cnt, 1), "force_launches": k_cnt,
-                    "integrate_ms": i_ms / max(i_cnt, 1), "bh_eval_ms": b_ms / max(b_cnt, 1), "bh_eval_launches": b_cnt,
-                    "exchange_us": 1e3 * x_ms / max(x_cnt, 1), "exchanges": x_cnt,
-                    "device_tree_build_ms": t_ms / max(t_cnt, 1), "device_tree_builds": t_cnt})
-        e.profile(False)
-    if host_kind == "torch" and world > 1:
-        rows = host.gather_floats([per[0]["slab"][0], per[0]["slab"][1], per[0]["force_ms"], per[0]["force_launches"],
-                                   per[0]["integrate_ms"], per[0]["bh_eval_ms"], per[0]["bh_eval_launches"]])
-        per = [{"slab": [int(r[0]), int(r[1])], "force_ms": r[2], "force_launches": int(r[3]), "integrate_ms": r[4],
-                "bh_eval_ms": r[5], "bh_eval_launches": int(r[6]), "exchange_us": None, "exchanges": 0} for r in rows]
-        per[0]["exchange_us"] = None   # torch's collective runs on ProcessGroupNCCL's own stream: see ms_per_step minus kernels
+    per = per_gpu_rows(host, rx, host_kind, world)
+    stage("verify / steady state / companions", per_gpu=per)
 
     engine = host.eng
     launch = engine.last_launch()   # of the timed loop (the blocks below launch other shapes)
@@ -742,6 +852,19 @@ def main():
                 traffic_info = measure_traffic(tail + ["--no-cpu-baseline", "--no-traffic"], "k_force")
                 if traffic_info:
                     traffic = traffic_info["bytes_per_launch"]
+            # Instruction-mix ceiling of the packed sweep ("Why K1 stops"): per wave and source -- 128 interactions, two
+            # targets per lane -- 3 (2-D: 2) v_pk_add for d, 3 (2) v_pk_fma for r^2 + eps, 2 v_rcp_f32, [1 v_pk_mul by m_j unless every
+            # body has the same mass], 3 (2) v_pk_fma for the sums; issue cost per wave64 instruction and SIMD, measured
+            # (tools/ubench_valu.hip; PMC of the kernel: 4.87 cycles per VALU instruction against this mix's 4.73): packed 3.85
+            # cycles, v_rcp_f32 8.7 (quarter rate, nothing overlaps it).  A SIMD's peak is 64 flop per cycle.
+            def mix_ceiling(dim, unit_mass):
+                pk = 3 * dim + (0 if unit_mass else 1)
+                return (17.0 if dim == 3 else 12.0) * 128.0 / (pk * 3.85 + 2 * 8.7) / 64.0
+            packed = launch["variant"] in (1, 5, 6, 7, 17, 18)
+            ceiling = mix_ceiling(launch["dim"], launch["variant"] in (7, 18)) if packed else None
+            if general:
+                general["ceiling_frac"] = mix_ceiling(general["launch"]["dim"], False)
+                general["frac_of_ceiling"] = general["frac"] / general["ceiling_frac"]
             out.update({
                 "metric": f"body-pair interactions/s at N={n} (brute-force O(N^2) step)",
                 "value": value, "unit": "interactions/s",
@@ -761,6 +884,12 @@ def main():
                              "bound_contract_class": "mfma (dense fp32 peak: the f32 MFMA rate equals the fp32 vector rate, "
                                                      "157.3 TFLOP/s; no MFMA is used)",
                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                             "ceiling_frac": ceiling, "frac_of_ceiling": (achieved / peak / ceiling) if ceiling else None,
+                             "ceiling_note": "what this kernel's own instruction mix allows at the nominal 2.4 GHz: 17 (12) flop x 128 "
+                                             "interactions / (packed ops x 3.85 + 2 v_rcp_f32 x 8.7 issue cycles) / 64 flop per cycle and "
+                                             "SIMD; the sweep runs with the VALU 97 % busy at the board's power cap (clock ~2.3 of 2.4 GHz): "
+                                             "what is left between frac and ceiling_frac is that clock, not idle issue slots",
+                             "general_masses_frac": general["frac"] if general else None,
                              "traffic": traffic, "traffic_measurement": traffic_info,
                              "kernel": KERNEL_NAMES.get(launch["variant"], "k_force"),
                              "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": worst["force_launches"],
@@ -850,24 +979,8 @@ def main():
                              "traffic_measurement": bh_traffic_info},
             })
         if world > 1 or host_kind != "single":
-            out["per_gpu"] = per
-            kk = "bh_eval_ms" if is_bh else "force_ms"
-            out["rank_skew"] = {"kernel_ms_min": min(r[kk] for r in per), "kernel_ms_max": max(r[kk] for r in per),
-                                "note": "per-rank average of the dominant kernel inside the timed loop (HIP events on each rank's stream)"}
-            if host_kind == "group":
-                out["all_gather_us_per_step"] = float(np.mean([r["exchange_us"] for r in per]))
-                xs = [r["exchange_us"] for r in per]
-                out["rank_skew"].update({"exchange_us_min": min(xs), "exchange_us_max": max(xs),
-                                         "exchange_note": "as seen from each rank's stream: includes the wait for the slowest peer"})
-                gi = host.group.info()
-                out["exchange"] = gi["exchange"]
-                out["rccl_ranks"] = gi["rccl_ranks"]
-                out["enqueue_threads"] = gi["enqueue_threads"]
-                if gi["note"]:
-                    out["exchange_note"] = gi["note"]
-            elif host_kind == "torch":
-                out["exchange"] = "torch.distributed " + os.environ.get("NBX_DIST_BACKEND", "nccl")
-                out["rccl_ranks"] = world if os.environ.get("NBX_DIST_BACKEND", "nccl") == "nccl" else 0
+            out.update(multi_gpu_fields(per, host_kind, world, is_bh, host.group.info() if host_kind == "group" else None,
+                                        os.environ.get("NBX_DIST_BACKEND", "nccl")))
         if verify is not None:
             out["verify"] = verify
         if steady is not None:

@@ -199,11 +199,12 @@ __device__ __forceinline__ int common_digits(const unsigned long long x, const u
 
 struct ScanItem {
     double m, mx, my;
-    int cnt;
+    int cnt;     // nodes starting at the body
+    int ent;     // 1 if the body starts an entity (a leaf), i.e. if it starts any node at all
 };
 __device__ __forceinline__ ScanItem scan_add(const ScanItem& a, const ScanItem& b)
 {
-    return ScanItem{a.m + b.m, a.mx + b.mx, a.my + b.my, a.cnt + b.cnt};
+    return ScanItem{a.m + b.m, a.mx + b.mx, a.my + b.my, a.cnt + b.cnt, a.ent + b.ent};
 }
 constexpr int kScanPerThread = 4;
 constexpr int kScanBlock = kTile * kScanPerThread;
@@ -815,9 +816,10 @@ __global__ __launch_bounds__(kTile) void k_merge_keys(const unsigned long long* 
 __device__ __forceinline__ ScanItem scan_item(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
                                               const int j, const int n)
 {
-    if (j >= n) return ScanItem{0.0, 0.0, 0.0, 0};
+    if (j >= n) return ScanItem{0.0, 0.0, 0.0, 0, 0};
     const float4 p = sb[j];
-    return ScanItem{(double)p.w, (double)p.w * (double)p.x, (double)p.w * (double)p.y, nodes_starting_at(keys, j, n)};
+    const int cnt = nodes_starting_at(keys, j, n);
+    return ScanItem{(double)p.w, (double)p.w * (double)p.x, (double)p.w * (double)p.y, cnt, cnt > 0 ? 1 : 0};
 }
 
 // Deterministic three-kernel exclusive scan (fixed summation tree: the same inputs give the same bits on every run,
@@ -831,12 +833,13 @@ __device__ __forceinline__ ScanItem block_exclusive(const ScanItem mine, ScanIte
     for (int off = 1; off < 64; off <<= 1) {
         ScanItem o;
         o.m = __shfl_up(inc.m, off); o.mx = __shfl_up(inc.mx, off); o.my = __shfl_up(inc.my, off); o.cnt = __shfl_up(inc.cnt, off);
+        o.ent = __shfl_up(inc.ent, off);
         if (lane >= off) inc = scan_add(o, inc);
     }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    ScanItem before{0.0, 0.0, 0.0, 0};
-    ScanItem all{0.0, 0.0, 0.0, 0};
+    ScanItem before{0.0, 0.0, 0.0, 0, 0};
+    ScanItem all{0.0, 0.0, 0.0, 0, 0};
 #pragma unroll
     for (int w = 0; w < kTile / 64; w++) {
         if (w < wave) before = scan_add(before, wsum[w]);
@@ -847,7 +850,8 @@ __device__ __forceinline__ ScanItem block_exclusive(const ScanItem mine, ScanIte
     // exclusive = everything before this wave + the wave-inclusive value minus this thread's own item
     ScanItem ex;
     ex.m = __shfl_up(inc.m, 1); ex.mx = __shfl_up(inc.mx, 1); ex.my = __shfl_up(inc.my, 1); ex.cnt = __shfl_up(inc.cnt, 1);
-    if (lane == 0) ex = ScanItem{0.0, 0.0, 0.0, 0};
+    ex.ent = __shfl_up(inc.ent, 1);
+    if (lane == 0) ex = ScanItem{0.0, 0.0, 0.0, 0, 0};
     return scan_add(before, ex);
 }
 
@@ -881,7 +885,7 @@ __device__ __forceinline__ void scan_blocks(ScanItem* __restrict__ block_sums, c
 {
     const int chunk = (nb + kTile - 1) / kTile;
     const int a = threadIdx.x * chunk, b = min(a + chunk, nb);
-    ScanItem s{0.0, 0.0, 0.0, 0};
+    ScanItem s{0.0, 0.0, 0.0, 0, 0};
     for (int i = a; i < b; i++) s = scan_add(s, block_sums[i]);
     ScanItem total;
     ScanItem run = block_exclusive(s, &total);
@@ -898,6 +902,8 @@ struct Prefix {
     double* mx;
     double* my;
     int* base;    // [n+1] pre-order slot of the first node starting at body j; base[n] = number of nodes
+    int* ent;     // [n+1] entities (leaves) that start before body j: a node at slot k that starts at body a has ent[a] leaves and
+                  //       k - ent[a] interior nodes before it in pre-order (its own leaf is the last node starting at a)
 };
 
 __global__ __launch_bounds__(kTile) void k_scan_write(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
@@ -906,7 +912,7 @@ __global__ __launch_bounds__(kTile) void k_scan_write(const float4* __restrict__
 {
     const int j0 = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
     ScanItem it[kScanPerThread];
-    ScanItem s{0.0, 0.0, 0.0, 0};
+    ScanItem s{0.0, 0.0, 0.0, 0, 0};
 #pragma unroll
     for (int u = 0; u < kScanPerThread; u++) {
         it[u] = scan_item(sb, keys, j0 + u, n);
@@ -916,10 +922,10 @@ __global__ __launch_bounds__(kTile) void k_scan_write(const float4* __restrict__
 #pragma unroll
     for (int u = 0; u < kScanPerThread; u++) {
         const int j = j0 + u;
-        if (j < n) { p.m[j] = run.m; p.mx[j] = run.mx; p.my[j] = run.my; p.base[j] = run.cnt; }
+        if (j < n) { p.m[j] = run.m; p.mx[j] = run.mx; p.my[j] = run.my; p.base[j] = run.cnt; p.ent[j] = run.ent; }
         run = scan_add(run, it[u]);
         if (j == n - 1) {
-            p.m[n] = run.m; p.mx[n] = run.mx; p.my[n] = run.my; p.base[n] = run.cnt;
+            p.m[n] = run.m; p.mx[n] = run.mx; p.my[n] = run.my; p.base[n] = run.cnt; p.ent[n] = run.ent;
             counters[0] = run.cnt;
         }
     }
@@ -1007,7 +1013,9 @@ __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const u
     for (int d = 0; d < l; d++) descend_digit(x1, y1, x2, y2, (int)(ka >> (2 * (kLevels - 1 - d))) & 3);
     BhNode o;
     o.s = __fsub_rn(x2, x1);                        // nbody.rs:341
-    o.pad1 = 0;
+    // interior nodes before this one in pre-order (meaningful for an interior node: where the fast walk files its child group,
+    // bh_walk.hip): every node before slot k is interior except the leaves of the entities that start before body a
+    o.pad1 = k - pre.ent[a];
     if (l == leaf) {
         // the leaf: this body, or the bodies that share its key (same level-31 cell / EPS-merged pair of entities), folded in
         // ARRIVAL order like the reference's add_mass (nbody.rs:303-320).  Equal keys come out of the stable sort in index order;
@@ -1414,6 +1422,7 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     add(sizeof(float4) * (size_t)n);                   // sorted bodies
     add(sizeof(double) * ((size_t)n + 1) * 3);         // prefix sums m, m*x, m*y
     add(sizeof(int) * ((size_t)n + 1));                // pre-order base
+    add(sizeof(int) * ((size_t)n + 1));                // entities before every body
     add(sizeof(ScanItem) * (nb + 1));                  // block sums
     add((size_t)n);                                    // EPS-merge links / pmin
     add(sizeof(int4) * (size_t)n);                     // nodes queued for k_fold_big (more than n of them -> host build)
@@ -1669,6 +1678,7 @@ Workspace carve(void* workspace, int n, size_t sort_tmp)
     double* d = reinterpret_cast<double*>(take(sizeof(double) * ((size_t)n + 1) * 3));
     k.pre.m = d; k.pre.mx = d + (size_t)n + 1; k.pre.my = d + 2 * ((size_t)n + 1);
     k.pre.base = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)n + 1)));
+    k.pre.ent = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)n + 1)));
     k.block_sums = reinterpret_cast<ScanItem*>(take(sizeof(ScanItem) * (nb + 1)));
     k.link = reinterpret_cast<unsigned char*>(take((size_t)n));
     k.big = reinterpret_cast<int4*>(take(sizeof(int4) * (size_t)n));

@@ -42,17 +42,20 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
 // ---- tree -> groups ------------------------------------------------------------------------------------------------------
-// Group k + 1 = the children of node k (pre-order index) if node k is interior; group 0 = the root alone (the reference tests
-// the root like any other node, nbody.rs:338-345: a tall root box can be accepted from its far ends).  Indexing the groups by
-// node keeps this a map without a scan; the slots of exterior nodes are never touched.
+// Group 0 = the root alone (the reference tests the root like any other node, nbody.rs:338-345: a tall root box can be accepted
+// from its far ends); group r + 1 = the children of the r-th interior node in pre-order.  The device build hands every interior
+// node its r (BhNode::pad1: its pre-order slot minus the leaves before it, both known where the node is emitted), so this is a
+// map without a scan AND the records lie in the depth-first order the walk visits them in: descending into a node's first opened
+// child is a step to the next 80 bytes.  Host-built trees (no r): r = the node's pre-order index -- gaps that are never touched.
 // kid[c]: BYTE offset of child c's own group record (interior child), kGroupLeaf, or kGroupAbsent (present children first).
 constexpr int kGroupLeaf = -1, kGroupAbsent = -2;
 
-__device__ __forceinline__ void group_slot(const BhNode nd, const int index, const float theta, float4& rec, int& kid)
+__device__ __forceinline__ void group_slot(const BhNode nd, const int index, const float theta, const bool compact, float4& rec,
+                                           int& kid)
 {
     if (nd.interior) {
         rec = make_float4(nd.px, nd.py, nd.m, bh_take_threshold(nd.s, theta));
-        kid = (index + 1) * (int)sizeof(BhGroup);
+        kid = ((compact ? nd.pad1 : index) + 1) * (int)sizeof(BhGroup);
     } else {
         // a leaf is always evaluated (nbody.rs:371); the body's own leaf adds m * 0 / (0 + EPS) = exactly 0 (nbody.rs:365)
         rec = make_float4(nd.px, nd.py, nd.m, -1.0f);
@@ -61,7 +64,7 @@ __device__ __forceinline__ void group_slot(const BhNode nd, const int index, con
 }
 
 __global__ __launch_bounds__(kTile) void k_bh_groups(const BhNode* __restrict__ nodes, int n_nodes, const float theta,
-                                                     BhGroup* __restrict__ groups, const BuildGate gate)
+                                                     BhGroup* __restrict__ groups, const int compact, const BuildGate gate)
 {
     if (!gate_open(gate, n_nodes)) return;
     const int k = blockIdx.x * kTile + threadIdx.x;
@@ -70,12 +73,12 @@ __global__ __launch_bounds__(kTile) void k_bh_groups(const BhNode* __restrict__ 
         // an empty tree: one massless leaf, so that the walk has something harmless to evaluate
         float4 r0 = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
         int kid0 = kGroupLeaf;
-        if (n_nodes > 0) group_slot(nodes[0], 0, theta, r0, kid0);
+        if (n_nodes > 0) group_slot(nodes[0], 0, theta, compact != 0, r0, kid0);
         groups[0].c[0] = r0; groups[0].c[1] = none; groups[0].c[2] = none; groups[0].c[3] = none;
         groups[0].kid = make_int4(kid0, kGroupAbsent, kGroupAbsent, kGroupAbsent);
     }
     if (k >= n_nodes) return;
-    const int2 hdr = *reinterpret_cast<const int2*>(&nodes[k].skip);   // skip, interior
+    const int4 hdr = *reinterpret_cast<const int4*>(&nodes[k].skip);   // skip, interior, q, pad1
     if (!hdr.y) return;
     float4 rec[4] = {none, none, none, none};
     int kid[4] = {kGroupAbsent, kGroupAbsent, kGroupAbsent, kGroupAbsent};
@@ -84,11 +87,11 @@ __global__ __launch_bounds__(kTile) void k_bh_groups(const BhNode* __restrict__ 
     for (int slot = 0; slot < 4; slot++) {
         if (c < hdr.x) {
             const BhNode nd = nodes[c];
-            group_slot(nd, c, theta, rec[slot], kid[slot]);
+            group_slot(nd, c, theta, compact != 0, rec[slot], kid[slot]);
             c = nd.skip;
         }
     }
-    BhGroup* g = &groups[k + 1];
+    BhGroup* g = &groups[(compact ? hdr.w : k) + 1];
     g->c[0] = rec[0]; g->c[1] = rec[1]; g->c[2] = rec[2]; g->c[3] = rec[3];
     g->kid = make_int4(kid[0], kid[1], kid[2], kid[3]);
 }
@@ -429,13 +432,13 @@ hipError_t launch_bh_count_groups(const float4* posm, int lo, int n_targets, con
 size_t bh_groups_count(int node_cap) { return (size_t)node_cap + 1; }
 bool bh_groups_addressable(int node_cap) { return ((size_t)node_cap + 1) * sizeof(BhGroup) < ((size_t)1 << 31); }
 
-hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta, BhGroup* groups, hipStream_t stream,
+hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta, BhGroup* groups, bool compact, hipStream_t stream,
                             int* gate_counters, int gate_node_cap, int gate_crowd_limit, int gate_queue_limit)
 {
     const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit, nullptr};
     const int threads = n_nodes_or_cap > 0 ? n_nodes_or_cap : 1;   // an empty tree still gets its group 0
     hipLaunchKernelGGL(k_bh_groups, dim3((unsigned)((threads + kTile - 1) / kTile)), dim3(kTile), 0, stream, nodes, n_nodes_or_cap,
-                       theta, groups, gate);
+                       theta, groups, compact ? 1 : 0, gate);
     return hipGetLastError();
 }
 

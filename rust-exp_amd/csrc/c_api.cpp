@@ -718,7 +718,7 @@ int32_t nbx_bh_work_detail(nbx_engine* e, float theta, uint64_t* out4)
     if (e->bh_walk != 0 && e->force_mode == 0 && nbx::bh_groups_addressable((int)e->n_flat)) {   // counted over the structure the selected walk uses
         rc = grow(&e->d_groups, &e->groups_cap, nbx::bh_groups_count((int)e->n_flat));
         if (rc != NBX_OK) { (void)hipFree(d_tot); return rc; }
-        HIP_TRY(nbx::launch_bh_groups(e->d_nodes, (int)e->n_flat, theta, e->d_groups, e->stream));
+        HIP_TRY(nbx::launch_bh_groups(e->d_nodes, (int)e->n_flat, theta, e->d_groups, /*compact=*/on_device, e->stream));
         HIP_TRY(nbx::launch_bh_count_groups(e->d_posm, e->lo, e->slab(), e->d_groups, d_tot, e->stream));
     } else {
         HIP_TRY(nbx::launch_bh_count(e->d_posm, e->lo, e->slab(), e->d_nodes, (int)e->n_flat, theta, d_tot, e->stream));

@@ -653,8 +653,8 @@ int launch_fast_walk(nbx_engine* e, float theta, const unsigned* perm, bool wave
     if (e->bh_walk != 0 && nbx::bh_groups_addressable(nodes_or_cap)) {
         const int rc = grow(&e->d_groups, &e->groups_cap, nbx::bh_groups_count(nodes_or_cap));
         if (rc != NBX_OK) return rc;
-        HIP_TRY(nbx::launch_bh_groups(e->d_nodes, nodes_or_cap, theta, e->d_groups, e->stream, gate, gate_node_cap, gate_crowd_limit,
-                                      gate_queue_limit));
+        HIP_TRY(nbx::launch_bh_groups(e->d_nodes, nodes_or_cap, theta, e->d_groups, /*compact=*/on_device, e->stream, gate, gate_node_cap,
+                                      gate_crowd_limit, gate_queue_limit));
         HIP_TRY(nbx::launch_bh_walk_groups(e->d_posm, e->lo, slab, e->d_groups, e->d_f2, e->stream, perm, wave, e->bh_walk == 1, gate,
                                            gate_node_cap, gate_crowd_limit, gate_queue_limit));
         return NBX_OK;

@@ -15,7 +15,7 @@ struct BhNode {
     int32_t interior;        // 1 = has children (nbody.rs:338), 0 = exterior (leaf)
     float q;                 // opening threshold of the fast walks: s*s for an interior node, -1 for a leaf, so that
                              // "q < theta^2 * d^2" is the MAC for interior nodes and always true for leaves
-    int32_t pad1;
+    int32_t pad1;            // device build: interior nodes before this one in pre-order (where the fast walk files its child group)
 };
 inline __host__ __device__ float bh_node_q(float s, bool interior) { return interior ? s * s : -1.0f; }
 
@@ -30,22 +30,23 @@ struct BhWalk16 {
     int32_t skip;
 };
 
-// Round 4: the fast walk's copy of the tree (bh_walk.hip).  One record per OPENED node: the (x, y, m, T) of its up to four
-// children -- 64 bytes, one scalar-cache line, one s_load_dwordx16 -- present ones first, in the reference's child order
-// (nbody.rs:295-300), then four child words.  T = the opening threshold of bh_threshold.h for an interior child (take <=>
-// dist_sq > T: the reference's s/sqrt(dist_sq) < theta exactly), -1 for a leaf (always evaluated), +inf for an absent slot.
-// kid = BYTE offset of that child's own record (>= 0), -1 = leaf, -2 = absent.  Record 0 holds the root; record k + 1 the
-// children of pre-order node k.
-struct alignas(128) BhGroup {
+// Round 4: the fast walk's copy of the tree (bh_walk.hip).  One 80-byte record per OPENED node: the (x, y, m, T) of its up to four
+// children -- 64 bytes, one s_load_dwordx16 -- present ones first, in the reference's child order (nbody.rs:295-300), then four
+// child words.  T = the opening threshold of bh_threshold.h for an interior child (take <=> dist_sq > T: the reference's
+// s/sqrt(dist_sq) < theta exactly), -1 for a leaf (always evaluated), +inf for an absent slot.  kid = BYTE offset of that child's
+// own record (>= 0), -1 = leaf, -2 = absent.  Record 0 holds the root; the children of the r-th interior node in pre-order are
+// record r + 1 -- the records follow the depth-first order of the walk, a node's first opened child is the next record in memory
+// (device-built trees: BhNode::pad1 carries r; host-built trees use r = the node's pre-order index: gaps, never touched).
+struct alignas(16) BhGroup {
     float4 c[4];
     int4 kid;
-    int4 unused[3];
 };
 size_t bh_groups_count(int node_cap);        // records a tree of node_cap nodes needs
 bool bh_groups_addressable(int node_cap);    // their byte offsets fit the 31 bits a child word has
 // records from the flattened tree, with the step's theta.  n_nodes_or_cap = the node count, or (gated: the count is still on the
 // device, bh_gate.h) the capacity of the node array -- the kernel then reads the count itself
-hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta, BhGroup* groups, hipStream_t stream,
+// compact: the interior nodes carry their pre-order rank among interior nodes in pad1 (device build)
+hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta, BhGroup* groups, bool compact, hipStream_t stream,
                             int* gate_counters = nullptr, int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0);
 // accelerations of the slab's bodies (fast mode).  wave && perm: one walk per wave (bodies in the spatial order perm; hand_scheduled:
 // the assembly loop, else the compiler's), else one per lane; bit-identical results whichever runs

@@ -1,0 +1,77 @@
+"""CPU: bench.py's one-JSON-line contract on the multi-GPU path, without a GPU (VERDICT r03 next #5c).
+
+The first time bench.py meets an 8-GPU node is the driver's round-end scaling run: nothing of the assembly of that line may
+depend on code that has only ever run with one rank.  multi_gpu_fields() builds the multi-GPU part of the line from plain rows;
+here it is driven with a faked 8-engine `per_gpu` for every host kind.  And a run that dies must still say where."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _rows(world, n=262144, torch_host=False):
+    rows = []
+    per = n // world
+    for r in range(world):
+        lo, hi = r * per, (n if r == world - 1 else (r + 1) * per)          # the reference split, nbody.rs:426-428
+        rows.append({"slab": [lo, hi], "force_ms": 1.60 + 0.01 * r, "force_launches": 20, "integrate_ms": 0.004,
+                     "bh_eval_ms": 0.0, "bh_eval_launches": 0, "exchange_us": None if torch_host else 30.0 + r, "exchanges": 0 if torch_host else 20,
+                     "device_tree_build_ms": 0.0, "device_tree_builds": 0})
+    return rows
+
+
+def test_multi_gpu_fields_for_eight_engines_of_a_group():
+    per = _rows(8)
+    info = {"exchange": "rccl", "rccl_ranks": 8, "enqueue_threads": 0, "fp32_stale": False, "note": ""}
+    out = bench.multi_gpu_fields(per, "group", 8, False, info)
+    line = json.loads(json.dumps(out))                                      # serialisable, as the line must be
+    assert line["rccl_ranks"] == 8 and line["exchange"] == "rccl" and "exchange_note" not in line
+    assert len(line["per_gpu"]) == 8 and line["per_gpu"][7]["slab"] == [229376, 262144]
+    assert abs(line["all_gather_us_per_step"] - np.mean([30.0 + r for r in range(8)])) < 1e-12
+    assert line["rank_skew"]["kernel_ms_min"] == 1.60 and abs(line["rank_skew"]["kernel_ms_max"] - 1.67) < 1e-12
+    assert line["rank_skew"]["exchange_us_max"] == 37.0
+    # a group that fell back to peer copies says so
+    info = dict(info, exchange="peer_copy_after_rccl_failure", rccl_ranks=0, note="ncclCommInitAll failed: unhandled system error")
+    line = json.loads(json.dumps(bench.multi_gpu_fields(per, "group", 8, False, info)))
+    assert line["rccl_ranks"] == 0 and line["exchange_note"].startswith("ncclCommInitAll failed")
+
+
+def test_multi_gpu_fields_for_eight_ranks_of_torch_distributed():
+    per = _rows(8, torch_host=True)
+    line = json.loads(json.dumps(bench.multi_gpu_fields(per, "torch", 8, False, None, "nccl")))
+    assert line["rccl_ranks"] == 8 and line["exchange"] == "torch.distributed nccl"
+    assert "all_gather_us_per_step" not in line and line["per_gpu"][0]["exchange_us"] is None
+    line = json.loads(json.dumps(bench.multi_gpu_fields(per, "torch", 8, False, None, "gloo")))
+    assert line["rccl_ranks"] == 0
+    # Barnes-Hut: the skew is that of the traversal
+    bh = [dict(r, bh_eval_ms=0.07 + 0.001 * i, force_ms=0.0) for i, r in enumerate(per)]
+    line = bench.multi_gpu_fields(bh, "torch", 8, True, None, "nccl")
+    assert line["rank_skew"]["kernel_ms_min"] == 0.07
+
+
+def test_a_run_that_dies_says_where():
+    """No GPU here: an 8-engine group cannot be built.  bench.py must exit non-zero, print ONE JSON line on stdout with the stage
+    it died in, and the same diagnostics on stderr."""
+    if __import__("rust_exp_amd").device_count() > 0:
+        import pytest
+
+        pytest.skip("needs a box without a GPU")
+    env = dict(os.environ, NBX_GROUP_EXCHANGE="copy")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--n", "4096", "--no-cpu-baseline", "--dry-run"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 4, (r.returncode, r.stderr[-400:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["error"]
+    # (engines come up lazily: without a device the first thing that needs one is the first exchange)
+    st = d["diagnostics"]["stage"]
+    assert st.startswith("host construction") or st.startswith("dry-run: first exchange"), st
+    assert d["diagnostics"]["gpus"] == 8 and d["diagnostics"]["host"] == "group"
+    assert "FAILED at stage '" + st in r.stderr
