@@ -202,7 +202,7 @@ __device__ __forceinline__ v2f walk_groups_compiled(const BhGroup* __restrict__ 
 // The same walk with the scalar side written by hand.  Registers (fixed; bound through the asm constraints):
 //   s[36:51] group record (x,y,m,T) x 4    s[52:55] child words        s[56:57] M        s[58:59] lanes that open the child
 //   s60 stack pointer   s61 byte offset of the group   s[62:63] EXEC at entry   s[64:65] groups   s[66:67] groups + 64   s68 overflow
-//   s72, s[70:71] newest stack entry (group, mask; s72 < 0: none)
+//   s72, s[70:71] newest stack entry (group, mask; s72 < 0: none)   s73 groups loaded (the walk's cost)
 //   v[10:11] p   v[12:13] sum   v[14:15] d   v[16:17] (dx^2, dy^2)   v18 dist_sq   v[20:21] m/(dist_sq+EPS)   v22 v23 v24 stack
 // Per child: 8 VALU (v_pk_add, v_pk_mul, v_add, v_cmpx, v_add, v_rcp, v_mul, v_pk_fma; the last three skipped when no lane takes
 // the child) + s_andn2 + s_mov exec + 2 branches.  The s_nop 0 after each packed op and after v_rcp are the wait states gfx950
@@ -245,7 +245,7 @@ __device__ __forceinline__ v2f walk_groups_compiled(const BhGroup* __restrict__ 
     " s_mov_b64 s[70:71], s[58:59]\n"                                                                      \
     " s_branch Lback" #c "_%=\n"
 
-__device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ groups, const v2f p, u64 M, int& overflow)
+__device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ groups, const v2f p, u64 M, int& overflow, int& turns)
 {
     v2f acc = {0.0f, 0.0f};
     const char* base = reinterpret_cast<const char*>(groups);
@@ -255,6 +255,7 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
         " s_mov_b32 s61, 0\n"
         " s_mov_b32 s68, 0\n"
         " s_mov_b32 s72, -1\n"
+        " s_mov_b32 s73, 0\n"
         " s_branch Lload_%=\n"
         "Lpop_%=:\n"
         " s_cmp_lt_i32 s72, 0\n"
@@ -271,6 +272,7 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
         " v_readlane_b32 s56, v23, s60\n"
         " v_readlane_b32 s57, v24, s60\n"
         "Lload_%=:\n"
+        " s_add_u32 s73, s73, 1\n"                // groups loaded so far: the walk's cost (next step's launch order)
         " s_load_dwordx16 s[36:51], s[64:65], s61\n"
         " s_load_dwordx4 s[52:55], s[66:67], s61\n"
         " s_mov_b64 exec, s[56:57]\n"
@@ -296,7 +298,7 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
         " s_mov_b32 s68, 1\n"
         "Ldone_%=:\n"
         " s_mov_b64 exec, s[62:63]\n"
-        : "+{v[12:13]}"(acc), "={s68}"(overflow), "+{s[56:57]}"(M)
+        : "+{v[12:13]}"(acc), "={s68}"(overflow), "+{s[56:57]}"(M), "={s73}"(turns)
         : "{s[64:65]}"(base), "{s[66:67]}"(base + 64), "{v[10:11]}"(p)
         : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
           "s54", "s55", "s58", "s59", "s60", "s61", "s62", "s63", "s70", "s71", "s72", "v14", "v15", "v16", "v17", "v18", "v20", "v21", "v22", "v23", "v24",
@@ -304,16 +306,22 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
     return acc;
 }
 
+// order / cost (optional): the walks differ in length (a dense core's bodies sit deep in the tree), and 16 384 of them on 8 192
+// wave slots are two rounds and a tail whose length is the spread of those lengths.  Every walk leaves its cost (groups
+// loaded) in cost[]; k_walk_order turns last step's costs into this step's launch order -- longest first within every XCD's
+// eighth, so each slot's second walk is the shorter the longer its first was.  Which walk runs where changes no result.
 template <int BPW, bool ASM>
 __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* __restrict__ posm, const int lo, const int n_targets,
                                                        const BhGroup* __restrict__ groups, float2* __restrict__ out,
-                                                       const unsigned* __restrict__ perm, const int xcd_order, const BuildGate gate)
+                                                       const unsigned* __restrict__ perm, const int xcd_order, const BuildGate gate,
+                                                       const int* __restrict__ order, int* __restrict__ cost)
 {
     __shared__ int spill_mem[3 * kSpill];
     int n_nodes_unused = 0;
     if (!gate_open(gate, n_nodes_unused)) return;
     // XCD-aware order (as the node walk, bh_eval.hip): XCD k walks the k-th contiguous eighth of the Morton-ordered bodies
-    const int blk = xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int blk = xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (order) blk = order[blk];
     const int t = blk * BPW + threadIdx.x;
     const bool valid = (int)threadIdx.x < BPW && t < n_targets;
     const u64 M = __ballot(valid);
@@ -322,10 +330,11 @@ __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* __restrict_
     const float4 pi = posm[lo + it];
     const v2f p = {pi.x, pi.y};
     v2f acc;
-    int overflow = ASM ? 0 : 1;
-    if (ASM) acc = walk_groups_asm(groups, p, M, overflow);
+    int overflow = ASM ? 0 : 1, turns = 0;
+    if (ASM) acc = walk_groups_asm(groups, p, M, overflow, turns);
     if (__builtin_amdgcn_readfirstlane(overflow)) acc = walk_groups_compiled(groups, p, M, spill_mem);   // (uniform: the asm's output is an SGPR)
     if (valid) out[it] = make_float2(acc.x, acc.y);
+    if (ASM && cost && threadIdx.x == 0) cost[blk] = __builtin_amdgcn_readfirstlane(turns);
 }
 
 // ---- the same walk, private to a lane (bodies in particle-index order: host tree below 65 536 bodies, NBX_OPT_BH_WAVE = 0) ---
@@ -442,11 +451,63 @@ hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta
     return hipGetLastError();
 }
 
+// Launch order of the next step's walks from this step's costs: per eighth of the walks (= per XCD, see the kernel), a counting
+// sort by cost, longest first (64 cost classes; the order inside a class is whatever the atomics make it -- it changes no result).
+__global__ __launch_bounds__(1024) void k_walk_order(const int* __restrict__ cost, int* __restrict__ order, const int per_eighth)
+{
+    __shared__ int hist[64], base[64], top;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) hist[tid] = 0;
+    if (tid == 0) top = 1;
+    __syncthreads();
+    int mx = 1;
+    for (int j = tid; j < per_eighth; j += 1024) mx = max(mx, cost[k * per_eighth + j]);
+    atomicMax(&top, mx);
+    __syncthreads();
+    const int scale = top + 1;
+    for (int j = tid; j < per_eighth; j += 1024) {
+        const int c = min(max(cost[k * per_eighth + j], 0), top);
+        atomicAdd(&hist[63 - (int)(((long long)c * 64) / scale)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int b = 0; b < 64; b++) { base[b] = run; run += hist[b]; }
+    }
+    __syncthreads();
+    for (int j = tid; j < per_eighth; j += 1024) {
+        const int c = min(max(cost[k * per_eighth + j], 0), top);
+        const int pos = atomicAdd(&base[63 - (int)(((long long)c * 64) / scale)], 1);
+        order[k * per_eighth + pos] = k * per_eighth + j;
+    }
+}
+
+hipError_t launch_walk_order(const int* cost, int* order, int walks, hipStream_t stream)
+{
+    if (walks <= 0 || (walks & 7)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_walk_order, dim3(8), dim3(1024), 0, stream, cost, order, walks / 8);
+    return hipGetLastError();
+}
+
+// how many walks (workgroups) launch_bh_walk_groups starts for n_targets bodies in the wave form, and with how many bodies each
+int bh_walk_count(int n_targets, int* bodies_per_walk)
+{
+    int bpw = 64;
+    while (bpw > 4 && (n_targets + bpw - 1) / bpw < 4096) bpw >>= 1;
+    static const int forced = [] { const char* v = std::getenv("NBX_BH_BPW"); return v ? std::atoi(v) : 0; }();   // (A/B knob)
+    if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) bpw = forced;
+    if (bodies_per_walk) *bodies_per_walk = bpw;
+    const int nblk = (n_targets + bpw - 1) / bpw;
+    return (nblk + 7) / 8 * 8;
+}
+
 template <bool ASM>
 static void launch_wave_walk(int bpw, dim3 g, hipStream_t stream, const float4* posm, int lo, int n_targets, const BhGroup* groups,
-                             float2* out, const unsigned* perm, BuildGate gate)
+                             float2* out, const unsigned* perm, BuildGate gate, const int* order, int* cost)
 {
-    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, g, dim3(64), 0, stream, posm, lo, n_targets, groups, out, perm, 1, gate); };
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, g, dim3(64), 0, stream, posm, lo, n_targets, groups, out, perm, 1, gate, order, cost);
+    };
     if (bpw == 64) go(k_bh_walk_groups<64, ASM>);
     else if (bpw == 32) go(k_bh_walk_groups<32, ASM>);
     else if (bpw == 16) go(k_bh_walk_groups<16, ASM>);
@@ -456,20 +517,16 @@ static void launch_wave_walk(int bpw, dim3 g, hipStream_t stream, const float4* 
 
 hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, float2* out, hipStream_t stream,
                                  const unsigned* perm, bool wave, bool hand_scheduled, int* gate_counters, int gate_node_cap,
-                                 int gate_crowd_limit, int gate_queue_limit)
+                                 int gate_crowd_limit, int gate_queue_limit, const int* order, int* cost)
 {
     if (n_targets <= 0) return hipSuccess;
     const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit, nullptr};
     if (wave && perm) {
         // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 4 and 64 bodies each (as the node walk)
         int bpw = 64;
-        while (bpw > 4 && (n_targets + bpw - 1) / bpw < 4096) bpw >>= 1;
-        static const int forced = [] { const char* v = std::getenv("NBX_BH_BPW"); return v ? std::atoi(v) : 0; }();   // (A/B knob)
-        if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) bpw = forced;
-        const int nblk = (n_targets + bpw - 1) / bpw;
-        const dim3 g((unsigned)((nblk + 7) / 8 * 8));
-        if (hand_scheduled) launch_wave_walk<true>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate);
-        else launch_wave_walk<false>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate);
+        const dim3 g((unsigned)bh_walk_count(n_targets, &bpw));
+        if (hand_scheduled) launch_wave_walk<true>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, order, cost);
+        else launch_wave_walk<false>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, nullptr, nullptr);
     } else {
         const int block = n_targets <= 65536 ? 64 : kTile;
         hipLaunchKernelGGL(k_bh_walk_groups_lane, dim3((unsigned)((n_targets + block - 1) / block)), dim3(block), 0, stream, posm, lo,

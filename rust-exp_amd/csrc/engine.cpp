@@ -655,8 +655,30 @@ int launch_fast_walk(nbx_engine* e, float theta, const unsigned* perm, bool wave
         if (rc != NBX_OK) return rc;
         HIP_TRY(nbx::launch_bh_groups(e->d_nodes, nodes_or_cap, theta, e->d_groups, /*compact=*/on_device, e->stream, gate, gate_node_cap,
                                       gate_crowd_limit, gate_queue_limit));
+        // Two rounds of walks or more (> 8192 of them on the chip's 8192 wave slots): launch them longest first, by the costs the
+        // previous step's walks left behind (a stale or missing order costs time, never a result)
+        const int* order = nullptr;
+        int* cost = nullptr;
+        const int walks = (wave && perm && e->bh_walk == 1 && e->bh_walk_lpt) ? nbx::bh_walk_count(slab) : 0;
+        if (walks > 8192) {
+            const size_t had = e->walk_cost_cap;
+            int rc2 = grow(&e->d_walk_cost, &e->walk_cost_cap, (size_t)walks);
+            if (rc2 == NBX_OK) rc2 = grow(&e->d_walk_order, &e->walk_order_cap, (size_t)walks);
+            if (rc2 != NBX_OK) return rc2;
+            if (e->walk_cost_cap != had) {   // fresh memory: walks that write no cost (no body of theirs in the slab; a refused, gated step) read as zero
+                HIP_TRY(hipMemsetAsync(e->d_walk_cost, 0, sizeof(int) * e->walk_cost_cap, e->stream));
+                e->walk_order_walks = 0;
+            }
+            cost = e->d_walk_cost;
+            if (e->walk_order_walks == walks && e->walk_order_slab == slab) order = e->d_walk_order;
+        }
         HIP_TRY(nbx::launch_bh_walk_groups(e->d_posm, e->lo, slab, e->d_groups, e->d_f2, e->stream, perm, wave, e->bh_walk == 1, gate,
-                                           gate_node_cap, gate_crowd_limit, gate_queue_limit));
+                                           gate_node_cap, gate_crowd_limit, gate_queue_limit, order, cost));
+        if (cost) {
+            HIP_TRY(nbx::launch_walk_order(cost, e->d_walk_order, walks, e->stream));
+            e->walk_order_walks = walks;
+            e->walk_order_slab = slab;
+        }
         return NBX_OK;
     }
     const bool w16 = on_device && wave && e->walk16_valid;
@@ -919,6 +941,8 @@ void free_device(nbx_engine* e)
     if (e->d_out4) (void)hipFree(e->d_out4);
     if (e->d_nodes) (void)hipFree(e->d_nodes);
     if (e->d_groups) (void)hipFree(e->d_groups);
+    if (e->d_walk_cost) (void)hipFree(e->d_walk_cost);
+    if (e->d_walk_order) (void)hipFree(e->d_walk_order);
     if (e->d_walk16) (void)hipFree(e->d_walk16);
     if (e->d_wmass) (void)hipFree(e->d_wmass);
     if (e->d_guard) (void)hipFree(e->d_guard);

@@ -50,9 +50,15 @@ hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta
                             int* gate_counters = nullptr, int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0);
 // accelerations of the slab's bodies (fast mode).  wave && perm: one walk per wave (bodies in the spatial order perm; hand_scheduled:
 // the assembly loop, else the compiler's), else one per lane; bit-identical results whichever runs
+// order / cost (hand-scheduled wave form only; both optional, bh_walk_count(n_targets) ints each): every walk leaves the number of
+// groups it loaded in cost[]; order[] = the launch order of the walks (launch_walk_order makes it from the previous step's costs:
+// longest first within every XCD's eighth).  The order changes no result.
 hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, float2* out, hipStream_t stream,
                                  const unsigned* perm, bool wave, bool hand_scheduled, int* gate_counters = nullptr,
-                                 int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0);
+                                 int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0,
+                                 const int* order = nullptr, int* cost = nullptr);
+int bh_walk_count(int n_targets, int* bodies_per_walk = nullptr);   // walks (workgroups) of the wave form, a multiple of 8
+hipError_t launch_walk_order(const int* cost, int* order, int walks, hipStream_t stream);
 hipError_t launch_bh_count_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, unsigned long long* totals,
                                   hipStream_t stream);   // totals[0] children visited, [1] pair laws, [2] opening tests (visits of
                                                          // interior nodes), [3] groups loaded (per body)

@@ -504,7 +504,12 @@ def test_bench_host_selection_without_a_gpu():
         r = run(["--gpus", "2", "--bodies", "1024", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
         assert r.returncode != 0 and "HIP device" in r.stderr and r.stdout.strip() == ""
         r = run(["--bodies", "1024", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
-        assert r.returncode != 0 and "no CPU fallback" in r.stderr and r.stdout.strip() == ""
+        # round 4: a run that dies still prints ONE line -- no value, but the stage it died in (tests/test_bench_contract.py)
+        import json
+
+        assert r.returncode == 4 and "no CPU fallback" in r.stderr
+        d = json.loads(r.stdout.strip())
+        assert d["value"] is None and "no CPU fallback" in d["error"] and d["diagnostics"]["stage"].startswith("first exchange")
     r = run(["--host", "torch", "--gpus", "4", "--bodies", "1024"])
     assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 4" in r.stderr
     r = run(["--host", "single", "--gpus", "2"])

@@ -20,6 +20,9 @@ def run(n, theta, walk, wave=1, steps=30, fold="exact"):
     e = rx.NBodyEngine(mode="fast")
     e.set_bh_fold(fold)
     e.set_option(NBX_OPT_BH_WALK, walk)
+    if os.environ.get("NBX_AB_WALK_ORDER"):
+        from rust_exp_amd.engine import NBX_OPT_BH_WALK_ORDER
+        e.set_option(NBX_OPT_BH_WALK_ORDER, int(os.environ["NBX_AB_WALK_ORDER"]))
     e.set_option(NBX_OPT_BH_WAVE, wave)
     if n == 10000:
         e.seed(1); e.stable_orbits(n, 0.5, 30.0)

@@ -9,7 +9,7 @@ for W in ${WALKS:-0 2 1}; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/bhw_stats_$W -o p --output-format csv -- python $R/bench.py --workload bh --bodies $N --theta $TH --bh-walk $W --no-cpu-baseline --no-traffic --steady-seconds 0 --steps 10 --warmup 3 > /dev/null 2> $O/bhw_stats_$W.err
   find $O/bhw_stats_$W -name '*kernel_stats.csv' -exec cp {} $O/${TAG}_bh_walk_stats_n${N}_walk$W.csv \;
   i=0
-  for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SMEM SQ_INSTS_LDS" "GRBM_GUI_ACTIVE GRBM_COUNT" "FETCH_SIZE" "WRITE_SIZE"; do
+  for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SMEM SQ_INSTS_LDS" "GRBM_GUI_ACTIVE GRBM_COUNT" "FETCH_SIZE" "WRITE_SIZE" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_DATA_READ_REQ"; do
     i=$((i+1)); rm -rf $O/bhw_pmc_${W}_$i
     timeout 300 rocprofv3 --kernel-trace --pmc $grp -d $O/bhw_pmc_${W}_$i -o p --output-format csv -- python $R/bench.py --workload bh --bodies $N --theta $TH --bh-walk $W --no-cpu-baseline --no-traffic --steady-seconds 0 --steps 3 --warmup 1 > /dev/null 2> $O/bhw_pmc_${W}_$i.err
   done
@@ -39,6 +39,8 @@ for W in (0, 1, 2):
             for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH"):
                 if n in rec: rec[n + "_per_smem"] = rec[n] / rec["SQ_INSTS_SMEM"]
         if rec.get("SQ_WAVE_CYCLES") and rec.get("SQ_WAIT_INST_ANY"): rec["wait_inst_any_share"] = rec["SQ_WAIT_INST_ANY"] / rec["SQ_WAVE_CYCLES"]
+        if rec.get("SQC_DCACHE_REQ"): rec["scalar_cache_hit_rate"] = rec.get("SQC_DCACHE_HITS", 0.0) / rec["SQC_DCACHE_REQ"]
+        if "SQ_WAVE_CYCLES" in rec and "kernel_cycles" in rec: rec["wave_slots_occupied_frac"] = 4.0 * rec["SQ_WAVE_CYCLES"] / (1024.0 * 8.0) / rec["kernel_cycles"]
         if "FETCH_SIZE" in rec: rec["hbm_read_bytes"] = rec["FETCH_SIZE"] * 1024 * 2     # KiB -> B, x2 gfx950 correction (MI355X_MICROARCH.md)
         if "WRITE_SIZE" in rec: rec["hbm_write_bytes"] = rec["WRITE_SIZE"] * 1024
         out[f"walk{W}:{k}"] = rec

@@ -17,8 +17,11 @@
 #   strict  bit-exact all-pairs kernels: kernel sweep by size + PMC summaries
 #   xlat / verify8 / fold / frames / fallback   exchange floor + scaling bound; the self-validating 8-engine line; device tree with the
 #           reference fold (bit-equality, ms per step, kernel trace); the level-1 frame loop; hand-over rate of long runs
+#   walk    round 4: the three fast Barnes-Hut walks (nodes / child groups compiled / child groups hand-scheduled) -- A/B table,
+#           kernel trace + PMC counters at 1 M and 10 000 bodies; small: per-kernel trace of the reference's own scene;
+#           dry: bench.py --gpus 8 --dry-run (first contact with a multi-GPU node)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-TAG="${TAG:-r03}"
+TAG="${TAG:-r04}"
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
@@ -134,6 +137,18 @@ PY
       timeout 1500 python tools/bh_fallback_rate.py stable_orbits:10000 random_disk:10000 random_disk:2000 random_disk:20000 random_disk:30000 stable_orbits:65536 random_disk:65536 > $O/${TAG}_bh_fallback_rate.jsonl 2> $O/${TAG}_bh_fallback_rate.err
       NBX_BH_BACKOFF_MAX=0 timeout 600 python tools/bh_fallback_rate.py random_disk:65536 | sed 's/^{/{"note": "NBX_BH_BACKOFF_MAX=0: every step tries the device first", /' >> $O/${TAG}_bh_fallback_rate.jsonl
       cut -c1-200 $O/${TAG}_bh_fallback_rate.jsonl ;;
+    walk)   # the fast Barnes-Hut walks side by side
+      timeout 900 python tools/bh_walk_ab.py > $O/${TAG}_bh_walk_ab.jsonl 2> $O/${TAG}_bh_walk_ab.err; cut -c1-150 $O/${TAG}_bh_walk_ab.jsonl
+      bash tools/bh_walk_pmc.sh 1048576 0.5 $TAG > $O/${TAG}_bh_walk_pmc_1m.log 2>&1
+      bash tools/bh_walk_pmc.sh 10000 0.85 $TAG > $O/${TAG}_bh_walk_pmc_10k.log 2>&1
+      python tools/bh_walk_table.py $TAG | tee $O/${TAG}_bh_walk_table.txt ;;
+    small)  # the reference's own scene (10 000 bodies): per-kernel trace of the step, both tree classes; front-end A/B
+      bash tools/prof_bh_small.sh 10000 $TAG | tee $O/${TAG}_bh_small_kernels.txt
+      for f in 16384 0; do echo "NBX_SMALL_FRONT_MAX=$f"; NBX_SMALL_FRONT_MAX=$f python tools/bh_walk_ab.py 2000:0.85 10000:0.85 16384:0.85 2>&1 | grep '"groups"' | cut -c1-200; done | tee $O/${TAG}_bh_small_front_ab.txt ;;
+    dry)    # first contact with a multi-GPU node, rehearsed on whatever this box has
+      if [ "$(python -c 'import rust_exp_amd as r; print(r.device_count())' 2>/dev/null)" -ge 8 ]; then X=""; else X="NBX_GROUP_EXCHANGE=copy"; fi
+      env $X timeout 600 python bench.py --gpus 8 --dry-run --no-cpu-baseline > $O/${TAG}_bench_group8_dry_run.json 2> $O/${TAG}_bench_group8_dry_run.err; echo "dry rc=$?"; cut -c1-1000 $O/${TAG}_bench_group8_dry_run.json
+      NBX_GROUP_RCCL_FAIL=init timeout 600 python bench.py --gpus 2 --dry-run --no-cpu-baseline > $O/${TAG}_bench_group2_dry_run_rccl_failure.json 2> $O/${TAG}_bench_group2_dry_run_rccl_failure.err; echo "dry (simulated RCCL failure) rc=$?"; cut -c1-600 $O/${TAG}_bench_group2_dry_run_rccl_failure.json ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
