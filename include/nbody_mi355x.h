@@ -167,10 +167,12 @@ enum nbx_option {
                                     * K3).  0 = the node-by-node walk of rounds 1-3 (bh_eval.hip).  All make the reference's
                                     * decision for every body and node; 0 differs from 1 / 2 in the order the terms are added
                                     * (the fast mode's stated tolerance) */
-    NBX_OPT_BH_WALK_ORDER = 19,    /* child-group walk, two rounds of walks or more (> 8 192 waves): 1 (default) = launch the walks longest
-                                    * first within every XCD's share, by the number of groups each loaded in the previous step (a walk's
-                                    * length follows the local depth of the tree; with 16 384 walks on 8 192 wave slots the kernel's tail
-                                    * is the spread of those lengths); 0 = in Morton order.  The order changes no result */
+    NBX_OPT_BH_WALK_ORDER = 19,    /* child-group walk, two rounds of walks or more (> 8 192 waves): 1 = launch the walks longest first
+                                    * within every XCD's share, by the number of groups each loaded in the previous step; 0 (default) =
+                                    * in Morton order.  The order changes no result.  Kept as the measured A/B of round 4: the kernel's
+                                    * tail (29 % of the wave slots idle) suggested it, but walks that are neighbours in space then no
+                                    * longer run side by side and what the tail gains the L2 loses: traversal 0.449 vs 0.430 ms at
+                                    * 1 048 576 bodies, no difference at 262 144 */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };
