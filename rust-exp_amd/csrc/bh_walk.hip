@@ -200,13 +200,15 @@ __device__ __forceinline__ v2f walk_groups_compiled(const BhGroup* __restrict__ 
 
 // ---- the shared walk, hand-scheduled ---------------------------------------------------------------------------------------
 // The same walk with the scalar side written by hand.  Registers (fixed; bound through the asm constraints):
-//   s[36:51] group record (x,y,m,T) x 4    s[52:55] child words        s[56:57] M        s[58:59] lanes that open the child
-//   s60 stack pointer   s61 byte offset of the group   s[62:63] EXEC at entry   s[64:65] groups   s[66:67] groups + 64   s68 overflow
-//   s72, s[70:71] newest stack entry (group, mask; s72 < 0: none)   s73 groups loaded (the walk's cost)
+//   s[20:35] group record (x,y,m,T) x 4    s[36:39] child words        s[40:41] M        s[42:43] lanes that open the child
+//   s44 stack pointer   s45 byte offset of the group   s[46:47] EXEC at entry   s[48:49] groups   s[50:51] groups + 64   s52 overflow
+//   s53, s[54:55] newest stack entry (group, mask; s53 < 0: none)   s56 groups loaded (the walk's cost)
 //   v[10:11] p   v[12:13] sum   v[14:15] d   v[16:17] (dx^2, dy^2)   v18 dist_sq   v[20:21] m/(dist_sq+EPS)   v22 v23 v24 stack
+// (The register numbers are low on purpose: with 68 numbered SGPRs the kernel runs 8 waves per SIMD, with 82 it ran 7 -- and
+//  16 384 walks on 7 168 slots are two rounds plus a third of 256 walks per XCD, visible in tools/bh_walk_trace.py's timeline.)
 // Per child: 8 VALU (v_pk_add, v_pk_mul, v_add, v_cmpx, v_add, v_rcp, v_mul, v_pk_fma; the last three skipped when no lane takes
 // the child) + s_andn2 + s_mov exec + 2 branches.  The s_nop 0 after each packed op and after v_rcp are the wait states gfx950
-// asks for (packed-result forwarding; transcendental result).  A wave whose stack would pass 64 entries leaves with s68 = 1 and redoes its
+// asks for (packed-result forwarding; transcendental result).  A wave whose stack would pass 64 entries leaves with s52 = 1 and redoes its
 // walk in the compiled form (LDS spill) -- the same sums in the same order.
 #define NBX_ASM_CHILD(x, m, T, K, c)                                                                       \
     "Lc" #c "_%=:\n"                                                                                       \
@@ -217,32 +219,32 @@ __device__ __forceinline__ v2f walk_groups_compiled(const BhGroup* __restrict__ 
     " v_add_f32 v18, v16, v17\n"                                                                           \
     " v_cmpx_nge_f32 vcc, " T ", v18\n"               /* EXEC = lanes of M with not (T >= dist_sq): they take the child */ \
     " v_add_f32 v20, 0x38d1b717, v18\n"               /* dist_sq + EPS (nbody.rs:180) */                   \
-    " s_andn2_b64 s[58:59], s[56:57], exec\n"         /* the lanes of M that open it; SCC = anybody */      \
+    " s_andn2_b64 s[42:43], s[40:41], exec\n"         /* the lanes of M that open it; SCC = anybody */      \
     " s_cbranch_execz Lskip" #c "_%=\n"               /* nobody takes it (the top of every walk) */        \
     " v_rcp_f32 v20, v20\n"                                                                                \
     " s_nop 0\n"                                                                                           \
     " v_mul_f32 v20, " m ", v20\n"                                                                         \
     " v_pk_fma_f32 v[12:13], v[20:21], v[14:15], v[12:13] op_sel_hi:[0,1,1]\n"                             \
     "Lskip" #c "_%=:\n"                                                                                    \
-    " s_mov_b64 exec, s[56:57]\n"                                                                          \
+    " s_mov_b64 exec, s[40:41]\n"                                                                          \
     " s_cbranch_scc1 Lpush" #c "_%=\n"                                                                     \
     "Lback" #c "_%=:\n"
-// push (group K, mask s[58:59]): the newest entry stays in scalar registers (s72, s[70:71]; s72 < 0 = none) -- it is what the next
-// pop wants whenever this group opens anything -- and only an entry it displaces goes to lane s60 of the stack registers
+// push (group K, mask s[42:43]): the newest entry stays in scalar registers (s53, s[54:55]; s53 < 0 = none) -- it is what the next
+// pop wants whenever this group opens anything -- and only an entry it displaces goes to lane s44 of the stack registers
 #define NBX_ASM_PUSH(K, c)                                                                                 \
     "Lpush" #c "_%=:\n"                                                                                    \
-    " s_cmp_lt_i32 s72, 0\n"                                                                               \
+    " s_cmp_lt_i32 s53, 0\n"                                                                               \
     " s_cbranch_scc1 Lfill" #c "_%=\n"                                                                     \
-    " s_cmp_ge_u32 s60, 64\n"                                                                              \
+    " s_cmp_ge_u32 s44, 64\n"                                                                              \
     " s_cbranch_scc1 Lovf_%=\n"                                                                            \
-    " s_mov_b32 m0, s60\n"                                                                                 \
-    " s_add_u32 s60, s60, 1\n"                                                                             \
-    " v_writelane_b32 v22, s72, m0\n"                                                                      \
-    " v_writelane_b32 v23, s70, m0\n"                                                                      \
-    " v_writelane_b32 v24, s71, m0\n"                                                                      \
+    " s_mov_b32 m0, s44\n"                                                                                 \
+    " s_add_u32 s44, s44, 1\n"                                                                             \
+    " v_writelane_b32 v22, s53, m0\n"                                                                      \
+    " v_writelane_b32 v23, s54, m0\n"                                                                      \
+    " v_writelane_b32 v24, s55, m0\n"                                                                      \
     "Lfill" #c "_%=:\n"                                                                                    \
-    " s_mov_b32 s72, " K "\n"                                                                              \
-    " s_mov_b64 s[70:71], s[58:59]\n"                                                                      \
+    " s_mov_b32 s53, " K "\n"                                                                              \
+    " s_mov_b64 s[54:55], s[42:43]\n"                                                                      \
     " s_branch Lback" #c "_%=\n"
 
 __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ groups, const v2f p, u64 M, int& overflow, int& turns)
@@ -250,58 +252,58 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
     v2f acc = {0.0f, 0.0f};
     const char* base = reinterpret_cast<const char*>(groups);
     asm volatile(
-        " s_mov_b64 s[62:63], exec\n"
-        " s_mov_b32 s60, 0\n"
-        " s_mov_b32 s61, 0\n"
-        " s_mov_b32 s68, 0\n"
-        " s_mov_b32 s72, -1\n"
-        " s_mov_b32 s73, 0\n"
+        " s_mov_b64 s[46:47], exec\n"
+        " s_mov_b32 s44, 0\n"
+        " s_mov_b32 s45, 0\n"
+        " s_mov_b32 s52, 0\n"
+        " s_mov_b32 s53, -1\n"
+        " s_mov_b32 s56, 0\n"
         " s_branch Lload_%=\n"
         "Lpop_%=:\n"
-        " s_cmp_lt_i32 s72, 0\n"
+        " s_cmp_lt_i32 s53, 0\n"
         " s_cbranch_scc1 Lpopv_%=\n"
-        " s_mov_b32 s61, s72\n"                   // the entry in scalar registers
-        " s_mov_b64 s[56:57], s[70:71]\n"
-        " s_mov_b32 s72, -1\n"
+        " s_mov_b32 s45, s53\n"                   // the entry in scalar registers
+        " s_mov_b64 s[40:41], s[54:55]\n"
+        " s_mov_b32 s53, -1\n"
         " s_branch Lload_%=\n"
         "Lpopv_%=:\n"
-        " s_cmp_eq_u32 s60, 0\n"
+        " s_cmp_eq_u32 s44, 0\n"
         " s_cbranch_scc1 Ldone_%=\n"
-        " s_add_u32 s60, s60, -1\n"
-        " v_readlane_b32 s61, v22, s60\n"
-        " v_readlane_b32 s56, v23, s60\n"
-        " v_readlane_b32 s57, v24, s60\n"
+        " s_add_u32 s44, s44, -1\n"
+        " v_readlane_b32 s45, v22, s44\n"
+        " v_readlane_b32 s40, v23, s44\n"
+        " v_readlane_b32 s41, v24, s44\n"
         "Lload_%=:\n"
-        " s_add_u32 s73, s73, 1\n"                // groups loaded so far: the walk's cost (next step's launch order)
-        " s_load_dwordx16 s[36:51], s[64:65], s61\n"
-        " s_load_dwordx4 s[52:55], s[66:67], s61\n"
-        " s_mov_b64 exec, s[56:57]\n"
+        " s_add_u32 s56, s56, 1\n"                // groups loaded so far: the walk's cost (next step's launch order)
+        " s_load_dwordx16 s[20:35], s[48:49], s45\n"
+        " s_load_dwordx4 s[36:39], s[50:51], s45\n"
+        " s_mov_b64 exec, s[40:41]\n"
         " s_waitcnt lgkmcnt(0)\n"
-        " s_cmp_eq_u32 s54, -2\n"                 // slot 2 absent: one or two children
+        " s_cmp_eq_u32 s38, -2\n"                 // slot 2 absent: one or two children
         " s_cbranch_scc1 Lle2_%=\n"
-        " s_cmp_eq_u32 s55, -2\n"
+        " s_cmp_eq_u32 s39, -2\n"
         " s_cbranch_scc1 Lc2_%=\n"
-        NBX_ASM_CHILD("s[48:49]", "s50", "s51", "s55", 3)
-        NBX_ASM_CHILD("s[44:45]", "s46", "s47", "s54", 2)
-        NBX_ASM_CHILD("s[40:41]", "s42", "s43", "s53", 1)
-        NBX_ASM_CHILD("s[36:37]", "s38", "s39", "s52", 0)
+        NBX_ASM_CHILD("s[32:33]", "s34", "s35", "s39", 3)
+        NBX_ASM_CHILD("s[28:29]", "s30", "s31", "s38", 2)
+        NBX_ASM_CHILD("s[24:25]", "s26", "s27", "s37", 1)
+        NBX_ASM_CHILD("s[20:21]", "s22", "s23", "s36", 0)
         " s_branch Lpop_%=\n"
         "Lle2_%=:\n"
-        " s_cmp_eq_u32 s53, -2\n"
+        " s_cmp_eq_u32 s37, -2\n"
         " s_cbranch_scc0 Lc1_%=\n"
         " s_branch Lc0_%=\n"
-        NBX_ASM_PUSH("s55", 3)
-        NBX_ASM_PUSH("s54", 2)
-        NBX_ASM_PUSH("s53", 1)
-        NBX_ASM_PUSH("s52", 0)
+        NBX_ASM_PUSH("s39", 3)
+        NBX_ASM_PUSH("s38", 2)
+        NBX_ASM_PUSH("s37", 1)
+        NBX_ASM_PUSH("s36", 0)
         "Lovf_%=:\n"
-        " s_mov_b32 s68, 1\n"
+        " s_mov_b32 s52, 1\n"
         "Ldone_%=:\n"
-        " s_mov_b64 exec, s[62:63]\n"
-        : "+{v[12:13]}"(acc), "={s68}"(overflow), "+{s[56:57]}"(M), "={s73}"(turns)
-        : "{s[64:65]}"(base), "{s[66:67]}"(base + 64), "{v[10:11]}"(p)
-        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
-          "s54", "s55", "s58", "s59", "s60", "s61", "s62", "s63", "s70", "s71", "s72", "v14", "v15", "v16", "v17", "v18", "v20", "v21", "v22", "v23", "v24",
+        " s_mov_b64 exec, s[46:47]\n"
+        : "+{v[12:13]}"(acc), "={s52}"(overflow), "+{s[40:41]}"(M), "={s56}"(turns)
+        : "{s[48:49]}"(base), "{s[50:51]}"(base + 64), "{v[10:11]}"(p)
+        : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37",
+          "s38", "s39", "s42", "s43", "s44", "s45", "s46", "s47", "s54", "s55", "s53", "v14", "v15", "v16", "v17", "v18", "v20", "v21", "v22", "v23", "v24",
           "vcc", "scc", "m0");
     return acc;
 }
@@ -314,11 +316,13 @@ template <int BPW, bool ASM>
 __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* __restrict__ posm, const int lo, const int n_targets,
                                                        const BhGroup* __restrict__ groups, float2* __restrict__ out,
                                                        const unsigned* __restrict__ perm, const int xcd_order, const BuildGate gate,
-                                                       const int* __restrict__ order, int* __restrict__ cost)
+                                                       const int* __restrict__ order, int* __restrict__ cost,
+                                                       unsigned long long* __restrict__ trace)
 {
     __shared__ int spill_mem[3 * kSpill];
     int n_nodes_unused = 0;
     if (!gate_open(gate, n_nodes_unused)) return;
+    const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;   // the 100 MHz clock all XCDs share
     // XCD-aware order (as the node walk, bh_eval.hip): XCD k walks the k-th contiguous eighth of the Morton-ordered bodies
     int blk = xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (order) blk = order[blk];
@@ -335,6 +339,13 @@ __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* __restrict_
     if (__builtin_amdgcn_readfirstlane(overflow)) acc = walk_groups_compiled(groups, p, M, spill_mem);   // (uniform: the asm's output is an SGPR)
     if (valid) out[it] = make_float2(acc.x, acc.y);
     if (ASM && cost && threadIdx.x == 0) cost[blk] = __builtin_amdgcn_readfirstlane(turns);
+    if (trace && threadIdx.x == 0) {   // tools/bh_walk_trace.py: when and where this walk ran (s_memrealtime: 10 ns ticks; HW_ID, XCC_ID)
+        trace[4 * (size_t)blockIdx.x + 0] = t_start;
+        trace[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        trace[4 * (size_t)blockIdx.x + 2] = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(turns) | ((unsigned long long)(unsigned)blk << 32);
+        trace[4 * (size_t)blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+                                            ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);
+    }
 }
 
 // ---- the same walk, private to a lane (bodies in particle-index order: host tree below 65 536 bodies, NBX_OPT_BH_WAVE = 0) ---
@@ -503,10 +514,10 @@ int bh_walk_count(int n_targets, int* bodies_per_walk)
 
 template <bool ASM>
 static void launch_wave_walk(int bpw, dim3 g, hipStream_t stream, const float4* posm, int lo, int n_targets, const BhGroup* groups,
-                             float2* out, const unsigned* perm, BuildGate gate, const int* order, int* cost)
+                             float2* out, const unsigned* perm, BuildGate gate, const int* order, int* cost, unsigned long long* trace)
 {
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, g, dim3(64), 0, stream, posm, lo, n_targets, groups, out, perm, 1, gate, order, cost);
+        hipLaunchKernelGGL(kernel, g, dim3(64), 0, stream, posm, lo, n_targets, groups, out, perm, 1, gate, order, cost, trace);
     };
     if (bpw == 64) go(k_bh_walk_groups<64, ASM>);
     else if (bpw == 32) go(k_bh_walk_groups<32, ASM>);
@@ -517,7 +528,7 @@ static void launch_wave_walk(int bpw, dim3 g, hipStream_t stream, const float4* 
 
 hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, float2* out, hipStream_t stream,
                                  const unsigned* perm, bool wave, bool hand_scheduled, int* gate_counters, int gate_node_cap,
-                                 int gate_crowd_limit, int gate_queue_limit, const int* order, int* cost)
+                                 int gate_crowd_limit, int gate_queue_limit, const int* order, int* cost, unsigned long long* trace)
 {
     if (n_targets <= 0) return hipSuccess;
     const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit, nullptr};
@@ -525,8 +536,8 @@ hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, cons
         // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 4 and 64 bodies each (as the node walk)
         int bpw = 64;
         const dim3 g((unsigned)bh_walk_count(n_targets, &bpw));
-        if (hand_scheduled) launch_wave_walk<true>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, order, cost);
-        else launch_wave_walk<false>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, nullptr, nullptr);
+        if (hand_scheduled) launch_wave_walk<true>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, order, cost, trace);
+        else launch_wave_walk<false>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, nullptr, nullptr, trace);
     } else {
         const int block = n_targets <= 65536 ? 64 : kTile;
         hipLaunchKernelGGL(k_bh_walk_groups_lane, dim3((unsigned)((n_targets + block - 1) / block)), dim3(block), 0, stream, posm, lo,

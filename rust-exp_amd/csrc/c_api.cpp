@@ -736,6 +736,32 @@ int32_t nbx_bh_work_detail(nbx_engine* e, float theta, uint64_t* out4)
     return NBX_OK;
 }
 
+int32_t nbx_bh_walk_trace(nbx_engine* e, float theta, int32_t cap_walks, uint64_t* out)
+{
+    if (!e || !out || cap_walks <= 0) return fail(NBX_ERR_INVALID, "bad arguments");
+    if (e->force_mode != 0 || e->bh_walk == 0) return fail(NBX_ERR_STATE, "the trace is of the child-group walk (fast mode)");
+    int rc = upload(e);
+    if (rc != NBX_OK) return rc;
+    rc = resolve_pending(e);
+    if (rc != NBX_OK) return rc;
+    const int slab = e->slab();
+    const int walks = nbx::bh_walk_count(slab);
+    if (walks > cap_walks) return walks;
+    HIP_TRY(hipSetDevice(e->device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned long long) * 4 * (size_t)walks));
+    hipError_t err = hipMemsetAsync(d, 0, sizeof(unsigned long long) * 4 * (size_t)walks, e->stream);
+    e->d_walk_trace = d;
+    std::vector<float> fx((size_t)slab), fy((size_t)slab);
+    rc = err == hipSuccess ? nbx_forces(e, theta, slab, fx.data(), fy.data(), nullptr) : NBX_ERR_HIP;
+    e->d_walk_trace = nullptr;
+    if (rc >= 0) err = hipMemcpy(out, d, sizeof(unsigned long long) * 4 * (size_t)walks, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (rc < 0) return rc;
+    HIP_TRY(err);
+    return walks;
+}
+
 float nbx_bh_take_threshold(float s, float theta) { return nbx::bh_take_threshold(s, theta); }
 
 int32_t nbx_bh_take_thresholds_device(nbx_engine* e, int32_t count, const float* s, const float* theta, float* out)

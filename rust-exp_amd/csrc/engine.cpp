@@ -673,7 +673,7 @@ int launch_fast_walk(nbx_engine* e, float theta, const unsigned* perm, bool wave
             if (e->walk_order_walks == walks && e->walk_order_slab == slab) order = e->d_walk_order;
         }
         HIP_TRY(nbx::launch_bh_walk_groups(e->d_posm, e->lo, slab, e->d_groups, e->d_f2, e->stream, perm, wave, e->bh_walk == 1, gate,
-                                           gate_node_cap, gate_crowd_limit, gate_queue_limit, order, cost));
+                                           gate_node_cap, gate_crowd_limit, gate_queue_limit, order, cost, e->d_walk_trace));
         if (cost) {
             HIP_TRY(nbx::launch_walk_order(cost, e->d_walk_order, walks, e->stream));
             e->walk_order_walks = walks;

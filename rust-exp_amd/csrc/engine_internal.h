@@ -64,6 +64,7 @@ struct nbx_engine {
     size_t walk_cost_cap = 0, walk_order_cap = 0;
     int walk_order_walks = 0;            // > 0: d_walk_order holds an order for that many walks (same slab, same bodies per walk)
     int walk_order_slab = 0;
+    unsigned long long* d_walk_trace = nullptr;   // nbx_bh_walk_trace: set for the one evaluation it traces
     int bh_walk_lpt = 0;                 // NBX_OPT_BH_WALK_ORDER: 1 = longest-first from the previous step's costs, 0 (default) = Morton order
                                          // (measured, round 4: 0.449 vs 0.430 ms at 1 M bodies -- spatially adjacent walks no longer run side by side)
     int bh_walk = 1;                     // NBX_OPT_BH_WALK: 1 = child groups, hand-scheduled loop (default), 2 = child groups, compiled

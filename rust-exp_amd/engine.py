@@ -254,6 +254,8 @@ def lib():
     L.nbx_bh_work.restype = i32
     L.nbx_bh_work_detail.argtypes = [E, C.c_float, C.POINTER(C.c_uint64)]
     L.nbx_bh_work_detail.restype = i32
+    L.nbx_bh_walk_trace.argtypes = [E, C.c_float, i32, C.c_void_p]
+    L.nbx_bh_walk_trace.restype = i32
     L.nbx_bh_take_threshold.argtypes = [C.c_float, C.c_float]
     L.nbx_bh_take_threshold.restype = C.c_float
     L.nbx_bh_take_thresholds_device.argtypes = [E, i32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -544,6 +546,13 @@ class NBodyEngine:
         out = (C.c_uint64 * 4)()
         _check(self._L.nbx_bh_work_detail(self._h, theta, out))
         return {"node_visits": out[0], "pair_evals": out[1], "opening_tests": out[2], "group_loads": out[3]}
+
+    def bh_walk_trace(self, theta):
+        """[walks, 4] uint64: s_memrealtime (10 ns ticks) start, end, groups loaded | chunk << 32, HW_ID | XCC_ID << 32 of every walk of one traversal."""
+        n = _check(self._L.nbx_bh_walk_trace(self._h, theta, 1, np.zeros(4, np.uint64).ctypes.data))
+        out = np.zeros((n, 4), np.uint64)
+        _check(self._L.nbx_bh_walk_trace(self._h, theta, n, out.ctypes.data))
+        return out
 
     def bh_take_thresholds(self, s, theta):
         """bh_threshold.h's T for every (s[i], theta[i]), evaluated on this engine's GPU (test hook)."""
