@@ -49,6 +49,13 @@
 
 namespace nbx {
 
+// rocPRIM's (key, index) sort for systems above kSmallFrontMax bodies: its merge-sort path (the library's choice up to 2^20 pairs)
+// with first-level blocks of 512 x 8 pairs instead of 256 x 4 -- two merge passes fewer: 183 vs 206 us at 1 048 576 pairs,
+// 109 vs 111 at 262 144 (tools/ubench_sort_cfg.hip, profiles/r04_ubench_sort_cfg.txt)
+constexpr int kBigSortFrom = 262144;   // (below: the library's own shape -- 65 536 pairs lose 10 us to the bigger blocks, too few of them)
+using BuildSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<512, 512, 8, 128, 128, 4>,
+                                                   rocprim::default_config, (size_t)1 << 20>;
+
 constexpr int kLevels = 31;   // 62-bit keys
 
 __device__ __forceinline__ unsigned enc_f32(float f)
@@ -1409,8 +1416,12 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
 {
     (void)node_cap;   // the build needs no per-node scratch: nodes are written straight into the caller's array
     size_t tmp = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
-                              (unsigned*)nullptr, (size_t)n, 0, 2 * kLevels, (hipStream_t)0);
+    size_t tmp_small = 0;   // (the workspace serves either shape: which one runs depends on n alone, but n may shrink below the switch)
+    (void)rocprim::radix_sort_pairs<BuildSortConfig>(nullptr, tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                                     (unsigned*)nullptr, (unsigned*)nullptr, (size_t)n, 0, 2 * kLevels, (hipStream_t)0);
+    (void)rocprim::radix_sort_pairs(nullptr, tmp_small, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
+                                    (unsigned*)nullptr, (size_t)n, 0, 2 * kLevels, (hipStream_t)0);
+    if (tmp_small > tmp) tmp = tmp_small;
     if (sort_tmp_bytes) *sort_tmp_bytes = tmp;
     const size_t nb = ((size_t)n + kScanBlock - 1) / kScanBlock;
     size_t bytes = 0;
@@ -1704,6 +1715,8 @@ hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sor
     hipLaunchKernelGGL(k_bbox, dim3(nb < 256 ? nb : 256), dim3(kTile), 0, stream, posm, n, k.box, k.part, k.counters + 8);
     hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, k.box, k.keys0, k.idx0, k.counters, k.hk,
                        cell_table ? (int)(k.hmask + 1u) : 0);
+    if (n >= kBigSortFrom)
+        return rocprim::radix_sort_pairs<BuildSortConfig>(k.sort_tmp, sort_tmp, k.keys0, k.keys1, k.idx0, k.idx1, (size_t)n, 0, 2 * kLevels, stream);
     return rocprim::radix_sort_pairs(k.sort_tmp, sort_tmp, k.keys0, k.keys1, k.idx0, k.idx1, (size_t)n, 0, 2 * kLevels, stream);
 }
 }  // namespace
