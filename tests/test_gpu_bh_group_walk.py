@@ -170,3 +170,46 @@ def test_group_walk_degenerate_trees(rx, ob):
                 assert rc == 0
                 scale = max(np.abs(ofx).max(), np.abs(ofy).max(), 1e-30)
                 assert max(np.abs(gx - ofx).max(), np.abs(gy - ofy).max()) <= 1e-5 * scale, (name, theta, tree)
+
+
+def test_launch_order_of_the_walks_changes_no_result(rx):
+    """NBX_OPT_BH_WALK_ORDER = 1 (opt-in A/B of round 4): more than 8 192 walks are launched longest-first by the previous step's
+    costs.  Which walk runs where and when must not change a bit of the state."""
+    from rust_exp_amd.engine import NBX_OPT_BH_WALK_ORDER
+
+    st = rx.plummer_sphere(600000, dim=2)
+    res = []
+    for order in (0, 1):
+        e = rx.NBodyEngine()
+        e.set_option(NBX_OPT_BH_WALK_ORDER, order)
+        e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+        for _ in range(4):
+            e.step_barnes_hut(0.5, 0.01, 1)
+        res.append(e.get_particles())
+    for k in ("px", "py", "vx", "vy"):
+        assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
+    assert np.abs(res[0]["px"] - st["px"]).max() > 0
+
+
+def test_walk_trace_reports_every_walk(rx):
+    """nbx_bh_walk_trace (tools/bh_walk_trace.py): one record per workgroup of the walk kernel -- start <= end on the device-wide
+    clock, the groups it loaded, and every chunk of 64 bodies exactly once."""
+    n = 100000
+    st = rx.plummer_sphere(n, dim=2)
+    e = rx.NBodyEngine()
+    e.set_bh_fold("exact")
+    e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    fx0, fy0, _ = e.forces(0.5)
+    tr = e.bh_walk_trace(0.5)
+    ran = tr[:, 1] > 0
+    bpw = 64
+    while bpw > 4 and (n + bpw - 1) // bpw < 4096:          # the launcher's rule: at least 4 096 walks, 4 ... 64 bodies each
+        bpw >>= 1
+    assert bpw == 16 and ran.sum() == (n + bpw - 1) // bpw
+    assert np.all(tr[ran, 1] >= tr[ran, 0])
+    turns = (tr[ran, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    chunk = (tr[ran, 2] >> np.uint64(32)).astype(np.int64)
+    assert turns.min() >= 1 and turns.max() < 5000
+    assert np.array_equal(np.sort(chunk), np.arange(ran.sum()))
+    fx1, fy1, _ = e.forces(0.5)                             # tracing changed nothing
+    assert np.array_equal(fx0.view(np.uint32), fx1.view(np.uint32)) and np.array_equal(fy0.view(np.uint32), fy1.view(np.uint32))
