@@ -354,7 +354,7 @@ int32_t nbx_bh_work(nbx_engine *e, float theta, uint64_t *node_visits, uint64_t 
  * child groups loaded per body summed over the slab (NBX_OPT_BH_WALK = 1; 0 for the node walk) }. */
 int32_t nbx_bh_work_detail(nbx_engine *e, float theta, uint64_t *out4);
 /* Timeline of one traversal by the child-group walk (fast mode; tools/bh_walk_trace.py): 4 words per walk (= workgroup, in launch
- * order) -- s_memrealtime (10 ns ticks) at its start and end, groups loaded | first-body chunk << 32, HW_ID | XCC_ID << 32.  Returns the number of
+ * order) -- s_memrealtime (10 ns ticks) at its start and end, groups loaded (bit 31: the walk outgrew its register stack and was redone with the LDS spill) | first-body chunk << 32, HW_ID | XCC_ID << 32.  Returns the number of
  * walks (may exceed cap_walks: nothing is written then) or a negative status. */
 int32_t nbx_bh_walk_trace(nbx_engine *e, float theta, int32_t cap_walks, uint64_t *out);
 /* The opening threshold of bh_threshold.h: the float T with  (s / sqrt(d2) < theta, nbody.rs:344-345)  <=>  d2 > T  for every

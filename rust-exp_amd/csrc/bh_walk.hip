@@ -342,7 +342,9 @@ __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* __restrict_
     if (trace && threadIdx.x == 0) {   // tools/bh_walk_trace.py: when and where this walk ran (s_memrealtime: 10 ns ticks; HW_ID, XCC_ID)
         trace[4 * (size_t)blockIdx.x + 0] = t_start;
         trace[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-        trace[4 * (size_t)blockIdx.x + 2] = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(turns) | ((unsigned long long)(unsigned)blk << 32);
+        trace[4 * (size_t)blockIdx.x + 2] = (unsigned long long)((unsigned)__builtin_amdgcn_readfirstlane(turns) & 0x7FFFFFFFu) |
+                                            ((ASM && __builtin_amdgcn_readfirstlane(overflow)) ? 0x80000000ull : 0ull) |   // redone with the LDS spill
+                                            ((unsigned long long)(unsigned)blk << 32);
         trace[4 * (size_t)blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
                                             ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);
     }

@@ -57,7 +57,7 @@ hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, cons
                                  const unsigned* perm, bool wave, bool hand_scheduled, int* gate_counters = nullptr,
                                  int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0,
                                  const int* order = nullptr, int* cost = nullptr, unsigned long long* trace = nullptr);
-// trace (optional, 4 words per walk = workgroup): s_memrealtime (10 ns ticks) at its start and end, groups loaded | chunk << 32, HW_ID | XCC_ID << 32
+// trace (optional, 4 words per walk = workgroup): s_memrealtime (10 ns ticks) at its start and end, groups loaded (bit 31: redone with the LDS spill) | chunk << 32, HW_ID | XCC_ID << 32
 int bh_walk_count(int n_targets, int* bodies_per_walk = nullptr);   // walks (workgroups) of the wave form, a multiple of 8
 hipError_t launch_walk_order(const int* cost, int* order, int walks, hipStream_t stream);
 hipError_t launch_bh_count_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, unsigned long long* totals,

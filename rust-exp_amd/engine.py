@@ -548,7 +548,7 @@ class NBodyEngine:
         return {"node_visits": out[0], "pair_evals": out[1], "opening_tests": out[2], "group_loads": out[3]}
 
     def bh_walk_trace(self, theta):
-        """[walks, 4] uint64: s_memrealtime (10 ns ticks) start, end, groups loaded | chunk << 32, HW_ID | XCC_ID << 32 of every walk of one traversal."""
+        """[walks, 4] uint64: s_memrealtime (10 ns ticks) start, end, groups loaded (bit 31: redone with the LDS spill) | chunk << 32, HW_ID | XCC_ID << 32 of every walk of one traversal."""
         n = _check(self._L.nbx_bh_walk_trace(self._h, theta, 1, np.zeros(4, np.uint64).ctypes.data))
         out = np.zeros((n, 4), np.uint64)
         _check(self._L.nbx_bh_walk_trace(self._h, theta, n, out.ctypes.data))

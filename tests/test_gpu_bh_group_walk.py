@@ -61,7 +61,8 @@ def test_take_threshold_is_the_references_test_on_host_and_device(rx):
     assert np.all(np.isinf(T[never]))
     ok = ~never
     assert not np.any(_reference_accepts(s[ok], T[ok], theta[ok]))
-    up = np.nextafter(T[ok], np.float32(np.inf), dtype=np.float32)
+    with np.errstate(over="ignore"):                  # (T = FLT_MAX -> +inf: the threshold of "accepted at infinity only")
+        up = np.nextafter(T[ok], np.float32(np.inf), dtype=np.float32)
     assert np.all(_reference_accepts(s[ok], up, theta[ok]))
     # and on a window of floats around T: the decision is "dist_sq > T", float by float
     for k in (-3, -2, -1, 1, 2, 3, 50):
@@ -207,9 +208,43 @@ def test_walk_trace_reports_every_walk(rx):
         bpw >>= 1
     assert bpw == 16 and ran.sum() == (n + bpw - 1) // bpw
     assert np.all(tr[ran, 1] >= tr[ran, 0])
-    turns = (tr[ran, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    turns = (tr[ran, 2] & np.uint64(0x7FFFFFFF)).astype(np.int64)
     chunk = (tr[ran, 2] >> np.uint64(32)).astype(np.int64)
     assert turns.min() >= 1 and turns.max() < 5000
     assert np.array_equal(np.sort(chunk), np.arange(ran.sum()))
     fx1, fy1, _ = e.forces(0.5)                             # tracing changed nothing
     assert np.array_equal(fx0.view(np.uint32), fx1.view(np.uint32)) and np.array_equal(fy0.view(np.uint32), fy1.view(np.uint32))
+
+
+def test_a_walk_that_outgrows_its_register_stack_is_redone_with_the_spill(rx, ob):
+    """64 entries of pending groups live in VGPR lanes.  A chain of 24 nested cells towards one corner of a 65 536-wide box, with a
+    small clump (an interior node of four leaves) in each of the three sibling quadrants on every level: the bodies in the innermost
+    cell open every clump (theta = 0.3: the diagonal sibling is 0.47 of its distance wide), and while the walk descends the chain (slot 0 on every level) three opened siblings per level wait on
+    the stack -- 72 entries.  The hand-scheduled loop then leaves with its overflow flag and the wave redoes its walk in the
+    compiled form with the LDS spill: the trace must show such a walk, and the forces must equal the per-lane walk's bit for bit."""
+    pts = [(65536.0, -65536.0)]                           # pins the root box to [0, 65536] x [-65536, 0]
+    for L in range(1, 25):
+        w = 65536.0 / 2 ** L                              # the chain's cell on level L is [0, w] x [-w, 0] (upper left: slot 0)
+        for cx, cy in ((1.5 * w, -0.5 * w), (0.5 * w, -1.5 * w), (1.5 * w, -1.5 * w)):
+            for dx, dy in ((-0.2, -0.2), (0.2, -0.2), (-0.2, 0.2), (0.2, 0.2)):
+                pts.append((cx + dx * w, cy + dy * w))
+    w = 65536.0 / 2 ** 24
+    for dx, dy in ((0.0, 0.0), (0.3, -0.3), (0.6, -0.2), (0.2, -0.7)):
+        pts.append((dx * w, dy * w))                      # the innermost cell's bodies (every clump is >= 4e-4 across: no EPS merge)
+    xy = np.array(pts, dtype=np.float32)
+    n = len(xy)
+    p = ob.particles(xy[:, 0], xy[:, 1], np.zeros(n), np.zeros(n), np.ones(n))
+    res, spilled = [], 0
+    for wave in (0, 1):
+        e = _engine(rx, p, 1, tree="device", fold="exact", wave=wave)
+        res.append(e.forces(0.3)[:2])
+        if wave:
+            tr = e.bh_walk_trace(0.3)
+            spilled = int(((tr[:, 2] >> np.uint64(31)) & np.uint64(1)).sum())
+    assert spilled > 0, "no walk outgrew the register stack: the case does not exercise the spill"
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # ... and against the all-pairs sum of the oracle: the walk's approximation at theta = 0.3, nothing worse
+    fx, fy = ob.brute_forces(p)
+    scale = max(np.abs(fx).max(), np.abs(fy).max())
+    assert max(np.abs(res[1][0] - fx).max(), np.abs(res[1][1] - fy).max()) <= 0.05 * scale
