@@ -204,7 +204,7 @@ def test_walk_trace_reports_every_walk(rx):
     tr = e.bh_walk_trace(0.5)
     ran = tr[:, 1] > 0
     bpw = 64
-    while bpw > 4 and (n + bpw - 1) // bpw < 4096:          # the launcher's rule: at least 4 096 walks, 4 ... 64 bodies each
+    while bpw > 2 and (n + bpw - 1) // bpw < 4096:          # the launcher's rule: at least 4 096 walks, 2 ... 64 bodies each
         bpw >>= 1
     assert bpw == 16 and ran.sum() == (n + bpw - 1) // bpw
     assert np.all(tr[ran, 1] >= tr[ran, 0])
