@@ -821,11 +821,13 @@ __global__ __launch_bounds__(kTile) void k_merge_keys(const unsigned long long* 
 }
 
 __device__ __forceinline__ ScanItem scan_item(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
-                                              const int j, const int n)
+                                              const int j, const int n, const unsigned char* __restrict__ cached = nullptr,
+                                              unsigned char* __restrict__ cache = nullptr)
 {
     if (j >= n) return ScanItem{0.0, 0.0, 0.0, 0, 0};
     const float4 p = sb[j];
-    const int cnt = nodes_starting_at(keys, j, n);
+    const int cnt = cached ? (int)cached[j] : nodes_starting_at(keys, j, n);
+    if (cache) cache[j] = (unsigned char)cnt;   // (at most 32)
     return ScanItem{(double)p.w, (double)p.w * (double)p.x, (double)p.w * (double)p.y, cnt, cnt > 0 ? 1 : 0};
 }
 
@@ -868,12 +870,13 @@ __device__ __forceinline__ void scan_blocks(ScanItem* __restrict__ block_sums, c
 // Block sums, then -- in the LAST workgroup to finish (ticket) -- their exclusive scan: the fixed summation tree of round 2's
 // separate k_scan_blocks launch (same bits on every run), without the launch.
 __global__ __launch_bounds__(kTile) void k_scan_reduce(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
-                                                       const int n, ScanItem* __restrict__ block_sums, int* __restrict__ ticket)
+                                                       const int n, ScanItem* __restrict__ block_sums, int* __restrict__ ticket,
+                                                       unsigned char* __restrict__ cnt_cache)
 {
     const int j0 = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
-    ScanItem s = scan_item(sb, keys, j0, n);
+    ScanItem s = scan_item(sb, keys, j0, n, nullptr, cnt_cache);
 #pragma unroll
-    for (int u = 1; u < kScanPerThread; u++) s = scan_add(s, scan_item(sb, keys, j0 + u, n));
+    for (int u = 1; u < kScanPerThread; u++) s = scan_add(s, scan_item(sb, keys, j0 + u, n, nullptr, cnt_cache));
     ScanItem total;
     (void)block_exclusive(s, &total);
     __shared__ int last;
@@ -911,6 +914,10 @@ struct Prefix {
     int* base;    // [n+1] pre-order slot of the first node starting at body j; base[n] = number of nodes
     int* ent;     // [n+1] entities (leaves) that start before body j: a node at slot k that starts at body a has ent[a] leaves and
                   //       k - ent[a] interior nodes before it in pre-order (its own leaf is the last node starting at a)
+    unsigned char* cnt;   // [n] nodes starting at body j: found by k_scan_reduce, reused by k_scan_write (round 4)
+    int* owner;           // [node_cap] the body at which the node of pre-order slot k starts: written by k_scan_write, so that
+                          //            k_emit need not search base[] (20 dependent loads per node at a million bodies)
+    int owner_cap;
 };
 
 __global__ __launch_bounds__(kTile) void k_scan_write(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
@@ -922,14 +929,18 @@ __global__ __launch_bounds__(kTile) void k_scan_write(const float4* __restrict__
     ScanItem s{0.0, 0.0, 0.0, 0, 0};
 #pragma unroll
     for (int u = 0; u < kScanPerThread; u++) {
-        it[u] = scan_item(sb, keys, j0 + u, n);
+        it[u] = scan_item(sb, keys, j0 + u, n, p.cnt);
         s = scan_add(s, it[u]);
     }
     ScanItem run = scan_add(block_sums[blockIdx.x], block_exclusive(s, nullptr));
 #pragma unroll
     for (int u = 0; u < kScanPerThread; u++) {
         const int j = j0 + u;
-        if (j < n) { p.m[j] = run.m; p.mx[j] = run.mx; p.my[j] = run.my; p.base[j] = run.cnt; p.ent[j] = run.ent; }
+        if (j < n) {
+            p.m[j] = run.m; p.mx[j] = run.mx; p.my[j] = run.my; p.base[j] = run.cnt; p.ent[j] = run.ent;
+            for (int t = 0; t < it[u].cnt; t++)          // the (at most 32) nodes that start here, shallow to deep
+                if (run.cnt + t < p.owner_cap) p.owner[run.cnt + t] = j;
+        }
         run = scan_add(run, it[u]);
         if (j == n - 1) {
             p.m[n] = run.m; p.mx[n] = run.mx; p.my[n] = run.my; p.base[n] = run.cnt; p.ent[n] = run.ent;
@@ -998,14 +1009,7 @@ __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const u
                                           const int big_cap, int* __restrict__ counters, const int root_aside, const int k,
                                           const unsigned char* __restrict__ pmin)
 {
-    int a = 0;
-    {
-        int hi = n;                                 // base[a] <= k < base[hi]
-        while (hi - a > 1) {
-            const int mid = (a + hi) >> 1;
-            if (pre.base[mid] <= k) a = mid; else hi = mid;
-        }
-    }
+    const int a = pre.owner[k];                     // the body this node starts at: base[a] <= k < base[a] + cnt(a)
     const int first = pre.base[a];
     const int count = pre.base[a + 1] - first;      // > 0: bodies that start no node share base[] with their successor
     const unsigned long long ka = keys[a];
@@ -1414,7 +1418,6 @@ static size_t cell_table_slots(int n)
 
 size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
 {
-    (void)node_cap;   // the build needs no per-node scratch: nodes are written straight into the caller's array
     size_t tmp = 0;
     size_t tmp_small = 0;   // (the workspace serves either shape: which one runs depends on n alone, but n may shrink below the switch)
     (void)rocprim::radix_sort_pairs<BuildSortConfig>(nullptr, tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
@@ -1434,6 +1437,8 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     add(sizeof(double) * ((size_t)n + 1) * 3);         // prefix sums m, m*x, m*y
     add(sizeof(int) * ((size_t)n + 1));                // pre-order base
     add(sizeof(int) * ((size_t)n + 1));                // entities before every body
+    add((size_t)n);                                    // nodes starting at every body (cache between the two scan kernels)
+    add(sizeof(int) * (size_t)node_cap);               // owner body of every node slot
     add(sizeof(ScanItem) * (nb + 1));                  // block sums
     add((size_t)n);                                    // EPS-merge links / pmin
     add(sizeof(int4) * (size_t)n);                     // nodes queued for k_fold_big (more than n of them -> host build)
@@ -1670,7 +1675,7 @@ struct Workspace {
     unsigned hmask;
     int* ghosts;
 };
-Workspace carve(void* workspace, int n, size_t sort_tmp)
+Workspace carve(void* workspace, int n, size_t sort_tmp, int node_cap)
 {
     char* w = static_cast<char*>(workspace);
     auto take = [&](size_t b) { char* p = w; w += (b + 255) & ~(size_t)255; return p; };
@@ -1690,6 +1695,9 @@ Workspace carve(void* workspace, int n, size_t sort_tmp)
     k.pre.m = d; k.pre.mx = d + (size_t)n + 1; k.pre.my = d + 2 * ((size_t)n + 1);
     k.pre.base = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)n + 1)));
     k.pre.ent = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)n + 1)));
+    k.pre.cnt = reinterpret_cast<unsigned char*>(take((size_t)n));
+    k.pre.owner = reinterpret_cast<int*>(take(sizeof(int) * (size_t)node_cap));
+    k.pre.owner_cap = node_cap;
     k.block_sums = reinterpret_cast<ScanItem*>(take(sizeof(ScanItem) * (nb + 1)));
     k.link = reinterpret_cast<unsigned char*>(take((size_t)n));
     k.big = reinterpret_cast<int4*>(take(sizeof(int4) * (size_t)n));
@@ -1730,7 +1738,7 @@ hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size
     if (n <= 0) return hipSuccess;
     size_t sort_tmp = 0;
     if (device_tree_workspace_bytes(n, 1, &sort_tmp) > workspace_bytes) return hipErrorInvalidValue;
-    const Workspace k = carve(workspace, n, sort_tmp);
+    const Workspace k = carve(workspace, n, sort_tmp, 1);
     const hipError_t e = sort_bodies(posm, n, k, sort_tmp, stream);
     if (e != hipSuccess) return e;
     *perm_dev = k.idx1;
@@ -1903,7 +1911,7 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     if (n <= 0) return hipSuccess;
     size_t sort_tmp = 0;
     if (device_tree_workspace_bytes(n, node_cap, &sort_tmp) > workspace_bytes) return hipErrorInvalidValue;
-    const Workspace k = carve(workspace, n, sort_tmp);
+    const Workspace k = carve(workspace, n, sort_tmp, node_cap);
     // side streams pay from a few thousand bodies on: a join costs ~10 us, the root's chain 16 ns per body
     // (NBX_SIDE_STREAMS_FROM overrides the measured crossover: profiles/r03_bh_side_stream_crossover.txt)
     static const int side_from = [] { const char* v = std::getenv("NBX_SIDE_STREAMS_FROM"); return v ? std::atoi(v) : kSideStreamsFrom; }();
@@ -1945,7 +1953,7 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     // (for small systems the pair merge and the scan were tried as phases of ONE 1024-thread workgroup: 90 us against 22 for the
     //  four launches at 10 000 bodies -- per-body work here is chains of dependent loads that miss the L2 after every kernel
     //  boundary, and one CU hides far less of that than forty)
-    hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.counters + 3);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.counters + 3, k.pre.cnt);
     hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.pre, k.counters);
     // one thread per node; the node count is only known on the device, so the grid covers the whole pool (threads beyond
     // base[n] leave at once; the pool check is inside)
