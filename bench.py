@@ -827,7 +827,7 @@ def run(real_stdout):
         sharding = ("single GPU" if world == 1 else
                     f"slab x{world} (reference split nbody.rs:426-428), one all-gather of "
                     f"{'half4' if args.source_bits == 16 and not is_bh else 'float4'} (x,y,z,m) per step; host = "
-                    + ("one process, library-issued RCCL (nbx_group_*)" if host_kind == "group" else "one process per GPU, torch.distributed nccl"))
+                    + ("one process, library-issued RCCL (nbx_group_*)" if host_kind == "group" else "one process per GPU, torch.distributed " + os.environ.get("NBX_DIST_BACKEND", "nccl")))
         if not is_bh:
             interactions_per_step = float(n) * float(n - 1)
             if args.shard_of > 1:
