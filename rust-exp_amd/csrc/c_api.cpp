@@ -341,7 +341,7 @@ int32_t nbx_synchronize(nbx_engine* e)
     HIP_TRY(hipSetDevice(e->device));
     const int prc = resolve_pending(e);
     if (prc != NBX_OK) return prc;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(wait_stream(e->stream));
     return NBX_OK;
 }
 

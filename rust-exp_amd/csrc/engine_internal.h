@@ -242,6 +242,42 @@ int grow(T** ptr, size_t* cap, size_t need)
     return NBX_OK;
 }
 
+// Host waits of the stepping path.  A 10 000-body step is ~0.1 ms of GPU work; the runtime's blocking wait adds its wake-up
+// latency to every such step, so poll first (NBX_SPIN_US microseconds, default 400; 0 = block at once) and block after that.
+inline int spin_budget_us()
+{
+    static const int us = [] {
+        const char* s = std::getenv("NBX_SPIN_US");
+        return s ? std::max(0, std::atoi(s)) : 400;
+    }();
+    return us;
+}
+template <typename Query>
+inline bool spin_until_done(Query query)
+{
+    const int budget = spin_budget_us();
+    if (budget <= 0) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int k = 0; k < 16; k++) {
+            const hipError_t st = query();
+            if (st == hipSuccess) return true;
+            if (st != hipErrorNotReady) { (void)hipGetLastError(); return false; }   // let the blocking call report it
+        }
+        if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= budget) return false;
+    }
+}
+inline hipError_t wait_stream(hipStream_t s)
+{
+    if (spin_until_done([&] { return hipStreamQuery(s); })) return hipSuccess;
+    return hipStreamSynchronize(s);
+}
+inline hipError_t wait_event(hipEvent_t ev)
+{
+    if (spin_until_done([&] { return hipEventQuery(ev); })) return hipSuccess;
+    return hipEventSynchronize(ev);
+}
+
 // Finished event pairs -> per-kernel totals; their events go back to the free list.  wait = false folds only the pairs
 // that have already completed (no synchronisation inside a step).
 inline void prof_fold(nbx_engine* e, bool wait)
