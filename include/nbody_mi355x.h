@@ -173,6 +173,11 @@ enum nbx_option {
                                     * tail (29 % of the wave slots idle) suggested it, but walks that are neighbours in space then no
                                     * longer run side by side and what the tail gains the L2 loses: traversal 0.449 vs 0.430 ms at
                                     * 1 048 576 bodies, no difference at 262 144 */
+    NBX_OPT_BH_FUSE_KICK = 20,     /* child-group walk, wave form, one GPU: 1 (default) = the walk kernel applies the step's kick-drift
+                                    * itself as soon as a body's acceleration is complete (same operations, bit-identical state: a walk
+                                    * reads no other body's position from the particle array -- the group records hold copies);
+                                    * 0 = separate kick-drift kernel (the A/B: 0.0932 -> 0.0899 ms per step at 10 000 bodies,
+                                    * 0.8375 -> 0.8252 at 1 048 576) */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
 };

@@ -313,15 +313,17 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
 // loaded) in cost[]; k_walk_order turns last step's costs into this step's launch order -- longest first within every XCD's
 // eighth, so each slot's second walk is the shorter the longer its first was.  Which walk runs where changes no result.
 template <int BPW, bool ASM>
-__global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* __restrict__ posm, const int lo, const int n_targets,
+__global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* posm, const int lo, const int n_targets,
                                                        const BhGroup* __restrict__ groups, float2* __restrict__ out,
                                                        const unsigned* __restrict__ perm, const int xcd_order, const BuildGate gate,
                                                        const int* __restrict__ order, int* __restrict__ cost,
-                                                       unsigned long long* __restrict__ trace)
+                                                       unsigned long long* __restrict__ trace, const BhKick kick)
 {
     __shared__ int spill_mem[3 * kSpill];
     int n_nodes_unused = 0;
-    if (!gate_open(gate, n_nodes_unused)) return;
+    // (with the kick folded in, this kernel is the last of a gated step: its first thread hands the build's counters to the host
+    //  and raises the poison flag of a refused step, as k_integrate_f2 does otherwise)
+    if (!gate_open(gate, n_nodes_unused, kick.vel != nullptr && blockIdx.x == 0 && threadIdx.x == 0)) return;
     const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;   // the 100 MHz clock all XCDs share
     // XCD-aware order (as the node walk, bh_eval.hip): XCD k walks the k-th contiguous eighth of the Morton-ordered bodies
     int blk = xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -337,7 +339,27 @@ __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* __restrict_
     int overflow = ASM ? 0 : 1, turns = 0;
     if (ASM) acc = walk_groups_asm(groups, p, M, overflow, turns);
     if (__builtin_amdgcn_readfirstlane(overflow)) acc = walk_groups_compiled(groups, p, M, spill_mem);   // (uniform: the asm's output is an SGPR)
-    if (valid) out[it] = make_float2(acc.x, acc.y);
+    if (valid) {
+        if (kick.vel) {   // kick-drift with the acceleration just found: the operations and order of k_integrate_f2 (is_accel)
+            float4 v = kick.vel[it];
+            float4 q = pi;
+            v.x = __fadd_rn(v.x, __fmul_rn(kick.dt, acc.x));
+            v.y = __fadd_rn(v.y, __fmul_rn(kick.dt, acc.y));
+            q.x = __fadd_rn(q.x, __fmul_rn(kick.dt, v.x));
+            q.y = __fadd_rn(q.y, __fmul_rn(kick.dt, v.y));
+            if (kick.killbox) {
+                const float lim = __fmul_rn(100.0f, 0.55f);
+                if (fabsf(__fsub_rn(0.0f, q.x)) > lim || fabsf(__fsub_rn(0.0f, q.y)) > lim) {
+                    v.x = 0.0f;
+                    v.y = 0.0f;
+                }
+            }
+            kick.vel[it] = v;
+            kick.posm[lo + it] = q;
+        } else {
+            out[it] = make_float2(acc.x, acc.y);
+        }
+    }
     if (ASM && cost && threadIdx.x == 0) cost[blk] = __builtin_amdgcn_readfirstlane(turns);
     if (trace && threadIdx.x == 0) {   // tools/bh_walk_trace.py: when and where this walk ran (s_memrealtime: 10 ns ticks; HW_ID, XCC_ID)
         trace[4 * (size_t)blockIdx.x + 0] = t_start;
@@ -518,10 +540,11 @@ int bh_walk_count(int n_targets, int* bodies_per_walk)
 
 template <bool ASM>
 static void launch_wave_walk(int bpw, dim3 g, hipStream_t stream, const float4* posm, int lo, int n_targets, const BhGroup* groups,
-                             float2* out, const unsigned* perm, BuildGate gate, const int* order, int* cost, unsigned long long* trace)
+                             float2* out, const unsigned* perm, BuildGate gate, const int* order, int* cost, unsigned long long* trace,
+                             BhKick kick)
 {
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, g, dim3(64), 0, stream, posm, lo, n_targets, groups, out, perm, 1, gate, order, cost, trace);
+        hipLaunchKernelGGL(kernel, g, dim3(64), 0, stream, posm, lo, n_targets, groups, out, perm, 1, gate, order, cost, trace, kick);
     };
     if (bpw == 64) go(k_bh_walk_groups<64, ASM>);
     else if (bpw == 32) go(k_bh_walk_groups<32, ASM>);
@@ -534,16 +557,19 @@ static void launch_wave_walk(int bpw, dim3 g, hipStream_t stream, const float4* 
 
 hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, float2* out, hipStream_t stream,
                                  const unsigned* perm, bool wave, bool hand_scheduled, int* gate_counters, int gate_node_cap,
-                                 int gate_crowd_limit, int gate_queue_limit, const int* order, int* cost, unsigned long long* trace)
+                                 int gate_crowd_limit, int gate_queue_limit, const int* order, int* cost, unsigned long long* trace,
+                                 const BhKick* kick)
 {
     if (n_targets <= 0) return hipSuccess;
-    const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit, nullptr};
+    const BhKick kd = kick ? *kick : BhKick{nullptr, nullptr, 0.0f, 0, nullptr};
+    if (kd.vel && !(wave && perm)) return hipErrorInvalidValue;   // (the per-lane form has no kick)
+    const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit, kd.vel ? kd.host_out : nullptr};
     if (wave && perm) {
         // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 4 and 64 bodies each (as the node walk)
         int bpw = 64;
         const dim3 g((unsigned)bh_walk_count(n_targets, &bpw));
-        if (hand_scheduled) launch_wave_walk<true>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, order, cost, trace);
-        else launch_wave_walk<false>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, nullptr, nullptr, trace);
+        if (hand_scheduled) launch_wave_walk<true>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, order, cost, trace, kd);
+        else launch_wave_walk<false>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, nullptr, nullptr, trace, kd);
     } else {
         const int block = n_targets <= 65536 ? 64 : kTile;
         hipLaunchKernelGGL(k_bh_walk_groups_lane, dim3((unsigned)((n_targets + block - 1) / block)), dim3(block), 0, stream, posm, lo,

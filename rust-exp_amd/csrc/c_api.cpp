@@ -65,7 +65,7 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
     switch (option) {   // a step that is still in flight was issued under the CURRENT options: settle it (and redo it, if its device
                         // build was refused) before any option that shapes a step changes
         case NBX_OPT_FORCE_MODE: case NBX_OPT_BH_TREE: case NBX_OPT_BH_FOLD: case NBX_OPT_BH_WAVE: case NBX_OPT_BH_ASYNC:
-        case NBX_OPT_SOURCE_PRECISION: case NBX_OPT_BH_WALK: case NBX_OPT_BH_WALK_RECORDS: case NBX_OPT_BH_WALK_ORDER: {
+        case NBX_OPT_SOURCE_PRECISION: case NBX_OPT_BH_WALK: case NBX_OPT_BH_WALK_RECORDS: case NBX_OPT_BH_WALK_ORDER: case NBX_OPT_BH_FUSE_KICK: {
             const int rc = resolve_pending(e);
             if (rc != NBX_OK) return rc;
             break;
@@ -132,6 +132,10 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
             e->bh_walk_lpt = value ? 1 : 0;
             e->walk_order_walks = 0;
             return NBX_OK;
+        case NBX_OPT_BH_FUSE_KICK:
+            if (value != 0 && value != 1) return fail(NBX_ERR_INVALID, "bh fuse kick must be 0 or 1");
+            e->bh_fuse_kick = (int)value;
+            return NBX_OK;
         case NBX_OPT_BH_WALK_RECORDS:
             if (value != 16 && value != 32 && value != -1) return fail(NBX_ERR_INVALID, "walk records must be 16, 32 or -1 (by size)");
             e->bh_walk_records = (int)value;
@@ -176,6 +180,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_BH_WALK_RECORDS: return e->bh_walk_records;
         case NBX_OPT_BH_WALK: return e->bh_walk;
         case NBX_OPT_BH_WALK_ORDER: return e->bh_walk_lpt;
+        case NBX_OPT_BH_FUSE_KICK: return e->bh_fuse_kick;
         case NBX_OPT_BH_FALLBACKS: return e->bh_fallbacks;
         case NBX_OPT_BH_LAST_TREE: return e->bh_last_tree_device;
         case NBX_OPT_BH_REFUSAL: return e->bh_last_refusal;
@@ -189,7 +194,7 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
 int32_t nbx_query_option(const nbx_engine* e, int32_t option, int64_t* value)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
-    if (option < NBX_OPT_FORCE_MODE || option > NBX_OPT_BH_REFUSAL) return fail(NBX_ERR_INVALID, "unknown option %d", option);
+    if (option < NBX_OPT_FORCE_MODE || option > NBX_OPT_BH_FUSE_KICK) return fail(NBX_ERR_INVALID, "unknown option %d", option);
     if (value) *value = nbx_get_option(e, option);
     return NBX_OK;
 }

@@ -644,8 +644,17 @@ int slab_order(nbx_engine* e)
 // its counters) for the slab's bodies, accelerations into e->d_f2.  NBX_OPT_BH_WALK = 1 (default) / 2: the tree is first re-laid as
 // child groups with the step's theta (k_bh_groups), then walked group by group (bh_walk.hip: hand-scheduled / compiled loop);
 // 0 (or a tree too large for 31-bit record offsets: beyond ~4 M bodies): the node walk of rounds 1-3.
+// May the child-group walk of this step apply the kick-drift itself (kernels.h BhKick)?  Only the wave form has it, on one GPU
+// (a group's exchange reads the kick-drift's output slab by slab).  One dependent kernel less per step: 0.0932 -> 0.0899 ms at
+// 10 000 bodies, 0.8375 -> 0.8252 at 1 M (the walk itself +0.002 ms there, the 0.018 ms kick-drift kernel gone).
+bool walk_takes_kick(const nbx_engine* e, const unsigned* perm, bool wave, int nodes_or_cap)
+{
+    if (!e->bh_fuse_kick || e->force_mode != 0 || e->world != 1 || e->source_half || e->bh_walk == 0 || !(wave && perm)) return false;
+    return nbx::bh_groups_addressable(nodes_or_cap);
+}
+
 int launch_fast_walk(nbx_engine* e, float theta, const unsigned* perm, bool wave, bool on_device, int* gate, int gate_node_cap,
-                     int gate_crowd_limit, int gate_queue_limit)
+                     int gate_crowd_limit, int gate_queue_limit, const nbx::BhKick* kick)
 {
     const int slab = e->slab();
     ProfScope ps(e, NBX_K_BH_EVAL);
@@ -673,7 +682,7 @@ int launch_fast_walk(nbx_engine* e, float theta, const unsigned* perm, bool wave
             if (e->walk_order_walks == walks && e->walk_order_slab == slab) order = e->d_walk_order;
         }
         HIP_TRY(nbx::launch_bh_walk_groups(e->d_posm, e->lo, slab, e->d_groups, e->d_f2, e->stream, perm, wave, e->bh_walk == 1, gate,
-                                           gate_node_cap, gate_crowd_limit, gate_queue_limit, order, cost, e->d_walk_trace));
+                                           gate_node_cap, gate_crowd_limit, gate_queue_limit, order, cost, e->d_walk_trace, kick));
         if (cost) {
             HIP_TRY(nbx::launch_walk_order(cost, e->d_walk_order, walks, e->stream));
             e->walk_order_walks = walks;
@@ -681,6 +690,7 @@ int launch_fast_walk(nbx_engine* e, float theta, const unsigned* perm, bool wave
         }
         return NBX_OK;
     }
+    if (kick) return fail(NBX_ERR_STATE, "kick-drift handed to a walk that cannot apply it");
     const bool w16 = on_device && wave && e->walk16_valid;
     HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, wave ? 2 : 0, e->d_f2, e->stream, perm, gate,
                                 gate_node_cap, gate_crowd_limit, gate_queue_limit, w16 ? e->d_walk16 : nullptr,
@@ -715,15 +725,18 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
     }
     e->bh_last_tree_device = on_device ? 1 : 0;
     const bool wave = perm != nullptr && e->bh_wave;   // shared walk per wave, in both modes (same results as the per-lane walks)
+    bool kicked = false;
     if (e->force_mode == 0) {
-        rc = launch_fast_walk(e, theta, perm, wave, on_device, gate, node_cap, crowd_limit, queue_limit);
+        const nbx::BhKick kick{e->d_vel, e->d_posm, dt, 1, gated ? gate_host_out : nullptr};
+        kicked = walk_takes_kick(e, perm, wave, gate ? node_cap : (int)e->n_flat);
+        rc = launch_fast_walk(e, theta, perm, wave, on_device, gate, node_cap, crowd_limit, queue_limit, kicked ? &kick : nullptr);
         if (rc != NBX_OK) return rc;
     } else {
         ProfScope ps(e, NBX_K_BH_EVAL);
         HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, wave ? 3 : e->force_mode, e->d_f2,
                                     e->stream, perm));
     }
-    {
+    if (!kicked) {
         ProfScope ps(e, NBX_K_INTEGRATE);
         HIP_TRY(nbx::launch_integrate_f2(e->d_posm, e->lo, slab, e->d_vel, e->d_f2, dt, e->force_mode == 0 ? 1 : 0, 1,
                                          e->stream, gate, node_cap, crowd_limit, queue_limit, gated ? gate_host_out : nullptr));

@@ -66,6 +66,7 @@ struct nbx_engine {
     int walk_order_slab = 0;
     unsigned long long* d_walk_trace = nullptr;   // nbx_bh_walk_trace: set for the one evaluation it traces
     int bh_walk_lpt = 0;                 // NBX_OPT_BH_WALK_ORDER: 1 = longest-first from the previous step's costs, 0 (default) = Morton order
+    int bh_fuse_kick = 1;                // NBX_OPT_BH_FUSE_KICK: 1 (default) = the child-group walk applies the kick-drift itself, 0 = separate kernel
                                          // (measured, round 4: 0.449 vs 0.430 ms at 1 M bodies -- spatially adjacent walks no longer run side by side)
     int bh_walk = 1;                     // NBX_OPT_BH_WALK: 1 = child groups, hand-scheduled loop (default), 2 = child groups, compiled
                                          // loop, 0 = the node walk of rounds 1-3 (bh_eval.hip)
@@ -352,7 +353,8 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
                           int* gate_host_out = nullptr);
 // the fast traversal of e->d_nodes for this engine's slab into e->d_f2 (accelerations): child-group walk or node walk (NBX_OPT_BH_WALK)
 int launch_fast_walk(nbx_engine* e, float theta, const unsigned* perm, bool wave, bool on_device, int* gate, int gate_node_cap,
-                     int gate_crowd_limit, int gate_queue_limit);
+                     int gate_crowd_limit, int gate_queue_limit, const nbx::BhKick* kick = nullptr);
+bool walk_takes_kick(const nbx_engine* e, const unsigned* perm, bool wave, int nodes_or_cap);
 int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt);
 int spatial_order(nbx_engine* e);
 int slab_order(nbx_engine* e);

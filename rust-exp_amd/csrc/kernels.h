@@ -53,10 +53,21 @@ hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta
 // order / cost (hand-scheduled wave form only; both optional, bh_walk_count(n_targets) ints each): every walk leaves the number of
 // groups it loaded in cost[]; order[] = the launch order of the walks (launch_walk_order makes it from the previous step's costs:
 // longest first within every XCD's eighth).  The order changes no result.
+// kick (optional, wave form only): the kick-drift of the step (nbody.rs:453-471, what k_integrate_f2 does) applied by the walk itself
+// as soon as a body's acceleration is complete -- legitimate because a walk reads no other body's position from posm (the group
+// records hold copies) -- so a small system's step is one dependent kernel shorter.  out is not written then.  host_out: see BuildGate.
+struct BhKick {
+    float4* vel;      // [n_targets] this slab's velocities; nullptr = no kick (the walk writes accelerations to out)
+    float4* posm;     // the same array the walk reads its bodies from
+    float dt;
+    int killbox;      // the reference's velocity kill outside +-55 (nbody.rs:466-471)
+    int* host_out;    // gated step: pinned words the build's counters are handed to (nullptr: none)
+};
 hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, float2* out, hipStream_t stream,
                                  const unsigned* perm, bool wave, bool hand_scheduled, int* gate_counters = nullptr,
                                  int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0,
-                                 const int* order = nullptr, int* cost = nullptr, unsigned long long* trace = nullptr);
+                                 const int* order = nullptr, int* cost = nullptr, unsigned long long* trace = nullptr,
+                                 const BhKick* kick = nullptr);
 // trace (optional, 4 words per walk = workgroup): s_memrealtime (10 ns ticks) at its start and end, groups loaded (bit 31: redone with the LDS spill) | chunk << 32, HW_ID | XCC_ID << 32
 int bh_walk_count(int n_targets, int* bodies_per_walk = nullptr);   // walks (workgroups) of the wave form, a multiple of 8
 hipError_t launch_walk_order(const int* cost, int* order, int walks, hipStream_t stream);

@@ -44,6 +44,7 @@ NBX_OPT_BH_WALK_RECORDS = 16
 NBX_OPT_BH_REFUSAL = 17
 NBX_OPT_BH_WALK = 18
 NBX_OPT_BH_WALK_ORDER = 19
+NBX_OPT_BH_FUSE_KICK = 20
 
 NBX_GROUP_INFO_EXCHANGE = 0
 NBX_GROUP_INFO_RCCL_RANKS = 1

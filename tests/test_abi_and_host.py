@@ -446,6 +446,17 @@ def test_group_info_threads_and_option_queries_without_device(rx, monkeypatch):
     assert e.query_option(NBX_OPT_BH_REFUSAL) == 0          # read only: no device build has refused anything yet
     with pytest.raises(rx.NBodyError):
         e.set_option(NBX_OPT_BH_REFUSAL, 1)
+    # the options of round 4 answer queries too (the range check of nbx_query_option ended at NBX_OPT_BH_REFUSAL)
+    from rust_exp_amd.engine import NBX_OPT_BH_FUSE_KICK, NBX_OPT_BH_WALK, NBX_OPT_BH_WALK_ORDER
+    assert e.query_option(NBX_OPT_BH_WALK) == 1 and e.query_option(NBX_OPT_BH_WALK_ORDER) == 0
+    assert e.query_option(NBX_OPT_BH_FUSE_KICK) == 1
+    for v in (0, 1):
+        e.set_option(NBX_OPT_BH_FUSE_KICK, v)
+        assert e.query_option(NBX_OPT_BH_FUSE_KICK) == v
+    with pytest.raises(rx.NBodyError):
+        e.set_option(NBX_OPT_BH_FUSE_KICK, 2)
+    with pytest.raises(rx.NBodyError):
+        e.query_option(NBX_OPT_BH_FUSE_KICK + 1)
 
 
 def test_host_worker_pool_serves_concurrent_builds(rx, ob):

@@ -192,6 +192,66 @@ def test_launch_order_of_the_walks_changes_no_result(rx):
     assert np.abs(res[0]["px"] - st["px"]).max() > 0
 
 
+@pytest.mark.parametrize("n,async_", [(300, 1), (3000, 1), (12000, 0), (12000, 1), (100000, 1), (600000, 1)])
+def test_kick_drift_folded_into_the_walk_changes_no_bit(rx, ob, n, async_):
+    """NBX_OPT_BH_FUSE_KICK (round 4, default on): the walk kernel applies the kick-drift
+    and the velocity kill itself.  Same operations on the same acceleration: positions and velocities equal the separate
+    kick-drift kernel's bit for bit, step after step -- bodies that cross the +-55 kill box included -- in the waiting and the
+    pipelined form of the step, and when a refused device build hands the step to the host tree."""
+    from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_FUSE_KICK, NBX_OPT_BH_LAST_TREE
+
+    p = ob.stable_orbits(n, 0.5, 30.0, 77)
+    rng = np.random.default_rng(n)
+    fast = rng.choice(n, min(max(2, n // 50), 240), replace=False)     # bodies near the right wall of the kill box
+    half = len(fast) // 2
+    p["px"][fast] = np.linspace(54.0, 54.9, len(fast)).astype(np.float32)
+    p["vx"][fast[:half]] = np.float32(1000.0)                          # these leave it in the first step (dx = 10), the others stay
+    p["vx"][fast[half:]] = np.float32(-5.0)
+    res = []
+    for fuse in (0, 1):
+        e = _engine(rx, p, 1, tree="device")
+        e.set_option(NBX_OPT_BH_ASYNC, async_)
+        e.set_option(NBX_OPT_BH_FUSE_KICK, fuse)
+        e.step_barnes_hut(0.6, 0.01, 1)
+        first = e.get_particles()
+        killed = np.abs(first["px"][fast]) > 55.0                  # the velocity kill of nbody.rs:466-471 took place
+        assert killed[:half].all() and not killed[half:].any()
+        assert np.all(first["vx"][fast[:half]] == 0.0) and np.all(first["vx"][fast[half:]] != 0.0)
+        for _ in range(4):
+            e.step_barnes_hut(0.6, 0.01, 1)
+        res.append(e.get_particles())
+        assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1 and e.get_option(NBX_OPT_BH_FALLBACKS) == 0
+    for k in ("px", "py", "vx", "vy"):
+        assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
+    assert np.abs(res[0]["px"] - p["px"]).max() > 0
+
+
+@pytest.mark.parametrize("fold", ["reference", "exact"])
+def test_a_refused_build_stops_the_folded_kick_too(rx, ob, fold):
+    """The gate of the pipelined step (bh_gate.h) in the kernel that now ends it: a device build that must refuse (node pool
+    exhausted by thousands of 18-level chains; EPS triples under the reference fold) leaves the state alone, the step is redone on
+    the host tree, the step enqueued behind it is enqueued again -- the same states as with the separate kick-drift kernel."""
+    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_FUSE_KICK
+
+    rng = np.random.default_rng(8)
+    x = rng.uniform(-20, 20, 4000).astype(np.float32); y = rng.uniform(-20, 20, 4000).astype(np.float32)
+    x2 = np.concatenate([x, x + np.float32(2e-4), x[:3] + np.float32(3e-5), x[:3] - np.float32(2e-5)])
+    y2 = np.concatenate([y, y, y[:3] + np.float32(1e-5), y[:3] + np.float32(4e-5)])
+    n = len(x2)
+    q = ob.particles(x2, y2, rng.normal(0, 1, n), rng.normal(0, 1, n), np.ones(n))
+    res, fallbacks = [], []
+    for fuse in (0, 1):
+        e = _engine(rx, q, 1, tree="device", fold=fold)
+        e.set_option(NBX_OPT_BH_FUSE_KICK, fuse)
+        for _ in range(4):
+            e.step_barnes_hut(0.5, 0.01, 1)
+        res.append(e.get_particles())
+        fallbacks.append(e.get_option(NBX_OPT_BH_FALLBACKS))
+    assert fallbacks[0] >= 1 and fallbacks[0] == fallbacks[1]
+    for k in ("px", "py", "vx", "vy"):
+        assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
+
+
 def test_walk_trace_reports_every_walk(rx):
     """nbx_bh_walk_trace (tools/bh_walk_trace.py): one record per workgroup of the walk kernel -- start <= end on the device-wide
     clock, the groups it loaded, and every chunk of 64 bodies exactly once."""

@@ -24,6 +24,9 @@ def run(n, theta, walk, wave=1, steps=30, fold="exact"):
         from rust_exp_amd.engine import NBX_OPT_BH_WALK_ORDER
         e.set_option(NBX_OPT_BH_WALK_ORDER, int(os.environ["NBX_AB_WALK_ORDER"]))
     e.set_option(NBX_OPT_BH_WAVE, wave)
+    if os.environ.get("NBX_AB_FUSE_KICK"):
+        from rust_exp_amd.engine import NBX_OPT_BH_FUSE_KICK
+        e.set_option(NBX_OPT_BH_FUSE_KICK, int(os.environ["NBX_AB_FUSE_KICK"]))
     if n == 10000:
         e.seed(1); e.stable_orbits(n, 0.5, 30.0)
     else:
@@ -43,12 +46,13 @@ def run(n, theta, walk, wave=1, steps=30, fold="exact"):
     e.synchronize()
     ev, cnt = e.profile_read(rx.NBX_K_BH_EVAL)
     tb, tcnt = e.profile_read(rx.NBX_K_TREE_BUILD)
+    ki, kcnt = e.profile_read(rx.NBX_K_INTEGRATE)      # (0 launches when the walk applies the kick-drift itself)
     e.profile(False)
     wk = e.bh_work_detail(theta)
     fx, fy, _ = e.forces(theta)
     out = {"bodies": n, "theta": theta, "walk": {0: "nodes", 1: "groups", 2: "groups_compiled"}[walk], "wave": wave, "fold": fold,
            "ms_per_step_back_to_back": round(ms_step, 4), "traversal_ms": round(ev / max(cnt, 1), 4),
-           "tree_build_ms": round(tb / max(tcnt, 1), 4), "nodes": e.bh_host_timing()["nodes"],
+           "tree_build_ms": round(tb / max(tcnt, 1), 4), "kick_drift_ms": round(ki / max(kcnt, 1), 4), "nodes": e.bh_host_timing()["nodes"],
            "visits_per_body": wk["node_visits"] / n, "pairs_per_body": wk["pair_evals"] / n,
            "opening_tests_per_body": wk["opening_tests"] / n, "group_loads_per_body": wk["group_loads"] / n,
            "force_checksum": float(np.abs(fx).sum() + np.abs(fy).sum())}
