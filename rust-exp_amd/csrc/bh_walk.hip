@@ -314,16 +314,19 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
 // eighth, so each slot's second walk is the shorter the longer its first was.  Which walk runs where changes no result.
 template <int BPW, bool ASM>
 __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* posm, const int lo, const int n_targets,
-                                                       const BhGroup* __restrict__ groups, float2* __restrict__ out,
+                                                       const BhGroup* __restrict__ groups, void* __restrict__ sink,
                                                        const unsigned* __restrict__ perm, const int xcd_order, const BuildGate gate,
                                                        const int* __restrict__ order, int* __restrict__ cost,
-                                                       unsigned long long* __restrict__ trace, const BhKick kick)
+                                                       unsigned long long* __restrict__ trace, float4* kick_posm, const float kick_dt)
 {
+    // sink: float2 out[] (accelerations) -- or, with the kick folded in (kick_posm != nullptr), float4 vel[]: ONE pointer, because
+    // every scalar register that lives across the walk loop counts (80 SGPRs + the trap handler's 16 = 96 is the last allocation
+    // that leaves eight waves per SIMD; two pointers, dt and a flag made it 82 -> seven)
     __shared__ int spill_mem[3 * kSpill];
     int n_nodes_unused = 0;
     // (with the kick folded in, this kernel is the last of a gated step: its first thread hands the build's counters to the host
     //  and raises the poison flag of a refused step, as k_integrate_f2 does otherwise)
-    if (!gate_open(gate, n_nodes_unused, kick.vel != nullptr && blockIdx.x == 0 && threadIdx.x == 0)) return;
+    if (!gate_open(gate, n_nodes_unused, kick_posm != nullptr && blockIdx.x == 0 && threadIdx.x == 0)) return;
     const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;   // the 100 MHz clock all XCDs share
     // XCD-aware order (as the node walk, bh_eval.hip): XCD k walks the k-th contiguous eighth of the Morton-ordered bodies
     int blk = xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -340,24 +343,23 @@ __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* posm, const
     if (ASM) acc = walk_groups_asm(groups, p, M, overflow, turns);
     if (__builtin_amdgcn_readfirstlane(overflow)) acc = walk_groups_compiled(groups, p, M, spill_mem);   // (uniform: the asm's output is an SGPR)
     if (valid) {
-        if (kick.vel) {   // kick-drift with the acceleration just found: the operations and order of k_integrate_f2 (is_accel)
-            float4 v = kick.vel[it];
+        if (kick_posm) {   // kick-drift with the acceleration just found: the operations and order of k_integrate_f2 (is_accel, killbox)
+            float4* const vel = static_cast<float4*>(sink);
+            float4 v = vel[it];
             float4 q = pi;
-            v.x = __fadd_rn(v.x, __fmul_rn(kick.dt, acc.x));
-            v.y = __fadd_rn(v.y, __fmul_rn(kick.dt, acc.y));
-            q.x = __fadd_rn(q.x, __fmul_rn(kick.dt, v.x));
-            q.y = __fadd_rn(q.y, __fmul_rn(kick.dt, v.y));
-            if (kick.killbox) {
-                const float lim = __fmul_rn(100.0f, 0.55f);
-                if (fabsf(__fsub_rn(0.0f, q.x)) > lim || fabsf(__fsub_rn(0.0f, q.y)) > lim) {
-                    v.x = 0.0f;
-                    v.y = 0.0f;
-                }
+            v.x = __fadd_rn(v.x, __fmul_rn(kick_dt, acc.x));
+            v.y = __fadd_rn(v.y, __fmul_rn(kick_dt, acc.y));
+            q.x = __fadd_rn(q.x, __fmul_rn(kick_dt, v.x));
+            q.y = __fadd_rn(q.y, __fmul_rn(kick_dt, v.y));
+            const float lim = __fmul_rn(100.0f, 0.55f);
+            if (fabsf(__fsub_rn(0.0f, q.x)) > lim || fabsf(__fsub_rn(0.0f, q.y)) > lim) {
+                v.x = 0.0f;
+                v.y = 0.0f;
             }
-            kick.vel[it] = v;
-            kick.posm[lo + it] = q;
+            vel[it] = v;
+            kick_posm[lo + it] = q;
         } else {
-            out[it] = make_float2(acc.x, acc.y);
+            static_cast<float2*>(sink)[it] = make_float2(acc.x, acc.y);
         }
     }
     if (ASM && cost && threadIdx.x == 0) cost[blk] = __builtin_amdgcn_readfirstlane(turns);
@@ -544,7 +546,9 @@ static void launch_wave_walk(int bpw, dim3 g, hipStream_t stream, const float4* 
                              BhKick kick)
 {
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, g, dim3(64), 0, stream, posm, lo, n_targets, groups, out, perm, 1, gate, order, cost, trace, kick);
+        void* sink = kick.vel ? static_cast<void*>(kick.vel) : static_cast<void*>(out);
+        hipLaunchKernelGGL(kernel, g, dim3(64), 0, stream, posm, lo, n_targets, groups, sink, perm, 1, gate, order, cost, trace,
+                           kick.vel ? kick.posm : nullptr, kick.dt);
     };
     if (bpw == 64) go(k_bh_walk_groups<64, ASM>);
     else if (bpw == 32) go(k_bh_walk_groups<32, ASM>);
@@ -561,8 +565,8 @@ hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, cons
                                  const BhKick* kick)
 {
     if (n_targets <= 0) return hipSuccess;
-    const BhKick kd = kick ? *kick : BhKick{nullptr, nullptr, 0.0f, 0, nullptr};
-    if (kd.vel && !(wave && perm)) return hipErrorInvalidValue;   // (the per-lane form has no kick)
+    const BhKick kd = kick ? *kick : BhKick{nullptr, nullptr, 0.0f, nullptr};
+    if (kd.vel && !(wave && perm && kd.posm)) return hipErrorInvalidValue;   // (the per-lane form has no kick)
     const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit, kd.vel ? kd.host_out : nullptr};
     if (wave && perm) {
         // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 4 and 64 bodies each (as the node walk)

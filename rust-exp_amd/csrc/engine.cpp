@@ -727,7 +727,7 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
     const bool wave = perm != nullptr && e->bh_wave;   // shared walk per wave, in both modes (same results as the per-lane walks)
     bool kicked = false;
     if (e->force_mode == 0) {
-        const nbx::BhKick kick{e->d_vel, e->d_posm, dt, 1, gated ? gate_host_out : nullptr};
+        const nbx::BhKick kick{e->d_vel, e->d_posm, dt, gated ? gate_host_out : nullptr};
         kicked = walk_takes_kick(e, perm, wave, gate ? node_cap : (int)e->n_flat);
         rc = launch_fast_walk(e, theta, perm, wave, on_device, gate, node_cap, crowd_limit, queue_limit, kicked ? &kick : nullptr);
         if (rc != NBX_OK) return rc;

@@ -59,8 +59,7 @@ hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta
 struct BhKick {
     float4* vel;      // [n_targets] this slab's velocities; nullptr = no kick (the walk writes accelerations to out)
     float4* posm;     // the same array the walk reads its bodies from
-    float dt;
-    int killbox;      // the reference's velocity kill outside +-55 (nbody.rs:466-471)
+    float dt;         // (the reference's velocity kill outside +-55, nbody.rs:466-471, is always applied: this is the Barnes-Hut step)
     int* host_out;    // gated step: pinned words the build's counters are handed to (nullptr: none)
 };
 hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, float2* out, hipStream_t stream,

@@ -96,3 +96,20 @@ def test_cluster_replay_kernels_of_the_device_tree_build(tmp_path):
     for name in ("k_cells", "k_place"):
         v = next(v for n, v in k.items() if name in n)
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 and v["vgpr_count"] <= 64, (name, v)
+
+
+def test_hand_scheduled_walk_keeps_eight_waves_per_simd(tmp_path):
+    """k_bh_walk_groups<*, true> (round 4): the loop owns s20-s56, everything else that lives across it -- kernel arguments used
+    after the walk -- comes on top.  80 SGPRs + the 16 the trap handler reserves = 96, the last allocation with eight waves per
+    SIMD (800 per SIMD); 82 meant seven: 16 384 walks then take three rounds instead of two and the traversal at a million
+    bodies went from 0.430 to 0.465 ms (measured when the folded kick-drift first brought two more pointers along)."""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    strict = re.search(r"^STRICT\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    k = _metadata(tmp_path, "bh_walk.hip", strict + ["-Wno-inline-asm"])
+    walks = {n: v for n, v in k.items() if "k_bh_walk_groupsILi" in n}
+    assert len(walks) == 14                                                # 64 ... 1 bodies per walk, hand-scheduled and compiled
+    for n, v in walks.items():
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0, (n, v)
+        assert v["vgpr_count"] <= 64, (n, v)
+        if "ELb1E" in n:
+            assert v["sgpr_count"] <= 80, (n, v)

@@ -41,7 +41,8 @@ for stage in "$@"; do
     bh)
       timeout 900 python bench.py --workload bh > $O/${TAG}_bench_bh_default.json 2> $O/${TAG}_bench_bh_default.err; echo "bh rc=$?"; cat $O/${TAG}_bench_bh_default.json
       timeout 900 python bench.py --workload bh --bh-tree host --no-cpu-baseline > $O/${TAG}_bench_bh_host.json 2> $O/${TAG}_bench_bh_host.err
-      timeout 900 python bench.py --workload bh --bh-tree device --no-cpu-baseline > $O/${TAG}_bench_bh_device.json 2> $O/${TAG}_bench_bh_device.err ;;
+      timeout 900 python bench.py --workload bh --bh-tree device --no-cpu-baseline > $O/${TAG}_bench_bh_device.json 2> $O/${TAG}_bench_bh_device.err
+      timeout 900 python bench.py --workload bh --bodies 10000 --theta 0.85 --no-cpu-baseline > $O/${TAG}_bench_bh_10000.json 2> $O/${TAG}_bench_bh_10000.err ;;
     prof)
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/${TAG}_prof -o p --output-format csv -- python $OLDPWD/bench.py --no-cpu-baseline --no-traffic > $OLDPWD/$O/${TAG}_prof_bench.json 2> $OLDPWD/$O/${TAG}_prof.err)
       find $O/${TAG}_prof -name '*kernel_stats.csv' -exec cp {} $O/${TAG}_bench_kernel_stats.csv \; ; head -5 $O/${TAG}_bench_kernel_stats.csv ;;
