@@ -464,7 +464,7 @@ static int draw_on_device(nbx_engine* e, int32_t w, int32_t h, uint32_t* fb)
     }
     HIP_TRY(hipMemcpyAsync(e->h_fb, e->d_fb, px * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(e->h_fb + px, d_cnt, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(wait_stream(e->stream));   // (a 512 x 512 frame is ~0.1 ms: poll before blocking, engine_internal.h)
     std::memcpy(fb, e->h_fb, px * 4);
     const unsigned n_amb = e->h_fb[px];
     e->draw_ambiguous = (int)n_amb;
