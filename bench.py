@@ -885,10 +885,15 @@ def run(real_stdout):
                                                      "157.3 TFLOP/s; no MFMA is used)",
                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                              "ceiling_frac": ceiling, "frac_of_ceiling": (achieved / peak / ceiling) if ceiling else None,
-                             "ceiling_note": "what this kernel's own instruction mix allows at the nominal 2.4 GHz: 17 (12) flop x 128 "
-                                             "interactions / (packed ops x 3.85 + 2 v_rcp_f32 x 8.7 issue cycles) / 64 flop per cycle and "
-                                             "SIMD; the sweep runs with the VALU 97 % busy at the board's power cap (clock ~2.3 of 2.4 GHz): "
-                                             "what is left between frac and ceiling_frac is that clock, not idle issue slots",
+                             "ceiling_note": ("what this kernel's own instruction mix allows at the nominal 2.4 GHz: 17 (12) flop x 128 "
+                                              "interactions / (packed ops x 3.85 + 2 v_rcp_f32 x 8.7 issue cycles) / 64 flop per cycle and "
+                                              "SIMD; the sweep runs with the VALU 97 % busy at the board's power cap (clock ~2.3 of 2.4 GHz): "
+                                              "what is left between frac and ceiling_frac is that clock, not idle issue slots") if ceiling else
+                                             ("no mix ceiling is quoted for the bit-exact kernels: frac counts the reference's 17 (12) flops "
+                                              "per interaction against the plain fp32 peak, while the kernel executes the reference's "
+                                              "arithmetic as written -- unfused multiplies and adds, an IEEE-correct sqrt and divide "
+                                              "(expanded into ~10 instructions each) and the per-target sum in ascending j, one rounding "
+                                              "at a time; those are what bit-exactness costs, not idle issue slots (DESIGN.md 5 K1s)"),
                              "general_masses_frac": general["frac"] if general else None,
                              "traffic": traffic, "traffic_measurement": traffic_info,
                              "kernel": KERNEL_NAMES.get(launch["variant"], "k_force"),
