@@ -192,8 +192,9 @@ def test_launch_order_of_the_walks_changes_no_result(rx):
     assert np.abs(res[0]["px"] - st["px"]).max() > 0
 
 
-@pytest.mark.parametrize("n,async_", [(300, 1), (3000, 1), (12000, 0), (12000, 1), (100000, 1), (600000, 1)])
-def test_kick_drift_folded_into_the_walk_changes_no_bit(rx, ob, n, async_):
+@pytest.mark.parametrize("n,async_,tree", [(300, 1, "device"), (3000, 1, "device"), (12000, 0, "device"), (12000, 1, "device"),
+                                          (100000, 1, "device"), (600000, 1, "device"), (70000, 1, "host")])
+def test_kick_drift_folded_into_the_walk_changes_no_bit(rx, ob, n, async_, tree):
     """NBX_OPT_BH_FUSE_KICK (round 4, default on): the walk kernel applies the kick-drift
     and the velocity kill itself.  Same operations on the same acceleration: positions and velocities equal the separate
     kick-drift kernel's bit for bit, step after step -- bodies that cross the +-55 kill box included -- in the waiting and the
@@ -209,7 +210,7 @@ def test_kick_drift_folded_into_the_walk_changes_no_bit(rx, ob, n, async_):
     p["vx"][fast[half:]] = np.float32(-5.0)
     res = []
     for fuse in (0, 1):
-        e = _engine(rx, p, 1, tree="device")
+        e = _engine(rx, p, 1, tree=tree)       # (host tree: the wave walk -- and with it the folded kick -- from 65 536 bodies on)
         e.set_option(NBX_OPT_BH_ASYNC, async_)
         e.set_option(NBX_OPT_BH_FUSE_KICK, fuse)
         e.step_barnes_hut(0.6, 0.01, 1)
@@ -220,7 +221,7 @@ def test_kick_drift_folded_into_the_walk_changes_no_bit(rx, ob, n, async_):
         for _ in range(4):
             e.step_barnes_hut(0.6, 0.01, 1)
         res.append(e.get_particles())
-        assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1 and e.get_option(NBX_OPT_BH_FALLBACKS) == 0
+        assert e.get_option(NBX_OPT_BH_LAST_TREE) == (1 if tree == "device" else 0) and e.get_option(NBX_OPT_BH_FALLBACKS) == 0
     for k in ("px", "py", "vx", "vy"):
         assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
     assert np.abs(res[0]["px"] - p["px"]).max() > 0
