@@ -174,7 +174,9 @@ enum nbx_option {
                                     * in Morton order.  The order changes no result.  Kept as the measured A/B of round 4: the kernel's
                                     * tail (29 % of the wave slots idle) suggested it, but walks that are neighbours in space then no
                                     * longer run side by side and what the tail gains the L2 loses: traversal 0.449 vs 0.430 ms at
-                                    * 1 048 576 bodies, no difference at 262 144 */
+                                    * 1 048 576 bodies, no difference at 262 144.  A stable variant (NBX_WALK_CLASSES = 2 ... 16 cost
+                                    * classes, Morton order kept inside a class; what the option now runs) is slower the more classes
+                                    * it has: 0.443 / 0.456 / 0.464 / 0.479 ms with 2 / 4 / 8 / 16 against 0.431 */
     NBX_OPT_BH_FUSE_KICK = 20,     /* child-group walk, wave form, one GPU: 1 (default) = the walk kernel applies the step's kick-drift
                                     * itself as soon as a body's acceleration is complete (same operations, bit-identical state: a walk
                                     * reads no other body's position from the particle array -- the group records hold copies);

@@ -488,41 +488,55 @@ hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta
     return hipGetLastError();
 }
 
-// Launch order of the next step's walks from this step's costs: per eighth of the walks (= per XCD, see the kernel), a counting
-// sort by cost, longest first (64 cost classes; the order inside a class is whatever the atomics make it -- it changes no result).
-__global__ __launch_bounds__(1024) void k_walk_order(const int* __restrict__ cost, int* __restrict__ order, const int per_eighth)
+// Launch order of the next step's walks from this step's costs: per eighth of the walks (= per XCD, see the kernel), a STABLE
+// counting sort by cost class, longest class first (classes = equal-width bins of the cost; inside a class the walks keep their
+// Morton order, so neighbours in space still run side by side).  The order changes no result.
+__global__ __launch_bounds__(1024) void k_walk_order(const int* __restrict__ cost, int* __restrict__ order, const int per_eighth,
+                                                     const int classes)
 {
-    __shared__ int hist[64], base[64], top;
-    const int k = blockIdx.x, tid = threadIdx.x;
-    if (tid < 64) hist[tid] = 0;
-    if (tid == 0) top = 1;
+    __shared__ int top, wave_sum[16], class_base;
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { top = 1; class_base = 0; }
     __syncthreads();
     int mx = 1;
     for (int j = tid; j < per_eighth; j += 1024) mx = max(mx, cost[k * per_eighth + j]);
     atomicMax(&top, mx);
     __syncthreads();
     const int scale = top + 1;
-    for (int j = tid; j < per_eighth; j += 1024) {
-        const int c = min(max(cost[k * per_eighth + j], 0), top);
-        atomicAdd(&hist[63 - (int)(((long long)c * 64) / scale)], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int b = 0; b < 64; b++) { base[b] = run; run += hist[b]; }
-    }
-    __syncthreads();
-    for (int j = tid; j < per_eighth; j += 1024) {
-        const int c = min(max(cost[k * per_eighth + j], 0), top);
-        const int pos = atomicAdd(&base[63 - (int)(((long long)c * 64) / scale)], 1);
-        order[k * per_eighth + pos] = k * per_eighth + j;
+    const int per_thread = (per_eighth + 1023) / 1024;            // contiguous items per thread: a stable order needs them in sequence
+    const int j0 = tid * per_thread, j1 = min(j0 + per_thread, per_eighth);
+    for (int c = classes - 1; c >= 0; c--) {                      // longest class first
+        int mine = 0;
+        for (int j = j0; j < j1; j++) {
+            const int v = min(max(cost[k * per_eighth + j], 0), top);
+            mine += ((int)(((long long)v * classes) / scale) == c) ? 1 : 0;
+        }
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        int before = class_base;
+        for (int w = 0; w < wave; w++) before += wave_sum[w];
+        int pos = before + incl - mine;
+        for (int j = j0; j < j1; j++) {
+            const int v = min(max(cost[k * per_eighth + j], 0), top);
+            if ((int)(((long long)v * classes) / scale) == c) order[k * per_eighth + pos++] = k * per_eighth + j;
+        }
+        __syncthreads();
+        if (tid == 1023) class_base = before + incl;              // (the last thread's inclusive count closes the class)
+        __syncthreads();
     }
 }
 
 hipError_t launch_walk_order(const int* cost, int* order, int walks, hipStream_t stream)
 {
     if (walks <= 0 || (walks & 7)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_walk_order, dim3(8), dim3(1024), 0, stream, cost, order, walks / 8);
+    static const int classes = [] { const char* v = std::getenv("NBX_WALK_CLASSES"); const int c = v ? std::atoi(v) : 8; return c >= 1 && c <= 64 ? c : 8; }();
+    hipLaunchKernelGGL(k_walk_order, dim3(8), dim3(1024), 0, stream, cost, order, walks / 8, classes);
     return hipGetLastError();
 }
 
