@@ -18,3 +18,12 @@ python tools/bench_bh.py > gpurun_out/${T}_bench_bh_tool.json 2> gpurun_out/benc
 python tools/frame_loop.py > gpurun_out/${T}_frame_loop_level1.txt 2>&1
 NB_BH_TREE=host NB_DRAW=host python tools/frame_loop.py > gpurun_out/${T}_frame_loop_level1_host_tree_host_draw.txt 2>&1
 python tools/pcie_inclusive.py > gpurun_out/${T}_pcie_inclusive.json 2>&1
+# round 4: the three fast walks side by side (A/B table, kernel trace, PMC), the reference's own scene kernel by kernel, the
+# first-contact dry runs, the walk kernel's timeline, the sort shapes, the torch host with two gloo ranks on one GPU
+bash tools/gpu_session.sh walk small dry
+python tools/bh_walk_trace.py > gpurun_out/${T}_bh_walk_trace_1m.json 2> gpurun_out/${T}_bh_walk_trace.err
+[ -x tools/ubench_sort_cfg ] || hipcc --offload-arch=gfx950 -O3 tools/ubench_sort_cfg.hip -o tools/ubench_sort_cfg
+tools/ubench_sort_cfg > gpurun_out/${T}_ubench_sort_cfg.txt 2>&1
+NBX_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --dry-run --bodies 65536 > gpurun_out/${T}_bench_torch2_gloo_one_gpu_dry_run.json 2> /dev/null
+NBX_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 5 --warmup 1 --bodies 65536 --no-cpu-baseline > gpurun_out/${T}_bench_torch2_gloo_one_gpu.json 2> /dev/null
+python tools/bh_union_model.py 1048576 > gpurun_out/${T}_bh_walk_union_model_n1048576.json 2> /dev/null   # (CPU: needs no GPU)
