@@ -22,6 +22,10 @@
 //    compiler's version of the same walk (NBX_OPT_BH_WALK = 2, walk_groups_compiled below; also what a wave falls back to if
 //    its stack outgrows the 64 lanes) spends 49 SALU + 20 branches per group on the same work: 0.55 ms against the node walk's
 //    0.62 at a million bodies -- scalar-issue bound like its predecessor.
+//  * the walk ends the step: it applies the kick-drift and the velocity kill (nbody.rs:453-471) to its own bodies as soon as their
+//    acceleration is complete (BhKick; no other walk reads a body's position from the particle array -- the records hold copies).
+//  * eight waves per SIMD are part of the design: 16 384 walks at a million bodies are exactly two rounds of the chip's 8 192
+//    wave slots.  The loop owns s20-s56; what lives across it must keep the kernel at <= 80 SGPRs (tests/test_kernel_resources.py).
 //
 // Order of accumulation (all three forms: assembly, compiled, per-lane): a group's present children in DESCENDING slot order,
 // every child's pair law added in the lanes that take it; then the subtrees of the opened children in ASCENDING slot order,
