@@ -1493,17 +1493,18 @@ __global__ __launch_bounds__(kTile) void k_front_chunks(const float4* __restrict
     // this build's counters and tickets, and the table of occupied grid cells (reference fold), as k_keys clears them
     if (blockIdx.x == 0 && tid < 8) counters[tid] = 0;
     for (int t = blockIdx.x * kTile + tid; t < cell_slots; t += (int)gridDim.x * kTile) cell_table[t] = 0ull;
-    // 1. root AABB (nbody.rs:388-398); eight independent loads in flight per thread
+    // 1. root AABB (nbody.rs:388-398); eight independent loads in flight per thread (16 / 20 / 32: no difference at 2 000 ... 16 384)
+    constexpr int kBoxFlight = 8;
     float x1 = 3.40282347e+38f, y1 = 3.40282347e+38f, x2 = -3.40282347e+38f, y2 = -3.40282347e+38f;
-    for (int i0 = tid; i0 < n; i0 += 8 * kTile) {
-        float4 q[8];
+    for (int i0 = tid; i0 < n; i0 += kBoxFlight * kTile) {
+        float4 q[kBoxFlight];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < kBoxFlight; u++) {
             const int i = i0 + u * kTile;
             q[u] = posm[i < n ? i : i0];
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < kBoxFlight; u++) {
             x1 = fminf(x1, q[u].x); y1 = fminf(y1, q[u].y); x2 = fmaxf(x2, q[u].x); y2 = fmaxf(y2, q[u].y);
         }
     }
@@ -1561,16 +1562,18 @@ __global__ __launch_bounds__(kTile) void k_front_chunks(const float4* __restrict
     }
 }
 
-constexpr int kRankThreads = kTile;
+// (threads x copy-in loads in flight: 256 x 16 -> build 0.0580 ms at 10 000 bodies / 0.0679 at 16 384; 128 x 20 0.0614 / 0.0759;
+//  128 x 32 0.0567 / 0.0638; 64 x 32 0.0592 / 0.0686: twice the CUs share the probing, each copy-in stays two batches deep)
+constexpr int kRankThreads = 128;
 __global__ __launch_bounds__(kRankThreads) void k_front_rank(const unsigned long long* __restrict__ ckeys, const unsigned* __restrict__ cidx,
                                                       const int n, unsigned long long* __restrict__ keys_out,
                                                       unsigned* __restrict__ idx_out)
 {
     extern __shared__ unsigned long long rkeys[];          // every chunk's sorted keys, padded to whole chunks
     const int chunks = (n + kChunk - 1) / kChunk;
-    {   // copy in: two keys per 16-byte load, sixteen loads in flight per thread (the chunks were written by the kernel before:
+    {   // copy in: two keys per 16-byte load, thirty-two loads in flight per thread (the chunks were written by the kernel before:
         // every first touch goes past the L2, a microsecond or two each)
-        constexpr int kFlight = 16;
+        constexpr int kFlight = 32;
         const int pairs = chunks * kChunk / 2;
         const ulonglong2* src = reinterpret_cast<const ulonglong2*>(ckeys);   // (the workspace arrays are 256-byte aligned)
         ulonglong2* dst = reinterpret_cast<ulonglong2*>(rkeys);
