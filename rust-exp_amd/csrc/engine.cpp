@@ -640,10 +640,6 @@ int slab_order(nbx_engine* e)
     return NBX_OK;
 }
 
-// Fast-mode traversal of the node array this engine holds (e->d_nodes, e->n_flat -- or, gated, the count the device build left in
-// its counters) for the slab's bodies, accelerations into e->d_f2.  NBX_OPT_BH_WALK = 1 (default) / 2: the tree is first re-laid as
-// child groups with the step's theta (k_bh_groups), then walked group by group (bh_walk.hip: hand-scheduled / compiled loop);
-// 0 (or a tree too large for 31-bit record offsets: beyond ~4 M bodies): the node walk of rounds 1-3.
 // May the child-group walk of this step apply the kick-drift itself (kernels.h BhKick)?  Only the wave form has it, on one GPU
 // (a group's exchange reads the kick-drift's output slab by slab).  One dependent kernel less per step: 0.0932 -> 0.0899 ms at
 // 10 000 bodies, 0.8375 -> 0.8252 at 1 M (the walk itself +0.002 ms there, the 0.018 ms kick-drift kernel gone).
@@ -653,6 +649,11 @@ bool walk_takes_kick(const nbx_engine* e, const unsigned* perm, bool wave, int n
     return nbx::bh_groups_addressable(nodes_or_cap);
 }
 
+// Fast-mode traversal of the node array this engine holds (e->d_nodes, e->n_flat -- or, gated, the count the device build left in
+// its counters) for the slab's bodies, accelerations into e->d_f2 -- or, with kick, straight into the bodies' velocities and
+// positions.  NBX_OPT_BH_WALK = 1 (default) / 2: the tree is first re-laid as child groups with the step's theta (k_bh_groups),
+// then walked group by group (bh_walk.hip: hand-scheduled / compiled loop); 0 (or a tree too large for 31-bit record offsets:
+// beyond ~4 M bodies): the node walk of rounds 1-3.
 int launch_fast_walk(nbx_engine* e, float theta, const unsigned* perm, bool wave, bool on_device, int* gate, int gate_node_cap,
                      int gate_crowd_limit, int gate_queue_limit, const nbx::BhKick* kick)
 {
