@@ -973,7 +973,8 @@ def run(real_stdout):
                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                              "frac_definition": "algorithmic flops of one evaluation (12 per pair law + 7 per opening test, the reference's "
                                                 "expressions as written, nbody.rs:164-184, :341-345) / traversal time (HIP events: tree -> "
-                                                "child groups + walk) / fp32 vector peak",
+                                                "child groups + walk; the child-group walk also applies the step's kick-drift, whose "
+                                                "flops are not counted) / fp32 vector peak",
                              "flops_per_launch": flops, "pair_evals_per_body": wk["pair_evals"] / n,
                              "opening_tests_per_body": wk["opening_tests"] / n, "node_visits_per_body": wk["node_visits"] / n,
                              "group_loads_per_body": wk["group_loads"] / n,
