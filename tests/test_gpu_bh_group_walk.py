@@ -309,3 +309,25 @@ def test_a_walk_that_outgrows_its_register_stack_is_redone_with_the_spill(rx, ob
     fx, fy = ob.brute_forces(p)
     scale = max(np.abs(fx).max(), np.abs(fy).max())
     assert max(np.abs(res[1][0] - fx).max(), np.abs(res[1][1] - fy).max()) <= 0.05 * scale
+
+
+def test_blocking_host_waits_give_the_same_state(rx):
+    """NBX_SPIN_US = 0: the host waits of the stepping path block at once instead of polling first (engine_internal.h).  Read once
+    per process, so the blocking form runs in a child process: same bits after the same steps."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, zlib, numpy as np; sys.path.insert(0, %r); import rust_exp_amd as rx\n"
+            "st = rx.plummer_sphere(20000, dim=2); e = rx.NBodyEngine()\n"
+            "e.set_particles(st['px'], st['py'], st['vx'], st['vy'], st['m'])\n"
+            "for _ in range(6):\n    e.step_barnes_hut(0.6, 0.01, 1)\n    e.synchronize()\n"
+            "p = e.get_particles(); print(zlib.crc32(np.concatenate([p[k] for k in ('px', 'py', 'vx', 'vy')]).tobytes()))\n" % root)
+    sums = []
+    for spin in ("0", "400"):
+        env = dict(os.environ, NBX_SPIN_US=spin)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        sums.append(out.stdout.strip().splitlines()[-1])
+    assert sums[0] == sums[1] and sums[0].isdigit()
