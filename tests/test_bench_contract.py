@@ -75,3 +75,32 @@ def test_a_run_that_dies_says_where():
     assert st.startswith("host construction") or st.startswith("dry-run: first exchange"), st
     assert d["diagnostics"]["gpus"] == 8 and d["diagnostics"]["host"] == "group"
     assert "FAILED at stage '" + st in r.stderr
+
+
+def test_companions_block_is_flat_scalars_and_survives_a_failed_child():
+    """BASELINE configs #2, #4, #5 ride on the driver-run line. The block is assembled from the children's
+    own JSON lines; what goes into `roofline` must be scalars (the driver's parser keeps scalars one level deep); a child that
+    fails leaves an `error`, not an exception."""
+    assert [k for k, _, _ in bench.COMPANIONS] == ["c2_brute_65536", "c4_barnes_hut_1048576", "c5_fp16_sources_524288"]
+    argv = {k: a for k, _, a in bench.COMPANIONS}
+    assert argv["c4_barnes_hut_1048576"][:6] == ["--workload", "bh", "--bodies", "1048576", "--theta", "0.5"]
+    assert "--source-bits" in argv["c5_fp16_sources_524288"] and "524288" in argv["c5_fp16_sources_524288"]
+    bh_line = {"value": 1.3e9, "unit": "body-steps/s", "ms_per_step": 0.79, "steps": 40,
+               "config": {"tree": "device (bh_build.hip)"},
+               "ms_split": {"tree_build": 0.36, "bh_eval_kernel": 0.43},
+               "roofline": {"frac": 0.14, "kernel_avg_ms": 0.43, "valu_busy_frac": 0.66, "traffic": 5.9e8,
+                            "hbm_algorithmic_bytes_per_launch": 3.7e8, "flops_per_launch": 9.7e9},
+               "cpu_baseline": {"value": 9.9e5, "cores": 16, "ms_per_step": 1060.0,
+                                "accuracy": {"p999": 1.1e-5, "max": 4e-4, "bodies_beyond_2e-5": 37, "vs": "arbiter"}}}
+    c4 = bench.companion_summary("c4_barnes_hut_1048576", bh_line)
+    assert c4["build_ms"] == 0.36 and c4["traversal_ms"] == 0.43 and c4["valu_busy"] == 0.66 and c4["cpu_ms_per_step"] == 1060.0
+    assert c4["err_p999"] == 1.1e-5 and c4["bodies_beyond_2e-5"] == 37 and c4["frac"] == 0.14
+    c2 = bench.companion_summary("c2_brute_65536", {"value": 5.4e12, "unit": "interactions/s", "ms_per_step": 0.79, "steps": 300,
+                                                    "roofline": {"frac": 0.6, "kernel_avg_ms": 0.78, "flops_per_interaction": 17,
+                                                                 "kernel": "k"}, "cpu_baseline": {"value": 6e9, "cores": 16}})
+    flat = bench.flatten_companions({"c2_brute_65536": dict(c2, config="x", argv="y", wall_s=1.0),
+                                     "c4_barnes_hut_1048576": dict(c4, config="x", argv="y", wall_s=2.0),
+                                     "c5_fp16_sources_524288": {"config": "x", "argv": "y", "error": "rc 1: boom", "wall_s": 0.1}})
+    assert flat["c2_value"] == 5.4e12 and flat["c2_frac"] == 0.6 and flat["c4_build_ms"] == 0.36 and flat["c5_error"] == "rc 1: boom"
+    assert all(v is None or isinstance(v, (int, float, str)) for v in flat.values())
+    json.dumps(flat)
