@@ -95,6 +95,12 @@ __global__ __launch_bounds__(kTile) void k_bh_groups(const BhNode* __restrict__ 
             c = nd.skip;
         }
     }
+    if (kid[0] == kGroupAbsent) {
+        // an interior node without a single child (no builder makes one): the walks assume a group has a present child in slot 0 --
+        // give it a massless leaf, which adds nothing, instead of a slot they would open
+        rec[0] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+        kid[0] = kGroupLeaf;
+    }
     BhGroup* g = &groups[(compact ? hdr.w : k) + 1];
     g->c[0] = rec[0]; g->c[1] = rec[1]; g->c[2] = rec[2]; g->c[3] = rec[3];
     g->kid = make_int4(kid[0], kid[1], kid[2], kid[3]);

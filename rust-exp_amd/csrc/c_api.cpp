@@ -724,10 +724,11 @@ int32_t nbx_bh_work_detail(nbx_engine* e, float theta, uint64_t* out4)
     }
     unsigned long long* d_tot = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tot), 32));
+    struct Free { unsigned long long* p; ~Free() { if (p) (void)hipFree(p); } } guard{d_tot};   // every return below releases it
     HIP_TRY(hipMemsetAsync(d_tot, 0, 32, e->stream));
     if (e->bh_walk != 0 && e->force_mode == 0 && nbx::bh_groups_addressable((int)e->n_flat)) {   // counted over the structure the selected walk uses
         rc = grow(&e->d_groups, &e->groups_cap, nbx::bh_groups_count((int)e->n_flat));
-        if (rc != NBX_OK) { (void)hipFree(d_tot); return rc; }
+        if (rc != NBX_OK) return rc;
         HIP_TRY(nbx::launch_bh_groups(e->d_nodes, (int)e->n_flat, theta, e->d_groups, /*compact=*/on_device, e->stream));
         HIP_TRY(nbx::launch_bh_count_groups(e->d_posm, e->lo, e->slab(), e->d_groups, d_tot, e->stream));
     } else {
@@ -736,7 +737,6 @@ int32_t nbx_bh_work_detail(nbx_engine* e, float theta, uint64_t* out4)
     unsigned long long h[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(h, d_tot, 32, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipFree(d_tot));
     for (int i = 0; i < 4; i++) out4[i] = h[i];
     return NBX_OK;
 }
@@ -757,13 +757,18 @@ int32_t nbx_bh_walk_trace(nbx_engine* e, float theta, int32_t cap_walks, uint64_
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned long long) * 4 * (size_t)walks));
     hipError_t err = hipMemsetAsync(d, 0, sizeof(unsigned long long) * 4 * (size_t)walks, e->stream);
     e->d_walk_trace = d;
+    e->walk_traced = false;
     std::vector<float> fx((size_t)slab), fy((size_t)slab);
     rc = err == hipSuccess ? nbx_forces(e, theta, slab, fx.data(), fy.data(), nullptr) : NBX_ERR_HIP;
     e->d_walk_trace = nullptr;
-    if (rc >= 0) err = hipMemcpy(out, d, sizeof(unsigned long long) * 4 * (size_t)walks, hipMemcpyDeviceToHost);
+    const bool traced = e->walk_traced;
+    if (rc >= 0 && traced) err = hipMemcpy(out, d, sizeof(unsigned long long) * 4 * (size_t)walks, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (rc < 0) return rc;
     HIP_TRY(err);
+    // only the shared (one walk per wave) form writes a trace: a host tree below 65 536 bodies, NBX_OPT_BH_WAVE = 0 or a sharded
+    // engine runs the per-lane form -- say so instead of returning rows of zeros
+    if (!traced) return fail(NBX_ERR_STATE, "this evaluation ran the per-lane walk, which leaves no trace (host tree below 65 536 bodies, wave walk off, or world > 1)");
     return walks;
 }
 

@@ -121,6 +121,7 @@ int upload(nbx_engine* e)
     if (e->dev_valid) return NBX_OK;
     if (!(e->host_pos_valid && e->host_vel_valid)) return fail(NBX_ERR_STATE, "no valid state to upload");
     const int n = e->n;
+    e->sort_warm_n = 0;   // new positions from the host: last step's order says nothing about them
     e->n_pad = ((n + kTile - 1) / kTile) * kTile;
     if (e->n_pad == 0) e->n_pad = kTile;
     if (e->posm_external) {
@@ -531,6 +532,7 @@ int build_tree_on_device_begin(nbx_engine* e, int* host_counters, bool publish_b
         e->tree_ws_bytes = 0;
         HIP_TRY(hipMalloc(&e->d_tree_ws, need));
         e->tree_ws_bytes = need;
+        e->sort_warm_n = 0;
         HIP_TRY(nbx::device_tree_workspace_init(e->d_tree_ws, e->stream));
     }
     if (!e->h_counters) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_counters), 64, hipHostMallocDefault));
@@ -556,7 +558,8 @@ int build_tree_on_device_begin(nbx_engine* e, int* host_counters, bool publish_b
                                          publish_by_kernel ? nullptr : (host_counters ? host_counters : e->h_counters), &e->d_perm,
                                          e->stream, fold, e->side_stream, e->ev_side_go, e->ev_side_done,
                                          want16 ? e->d_walk16 : nullptr, want16 ? e->d_wmass : nullptr,
-                                         /*depth_panic_guard=*/e->force_mode != 0));
+                                         /*depth_panic_guard=*/e->force_mode != 0, /*warm=*/e->sort_warm_n == e->n));
+    e->sort_warm_n = e->n;   // (a refusal -- of this build, or of one whose verdict is still in flight -- takes it back)
     return NBX_OK;
 }
 
@@ -583,6 +586,7 @@ int build_tree_on_device_end(nbx_engine* e, bool* done)
         e->note_refusal(backoff_max_steps());
         e->note_why(status, e->h_counters[5]);
         e->d_perm = nullptr;
+        e->sort_warm_n = 0;
         if (std::getenv("NBX_LOG"))
             std::fprintf(stderr, "[nbx] device tree build of %d bodies handed over to the host build: status %d (1 = pool / queue overflow, 2 = EPS "
                                  "clusters), nodes %d of %d, left-behind bodies %d (why 0x%x), queued folds %d\n", e->n, status, e->h_counters[0], node_cap,
@@ -617,9 +621,11 @@ int spatial_order(nbx_engine* e)
         e->tree_ws_bytes = 0;
         HIP_TRY(hipMalloc(&e->d_tree_ws, need));
         e->tree_ws_bytes = need;
+        e->sort_warm_n = 0;
         HIP_TRY(nbx::device_tree_workspace_init(e->d_tree_ws, e->stream));
     }
-    HIP_TRY(nbx::device_spatial_order(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, &e->d_perm, e->stream));
+    HIP_TRY(nbx::device_spatial_order(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, &e->d_perm, e->stream, e->sort_warm_n == e->n));
+    e->sort_warm_n = e->n;
     return NBX_OK;
 }
 
@@ -682,6 +688,7 @@ int launch_fast_walk(nbx_engine* e, float theta, const unsigned* perm, bool wave
             cost = e->d_walk_cost;
             if (e->walk_order_walks == walks && e->walk_order_slab == slab) order = e->d_walk_order;
         }
+        if (e->d_walk_trace && wave && perm) e->walk_traced = true;
         HIP_TRY(nbx::launch_bh_walk_groups(e->d_posm, e->lo, slab, e->d_groups, e->d_f2, e->stream, perm, wave, e->bh_walk == 1, gate,
                                            gate_node_cap, gate_crowd_limit, gate_queue_limit, order, cost, e->d_walk_trace, kick));
         if (cost) {
@@ -793,6 +800,7 @@ static int resolve_slot(nbx_engine* e, int slot)
     e->note_refusal(backoff_max_steps());
     e->note_why(status, e->h_verdict[slot][5]);
     e->d_perm = nullptr;
+    e->sort_warm_n = 0;
     const int other = slot ^ 1;
     const bool redo_later = e->pending[other].active;
     const nbx_engine::PendingStep later = e->pending[other];

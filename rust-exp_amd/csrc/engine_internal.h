@@ -65,6 +65,7 @@ struct nbx_engine {
     int walk_order_walks = 0;            // > 0: d_walk_order holds an order for that many walks (same slab, same bodies per walk)
     int walk_order_slab = 0;
     unsigned long long* d_walk_trace = nullptr;   // nbx_bh_walk_trace: set for the one evaluation it traces
+    bool walk_traced = false;                     // ... and whether the walk that ran was the shared (wave) form, the one that writes the trace
     int bh_walk_lpt = 0;                 // NBX_OPT_BH_WALK_ORDER: 1 = longest-first from the previous step's costs, 0 (default) = Morton order
     int bh_fuse_kick = 1;                // NBX_OPT_BH_FUSE_KICK: 1 (default) = the child-group walk applies the kick-drift itself, 0 = separate kernel
                                          // (measured, round 4: 0.449 vs 0.430 ms at 1 M bodies -- spatially adjacent walks no longer run side by side)
@@ -78,6 +79,9 @@ struct nbx_engine {
     hipEvent_t ev_side_go = nullptr, ev_side_done = nullptr;
     int* h_counters = nullptr;     // pinned: per-level node counters of the device build
     const unsigned* d_perm = nullptr;   // spatial body order produced by the device build
+    int sort_warm_n = 0;                // > 0: the tree workspace holds the sorted order of this many bodies as of the last build /
+                                        // spatial order of THIS state (one step old at most): the next sort starts from it (bh_build.hip,
+                                        // round 5). 0 after an upload of host state, a refused build, a new workspace
     const unsigned* d_slab_perm = nullptr;  // d_perm restricted to this engine's slab (world > 1)
     void* d_slab_ws = nullptr;
     size_t slab_ws_bytes = 0;

@@ -183,8 +183,11 @@ hipError_t launch_bh_count(const float4* posm, int lo, int n_targets, const BhNo
 size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes);
 // call once after every (re)allocation of the workspace, before its first use (clears the header's self-clearing ticket)
 hipError_t device_tree_workspace_init(void* workspace, hipStream_t stream);
+// warm (round 5): the workspace still holds the order an earlier call (this one or device_tree_build_begin) left for the SAME n
+// bodies, give or take a step's motion -- the sort then starts from it (k_splitters / k_keys_scatter / k_bucket_sort) instead
+// of from scratch; a warm sort whose buckets overflow refuses the build (counters[1], see bh_build.hip)
 hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size_t workspace_bytes, const unsigned** perm_dev,
-                                hipStream_t stream);
+                                hipStream_t stream, bool warm = false);
 // Routing + stable scatter for the host quadtree build (see bh_build.hip): top_host = ntop records of (x1, y1, x2, y2,
 // first_child, bucket); pbucket_host / events_host / offset_host are pinned, device-visible host arrays of rest ints,
 // rest 16-byte insert events and nb + 1 64-bit offsets.  Enqueues on `stream`; the caller waits.
@@ -207,7 +210,7 @@ constexpr int kFoldFaithfulMax = 65536;   // default: faithful fold up to this m
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters, const unsigned** perm_dev, hipStream_t stream, int fold = 0,
                                    hipStream_t side = nullptr, hipEvent_t ev_go = nullptr, hipEvent_t ev_done = nullptr,
-                                   BhWalk16* walk16 = nullptr, float* wmass = nullptr, bool depth_panic_guard = false);
+                                   BhWalk16* walk16 = nullptr, float* wmass = nullptr, bool depth_panic_guard = false, bool warm = false);
 hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status,
                                  hipStream_t stream, int fold = 0);
 // the device-side view of the same verdict: where the build's counters live (for launch_bh_eval / launch_integrate_f2 gates)

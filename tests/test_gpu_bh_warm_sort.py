@@ -1,0 +1,96 @@
+"""GPU: the device tree build's sort that starts from last step's order (bh_build.hip, round 5: k_splitters / k_keys_scatter /
+k_bucket_sort; replaces the serial insert loop nbody.rs:410-415 together with the rest of the build).
+
+(key, index) pairs are distinct, so the sorted order is unique and the tree must not depend on how it was reached: after EVERY
+step of a run the device tree -- built warm, from the previous build's order -- equals the host tree (= the oracle's,
+tests/test_gpu_bh_device_tree.py) bit for bit with the reference fold, and has its structure with exact sums; a build whose
+buckets overflow is refused and the step redone on the host tree, never wrong."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bit_equal_trees(host, dev):
+    assert len(host) == len(dev), (len(host), len(dev))
+    for k in ("skip", "interior"):
+        assert np.array_equal(host[k], dev[k]), k
+    for k in ("px", "py", "m", "s", "q"):
+        bad = np.flatnonzero(host[k].view(np.uint32) != dev[k].view(np.uint32))
+        assert bad.size == 0, (k, bad.size, bad[:5])
+
+
+def _state(rx, ob, make, n):
+    if make == "disk":
+        return ob.random_disk(n, 41)                      # velocities U[-3.5, 3.5): bodies cross cells every step
+    if make == "orbits":
+        return ob.stable_orbits(n, 0.5, 30.0, 42)         # v = sqrt(1000): 0.3 length units per step, the hot case
+    st = rx.plummer_sphere(n, dim=2)
+    return ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+
+
+@pytest.mark.parametrize("make,n,steps", [("orbits", 20000, 6), ("disk", 50000, 6), ("plummer", 65536, 4), ("orbits", 131072, 4),
+                                          ("disk", 300000, 3)])
+def test_warm_sort_builds_the_host_tree_bit_for_bit_after_every_step(rx, ob, make, n, steps):
+    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+
+    p = _state(rx, ob, make, n)
+    e = rx.NBodyEngine()
+    e.set_bh_fold("reference")                            # the class that promises the host tree node for node, at any size
+    e.set_bh_tree("device")
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    fallbacks0 = e.get_option(NBX_OPT_BH_FALLBACKS)
+    for k in range(steps):
+        e.step_barnes_hut(0.5, 0.01, 1)                   # build k is cold for k = 0, warm from then on
+        e.synchronize()
+        _bit_equal_trees(e.bh_flat_dump(False), e.bh_flat_dump("device"))   # (the dump builds once more: warm, same state)
+    # the steps ran on the device tree, warm builds included (a refused build would have counted as a fallback)
+    assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1
+    assert e.get_option(NBX_OPT_BH_FALLBACKS) == fallbacks0
+
+
+def test_warm_and_cold_sorts_step_to_the_same_bits(rx, ob):
+    """The same 8 steps with the warm sort and with the library sort every step (NBX_INC_SORT=0 in a child process): positions and
+    velocities bit-identical (the exact-sum class above 65 536 bodies: the tree does not depend on the sort)."""
+    import subprocess
+    import sys
+
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import rust_exp_amd as rx\n"
+            "st = rx.plummer_sphere(200000, dim=2)\n"
+            "rng = np.random.default_rng(5); vx = rng.normal(0, 8, 200000).astype(np.float32); vy = rng.normal(0, 8, 200000).astype(np.float32)\n"
+            "e = rx.NBodyEngine(); e.set_bh_tree('device'); e.set_particles(st['px'], st['py'], vx, vy, st['m'])\n"
+            "for _ in range(8): e.step_barnes_hut(0.5, 0.01, 1)\n"
+            "q = e.get_particles(); print(e.get_option(rx.engine.NBX_OPT_BH_FALLBACKS)); np.save(sys.argv[1], np.stack([q['px'], q['py'], q['vx'], q['vy']]))\n"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = []
+    for flag in ("1", "0"):
+        path = "/tmp/nbx_warm_%s.npy" % flag
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, NBX_INC_SORT=flag), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-500:]
+        assert r.stdout.strip().splitlines()[-1] == "0"          # no fallback either way
+        out.append(np.load(path))
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+
+
+def test_a_reshuffled_system_is_refused_not_wrong(rx, ob):
+    """Last step's order says nothing about bodies that were all moved by hand: through nbx_set_particles the engine forgets the
+    order (cold sort). If the order is stale anyway -- here: the SAME engine state, bodies teleported by one huge step -- the warm
+    sort's buckets may overflow: that build is refused, the step redone on the host tree; the result is the host-tree step's."""
+    n = 120000
+    p = ob.random_disk(n, 7)
+    a = rx.NBodyEngine(); a.set_bh_tree("device")
+    b = rx.NBodyEngine(); b.set_bh_tree("host")
+    for e in (a, b):
+        e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+        e.step_barnes_hut(0.5, 0.01, 1)
+        e.step_barnes_hut(0.5, 3.0, 1)        # every body moves ~10 length units: the order is scrambled
+        e.step_barnes_hut(0.5, 0.01, 1)       # warm build on a scrambled order: sorted all the same, or refused
+        e.step_barnes_hut(0.5, 0.01, 1)
+    qa, qb = a.get_particles(), b.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        assert np.isfinite(qa[k]).all()
+        # exact-sum device tree vs host tree: the fast mode's tolerance class, not bits; a wrong sort would be off by O(1)
+        assert np.abs(qa[k] - qb[k]).max() <= 2e-2 * max(1.0, np.abs(qb[k]).max()), k
