@@ -39,8 +39,7 @@ sys.path.insert(0, ROOT)
 FLOPS_PER_INTERACTION = 17   # 3 sub, 3 mul + 2 add, 1 add eps, 1 mul, 1 div, 3 mul, 3 add
 DT = 0.01                    # RustNBodyExperiment.hs:45
 
-KERNEL_NAMES = {0: "k_force_tile", 1: "k_force_tile_pk", 2: "k_force_smem", 3: "k_force_tile_pk", 4: "k_force_tile_pkb",
-                5: "k_force_smem_pk", 6: "k_force_smem_pkw<unit_mass=0>", 7: "k_force_smem_pkw<unit_mass=1>", 16: "k_force_tile_pk_h",
+KERNEL_NAMES = {1: "k_force_tile_pk", 6: "k_force_smem_pkw<unit_mass=0>", 7: "k_force_smem_pkw<unit_mass=1>", 16: "k_force_tile_pk_h",
                 17: "k_force_smem_pkw<unit_mass=0,self_image=1> on the widened fp16 copy", 18: "k_force_smem_pkw<unit_mass=1,self_image=1> on the widened fp16 copy",
                 -1: "k_force_strict", -8: "k_force_strict_pc<8,8>", -16: "k_force_strict_pc<16,4>"}
 
@@ -326,8 +325,6 @@ def parse_args():
                     help="stable_orbits = the reference's own preset (nb_stable_orbits n 0.5 30, seed 1; 2-D: unit planets + a 1000-mass sun)")
     ap.add_argument("--theta", type=float, default=0.5, help="--workload bh: opening angle")
     ap.add_argument("--bh-tree", default="default", choices=["default", "host", "device"])
-    ap.add_argument("--bh-walk-records", type=int, default=-1, choices=[-1, 16, 32],
-                    help="--workload bh, device tree: node record size the wave walk reads (16 = the compact copy: A/B of round 3, slower)")
     ap.add_argument("--bh-walk", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="--workload bh, fast mode: 1 = walk over child groups, hand-scheduled (round 4, default), 2 = the same walk "
                          "compiled, 0 = node walk of rounds 1-3")
@@ -513,8 +510,6 @@ class SingleHost:
         e.set_strict_kernel(args.strict_kernel)
         if args.bh_tree != "default":
             e.set_bh_tree(args.bh_tree)
-        if args.bh_walk_records > 0:
-            e.set_option(rx.engine.NBX_OPT_BH_WALK_RECORDS, args.bh_walk_records)
         if args.bh_walk >= 0:
             e.set_option(rx.engine.NBX_OPT_BH_WALK, args.bh_walk)
         if args.shard_of > 1:
@@ -967,7 +962,7 @@ def run(real_stdout):
             def mix_ceiling(dim, unit_mass):
                 pk = 3 * dim + (0 if unit_mass else 1)
                 return (17.0 if dim == 3 else 12.0) * 128.0 / (pk * 3.85 + 2 * 8.7) / 64.0
-            packed = launch["variant"] in (1, 5, 6, 7, 17, 18)
+            packed = launch["variant"] in (1, 6, 7, 17, 18)
             ceiling = mix_ceiling(launch["dim"], launch["variant"] in (7, 18)) if packed else None
             if general:
                 general["ceiling_frac"] = mix_ceiling(general["launch"]["dim"], False)
@@ -1067,7 +1062,7 @@ def run(real_stdout):
                 "value": value, "unit": "body-steps/s", "dtype": "f32",
                 "config": {"workload": f"plummer_disk_projection_N{n}_barnes_hut_theta{args.theta}_dt{DT}", "bodies": n,
                            "seed": "0x5EED0001", "force_mode": args.mode, "host": host_kind, "sharding": sharding,
-                           "tree": {0: "host (reference-faithful insertion build)", 1: "device (bh_build.hip)"}[engine.get_option(rx.engine.NBX_OPT_BH_LAST_TREE)],
+                           "tree": {0: "host (reference-faithful insertion build)", 1: "device (bh_build.hip)"}[engine.get_stat(rx.engine.NBX_STAT_BH_LAST_TREE)],
                            "walk": {0: "node by node (bh_eval.hip, rounds 1-3)", 1: "child groups, hand-scheduled loop (bh_walk.hip)",
                                     2: "child groups, compiled loop (bh_walk.hip)"}[walk_kind]},
                 "ms_split": {"bh_eval_kernel": per[0]["bh_eval_ms"], "integrate_kernel": per[0]["integrate_ms"],

@@ -90,6 +90,7 @@ enum nbx_status {
     NBX_ERR_STATE = -7       /* call not valid in the engine's current configuration */
 };
 
+/* 14 options (numbers are stable; 10-12 and 17 moved to nbx_stat, 16 and 19 -- measured losers -- were removed in round 5) */
 enum nbx_option {
     /* 0 = fast (default): a_i = sum_j m_j d/(|d|^2+eps) with v_rcp_f32 + FMA, tile order,
      *     parity within the stated fp32 tolerance.
@@ -97,7 +98,7 @@ enum nbx_option {
      *     contraction: BIT-EXACT with the reference arithmetic (2-D only, no j-split). */
     NBX_OPT_FORCE_MODE = 0,
     NBX_OPT_JSPLIT = 1,            /* source-range split factor S; 0 = auto */
-    NBX_OPT_BODIES_PER_THREAD = 2, /* register blocking B in {1,2,4}; 0 = auto */
+    NBX_OPT_BODIES_PER_THREAD = 2, /* variant 1: targets per thread, 2 or 4 (packed pairs); 0 = auto */
     NBX_OPT_DIM = 3,               /* 2 or 3; 0 = auto (2 when every z and vz is zero) */
     NBX_OPT_PROFILE = 4,           /* 1 = record a HIP event pair around every kernel launch */
     NBX_OPT_KERNEL_VARIANT = 5,    /* fast force kernel; -1 = auto (default: 7 / 6 for >= 16384 sources, else 1):
@@ -105,12 +106,11 @@ enum nbx_option {
                                     *      by m_j leaves the loop (a = m * sum d/(r^2+eps)); falls back to 6 otherwise
                                     *  6 = packed fp32, sources through the scalar cache as SGPR operands (no LDS in the
                                     *      loop); the 4 waves of a workgroup share 256 targets, split the source range and
-                                    *      reduce through LDS once (4x fewer partial slabs in HBM than 5)
-                                    *  5 = as 6 without the wave split (round-1 default)
+                                    *      reduce through LDS once
                                     *  1 = packed fp32, sources staged through LDS tiles
-                                    *  4 = 1 + batched reciprocals (guarded by max|coord| <= 1e4)
-                                    *  0 = compiler-scheduled LDS tiles, 2 = scalar-cache scalar math,
-                                    *  3 = 1 with 4-source LDS batches            (all A/B'd in DESIGN.md 6) */
+                                    * (0, 2, 3, 4, 5 of rounds 1-4 -- compiler-scheduled tiles, scalar-cache scalar math, 4-source
+                                    *  batches, batched reciprocals, 6 without the wave split -- lost every A/B and were removed in
+                                    *  round 5: docs/rounds/r01.md, r02.md hold their numbers) */
     NBX_OPT_DRAW_DEVICE = 7,       /* 1: nbx_draw/nb_draw splat on the GPU (count + resolve kernels, one w*h*4 B
                                     * download) instead of downloading the state. Pixel-identical to the host draw: the
                                     * few tails whose octant sits within 1e-5 of a step of the reference's f32 expression
@@ -127,13 +127,6 @@ enum nbx_option {
     NBX_OPT_BH_WAVE = 9,           /* 1 (default): with the device-built tree, walk the tree once per WAVE (node
                                     * records through the scalar cache, lanes park on accepted subtrees); 0: one
                                     * independent walk per lane. Bit-identical results either way */
-    NBX_OPT_BH_FALLBACKS = 10,     /* read only (nbx_get_option): Barnes-Hut evaluations since the engine was created that the
-                                    * device tree was selected for but the host tree served: builds the device refused (node
-                                    * pool exhausted; EPS clusters it cannot reproduce under NBX_OPT_BH_FOLD = 1) plus the steps
-                                    * sent straight to the host build after refusals in a row (2, 4 .. 32 steps, then the
-                                    * device is tried again; env NBX_BH_BACKOFF_MAX = longest run, 0 = always try the device) */
-    NBX_OPT_BH_LAST_TREE = 11,     /* read only: where the tree of the last Barnes-Hut evaluation was built: 0 host, 1 device */
-    NBX_OPT_DRAW_AMBIGUOUS = 12,   /* read only: tails the last device draw left to the host; -1 = the last draw ran on the host */
     NBX_OPT_STRICT_KERNEL = 13,    /* bit-exact all-pairs kernel: 0 = by targets per GPU (default), 16 or 8 = workgroups of that
                                     * many waves per 64 targets (term producers + one summing wave), 1 = one thread per body.
                                     * Bit-identical results whichever runs */
@@ -147,19 +140,6 @@ enum nbx_option {
                                     * build's verdict (node count, EPS clusters); walk and kick-drift check it on the device, the
                                     * host at the next call that needs the state (nbx_synchronize, get, draw, the next step) and
                                     * redoes the step on the host tree if the build had to refuse. 0: wait inside the step */
-    NBX_OPT_BH_WALK_RECORDS = 16,  /* wave walk of a device-built exact-sum tree: 16 = from a compact copy of the tree (16-byte
-                                    * decision records + a mass word per node, written next to the 32-byte records), 32 or -1
-                                    * (default) = from the 32-byte records. Bit-identical results; the compact copy moves 15 % fewer
-                                    * bytes and is 20-26 % SLOWER (its second scalar load per visit): kept as the measured A/B of
-                                    * round 3, profiles/r03_bh_walk_records_ab.jsonl */
-    NBX_OPT_BH_REFUSAL = 17,       /* read only: why the last device tree build that handed its evaluation to the host build did so
-                                    * (0: none has yet) -- 0x10000 = the node pool or the fold queue overflowed; else bits of the
-                                    * cluster replay (NBX_OPT_BH_FOLD = 1): 1 more than 512 entities around one point, 4 a cluster
-                                    * of more than 48 entities / 96 bodies, 8 a merge hinges on another cluster, 16 an outsider
-                                    * within EPS of a blob's centre, 32 two entities in one level-31 cell that do not merge,
-                                    * 64 more than 4 096 bodies to move, 128 a blob's successive centres part ways above its
-                                    * leaf, 512 (bit-exact mode) a leaf deeper than 25 levels, where the reference may panic, 256 a leaf of more bodies than the leaf fold orders; exact-sum class: 0x20000 = more
-                                    * bodies left unmerged than it tolerates */
     NBX_OPT_BH_WALK = 18,          /* fast-mode Barnes-Hut traversal: 1 (default) = over CHILD GROUPS (round 4, bh_walk.hip): the tree is
                                     * re-laid every step as one record per opened node -- its children's (x, y, m, T), T = the
                                     * reference's opening test s/sqrt(d^2) < theta turned into one exact threshold on d^2
@@ -169,14 +149,6 @@ enum nbx_option {
                                     * K3).  0 = the node-by-node walk of rounds 1-3 (bh_eval.hip).  All make the reference's
                                     * decision for every body and node; 0 differs from 1 / 2 in the order the terms are added
                                     * (the fast mode's stated tolerance) */
-    NBX_OPT_BH_WALK_ORDER = 19,    /* child-group walk, two rounds of walks or more (> 8 192 waves): 1 = launch the walks longest first
-                                    * within every XCD's share, by the number of groups each loaded in the previous step; 0 (default) =
-                                    * in Morton order.  The order changes no result.  Kept as the measured A/B of round 4: the kernel's
-                                    * tail (29 % of the wave slots idle) suggested it, but walks that are neighbours in space then no
-                                    * longer run side by side and what the tail gains the L2 loses: traversal 0.449 vs 0.430 ms at
-                                    * 1 048 576 bodies, no difference at 262 144.  A stable variant (NBX_WALK_CLASSES = 2 ... 16 cost
-                                    * classes, Morton order kept inside a class; what the option now runs) is slower the more classes
-                                    * it has: 0.443 / 0.456 / 0.464 / 0.479 ms with 2 / 4 / 8 / 16 against 0.431 */
     NBX_OPT_BH_FUSE_KICK = 20,     /* child-group walk, wave form, one GPU: 1 (default) = the walk kernel applies the step's kick-drift
                                     * itself as soon as a body's acceleration is complete (same operations, bit-identical state: a walk
                                     * reads no other body's position from the particle array -- the group records hold copies);
@@ -184,6 +156,26 @@ enum nbx_option {
                                     * 0.8375 -> 0.8252 at 1 048 576) */
     NBX_OPT_SOURCE_PRECISION = 6   /* 32 (default) or 16: all-pairs SOURCES read from a half4 (x,y,z,m) copy, 8 B/body;
                                     * targets, accumulators and the integrated state stay fp32 (fast mode only) */
+};
+
+/* What an engine has done so far (read only; nbx_get_stat).  Rounds 1-4 carried these among the options (10, 11, 12, 17). */
+enum nbx_stat {
+    NBX_STAT_BH_FALLBACKS = 0,     /* Barnes-Hut evaluations since the engine was created that the
+                                    * device tree was selected for but the host tree served: builds the device refused (node
+                                    * pool exhausted; a warm sort whose buckets overflowed; EPS clusters it cannot reproduce under NBX_OPT_BH_FOLD = 1) plus the steps
+                                    * sent straight to the host build after refusals in a row (2, 4 .. 32 steps, then the
+                                    * device is tried again; env NBX_BH_BACKOFF_MAX = longest run, 0 = always try the device) */
+    NBX_STAT_BH_LAST_TREE = 1,     /* where the tree of the last Barnes-Hut evaluation was built: 0 host, 1 device */
+    NBX_STAT_DRAW_AMBIGUOUS = 2,   /* tails the last device draw left to the host; -1 = the last draw ran on the host */
+    NBX_STAT_BH_REFUSAL = 3        /* why the last device tree build that handed its evaluation to the host build did so
+                                    * (0: none has yet) -- 0x10000 = the node pool or the fold queue overflowed; 0x100000 = a bucket of the warm sort outgrew its
+                                    * slots (bh_build.hip, round 5); else bits of the
+                                    * cluster replay (NBX_OPT_BH_FOLD = 1): 1 more than 512 entities around one point, 4 a cluster
+                                    * of more than 48 entities / 96 bodies, 8 a merge hinges on another cluster, 16 an outsider
+                                    * within EPS of a blob's centre, 32 two entities in one level-31 cell that do not merge,
+                                    * 64 more than 4 096 bodies to move, 128 a blob's successive centres part ways above its
+                                    * leaf, 512 (bit-exact mode) a leaf deeper than 25 levels, where the reference may panic, 256 a leaf of more bodies than the leaf fold orders; exact-sum class: 0x20000 = more
+                                    * bodies left unmerged than it tolerates */
 };
 
 enum nbx_kernel_id {
@@ -222,6 +214,7 @@ int64_t nbx_get_option(const nbx_engine *e, int32_t option);
 /* as nbx_get_option with the status apart from the value: -1 is a legitimate value of some options ("by size" of
  * NBX_OPT_DRAW_DEVICE / NBX_OPT_BH_TREE, "the last draw ran on the host" of NBX_OPT_DRAW_AMBIGUOUS) and also NBX_ERR_INVALID */
 int32_t nbx_query_option(const nbx_engine *e, int32_t option, int64_t *value);
+int64_t nbx_get_stat(const nbx_engine *e, int32_t stat); /* enum nbx_stat; -1 for an unknown one */
 
 /* Presets: same sampling as nbody.rs:39-104, but from a seedable generator (splitmix64 -> top 24
  * bits -> [0,1) f32, the rand 0.3 `next_f32` construction). */

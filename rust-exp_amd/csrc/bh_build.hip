@@ -1008,19 +1008,12 @@ __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, c
                                                 const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const Prefix pre,
                                                 const int n, const int node_cap, BhNode* __restrict__ out, const int fold,
                                                 int4* __restrict__ big, const int big_cap, int* __restrict__ counters,
-                                                const int root_aside, BhWalk16* __restrict__ walk16, float* __restrict__ wmass,
-                                                const unsigned char* __restrict__ pmin)
+                                                const int root_aside, const unsigned char* __restrict__ pmin)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = pre.base[n];
     if (k < total && total <= node_cap) {
         emit_node(sb, keys, idx, box, pre, n, out, fold, big, big_cap, counters, root_aside, k, pmin);
-        if (walk16) {   // the compact copy for the wave-uniform walk (fold = 0: every record is final here)
-            const float4* src = reinterpret_cast<const float4*>(&out[k]);
-            const float4 a = src[0], c = src[1];
-            walk16[k] = BhWalk16{a.x, a.y, c.z, __float_as_int(c.x)};
-            wmass[k] = a.z;
-        }
     }
 }
 
@@ -1850,9 +1843,20 @@ __global__ __launch_bounds__(kTile) void k_keys_scatter(const float4* __restrict
     for (int r = 0; r < EA; r++) { const float4 p = posm[id[r]]; px[r] = p.x; py[r] = p.y; }
     {   // the splitters: of the S ranked candidates, those of rank q * (S / B) - 1, q = 1 .. B - 1, ascending
         const int per = samples / buckets;     // = kOversample (samples = kOversample * buckets)
-        for (int i = tid; i < samples; i += kTile) {
-            const int r = srank[i] + 1;
-            if (r % per == 0 && r / per < buckets) s[r / per - 1] = skeys[i];
+        constexpr int kFlight = 8;             // ranks in flight per thread (one at a time: 26 dependent round trips, 11 us of this kernel)
+        for (int i0 = tid; i0 < samples; i0 += kFlight * kTile) {
+            int r[kFlight];
+#pragma unroll
+            for (int u = 0; u < kFlight; u++) { const int i = i0 + u * kTile; r[u] = i < samples ? srank[i] + 1 : 1; }
+            unsigned long long key[kFlight];
+#pragma unroll
+            for (int u = 0; u < kFlight; u++) {
+                const int i = i0 + u * kTile;
+                key[u] = skeys[i < samples ? i : 0];       // (unconditional: the load does not wait for the rank)
+            }
+#pragma unroll
+            for (int u = 0; u < kFlight; u++)
+                if (i0 + u * kTile < samples && r[u] % per == 0 && r[u] / per < buckets) s[r[u] / per - 1] = key[u];
         }
     }
     for (int b = tid; b < buckets; b += kTile) hist[b] = 0;
@@ -2416,9 +2420,8 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters /* pinned, >= 4 ints; null: the caller's gated kick-drift publishes them */,
                                    const unsigned** perm_dev, hipStream_t stream, int fold,
-                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, BhWalk16* walk16, float* wmass, bool depth_panic_guard, bool warm)
+                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, bool depth_panic_guard, bool warm)
 {
-    if (fold != 0) { walk16 = nullptr; wmass = nullptr; }   // (the fold kernels write centres and masses after k_emit)
     *perm_dev = nullptr;
     if (n <= 0) return hipSuccess;
     size_t sort_tmp = 0;
@@ -2471,7 +2474,7 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     // base[n] leave at once; the pool check is inside)
     const int eb = n <= 65536 ? 64 : kTile;   // spread a small system's few waves over the CUs
     hipLaunchKernelGGL(k_emit, dim3((unsigned)((node_cap + eb - 1) / eb)), dim3(eb), 0, stream, ms, mk, mi, k.box, k.pre, n, node_cap, out,
-                       fold, k.big, n, k.counters, (root_aside ? 1 : 0) | (depth_panic_guard ? 2 : 0), walk16, wmass, pmin);
+                       fold, k.big, n, k.counters, (root_aside ? 1 : 0) | (depth_panic_guard ? 2 : 0), pmin);
     if (fold == 1) {
         // one pair of waves per queued node; the count lives on the device: enough workgroups for every plausible queue
         // (a uniform system queues ~n/5 nodes), they loop when there are more

@@ -167,65 +167,6 @@ __global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave(const float4* 
     if (valid) out[it] = make_float2(ax, ay);
 }
 
-// The same walk over the COMPACT copy of the tree (BhWalk16 + mass words): a visit decides on 16 bytes, and the mass of a taken
-// node is requested behind the decision and used one visit later, after the next record has been requested -- so it never sits
-// between a record and the next index.  Same decisions, same contributions in the same order: bit-identical results.  `nodes`
-// (the 32-byte records) is read only for the exact re-test inside the 1e-5 band (the node's size s).
-template <int BPW>
-__global__ __launch_bounds__(kWaveBlock) void k_bh_eval_fast_wave16(const float4* __restrict__ posm, const int lo,
-                                                                    const int n_targets, const BhNode* __restrict__ nodes,
-                                                                    const BhWalk16* __restrict__ walk, const float* __restrict__ wmass,
-                                                                    int n_nodes, const float theta, float2* __restrict__ out,
-                                                                    const unsigned* __restrict__ perm, const int xcd_order,
-                                                                    const BuildGate gate)
-{
-    if (!gate_open(gate, n_nodes)) return;
-    const int blk = xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int t = blk * BPW + threadIdx.x;
-    const bool valid = (int)threadIdx.x < BPW && t < n_targets;
-    if (__ballot(valid) == 0ull) return;
-    const int it = valid ? (perm ? (int)perm[t] - lo : t) : 0;
-    const float4 pi = posm[lo + it];
-    const float th2 = theta > 0.0f ? theta * theta : 0.0f;
-    const float th2_lo = th2 * (1.0f - 1.0e-5f), th2_hi = th2 * (1.0f + 1.0e-5f);
-    float ax = 0.0f, ay = 0.0f;
-    int r = valid ? 0 : 0x7FFFFFFF;
-    int i = 0;
-    // the visit whose contribution is still owed: its lanes, their d, and the node's mass (requested, not yet used)
-    bool take_p = false;
-    float dx_p = 0.0f, dy_p = 0.0f, d2_p = 1.0f, m_p = 0.0f;
-    while (i < n_nodes) {
-        const unsigned iu = (unsigned)__builtin_amdgcn_readfirstlane(i);
-        const float4 rec = *reinterpret_cast<const float4*>(&walk[iu]);
-        if (take_p) {   // the previous visit's term, in walk order
-            const float s = m_p * __builtin_amdgcn_rcpf(d2_p + kEps);
-            ax = __builtin_fmaf(s, dx_p, ax);
-            ay = __builtin_fmaf(s, dy_p, ay);
-        }
-        const int skip = __float_as_int(rec.w);
-        const float q = rec.z;
-        const float dx = rec.x - pi.x;
-        const float dy = rec.y - pi.y;
-        const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-        bool take = q < th2_lo * d2;
-        const bool below_hi = q <= th2_hi * d2;
-        if (__builtin_expect((__ballot(below_hi) & ~__ballot(take)) != 0ull, 0)) {   // in the band: the reference's own test
-            if (below_hi && !take) take = take_node_exact(nodes[iu].s, dx, dy, theta);
-        }
-        take = take && (r <= i);
-        take_p = take; dx_p = dx; dy_p = dy; d2_p = d2;
-        if (take) r = skip;
-        m_p = wmass[iu];                                // requested now, used after the next record has been requested
-        i = (__ballot(r <= i) != 0ull) ? i + 1 : skip;
-    }
-    if (take_p) {
-        const float s = m_p * __builtin_amdgcn_rcpf(d2_p + kEps);
-        ax = __builtin_fmaf(s, dx_p, ax);
-        ay = __builtin_fmaf(s, dy_p, ay);
-    }
-    if (valid) out[it] = make_float2(ax, ay);
-}
-
 __global__ __launch_bounds__(kTile) void k_bh_eval_strict(const float4* __restrict__ posm, const int lo,
                                                           const int n_targets, const BhNode* __restrict__ nodes,
                                                           const int n_nodes, const float theta,
@@ -492,7 +433,7 @@ hipError_t launch_bh_count(const float4* posm, int lo, int n_targets, const BhNo
 
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
                           int mode, float2* force_out, hipStream_t stream, const unsigned* perm, int* gate_counters,
-                          int gate_node_cap, int gate_crowd_limit, int gate_queue_limit, const BhWalk16* walk16, const float* wmass)
+                          int gate_node_cap, int gate_crowd_limit, int gate_queue_limit)
 {
     if (n_targets <= 0) return hipSuccess;
     const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit, nullptr};
@@ -526,17 +467,7 @@ hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNod
             hipLaunchKernelGGL(kernel, g, dim3(kWaveBlock), 0, stream, posm, lo, n_targets, nodes, n_nodes, theta, force_out, perm,
                                xcd_order, gate);
         };
-        auto go16 = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, g, dim3(kWaveBlock), 0, stream, posm, lo, n_targets, nodes, walk16, wmass, n_nodes, theta,
-                               force_out, perm, xcd_order, gate);
-        };
-        if (walk16 && wmass) {
-            if (bpw == 64) go16(k_bh_eval_fast_wave16<64>);
-            else if (bpw == 32) go16(k_bh_eval_fast_wave16<32>);
-            else if (bpw == 16) go16(k_bh_eval_fast_wave16<16>);
-            else go16(k_bh_eval_fast_wave16<8>);
-        }
-        else if (bpw == 64) go(k_bh_eval_fast_wave<64>);
+        if (bpw == 64) go(k_bh_eval_fast_wave<64>);
         else if (bpw == 32) go(k_bh_eval_fast_wave<32>);
         else if (bpw == 16) go(k_bh_eval_fast_wave<16>);
         else if (bpw == 8) go(k_bh_eval_fast_wave<8>);

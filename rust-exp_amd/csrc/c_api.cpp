@@ -65,7 +65,7 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
     switch (option) {   // a step that is still in flight was issued under the CURRENT options: settle it (and redo it, if its device
                         // build was refused) before any option that shapes a step changes
         case NBX_OPT_FORCE_MODE: case NBX_OPT_BH_TREE: case NBX_OPT_BH_FOLD: case NBX_OPT_BH_WAVE: case NBX_OPT_BH_ASYNC:
-        case NBX_OPT_SOURCE_PRECISION: case NBX_OPT_BH_WALK: case NBX_OPT_BH_WALK_RECORDS: case NBX_OPT_BH_WALK_ORDER: case NBX_OPT_BH_FUSE_KICK: {
+        case NBX_OPT_SOURCE_PRECISION: case NBX_OPT_BH_WALK: case NBX_OPT_BH_FUSE_KICK: {
             const int rc = resolve_pending(e);
             if (rc != NBX_OK) return rc;
             break;
@@ -82,7 +82,7 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
             e->jsplit = (int)value;
             return NBX_OK;
         case NBX_OPT_BODIES_PER_THREAD:
-            if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NBX_ERR_INVALID, "bodies/thread must be 0,1,2,4");
+            if (value != 0 && value != 2 && value != 4) return fail(NBX_ERR_INVALID, "bodies/thread must be 0 (auto), 2 or 4 (packed pairs)");
             e->bpt = (int)value;
             return NBX_OK;
         case NBX_OPT_DIM:
@@ -103,7 +103,8 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
         case NBX_OPT_KERNEL_VARIANT:
             // (17 / 18 are what the engine REPORTS for the fp16-source sweeps; K2 and the force readout key off them, so a caller
             //  must not be able to set them)
-            if (value < -1 || value > 7) return fail(NBX_ERR_INVALID, "kernel variant must be -1 (auto) or 0..7");
+            if (value != -1 && value != 1 && value != 6 && value != 7)
+                return fail(NBX_ERR_INVALID, "kernel variant must be -1 (auto), 1 (LDS tiles), 6 or 7 (scalar-cache sweep, wave split)");
             e->variant = (int)value;
             return NBX_OK;
         case NBX_OPT_STRICT_KERNEL:
@@ -128,17 +129,9 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
                 return fail(NBX_ERR_INVALID, "bh walk must be 1 (child groups), 2 (child groups, compiled loop) or 0 (node walk)");
             e->bh_walk = (int)value;
             return NBX_OK;
-        case NBX_OPT_BH_WALK_ORDER:
-            e->bh_walk_lpt = value ? 1 : 0;
-            e->walk_order_walks = 0;
-            return NBX_OK;
         case NBX_OPT_BH_FUSE_KICK:
             if (value != 0 && value != 1) return fail(NBX_ERR_INVALID, "bh fuse kick must be 0 or 1");
             e->bh_fuse_kick = (int)value;
-            return NBX_OK;
-        case NBX_OPT_BH_WALK_RECORDS:
-            if (value != 16 && value != 32 && value != -1) return fail(NBX_ERR_INVALID, "walk records must be 16, 32 or -1 (by size)");
-            e->bh_walk_records = (int)value;
             return NBX_OK;
         case NBX_OPT_BH_FOLD:
             if (value != 0 && value != 1 && value != -1) return fail(NBX_ERR_INVALID, "bh fold must be 0 (exact sums), 1 (reference fold) or -1 (by size)");
@@ -161,8 +154,6 @@ int32_t nbx_set_option(nbx_engine* e, int32_t option, int64_t value)
 int64_t nbx_get_option(const nbx_engine* e, int32_t option)
 {
     if (!e) return NBX_ERR_INVALID;
-    if (e->any_pending() && (option == NBX_OPT_BH_FALLBACKS || option == NBX_OPT_BH_LAST_TREE))
-        (void)resolve_pending(const_cast<nbx_engine*>(e));   // what the last step ran on is known once its build's verdict is read
     switch (option) {
         case NBX_OPT_FORCE_MODE: return e->force_mode;
         case NBX_OPT_JSPLIT: return e->jsplit;
@@ -177,26 +168,42 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
         case NBX_OPT_BH_WAVE: return e->bh_wave;
         case NBX_OPT_BH_FOLD: return e->bh_fold;
         case NBX_OPT_BH_ASYNC: return e->bh_async;
-        case NBX_OPT_BH_WALK_RECORDS: return e->bh_walk_records;
         case NBX_OPT_BH_WALK: return e->bh_walk;
-        case NBX_OPT_BH_WALK_ORDER: return e->bh_walk_lpt;
         case NBX_OPT_BH_FUSE_KICK: return e->bh_fuse_kick;
-        case NBX_OPT_BH_FALLBACKS: return e->bh_fallbacks;
-        case NBX_OPT_BH_LAST_TREE: return e->bh_last_tree_device;
-        case NBX_OPT_BH_REFUSAL: return e->bh_last_refusal;
-        case NBX_OPT_DRAW_AMBIGUOUS: return e->draw_ambiguous;
         default: return NBX_ERR_INVALID;
     }
 }
 
-// nbx_get_option cannot tell the legitimate value -1 ("auto" of NBX_OPT_DRAW_DEVICE / NBX_OPT_BH_TREE, "host draw" of
-// NBX_OPT_DRAW_AMBIGUOUS) from NBX_ERR_INVALID: this form returns the status and the value separately.
+// What the engine has done so far (enum nbx_stat; rounds 1-4 had these among the options).  INT64_MIN for an unknown one:
+// -1 is a legitimate value of NBX_STAT_DRAW_AMBIGUOUS ("the last draw ran on the host").
+int64_t nbx_get_stat(const nbx_engine* e, int32_t stat)
+{
+    if (!e) return INT64_MIN;
+    if (e->any_pending() && (stat == NBX_STAT_BH_FALLBACKS || stat == NBX_STAT_BH_LAST_TREE || stat == NBX_STAT_BH_REFUSAL))
+        (void)resolve_pending(const_cast<nbx_engine*>(e));   // what the last step ran on is known once its build's verdict is read
+    switch (stat) {
+        case NBX_STAT_BH_FALLBACKS: return e->bh_fallbacks;
+        case NBX_STAT_BH_LAST_TREE: return e->bh_last_tree_device;
+        case NBX_STAT_BH_REFUSAL: return e->bh_last_refusal;
+        case NBX_STAT_DRAW_AMBIGUOUS: return e->draw_ambiguous;
+        default: return INT64_MIN;
+    }
+}
+
+// nbx_get_option cannot tell the legitimate value -1 ("auto" of NBX_OPT_DRAW_DEVICE / NBX_OPT_BH_TREE / NBX_OPT_BH_FOLD) from
+// NBX_ERR_INVALID: this form returns the status and the value separately.
 int32_t nbx_query_option(const nbx_engine* e, int32_t option, int64_t* value)
 {
     if (!e) return fail(NBX_ERR_INVALID, "null engine");
-    if (option < NBX_OPT_FORCE_MODE || option > NBX_OPT_BH_FUSE_KICK) return fail(NBX_ERR_INVALID, "unknown option %d", option);
-    if (value) *value = nbx_get_option(e, option);
-    return NBX_OK;
+    switch (option) {
+        case NBX_OPT_FORCE_MODE: case NBX_OPT_JSPLIT: case NBX_OPT_BODIES_PER_THREAD: case NBX_OPT_DIM: case NBX_OPT_PROFILE:
+        case NBX_OPT_KERNEL_VARIANT: case NBX_OPT_SOURCE_PRECISION: case NBX_OPT_DRAW_DEVICE: case NBX_OPT_BH_TREE: case NBX_OPT_BH_WAVE:
+        case NBX_OPT_STRICT_KERNEL: case NBX_OPT_BH_FOLD: case NBX_OPT_BH_ASYNC: case NBX_OPT_BH_WALK: case NBX_OPT_BH_FUSE_KICK:
+            if (value) *value = nbx_get_option(e, option);
+            return NBX_OK;
+        default:
+            return fail(NBX_ERR_INVALID, "unknown option %d", option);
+    }
 }
 
 int32_t nbx_seed(nbx_engine* e, uint64_t seed)
@@ -750,7 +757,9 @@ int32_t nbx_bh_walk_trace(nbx_engine* e, float theta, int32_t cap_walks, uint64_
     rc = resolve_pending(e);
     if (rc != NBX_OK) return rc;
     const int slab = e->slab();
-    const int walks = nbx::bh_walk_count(slab);
+    int walks = nbx::bh_walk_count(slab);
+    if (walks > 8192 && e->walk_split_pct > 0)   // (the round-5 experiment: the costliest walks run as two workgroups)
+        walks = (walks + (int)((long long)walks * e->walk_split_pct / 100) + 7) / 8 * 8;
     if (walks > cap_walks) return walks;
     HIP_TRY(hipSetDevice(e->device));
     unsigned long long* d = nullptr;

@@ -211,19 +211,20 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
     //    interactions) when every body has the same mass, else variant 6 (10 + 2); LDS tiles (variant 1) below that size.
     //  * variants 6 / 7: 256 targets per workgroup, S = smallest power of two giving >= 32 workgroups per CU (64 when a GPU
     //    owns < 131072 targets: tail effect), at most 64 and at least 4 source tiles per workgroup (one per wave).
-    //    N = 262144: S = 8 (34 MB of partial slabs per launch; variant 5 wrote 134 MB; S = 8..32 are within 1 % of each
+    //    N = 262144: S = 8 (34 MB of partial slabs per launch; S = 8..32 are within 1 % of each
     //    other), N = 65536: S = 64, 32768 targets x 262144 sources (8-way shard): S = 64.
-    //  * other variants: register blocking 4 (two packed pairs) when a GPU owns >= 32768 targets, else 2; S = smallest power
-    //    of two giving >= 32 workgroups per CU (64 for variant 5 with < 131072 targets), capped at 64 and half the tiles.
+    //  * variant 1: register blocking 4 (two packed pairs) when a GPU owns >= 32768 targets, else 2; S = smallest power
+    //    of two giving >= 32 workgroups per CU, capped at 64 and half the tiles.
     *dim = e->dim_opt ? e->dim_opt : (e->any_z ? 3 : 2);
     int v = e->variant;
     if (v < 0) v = (tiles_total * kTile >= 16384) ? 7 : 1;   // crossover measured in profiles/r02_small_n_variants.txt
+    if (v != 1 && v != 6 && v != 7) v = 1;      // (nbx_set_option admits no other)
     if (v == 7 && !e->unit_sweep_ok()) v = 6;   // unit-mass sweep needs one common mass (+ at most a handful of exceptions)
     *variant = v;
     // 256 targets per workgroup, 4 source quarters per workgroup; the fp16-source kernel (K4) keeps the 1024-target workgroups
     const bool wave_split = (v == 6 || v == 7);
     int b = wave_split ? 4 : (e->bpt ? e->bpt : (n_targets >= 32768 ? 4 : 2));
-    if (b != 1 && b != 2 && b != 4) b = 2;
+    if (b != 2 && b != 4) b = 2;                // packed pairs: two or four targets per thread
     *bpt = b;
     int s = e->jsplit;
     if (s <= 0) {
@@ -231,7 +232,7 @@ void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* var
         const int iblocks = (n_targets + per_wg - 1) / per_wg;
         // 64 workgroups per CU only where targets are scarce (sharded shapes: tail effect); 32 otherwise --
         // same speed at N = 262144 on one GPU and half the partial-slab traffic
-        const int want = e->cu_count * (((wave_split || v == 5) && n_targets < 131072) ? 64 : 32);
+        const int want = e->cu_count * ((wave_split && n_targets < 131072) ? 64 : 32);
         s = 1;
         while (iblocks * s < want && s < 64) s *= 2;
         // every workgroup keeps >= 2 tiles of sources; a wave-split workgroup >= 4 (one per wave).  Tiny systems (at most one
@@ -254,10 +255,6 @@ int launch_forces_fast(nbx_engine* e)
     const int stride = ((slab + kTile - 1) / kTile) * kTile;
     int rc = grow(&e->d_acc, &e->acc_cap, (size_t)jsplit * (size_t)std::max(stride, kTile));
     if (rc != NBX_OK) return rc;
-    if (variant == 4) {
-        rc = grow(&e->d_guard, &e->guard_cap, 1);
-        if (rc != NBX_OK) return rc;
-    }
     if (e->source_half && !(variant == 6 || variant == 7)) {   // small systems: the LDS-tile sweep on the half4 copy
         ProfScope ps(e, NBX_K_FORCE);
         HIP_TRY(nbx::launch_force_tile_half(e->d_posm, e->d_posh, e->lo, slab, tiles_total, jsplit, bpt, dim, e->d_acc,
@@ -284,8 +281,7 @@ int launch_forces_fast(nbx_engine* e)
     }
     {
         ProfScope ps(e, NBX_K_FORCE);
-        HIP_TRY(nbx::launch_force_tile(e->d_posm, e->lo, slab, tiles_total, jsplit, bpt, dim, variant, e->d_acc, stride,
-                                       variant == 4 ? e->d_guard : nullptr, e->stream, &e->last));
+        HIP_TRY(nbx::launch_force_tile(e->d_posm, e->lo, slab, tiles_total, jsplit, bpt, dim, e->d_acc, stride, e->stream, &e->last));
     }
     return NBX_OK;
 }
@@ -544,20 +540,10 @@ int build_tree_on_device_begin(nbx_engine* e, int* host_counters, bool publish_b
         HIP_TRY(hipEventCreateWithFlags(&e->ev_side_go, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_side_done, hipEventDisableTiming));
     }
-    // compact copy for the wave walk: opt-in (measured slower, profiles/r03_bh_walk_records_ab.jsonl), exact-sum trees only (every
-    // record is final when k_emit writes it)
-    const bool want16 = fold == 0 && e->bh_wave && e->bh_walk_records == 16;
-    if (want16) {
-        int rc16 = grow(&e->d_walk16, &e->walk16_cap, (size_t)node_cap);
-        if (rc16 == NBX_OK) rc16 = grow(&e->d_wmass, &e->wmass_cap, (size_t)node_cap);
-        if (rc16 != NBX_OK) return rc16;
-    }
-    e->walk16_valid = want16;
     ProfScope ps(e, NBX_K_TREE_BUILD);
     HIP_TRY(nbx::device_tree_build_begin(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes,
                                          publish_by_kernel ? nullptr : (host_counters ? host_counters : e->h_counters), &e->d_perm,
                                          e->stream, fold, e->side_stream, e->ev_side_go, e->ev_side_done,
-                                         want16 ? e->d_walk16 : nullptr, want16 ? e->d_wmass : nullptr,
                                          /*depth_panic_guard=*/e->force_mode != 0, /*warm=*/e->sort_warm_n == e->n));
     e->sort_warm_n = e->n;   // (a refusal -- of this build, or of one whose verdict is still in flight -- takes it back)
     return NBX_OK;
@@ -671,38 +657,44 @@ int launch_fast_walk(nbx_engine* e, float theta, const unsigned* perm, bool wave
         if (rc != NBX_OK) return rc;
         HIP_TRY(nbx::launch_bh_groups(e->d_nodes, nodes_or_cap, theta, e->d_groups, /*compact=*/on_device, e->stream, gate, gate_node_cap,
                                       gate_crowd_limit, gate_queue_limit));
-        // Two rounds of walks or more (> 8192 of them on the chip's 8192 wave slots): launch them longest first, by the costs the
-        // previous step's walks left behind (a stale or missing order costs time, never a result)
-        const int* order = nullptr;
+        // EXPERIMENT (NBX_WALK_SPLIT_PCT = p > 0; off by default): two rounds of walks or more (> 8192 of them on the chip's 8192 wave
+        // slots) -- the p percent that loaded the most groups in the previous step run as two halves of 32 bodies, in Morton order
+        // (bh_walk.hip k_walk_split_list; a stale or missing list costs time, never a result)
+        const int* list = nullptr;
         int* cost = nullptr;
-        const int walks = (wave && perm && e->bh_walk == 1 && e->bh_walk_lpt) ? nbx::bh_walk_count(slab) : 0;
+        int bpw = 0;
+        int walks = (wave && perm && e->bh_walk == 1 && e->walk_split_pct > 0) ? nbx::bh_walk_count(slab, &bpw) : 0;
+        if (bpw != 64) walks = 0;          // (halves are halves of 64-body walks)
+        const int budget = walks > 8192 ? (int)((long long)walks * e->walk_split_pct / 100) : 0;
         if (walks > 8192) {
             const size_t had = e->walk_cost_cap;
-            int rc2 = grow(&e->d_walk_cost, &e->walk_cost_cap, (size_t)walks);
-            if (rc2 == NBX_OK) rc2 = grow(&e->d_walk_order, &e->walk_order_cap, (size_t)walks);
+            int rc2 = grow(&e->d_walk_cost, &e->walk_cost_cap, 2 * (size_t)walks);
+            if (rc2 == NBX_OK) rc2 = grow(&e->d_walk_list, &e->walk_list_cap, (size_t)walks + (size_t)budget + 8);
             if (rc2 != NBX_OK) return rc2;
-            if (e->walk_cost_cap != had) {   // fresh memory: walks that write no cost (no body of theirs in the slab; a refused, gated step) read as zero
+            if (e->walk_cost_cap != had || e->walk_list_walks != walks || e->walk_list_slab != slab) {
+                // fresh memory or another shape: walks that write no cost (no body of theirs in the slab; a refused, gated step) read as zero
                 HIP_TRY(hipMemsetAsync(e->d_walk_cost, 0, sizeof(int) * e->walk_cost_cap, e->stream));
-                e->walk_order_walks = 0;
+                e->walk_list_walks = 0;
+                e->walk_cost_flip = 0;
             }
-            cost = e->d_walk_cost;
-            if (e->walk_order_walks == walks && e->walk_order_slab == slab) order = e->d_walk_order;
+            cost = e->d_walk_cost + (e->walk_cost_flip ? walks : 0);
+            if (e->walk_list_walks == walks && e->walk_list_slab == slab) list = e->d_walk_list;
         }
         if (e->d_walk_trace && wave && perm) e->walk_traced = true;
         HIP_TRY(nbx::launch_bh_walk_groups(e->d_posm, e->lo, slab, e->d_groups, e->d_f2, e->stream, perm, wave, e->bh_walk == 1, gate,
-                                           gate_node_cap, gate_crowd_limit, gate_queue_limit, order, cost, e->d_walk_trace, kick));
+                                           gate_node_cap, gate_crowd_limit, gate_queue_limit, list, cost, e->d_walk_trace, kick, budget));
         if (cost) {
-            HIP_TRY(nbx::launch_walk_order(cost, e->d_walk_order, walks, e->stream));
-            e->walk_order_walks = walks;
-            e->walk_order_slab = slab;
+            int* next = e->d_walk_cost + (e->walk_cost_flip ? 0 : walks);
+            HIP_TRY(nbx::launch_walk_split_list(cost, next, e->d_walk_list, walks, budget, e->stream));
+            e->walk_cost_flip ^= 1;
+            e->walk_list_walks = walks;
+            e->walk_list_slab = slab;
         }
         return NBX_OK;
     }
     if (kick) return fail(NBX_ERR_STATE, "kick-drift handed to a walk that cannot apply it");
-    const bool w16 = on_device && wave && e->walk16_valid;
     HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, wave ? 2 : 0, e->d_f2, e->stream, perm, gate,
-                                gate_node_cap, gate_crowd_limit, gate_queue_limit, w16 ? e->d_walk16 : nullptr,
-                                w16 ? e->d_wmass : nullptr));
+                                gate_node_cap, gate_crowd_limit, gate_queue_limit));
     return NBX_OK;
 }
 
@@ -964,9 +956,7 @@ void free_device(nbx_engine* e)
     if (e->d_nodes) (void)hipFree(e->d_nodes);
     if (e->d_groups) (void)hipFree(e->d_groups);
     if (e->d_walk_cost) (void)hipFree(e->d_walk_cost);
-    if (e->d_walk_order) (void)hipFree(e->d_walk_order);
-    if (e->d_walk16) (void)hipFree(e->d_walk16);
-    if (e->d_wmass) (void)hipFree(e->d_wmass);
+    if (e->d_walk_list) (void)hipFree(e->d_walk_list);
     if (e->d_guard) (void)hipFree(e->d_guard);
     if (e->d_exc_idx) (void)hipFree(e->d_exc_idx);
     if (e->d_src4) (void)hipFree(e->d_src4);

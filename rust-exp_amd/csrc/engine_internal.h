@@ -49,29 +49,26 @@ struct nbx_engine {
     size_t out4_cap = 0;
     nbx::BhNode* d_nodes = nullptr;
     size_t nodes_cap = 0;
-    nbx::BhWalk16* d_walk16 = nullptr;   // compact copy of the device-built tree for the wave walk (NBX_OPT_BH_WALK_RECORDS)
-    float* d_wmass = nullptr;
-    size_t walk16_cap = 0, wmass_cap = 0;
-    int bh_walk_records = -1;            // 16 = the wave walk reads the compact copy (A/B'd in round 3: slower; opt-in), else the 32-byte records
-    bool walk16_valid = false;           // the compact copy describes the tree in d_nodes
     // round 4: the fast walk's copy of the tree, one record of (x, y, m, T) x 4 + child words per opened node (bh_walk.hip);
     // rebuilt from d_nodes by every fast Barnes-Hut evaluation (T depends on the step's theta)
     nbx::BhGroup* d_groups = nullptr;
     size_t groups_cap = 0;
     // longest-first launch order of the walks: costs of the last walk, the order made from them, and what shape they belong to
-    int* d_walk_cost = nullptr;
-    int* d_walk_order = nullptr;
-    size_t walk_cost_cap = 0, walk_order_cap = 0;
-    int walk_order_walks = 0;            // > 0: d_walk_order holds an order for that many walks (same slab, same bodies per walk)
-    int walk_order_slab = 0;
+    // round-5 experiment (NBX_WALK_SPLIT_PCT): the costliest walks of the previous step run as two halves (engine.cpp launch_fast_walk)
+    int* d_walk_cost = nullptr;          // [2][walks]: groups every walk loaded, this step's and the next one's (halves add their share)
+    int* d_walk_list = nullptr;          // [1 + walks + budget]: the launch list made of the previous step's costs
+    size_t walk_cost_cap = 0, walk_list_cap = 0;
+    int walk_list_walks = 0;             // > 0: d_walk_list holds a list for that many walks (same slab, same bodies per walk)
+    int walk_list_slab = 0;
+    int walk_cost_flip = 0;
+    int walk_split_pct = [] { const char* v = std::getenv("NBX_WALK_SPLIT_PCT"); const int p = v ? std::atoi(v) : 0; return p < 0 ? 0 : (p > 100 ? 100 : p); }();
     unsigned long long* d_walk_trace = nullptr;   // nbx_bh_walk_trace: set for the one evaluation it traces
     bool walk_traced = false;                     // ... and whether the walk that ran was the shared (wave) form, the one that writes the trace
-    int bh_walk_lpt = 0;                 // NBX_OPT_BH_WALK_ORDER: 1 = longest-first from the previous step's costs, 0 (default) = Morton order
     int bh_fuse_kick = 1;                // NBX_OPT_BH_FUSE_KICK: 1 (default) = the child-group walk applies the kick-drift itself, 0 = separate kernel
                                          // (measured, round 4: 0.449 vs 0.430 ms at 1 M bodies -- spatially adjacent walks no longer run side by side)
     int bh_walk = 1;                     // NBX_OPT_BH_WALK: 1 = child groups, hand-scheduled loop (default), 2 = child groups, compiled
                                          // loop, 0 = the node walk of rounds 1-3 (bh_eval.hip)
-    unsigned* d_guard = nullptr;   // max|coord| word for the batched-reciprocal kernel
+    unsigned* d_guard = nullptr;   // max|coord| word for the bit-exact kernels' short division
     size_t guard_cap = 0;
     void* d_tree_ws = nullptr;     // device tree build workspace (NBX_OPT_BH_TREE = 1)
     size_t tree_ws_bytes = 0;
@@ -129,7 +126,7 @@ struct nbx_engine {
     // the next 2, 4, .. kBackoffMaxSteps steps go straight to the host build -- counted in bh_fallbacks like the refusals -- and
     // then ONE step tries the device again.  Any replaced state (after_host_state_change) and any accepted build reset it.
     int bh_refusal_streak = 0, bh_host_steps_left = 0;
-    int bh_last_refusal = 0;       // NBX_OPT_BH_REFUSAL: reasons of the last refused device build (status and counter word 5)
+    int bh_last_refusal = 0;       // NBX_STAT_BH_REFUSAL: reasons of the last refused device build (status and counter word 5)
     void note_why(int status, int why) { bh_last_refusal = status == 1 ? 0x10000 : (why ? why : 0x20000); }
     void note_refusal(int max_steps)
     {

@@ -16,6 +16,33 @@
 
 namespace nbx {
 
+// max over all sources of max(|x|,|y|,|z|) as float bits (NaN counts as +inf), into *out (pre-zeroed): the guard word of the
+// short correctly-rounded division below
+__global__ __launch_bounds__(kTile) void k_max_coord(const float4* __restrict__ posm, const int n, unsigned* out)
+{
+    float m = 0.0f;
+    for (int i = blockIdx.x * kTile + threadIdx.x; i < n; i += gridDim.x * kTile) {
+        const float4 p = posm[i];
+        float c = fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z));
+        if (!(c == c) || !(p.x == p.x) || !(p.y == p.y) || !(p.z == p.z)) c = __builtin_inff();
+        m = fmaxf(m, c);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+hipError_t launch_max_coord(const float4* posm, int n_records, unsigned* guard, hipStream_t stream)
+{
+    const hipError_t e = hipMemsetAsync(guard, 0, sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
+    if (n_records <= 0) return hipSuccess;
+    const int blocks = (n_records + kTile - 1) / kTile;
+    hipLaunchKernelGGL(k_max_coord, dim3(blocks < 256 ? blocks : 256), dim3(kTile), 0, stream, posm, n_records, guard);
+    return hipGetLastError();
+}
+
+
 // Correctly rounded a / b.  FASTDIV = false: the compiler's IEEE expansion (v_div_scale x2, v_rcp, five fma/mul,
 // v_div_fmas, v_div_fixup).  FASTDIV = true: the arithmetic core of that same expansion -- reciprocal refined once, quotient
 // refined twice -- without the three range-handling instructions.  The two agree bit for bit whenever v_div_scale has

@@ -21,81 +21,17 @@
 // round-robin over the 8 XCDs (block b -> XCD b % 8), so with jsplit a multiple or divisor of 8 every XCD's
 // private L2 only ever sees its own 1/jsplit of the source array.
 //
-// Variants (NBX_OPT_KERNEL_VARIANT; A/B evidence in DESIGN.md section 6 and profiles/):
-//   5  k_force_smem_pk   packed math, sources through the scalar cache as SGPR operands   <- default, >= 32768 sources
-//   1  k_force_tile_pk   packed math, sources staged through LDS tiles                   <- default below that
-//   4  k_force_tile_pkb  variant 1 + batched reciprocals (guarded)      3  variant 1, 4-source LDS batches
-//   0  k_force_tile      compiler-scheduled scalar math, LDS tiles      2  k_force_smem: scalar math, scalar cache
-// LDS variants: sources stream HBM/L2 -> VGPR (one coalesced 16-B float4 load per lane per tile, issued one
+// Variants (NBX_OPT_KERNEL_VARIANT):
+//   7 / 6  k_force_smem_pkw  packed math, sources through the scalar cache as SGPR operands, the four waves of a workgroup
+//                            share 256 targets and split the source range (7: one common mass)   <- default, >= 16 384 sources
+//   1      k_force_tile_pk   packed math, sources staged through LDS tiles                        <- default below that
+// (Rounds 1-4 also carried 0 = compiler-scheduled LDS tiles, 2 = scalar-cache scalar math, 3 = 4-source LDS batches, 4 = batched
+//  reciprocals, 5 = 6 without the wave split: measured losers, removed in round 5; their A/B numbers: docs/rounds/r01.md, r02.md.)
+// LDS tiles: sources stream HBM/L2 -> VGPR (one coalesced 16-B float4 load per lane per tile, issued one
 // tile ahead) -> LDS (double buffered, ONE barrier per tile) -> broadcast ds_read_b128 (conflict free).
 #include "kernels.h"
 
 namespace nbx {
-
-template <int DIM>
-__device__ __forceinline__ void interact(const float4 sj, const float xi, const float yi, const float zi,
-                                         float& ax, float& ay, float& az)
-{
-    const float dx = sj.x - xi;
-    const float dy = sj.y - yi;
-    float r2 = __builtin_fmaf(dx, dx, kEps);
-    r2 = __builtin_fmaf(dy, dy, r2);
-    float dz = 0.0f;
-    if (DIM == 3) {
-        dz = sj.z - zi;
-        r2 = __builtin_fmaf(dz, dz, r2);
-    }
-    const float s = sj.w * __builtin_amdgcn_rcpf(r2);
-    ax = __builtin_fmaf(s, dx, ax);
-    ay = __builtin_fmaf(s, dy, ay);
-    if (DIM == 3) az = __builtin_fmaf(s, dz, az);
-}
-
-// variant 0: LDS tiles. B bodies per thread, UNROLL sources per inner-loop trip.
-template <int B, int DIM, int UNROLL>
-__global__ __launch_bounds__(kTile) void k_force_tile(const float4* __restrict__ posm, const int lo,
-                                                      const int n_targets, const int tiles_total,
-                                                      const int jsplit, float4* __restrict__ acc_partial,
-                                                      const int acc_stride)
-{
-    __shared__ float4 tile[2][kTile];
-    const int tid = threadIdx.x;
-    const int split = blockIdx.x % jsplit;
-    const int iblk = blockIdx.x / jsplit;
-    const int t0 = (int)(((unsigned)tiles_total * (unsigned)split) / (unsigned)jsplit);
-    const int t1 = (int)(((unsigned)tiles_total * (unsigned)(split + 1)) / (unsigned)jsplit);
-
-    float xi[B], yi[B], zi[B], ax[B], ay[B], az[B];
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-        int i = iblk * (kTile * B) + b * kTile + tid;
-        i = i < n_targets ? i : n_targets - 1;  // clamp: tail threads compute a duplicate, never store
-        const float4 p = posm[lo + i];
-        xi[b] = p.x; yi[b] = p.y; zi[b] = p.z;
-        ax[b] = 0.0f; ay[b] = 0.0f; az[b] = 0.0f;
-    }
-
-    float4 nxt = posm[(size_t)t0 * kTile + tid];
-    int buf = 0;
-    for (int t = t0; t < t1; t++) {
-        tile[buf][tid] = nxt;
-        __syncthreads();
-        if (t + 1 < t1) nxt = posm[(size_t)(t + 1) * kTile + tid];  // in flight during the tile's math
-#pragma unroll UNROLL
-        for (int k = 0; k < kTile; k++) {
-            const float4 sj = tile[buf][k];
-#pragma unroll
-            for (int b = 0; b < B; b++) interact<DIM>(sj, xi[b], yi[b], zi[b], ax[b], ay[b], az[b]);
-        }
-        buf ^= 1;
-    }
-
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-        const int i = iblk * (kTile * B) + b * kTile + tid;
-        if (i < n_targets) acc_partial[(size_t)split * acc_stride + i] = make_float4(ax[b], ay[b], az[b], 0.0f);
-    }
-}
 
 // variant 1: LDS tiles, explicitly PACKED fp32 math.  Each thread owns P pairs of target bodies; a
 // pair lives in 64-bit VGPR pairs (xi = {x_a, x_b}, ...) and every per-interaction VALU op is a
@@ -137,161 +73,6 @@ __device__ __forceinline__ void interact_pk(const float4 sj, const v2f xi, const
     ax = __builtin_elementwise_fma(s, dx, ax);
     ay = __builtin_elementwise_fma(s, dy, ay);
     if (DIM == 3) az = __builtin_elementwise_fma(s, dz, az);
-}
-
-// variant 4: as variant 1 with BATCHED reciprocals.  v_rcp_f32 is a quarter-rate transcendental (8
-// cycles per wave64 vs 4 for a packed op, 2 for a plain VALU op; profiles/r01_ubench_banks.txt) and has
-// no packed form, so the 2 (P=1) or 4 (P=2) reciprocals a thread needs per source are obtained from ONE:
-//     t = product of the r2 values          q = rcp(t)        qm = q * m_j
-//     s_k = qm * (product of the OTHER r2 values) = m_j / r2_k
-// P=2: 4 rcp + 2 pk_mul  ->  1 rcp + 2 v_mul + 4 pk_mul   (-9 % issue cycles per source)
-// Valid while the product of four softened squared distances stays inside fp32 range, i.e. for
-// |d| < 6.5e4 (eps^4 = 1e-16 is far from underflow); the engine only selects this variant while every
-// coordinate is inside +-1e4 (it tracks max|coord| on the device) and falls back to variant 1 otherwise.
-template <int DIM>
-__device__ __forceinline__ void sep_r2(const float4 sj, const v2f xi, const v2f yi, const v2f zi, v2f& dx, v2f& dy,
-                                       v2f& dz, v2f& r2)
-{
-    const v2f sx = {sj.x, sj.x}, sy = {sj.y, sj.y};
-    const v2f eps = {kEps, kEps};
-    dx = sx - xi;
-    dy = sy - yi;
-    r2 = __builtin_elementwise_fma(dx, dx, eps);
-    r2 = __builtin_elementwise_fma(dy, dy, r2);
-    dz = v2f{0.f, 0.f};
-    if (DIM == 3) {
-        const v2f mz = {sj.z, sj.w};
-        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dz) : "v"(mz), "v"(zi));
-        r2 = __builtin_elementwise_fma(dz, dz, r2);
-    }
-}
-
-template <int DIM>
-__device__ __forceinline__ void accumulate(const v2f s, const v2f dx, const v2f dy, const v2f dz, v2f& ax, v2f& ay,
-                                           v2f& az)
-{
-    ax = __builtin_elementwise_fma(s, dx, ax);
-    ay = __builtin_elementwise_fma(s, dy, ay);
-    if (DIM == 3) az = __builtin_elementwise_fma(s, dz, az);
-}
-
-// max |coordinate| a batched launch may see (float bits; non-negative floats order like unsigned ints)
-constexpr unsigned kBatchGuardBits = 0x461C4000u;   // 1.0e4f
-
-template <int P, int DIM, int UNROLL, bool BATCH>
-__device__ __forceinline__ void tile_sweep(const float4* __restrict__ posm, float4 (*tile)[kTile], const int tid,
-                                           const int t0, const int t1, const v2f (&xi)[P], const v2f (&yi)[P],
-                                           const v2f (&zi)[P], v2f (&ax)[P], v2f (&ay)[P], v2f (&az)[P])
-{
-    float4 nxt = posm[(size_t)t0 * kTile + tid];
-    int buf = 0;
-    for (int t = t0; t < t1; t++) {
-        tile[buf][tid] = make_float4(nxt.x, nxt.y, nxt.w, nxt.z);  // (x, y, m, z)
-        __syncthreads();
-        if (t + 1 < t1) nxt = posm[(size_t)(t + 1) * kTile + tid];
-#pragma unroll 1
-        for (int k0 = 0; k0 < kTile; k0 += UNROLL) {
-            float4 sj[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) sj[u] = tile[buf][k0 + u];
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                const float mj = sj[u].z;
-                if (!BATCH) {
-#pragma unroll
-                    for (int p = 0; p < P; p++) interact_pk<DIM>(sj[u], xi[p], yi[p], zi[p], ax[p], ay[p], az[p]);
-                } else if (P == 1) {
-                    v2f dx, dy, dz, r2;
-                    sep_r2<DIM>(sj[u], xi[0], yi[0], zi[0], dx, dy, dz, r2);
-                    const float qm = __builtin_amdgcn_rcpf(r2.x * r2.y) * mj;
-                    const v2f s = v2f{qm, qm} * v2f{r2.y, r2.x};
-                    accumulate<DIM>(s, dx, dy, dz, ax[0], ay[0], az[0]);
-                } else {
-                    v2f dxa, dya, dza, ra, dxb, dyb, dzb, rb;
-                    sep_r2<DIM>(sj[u], xi[0], yi[0], zi[0], dxa, dya, dza, ra);
-                    sep_r2<DIM>(sj[u], xi[P - 1], yi[P - 1], zi[P - 1], dxb, dyb, dzb, rb);
-                    const v2f pr = ra * rb;                                     // {a0 b0, a1 b1}
-                    const float qm = __builtin_amdgcn_rcpf(pr.x * pr.y) * mj;   // m / (a0 b0 a1 b1)
-                    const v2f u2 = v2f{qm, qm} * v2f{pr.y, pr.x};               // {m/(a0 b0), m/(a1 b1)}
-                    const v2f sa = u2 * rb;                                     // {m/a0, m/a1}
-                    const v2f sb = u2 * ra;                                     // {m/b0, m/b1}
-                    accumulate<DIM>(sa, dxa, dya, dza, ax[0], ay[0], az[0]);
-                    accumulate<DIM>(sb, dxb, dyb, dzb, ax[P - 1], ay[P - 1], az[P - 1]);
-                }
-            }
-        }
-        buf ^= 1;
-    }
-}
-
-// `guard` points at the device word holding max|coordinate| of the CURRENT source array (float bits,
-// written by k_max_coord on the same stream just before this launch): the batched sweep runs only while
-// it is <= 1e4, otherwise the plain packed sweep does the work.
-template <int P, int DIM, int UNROLL, bool BATCH>
-__global__ __launch_bounds__(kTile) void k_force_tile_pkb(const float4* __restrict__ posm, const int lo,
-                                                          const int n_targets, const int tiles_total,
-                                                          const int jsplit, float4* __restrict__ acc_partial,
-                                                          const int acc_stride, const unsigned* __restrict__ guard)
-{
-    // Two instantiations are launched back to back; exactly one of them does the work (wave-uniform test
-    // of the guard word), the other returns at once.  Keeping the sweeps in separate kernels lets each
-    // have its own register budget (100 vs 156 VGPRs).
-    if ((guard[0] <= kBatchGuardBits) != BATCH) return;
-    __shared__ float4 tile[2][kTile];
-    constexpr int B = 2 * P;
-    const int tid = threadIdx.x;
-    const int split = blockIdx.x % jsplit;
-    const int iblk = blockIdx.x / jsplit;
-    const int t0 = (int)(((unsigned)tiles_total * (unsigned)split) / (unsigned)jsplit);
-    const int t1 = (int)(((unsigned)tiles_total * (unsigned)(split + 1)) / (unsigned)jsplit);
-
-    v2f xi[P], yi[P], zi[P], ax[P], ay[P], az[P];
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-        int ia = iblk * (kTile * B) + (2 * p) * kTile + tid;
-        int ib = ia + kTile;
-        ia = ia < n_targets ? ia : n_targets - 1;
-        ib = ib < n_targets ? ib : n_targets - 1;
-        const float4 pa = posm[lo + ia];
-        const float4 pb = posm[lo + ib];
-        xi[p] = v2f{pa.x, pb.x}; yi[p] = v2f{pa.y, pb.y}; zi[p] = v2f{pa.z, pb.z};
-        ax[p] = v2f{0.f, 0.f}; ay[p] = v2f{0.f, 0.f}; az[p] = v2f{0.f, 0.f};
-    }
-
-    tile_sweep<P, DIM, UNROLL, BATCH>(posm, tile, tid, t0, t1, xi, yi, zi, ax, ay, az);
-
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-        const int ia = iblk * (kTile * B) + (2 * p) * kTile + tid;
-        const int ib = ia + kTile;
-        if (ia < n_targets) acc_partial[(size_t)split * acc_stride + ia] = make_float4(ax[p].x, ay[p].x, az[p].x, 0.0f);
-        if (ib < n_targets) acc_partial[(size_t)split * acc_stride + ib] = make_float4(ax[p].y, ay[p].y, az[p].y, 0.0f);
-    }
-}
-
-// max over all sources of max(|x|,|y|,|z|) as float bits (NaN counts as +inf), into *out (pre-zeroed)
-__global__ __launch_bounds__(kTile) void k_max_coord(const float4* __restrict__ posm, const int n, unsigned* out)
-{
-    float m = 0.0f;
-    for (int i = blockIdx.x * kTile + threadIdx.x; i < n; i += gridDim.x * kTile) {
-        const float4 p = posm[i];
-        float c = fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z));
-        if (!(c == c) || !(p.x == p.x) || !(p.y == p.y) || !(p.z == p.z)) c = __builtin_inff();
-        m = fmaxf(m, c);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
-}
-
-hipError_t launch_max_coord(const float4* posm, int n_records, unsigned* guard, hipStream_t stream)
-{
-    const hipError_t e = hipMemsetAsync(guard, 0, sizeof(unsigned), stream);
-    if (e != hipSuccess) return e;
-    if (n_records <= 0) return hipSuccess;
-    const int blocks = (n_records + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_max_coord, dim3(blocks < 256 ? blocks : 256), dim3(kTile), 0, stream, posm, n_records, guard);
-    return hipGetLastError();
 }
 
 template <int P, int DIM, int UNROLL>
@@ -350,67 +131,8 @@ __global__ __launch_bounds__(kTile) void k_force_tile_pk(const float4* __restric
     }
 }
 
-// variant 5: packed math with sources through the SCALAR cache (no LDS, no barriers): posm[j] with a
-// wave-uniform j becomes s_load_dwordx4 and the source record feeds v_pk_* as an SGPR-pair operand.
-template <int P, int DIM, int UNROLL>
-__global__ __launch_bounds__(kTile) void k_force_smem_pk(const float4* __restrict__ posm, const int lo,
-                                                         const int n_targets, const int tiles_total,
-                                                         const int jsplit, float4* __restrict__ acc_partial,
-                                                         const int acc_stride)
-{
-    constexpr int B = 2 * P;
-    const int tid = threadIdx.x;
-    const int split = blockIdx.x % jsplit;
-    const int iblk = blockIdx.x / jsplit;
-    const int j0 = (int)(((unsigned)tiles_total * (unsigned)split) / (unsigned)jsplit) * kTile;
-    const int j1 = (int)(((unsigned)tiles_total * (unsigned)(split + 1)) / (unsigned)jsplit) * kTile;
-    v2f xi[P], yi[P], zi[P], ax[P], ay[P], az[P];
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-        int ia = iblk * (kTile * B) + (2 * p) * kTile + tid;
-        int ib = ia + kTile;
-        ia = ia < n_targets ? ia : n_targets - 1;
-        ib = ib < n_targets ? ib : n_targets - 1;
-        const float4 pa = posm[lo + ia];
-        const float4 pb = posm[lo + ib];
-        xi[p] = v2f{pa.x, pb.x}; yi[p] = v2f{pa.y, pb.y}; zi[p] = v2f{pa.z, pb.z};
-        ax[p] = v2f{0.f, 0.f}; ay[p] = v2f{0.f, 0.f}; az[p] = v2f{0.f, 0.f};
-    }
-#pragma unroll UNROLL
-    for (int j = j0; j < j1; j++) {
-        const float4 s = posm[j];
-        const v2f sx = {s.x, s.x}, sy = {s.y, s.y}, sz = {s.z, s.z}, sm = {s.w, s.w};
-        const v2f eps = {kEps, kEps};
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            const v2f dx = sx - xi[p];
-            const v2f dy = sy - yi[p];
-            v2f r2 = __builtin_elementwise_fma(dx, dx, eps);
-            r2 = __builtin_elementwise_fma(dy, dy, r2);
-            v2f dz = {0.f, 0.f};
-            if (DIM == 3) {
-                dz = sz - zi[p];
-                r2 = __builtin_elementwise_fma(dz, dz, r2);
-            }
-            v2f inv;
-            inv.x = __builtin_amdgcn_rcpf(r2.x);
-            inv.y = __builtin_amdgcn_rcpf(r2.y);
-            const v2f sc = sm * inv;
-            ax[p] = __builtin_elementwise_fma(sc, dx, ax[p]);
-            ay[p] = __builtin_elementwise_fma(sc, dy, ay[p]);
-            if (DIM == 3) az[p] = __builtin_elementwise_fma(sc, dz, az[p]);
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-        const int ia = iblk * (kTile * B) + (2 * p) * kTile + tid;
-        const int ib = ia + kTile;
-        if (ia < n_targets) acc_partial[(size_t)split * acc_stride + ia] = make_float4(ax[p].x, ay[p].x, az[p].x, 0.0f);
-        if (ib < n_targets) acc_partial[(size_t)split * acc_stride + ib] = make_float4(ax[p].y, ay[p].y, az[p].y, 0.0f);
-    }
-}
-
-// variants 6 / 7: variant 5's sweep with the FOUR WAVES of a workgroup sharing one block of 256 targets (64 lanes x 2 packed
+// variants 6 / 7: packed math with sources through the SCALAR cache (no LDS, no barriers in the loop: posm[j] with a wave-uniform j
+// becomes s_load_dwordx4 and the source record feeds v_pk_* as an SGPR-pair operand), the FOUR WAVES of a workgroup sharing one block of 256 targets (64 lanes x 2 packed
 // pairs) and each taking a quarter of the workgroup's source range; the four partial sums meet in LDS once, at the end, and
 // are added in wave order (fixed => bit-reproducible).  Same instruction stream per wave, same number of workgroups for a
 // given total split, but only a quarter of the partial-acceleration slabs ever reach HBM (N = 262 144: 8 slabs = 34 MB
@@ -508,46 +230,6 @@ __global__ __launch_bounds__(kTile) void k_force_smem_pkw(const float4* __restri
     }
 }
 
-// variant 2: no LDS. The source index is wave-uniform, so the compiler fetches sources through
-// the scalar cache (s_load_dwordx4..x16 into SGPRs) and feeds them to the VALU as scalar operands.
-template <int B, int DIM, int UNROLL>
-__global__ __launch_bounds__(kTile) void k_force_smem(const float4* __restrict__ posm, const int lo,
-                                                      const int n_targets, const int tiles_total,
-                                                      const int jsplit, float4* __restrict__ acc_partial,
-                                                      const int acc_stride)
-{
-    const int tid = threadIdx.x;
-    const int split = blockIdx.x % jsplit;
-    const int iblk = blockIdx.x / jsplit;
-    const int j0 = (int)(((unsigned)tiles_total * (unsigned)split) / (unsigned)jsplit) * kTile;
-    const int j1 = (int)(((unsigned)tiles_total * (unsigned)(split + 1)) / (unsigned)jsplit) * kTile;
-
-    float xi[B], yi[B], zi[B], ax[B], ay[B], az[B];
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-        int i = iblk * (kTile * B) + b * kTile + tid;
-        i = i < n_targets ? i : n_targets - 1;
-        const float4 p = posm[lo + i];
-        xi[b] = p.x; yi[b] = p.y; zi[b] = p.z;
-        ax[b] = 0.0f; ay[b] = 0.0f; az[b] = 0.0f;
-    }
-#pragma unroll UNROLL
-    for (int j = j0; j < j1; j++) {
-        const float4 sj = posm[j];
-#pragma unroll
-        for (int b = 0; b < B; b++) interact<DIM>(sj, xi[b], yi[b], zi[b], ax[b], ay[b], az[b]);
-    }
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-        const int i = iblk * (kTile * B) + b * kTile + tid;
-        if (i < n_targets) acc_partial[(size_t)split * acc_stride + i] = make_float4(ax[b], ay[b], az[b], 0.0f);
-    }
-}
-
-// The exceptional sources of a unit-mass sweep (kernels.h MassExceptions): a handful of bodies (the reference's
-// nb_stable_orbits has ONE: the 1000-mass sun among unit planets, nbody.rs:85-102) whose weight m_j - m_common the sweep
-// left out.  Their records were snapshot by the sweep kernel (K2 moves bodies in place, so it cannot read them from posm);
-// wave-uniform reads: they arrive through the scalar cache.  Same pair law, same rcp.
 __device__ __forceinline__ void add_exceptions(const MassExceptions exc, const float4 p, const int self, float4& a)
 {
     for (int k = 0; k < exc.count; k++) {
@@ -639,36 +321,11 @@ __global__ __launch_bounds__(kTile) void k_reduce_forces(const float4* __restric
 }
 
 template <int B, int DIM>
-static hipError_t launch_variant(int variant, dim3 grid, hipStream_t stream, const float4* posm, int lo,
-                                 int n_targets, int tiles_total, int jsplit, float4* acc_partial, int acc_stride,
-                                 unsigned* guard)
+static hipError_t launch_tiles(dim3 grid, hipStream_t stream, const float4* posm, int lo, int n_targets, int tiles_total, int jsplit,
+                               float4* acc_partial, int acc_stride)
 {
-    if (variant == 1 && (B % 2) == 0)
-        hipLaunchKernelGGL((k_force_tile_pk<(B >= 2 ? B / 2 : 1), DIM, 8>), grid, dim3(kTile), 0, stream, posm, lo,
-                           n_targets, tiles_total, jsplit, acc_partial, acc_stride);
-    else if (variant == 4 && (B % 2) == 0 && guard) {
-        // refresh max|coord| of the source array this launch will read, on the same stream
-        const hipError_t e = launch_max_coord(posm, tiles_total * kTile, guard, stream);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_force_tile_pkb<(B >= 2 ? B / 2 : 1), DIM, 8, true>), grid, dim3(kTile), 0, stream, posm,
-                           lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride, guard);
-        hipLaunchKernelGGL((k_force_tile_pkb<(B >= 2 ? B / 2 : 1), DIM, 8, false>), grid, dim3(kTile), 0, stream, posm,
-                           lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride, guard);
-    } else if (variant == 4 && (B % 2) == 0)
-        hipLaunchKernelGGL((k_force_tile_pk<(B >= 2 ? B / 2 : 1), DIM, 8>), grid, dim3(kTile), 0, stream, posm, lo,
-                           n_targets, tiles_total, jsplit, acc_partial, acc_stride);
-    else if (variant == 5 && (B % 2) == 0)
-        hipLaunchKernelGGL((k_force_smem_pk<(B >= 2 ? B / 2 : 1), DIM, 8>), grid, dim3(kTile), 0, stream, posm, lo,
-                           n_targets, tiles_total, jsplit, acc_partial, acc_stride);
-    else if (variant == 3 && (B % 2) == 0)
-        hipLaunchKernelGGL((k_force_tile_pk<(B >= 2 ? B / 2 : 1), DIM, 4>), grid, dim3(kTile), 0, stream, posm, lo,
-                           n_targets, tiles_total, jsplit, acc_partial, acc_stride);
-    else if (variant == 2)
-        hipLaunchKernelGGL((k_force_smem<B, DIM, 8>), grid, dim3(kTile), 0, stream, posm, lo, n_targets, tiles_total,
-                           jsplit, acc_partial, acc_stride);
-    else
-        hipLaunchKernelGGL((k_force_tile<B, DIM, 16>), grid, dim3(kTile), 0, stream, posm, lo, n_targets,
-                           tiles_total, jsplit, acc_partial, acc_stride);
+    hipLaunchKernelGGL((k_force_tile_pk<B / 2, DIM, 8>), grid, dim3(kTile), 0, stream, posm, lo, n_targets, tiles_total, jsplit,
+                       acc_partial, acc_stride);
     return hipGetLastError();
 }
 
@@ -695,28 +352,19 @@ hipError_t launch_force_wave_split(const float4* posm, int lo, int n_targets, in
 }
 
 hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tiles_total, int jsplit, int bpt, int dim,
-                             int variant, float4* acc_partial, int acc_stride, unsigned* guard, hipStream_t stream,
-                             ForceLaunch* info)
+                             float4* acc_partial, int acc_stride, hipStream_t stream, ForceLaunch* info)
 {
     if (n_targets <= 0 || tiles_total <= 0) return hipSuccess;
+    if (bpt != 2 && bpt != 4) return hipErrorInvalidValue;      // packed pairs: two or four targets per thread
     if (jsplit < 1) jsplit = 1;
     if (jsplit > tiles_total) jsplit = tiles_total;
     const int iblocks = (n_targets + kTile * bpt - 1) / (kTile * bpt);
     const dim3 grid((unsigned)(iblocks * jsplit));
-    if (info) *info = ForceLaunch{(int)grid.x, kTile, jsplit, bpt, dim, variant};
-#define NBX_DISPATCH(BB, DD) \
-    return launch_variant<BB, DD>(variant, grid, stream, posm, lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride, guard)
-    if (dim == 3) {
-        if (bpt == 1) NBX_DISPATCH(1, 3);
-        if (bpt == 2) NBX_DISPATCH(2, 3);
-        if (bpt == 4) NBX_DISPATCH(4, 3);
-    } else {
-        if (bpt == 1) NBX_DISPATCH(1, 2);
-        if (bpt == 2) NBX_DISPATCH(2, 2);
-        if (bpt == 4) NBX_DISPATCH(4, 2);
-    }
-#undef NBX_DISPATCH
-    return hipErrorInvalidValue;
+    if (info) *info = ForceLaunch{(int)grid.x, kTile, jsplit, bpt, dim, 1};
+    if (dim == 3) return bpt == 2 ? launch_tiles<2, 3>(grid, stream, posm, lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride)
+                                  : launch_tiles<4, 3>(grid, stream, posm, lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride);
+    return bpt == 2 ? launch_tiles<2, 2>(grid, stream, posm, lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride)
+                    : launch_tiles<4, 2>(grid, stream, posm, lo, n_targets, tiles_total, jsplit, acc_partial, acc_stride);
 }
 
 hipError_t launch_integrate(float4* posm, int lo, int n_targets, float4* vel, const float4* acc_partial, int jsplit,

@@ -19,17 +19,6 @@ struct BhNode {
 };
 inline __host__ __device__ float bh_node_q(float s, bool interior) { return interior ? s * s : -1.0f; }
 
-// Compact copy of the tree for the wave-uniform fast walk (round 3): what a visit DECIDES on -- centre, opening threshold, skip --
-// in 16 bytes, the mass (needed only by the lanes that take the node, and not before the next record has been requested) in a
-// separate word array.  Fewer bytes per visited node (the ~13 % of a million-body tree that an XCD's walks touch are 7.9 MB of
-// 32-byte records, profiles/r03_bh_walk_lines_model.json, against a 4 MB L2).  MEASURED (profiles/r03_bh_walk_records_ab.jsonl):
-// 15 % less HBM traffic, 20-26 % MORE time -- the walk is bound by its dependent scalar loads, and this adds one per visit.
-// Opt-in (NBX_OPT_BH_WALK_RECORDS = 16); written by k_emit next to the BhNode array.
-struct BhWalk16 {
-    float px, py, q;
-    int32_t skip;
-};
-
 // Round 4: the fast walk's copy of the tree (bh_walk.hip).  One 80-byte record per OPENED node: the (x, y, m, T) of its up to four
 // children -- 64 bytes, one s_load_dwordx16 -- present ones first, in the reference's child order (nbody.rs:295-300), then four
 // child words.  T = the opening threshold of bh_threshold.h for an interior child (take <=> dist_sq > T: the reference's
@@ -50,9 +39,9 @@ hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta
                             int* gate_counters = nullptr, int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0);
 // accelerations of the slab's bodies (fast mode).  wave && perm: one walk per wave (bodies in the spatial order perm; hand_scheduled:
 // the assembly loop, else the compiler's), else one per lane; bit-identical results whichever runs
-// order / cost (hand-scheduled wave form only; both optional, bh_walk_count(n_targets) ints each): every walk leaves the number of
-// groups it loaded in cost[]; order[] = the launch order of the walks (launch_walk_order makes it from the previous step's costs:
-// longest first within every XCD's eighth).  The order changes no result.
+// order / cost (hand-scheduled wave form only; both optional): every walk leaves the number of groups it loaded in cost[]
+// (bh_walk_count(n_targets) ints); order = the launch list launch_walk_split_list makes of the previous step's costs (1 + walks +
+// split_budget ints: the costliest walks entered as two halves of 32 bodies; round-5 experiment, off by default).  No result changes.
 // kick (optional, wave form only): the kick-drift of the step (nbody.rs:453-471, what k_integrate_f2 does) applied by the walk itself
 // as soon as a body's acceleration is complete -- legitimate because a walk reads no other body's position from posm (the group
 // records hold copies) -- so a small system's step is one dependent kernel shorter.  out is not written then.  host_out: see BuildGate.
@@ -66,10 +55,10 @@ hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, cons
                                  const unsigned* perm, bool wave, bool hand_scheduled, int* gate_counters = nullptr,
                                  int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0,
                                  const int* order = nullptr, int* cost = nullptr, unsigned long long* trace = nullptr,
-                                 const BhKick* kick = nullptr);
+                                 const BhKick* kick = nullptr, int split_budget = 0);
 // trace (optional, 4 words per walk = workgroup): s_memrealtime (10 ns ticks) at its start and end, groups loaded (bit 31: redone with the LDS spill) | chunk << 32, HW_ID | XCC_ID << 32
 int bh_walk_count(int n_targets, int* bodies_per_walk = nullptr);   // walks (workgroups) of the wave form, a multiple of 8
-hipError_t launch_walk_order(const int* cost, int* order, int walks, hipStream_t stream);
+hipError_t launch_walk_split_list(const int* cost, int* cost_next, int* list, int walks, int budget, hipStream_t stream);
 hipError_t launch_bh_count_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, unsigned long long* totals,
                                   hipStream_t stream);   // totals[0] children visited, [1] pair laws, [2] opening tests (visits of
                                                          // interior nodes), [3] groups loaded (per body)
@@ -81,11 +70,9 @@ struct ForceLaunch {
 
 // K1: all-pairs accelerations for slab targets [lo, lo+n_targets) against tiles_total*kTile sources.
 // acc_partial: [jsplit][acc_stride] float4 (ax, ay, az, unused).
-// guard: device word for variant 4 (batched reciprocals): refreshed with max|coord| of posm before the
-// launch; the kernel falls back to the plain packed sweep when it exceeds 1e4. May be null (-> variant 1).
+// Variant 1 (k_force_tile_pk: packed math, sources through LDS tiles), bpt = 2 or 4 targets per thread.
 hipError_t launch_force_tile(const float4* posm, int lo, int n_targets, int tiles_total, int jsplit, int bpt,
-                             int dim, int variant, float4* acc_partial, int acc_stride, unsigned* guard,
-                             hipStream_t stream, ForceLaunch* info);
+                             int dim, float4* acc_partial, int acc_stride, hipStream_t stream, ForceLaunch* info);
 
 // K1, variants 6 / 7 (k_force_smem_pkw): the four waves of a workgroup share 256 targets and split the workgroup's source
 // range; partial sums meet in LDS, so only `jsplit` slabs are written for 4 * jsplit source ranges. unit_mass: every body
@@ -167,11 +154,10 @@ hipError_t launch_integrate_f2(float4* posm, int lo, int n_targets, float4* vel,
 // perm (optional): thread t evaluates body perm[t] -- a GLOBAL body index inside the slab
 // [lo, lo + n_targets) -- instead of body lo + t (spatial order => coherent waves); force_out is indexed by body - lo
 // gate_* (fast walks only): as launch_integrate_f2; n_nodes is then read from gate_counters[0] on the device
-// walk16 / wmass (mode 2 only): the compact copy of the tree (BhWalk16 + masses); same results, bit for bit
 hipError_t launch_bh_eval(const float4* posm, int lo, int n_targets, const BhNode* nodes, int n_nodes, float theta,
                           int mode, float2* force_out, hipStream_t stream, const unsigned* perm = nullptr,
                           int* gate_counters = nullptr, int gate_node_cap = 0, int gate_crowd_limit = 0,
-                          int gate_queue_limit = 0, const BhWalk16* walk16 = nullptr, const float* wmass = nullptr);
+                          int gate_queue_limit = 0);
 
 // planar (x, y) of posm[0..n) into device-visible pinned host arrays (input of the host quadtree build)
 hipError_t launch_split_xy(const float4* posm, int n, float* xs_host_pinned, float* ys_host_pinned, hipStream_t stream);
@@ -210,7 +196,7 @@ constexpr int kFoldFaithfulMax = 65536;   // default: faithful fold up to this m
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters, const unsigned** perm_dev, hipStream_t stream, int fold = 0,
                                    hipStream_t side = nullptr, hipEvent_t ev_go = nullptr, hipEvent_t ev_done = nullptr,
-                                   BhWalk16* walk16 = nullptr, float* wmass = nullptr, bool depth_panic_guard = false, bool warm = false);
+                                   bool depth_panic_guard = false, bool warm = false);
 hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, int* n_nodes_host, int* status,
                                  hipStream_t stream, int fold = 0);
 // the device-side view of the same verdict: where the build's counters live (for launch_bh_eval / launch_integrate_f2 gates)

@@ -34,17 +34,17 @@ NBX_OPT_SOURCE_PRECISION = 6
 NBX_OPT_DRAW_DEVICE = 7
 NBX_OPT_BH_TREE = 8
 NBX_OPT_BH_WAVE = 9
-NBX_OPT_BH_FALLBACKS = 10
-NBX_OPT_BH_LAST_TREE = 11
-NBX_OPT_DRAW_AMBIGUOUS = 12
 NBX_OPT_STRICT_KERNEL = 13
 NBX_OPT_BH_FOLD = 14
 NBX_OPT_BH_ASYNC = 15
-NBX_OPT_BH_WALK_RECORDS = 16
-NBX_OPT_BH_REFUSAL = 17
 NBX_OPT_BH_WALK = 18
-NBX_OPT_BH_WALK_ORDER = 19
 NBX_OPT_BH_FUSE_KICK = 20
+# (10-12 and 17 became enum nbx_stat in round 5; 16 and 19 -- measured losers -- were removed)
+
+NBX_STAT_BH_FALLBACKS = 0
+NBX_STAT_BH_LAST_TREE = 1
+NBX_STAT_DRAW_AMBIGUOUS = 2
+NBX_STAT_BH_REFUSAL = 3
 
 NBX_GROUP_INFO_EXCHANGE = 0
 NBX_GROUP_INFO_RCCL_RANKS = 1
@@ -168,6 +168,8 @@ def lib():
     L.nbx_two_galaxies.restype = i32
     L.nbx_query_option.argtypes = [E, i32, C.POINTER(C.c_int64)]
     L.nbx_query_option.restype = i32
+    L.nbx_get_stat.argtypes = [E, i32]
+    L.nbx_get_stat.restype = C.c_int64
     L.nbx_num_particles.argtypes = [E]
     L.nbx_num_particles.restype = i32
     L.nbx_set_particles.argtypes = [E, i32] + [C.c_void_p] * 5
@@ -380,6 +382,13 @@ class NBodyEngine:
 
     def get_option(self, opt):
         return int(self._L.nbx_get_option(self._h, opt))
+
+    def get_stat(self, stat):
+        """What the engine has done so far (enum nbx_stat): fallbacks, where the last tree was built, ..."""
+        v = int(self._L.nbx_get_stat(self._h, stat))
+        if v == -(1 << 63):
+            raise NBodyError(NBX_ERR_INVALID, "unknown stat %d" % stat)
+        return v
 
     def query_option(self, opt):
         """Value of an option with the status checked apart from it (-1 is a legitimate value of some options)."""

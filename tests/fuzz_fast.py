@@ -119,9 +119,9 @@ def main():
                                    % (np.percentile(err, 99.0), beyond, allowed))
                 elif np.percentile(err, 99.9) > (4e-4 if n > 100000 else 2e-4) or err.max() > (1e-2 if theta > 0.8 else 5e-3):
                     why.append("device tree p99.9 %.2e max %.2e" % (np.percentile(err, 99.9), err.max()))
-                from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_OPT_BH_LAST_TREE
-                kept[int(clumps > 0)][int(fd.get_option(NBX_OPT_BH_LAST_TREE) == 1)] += 1
-                if 512 <= n <= 65536 and fd.get_option(NBX_OPT_BH_LAST_TREE) == 1:   # reference fold kept: the host tree, bit for bit
+                from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_STAT_BH_LAST_TREE
+                kept[int(clumps > 0)][int(fd.get_stat(NBX_STAT_BH_LAST_TREE) == 1)] += 1
+                if 512 <= n <= 65536 and fd.get_stat(NBX_STAT_BH_LAST_TREE) == 1:   # reference fold kept: the host tree, bit for bit
                     if not (np.array_equal(dx_.view(np.uint32), bfx.view(np.uint32)) and np.array_equal(dy_.view(np.uint32), bfy.view(np.uint32))):
                         why.append("reference-fold device tree != host tree (%d words)" % int((dx_.view(np.uint32) != bfx.view(np.uint32)).sum()))
                 # (once the bodies have moved a tree may be one the reference panics on -- two bodies an ulp apart at |x| ~ 3000

@@ -410,7 +410,7 @@ def test_group_info_threads_and_option_queries_without_device(rx, monkeypatch):
     """Host-side facts of the group added in round 3: how the exchange runs (nothing created yet: kind 'rccl', 0 ranks), the
     enqueue-thread switch (threads start and stop without a device), NBX_GROUP_EXCHANGE=copy, and the option round trips of
     ADVICE r02 (NBX_OPT_BH_TREE accepts -1 again; nbx_query_option tells the value -1 from an error)."""
-    from rust_exp_amd.engine import NBX_OPT_BH_TREE, NBX_OPT_DRAW_AMBIGUOUS, NBX_OPT_DRAW_DEVICE
+    from rust_exp_amd.engine import NBX_OPT_BH_TREE, NBX_STAT_DRAW_AMBIGUOUS, NBX_OPT_DRAW_DEVICE
 
     monkeypatch.delenv("NBX_GROUP_EXCHANGE", raising=False)
     if rx.device_count() == 0:
@@ -439,16 +439,21 @@ def test_group_info_threads_and_option_queries_without_device(rx, monkeypatch):
         assert e.query_option(NBX_OPT_BH_TREE) == val
     with pytest.raises(rx.NBodyError):
         e.set_option(NBX_OPT_BH_TREE, 2)
-    assert e.query_option(NBX_OPT_DRAW_DEVICE) == -1 and e.query_option(NBX_OPT_DRAW_AMBIGUOUS) == 0
+    assert e.query_option(NBX_OPT_DRAW_DEVICE) == -1 and e.get_stat(NBX_STAT_DRAW_AMBIGUOUS) == 0
     with pytest.raises(rx.NBodyError):
         e.query_option(99)
-    from rust_exp_amd.engine import NBX_OPT_BH_REFUSAL
-    assert e.query_option(NBX_OPT_BH_REFUSAL) == 0          # read only: no device build has refused anything yet
+    from rust_exp_amd.engine import NBX_STAT_BH_REFUSAL
+    assert e.get_stat(NBX_STAT_BH_REFUSAL) == 0             # no device build has refused anything yet
     with pytest.raises(rx.NBodyError):
-        e.set_option(NBX_OPT_BH_REFUSAL, 1)
-    # the options of round 4 answer queries too (the range check of nbx_query_option ended at NBX_OPT_BH_REFUSAL)
-    from rust_exp_amd.engine import NBX_OPT_BH_FUSE_KICK, NBX_OPT_BH_WALK, NBX_OPT_BH_WALK_ORDER
-    assert e.query_option(NBX_OPT_BH_WALK) == 1 and e.query_option(NBX_OPT_BH_WALK_ORDER) == 0
+        e.get_stat(99)
+    # round 5: the read-only words are stats, no longer options (10-12, 17); the measured losers 16 and 19 are gone
+    for retired in (10, 11, 12, 16, 17, 19):
+        with pytest.raises(rx.NBodyError):
+            e.query_option(retired)
+        with pytest.raises(rx.NBodyError):
+            e.set_option(retired, 1)
+    from rust_exp_amd.engine import NBX_OPT_BH_FUSE_KICK, NBX_OPT_BH_WALK
+    assert e.query_option(NBX_OPT_BH_WALK) == 1
     assert e.query_option(NBX_OPT_BH_FUSE_KICK) == 1
     for v in (0, 1):
         e.set_option(NBX_OPT_BH_FUSE_KICK, v)

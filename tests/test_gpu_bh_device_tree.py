@@ -53,12 +53,12 @@ def test_device_tree_with_the_reference_fold_equals_the_host_tree_bit_for_bit(rx
     # fast mode's 2e-5 of the oracle for EVERY body
     a = engines(rx, p); a.set_bh_tree("host")
     b = engines(rx, p, fold="reference"); b.set_bh_tree("device")
-    from rust_exp_amd.engine import NBX_OPT_BH_LAST_TREE
+    from rust_exp_amd.engine import NBX_STAT_BH_LAST_TREE
 
     for theta in (0.5, 0.85):
         fx, fy, _ = a.forces(theta)
         gx, gy, _ = b.forces(theta)
-        assert a.get_option(NBX_OPT_BH_LAST_TREE) == 0 and b.get_option(NBX_OPT_BH_LAST_TREE) == 1
+        assert a.get_stat(NBX_STAT_BH_LAST_TREE) == 0 and b.get_stat(NBX_STAT_BH_LAST_TREE) == 1
         assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
         if n <= 20000:
             rc, ofx, ofy = ob.bh_forces(p, theta, nthreads=8)
@@ -71,7 +71,7 @@ def test_device_tree_reference_fold_replays_eps_clusters(rx, ob):
     moving centre): the reference-fold class replays every connected cluster's arrivals in index order on the device (k_blobs)
     and the flattened tree is the host tree, bit for bit -- no hand-over.  (The exact-sum class merges pairs only and tolerates
     up to max(16, n/2000) bodies left behind.)"""
-    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+    from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE
 
     rng = np.random.default_rng(17)
     x = rng.uniform(-20, 20, 6000).astype(np.float32); y = rng.uniform(-20, 20, 6000).astype(np.float32)
@@ -86,8 +86,8 @@ def test_device_tree_reference_fold_replays_eps_clusters(rx, ob):
     fx, fy, _ = a.forces(0.5)
     gx, gy, _ = b.forces(0.5)
     hx, hy, _ = c.forces(0.5)
-    assert b.get_option(NBX_OPT_BH_FALLBACKS) == 0 and b.get_option(NBX_OPT_BH_LAST_TREE) == 1
-    assert c.get_option(NBX_OPT_BH_FALLBACKS) == 0 and c.get_option(NBX_OPT_BH_LAST_TREE) == 1
+    assert b.get_stat(NBX_STAT_BH_FALLBACKS) == 0 and b.get_stat(NBX_STAT_BH_LAST_TREE) == 1
+    assert c.get_stat(NBX_STAT_BH_FALLBACKS) == 0 and c.get_stat(NBX_STAT_BH_LAST_TREE) == 1
     assert np.array_equal(gx.view(np.uint32), fx.view(np.uint32)) and np.array_equal(gy.view(np.uint32), fy.view(np.uint32))
     host, dev = b.bh_flat_dump(False), b.bh_flat_dump("device")
     _bit_equal_trees(host, dev)
@@ -118,10 +118,10 @@ def test_device_tree_reference_fold_clusters_in_random_arrival_order(rx, ob, see
     of other bodies; clusters that straddle cell boundaries of every level).  Tight clusters (every member within EPS of the
     moving centre) the device build replays and files under their centre's path: the host tree bit for bit.  Looser ones leave
     unmerged bodies a fraction of EPS beside a blob of several bodies, its leaf is then ~18 levels deep and the blob's successive
-    centres often sit in different cells at that depth: the build says so (NBX_OPT_BH_REFUSAL: 0x80) and the step runs on the host tree.  Either
+    centres often sit in different cells at that depth: the build says so (NBX_STAT_BH_REFUSAL: 0x80) and the step runs on the host tree.  Either
     way the forces are the host tree's, bit for bit; a system made of nothing but clusters (the last case: more bodies to move
     than the build lists, more nodes than its pool holds) goes to the host build as a whole."""
-    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+    from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE
 
     rng = np.random.default_rng(1000 + seed)
     x, y, m = _clumps(rng, n_base, n_clumps, spread)
@@ -132,10 +132,10 @@ def test_device_tree_reference_fold_clusters_in_random_arrival_order(rx, ob, see
     fx, fy, _ = h.forces(0.85)
     gx, gy, _ = d.forces(0.85)
     assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
-    device = d.get_option(NBX_OPT_BH_LAST_TREE) == 1
-    assert d.get_option(NBX_OPT_BH_FALLBACKS) == (0 if device else 1)
-    from rust_exp_amd.engine import NBX_OPT_BH_REFUSAL
-    why = d.get_option(NBX_OPT_BH_REFUSAL)                  # the build says why it handed the system over
+    device = d.get_stat(NBX_STAT_BH_LAST_TREE) == 1
+    assert d.get_stat(NBX_STAT_BH_FALLBACKS) == (0 if device else 1)
+    from rust_exp_amd.engine import NBX_STAT_BH_REFUSAL
+    why = d.get_stat(NBX_STAT_BH_REFUSAL)                  # the build says why it handed the system over
     assert (why == 0) == device and (device or why & (0x10000 | 8 | 16 | 32 | 64 | 128))
     if on_device is not None:
         assert device == on_device
@@ -275,7 +275,7 @@ def test_device_tree_duplicates_with_partners_and_crowded_clusters(rx, ob):
     Clusters of three or more DISTINCT positions within EPS are another matter: the reference grows multi-body blobs in arrival
     order, which the pairs-only merge does not reproduce.  A few such bodies (<= max(16, n/2000)) are tolerated; a system
     full of them -- dense clumps -- is detected by the device build and redone on the host: the host-tree result bit for bit."""
-    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+    from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE
 
     rng = np.random.default_rng(7)
     x = rng.uniform(-20, 20, 3000).astype(np.float32)
@@ -289,7 +289,7 @@ def test_device_tree_duplicates_with_partners_and_crowded_clusters(rx, ob):
     assert leaves == 3000                       # 500 pairs, 100 of them with two more bodies on top: one leaf each
     e.set_bh_tree("device")
     gx, gy, _ = e.forces(0.3)
-    assert e.get_option(NBX_OPT_BH_FALLBACKS) == 0 and e.get_option(NBX_OPT_BH_LAST_TREE) == 1
+    assert e.get_stat(NBX_STAT_BH_FALLBACKS) == 0 and e.get_stat(NBX_STAT_BH_LAST_TREE) == 1
     rc, ofx, ofy = ob.bh_forces(p, 0.3, nthreads=8)
     err = np.maximum(np.abs(gx - ofx), np.abs(gy - ofy)) / max(np.abs(ofx).max(), np.abs(ofy).max())
     assert rc == 0 and np.percentile(err, 99.9) <= 2e-5 and err.max() <= 2e-3
@@ -301,7 +301,7 @@ def test_device_tree_duplicates_with_partners_and_crowded_clusters(rx, ob):
     b = engines(rx, p, fold="exact"); b.set_bh_tree("device")
     fx, fy, _ = a.forces(0.3)
     gx, gy, _ = b.forces(0.3)
-    assert b.get_option(NBX_OPT_BH_FALLBACKS) == 1 and b.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    assert b.get_stat(NBX_STAT_BH_FALLBACKS) == 1 and b.get_stat(NBX_STAT_BH_LAST_TREE) == 0
     assert np.array_equal(gx.view(np.uint32), fx.view(np.uint32)) and np.array_equal(gy.view(np.uint32), fy.view(np.uint32))
     rc, ofx, ofy = ob.bh_forces(p, 0.3, nthreads=8)
     scale = max(np.abs(ofx).max(), np.abs(ofy).max())
@@ -318,7 +318,7 @@ def test_device_tree_exact_sums_are_at_least_as_close_to_exact_arithmetic_as_the
         |F_dev - F_oracle|  <= |F_oracle - F_arbiter| + 2e-5 max|F|   (what separates it from the reference is the reference's own drift)
     for 99.9 % of the bodies; the rest may sit on a flipped opening decision (centres that differ in the last bits put s/d on
     the other side of theta about once per million visits) and are bounded by one node's approximation error: 2e-3 max|F|."""
-    from rust_exp_amd.engine import NBX_OPT_BH_LAST_TREE
+    from rust_exp_amd.engine import NBX_STAT_BH_LAST_TREE
 
     if make == "orbits":
         p = ob.stable_orbits(n, 0.5, 30.0, 44)
@@ -332,13 +332,13 @@ def test_device_tree_exact_sums_are_at_least_as_close_to_exact_arithmetic_as_the
     assert rc == 0 and rc2 == 0
     e = engines(rx, p, fold="exact")         # fast mode, n >= 512 -> device tree; exact sums (the default only above 65 536)
     fx, fy, _ = e.forces(theta)
-    assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1
+    assert e.get_stat(NBX_STAT_BH_LAST_TREE) == 1
     scale = max(np.abs(ex).max(), np.abs(ey).max())
     if n <= 65536:
         # the DEFAULT at this size (reference fold): within the fast mode's 2e-5 of the oracle for every single body
         d = engines(rx, p)
         dx, dy, _ = d.forces(theta)
-        assert d.get_option(NBX_OPT_BH_LAST_TREE) == 1
+        assert d.get_stat(NBX_STAT_BH_LAST_TREE) == 1
         assert max(np.abs(dx - ofx).max(), np.abs(dy - ofy).max()) <= 2e-5 * max(np.abs(ofx).max(), np.abs(ofy).max())
     dev_arb = np.maximum(np.abs(fx - ex), np.abs(fy - ey)) / scale
     orc_arb = np.maximum(np.abs(ofx - ex), np.abs(ofy - ey)) / scale
@@ -351,7 +351,7 @@ def test_device_tree_exact_sums_are_at_least_as_close_to_exact_arithmetic_as_the
 def test_tree_choice_by_mode_and_size(rx, ob):
     """NBX_OPT_BH_TREE = -1 (default): device build in the fast mode from 1 024 bodies on (512 with exactly summed nodes), host
     build below and in the bit-exact mode; 0 / 1 force one or the other."""
-    from rust_exp_amd.engine import NBX_OPT_BH_LAST_TREE, NBX_OPT_BH_TREE
+    from rust_exp_amd.engine import NBX_STAT_BH_LAST_TREE, NBX_OPT_BH_TREE
 
     for n, mode, want in ((4096, "fast", 1), (1024, "fast", 1), (1023, "fast", 0), (20000, "strict", 0)):
         p = ob.random_disk(n, 3)
@@ -359,23 +359,23 @@ def test_tree_choice_by_mode_and_size(rx, ob):
         assert e.get_option(NBX_OPT_BH_TREE) == -1
         e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
         e.step_barnes_hut(0.5, 0.01, 1)
-        assert e.get_option(NBX_OPT_BH_LAST_TREE) == want, (n, mode)
+        assert e.get_stat(NBX_STAT_BH_LAST_TREE) == want, (n, mode)
     e.set_bh_tree("device")                  # strict takes the device build only on request, and only with the reference fold
     e.step_barnes_hut(0.5, 0.01, 1)
-    assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1
+    assert e.get_stat(NBX_STAT_BH_LAST_TREE) == 1
     e.set_bh_fold("exact")
     e.step_barnes_hut(0.5, 0.01, 1)
-    assert e.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    assert e.get_stat(NBX_STAT_BH_LAST_TREE) == 0
     f = rx.NBodyEngine()
     f.set_bh_tree("host")
     f.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     f.step_barnes_hut(0.5, 0.01, 1)
-    assert f.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    assert f.get_stat(NBX_STAT_BH_LAST_TREE) == 0
     for n, want in ((512, 1), (511, 0)):     # exactly summed nodes: no root chain, the device build pays earlier
         p = ob.random_disk(n, 3)
         g = engines(rx, p, fold="exact")
         g.step_barnes_hut(0.5, 0.01, 1)
-        assert g.get_option(NBX_OPT_BH_LAST_TREE) == want, n
+        assert g.get_stat(NBX_STAT_BH_LAST_TREE) == want, n
 
 
 @pytest.mark.parametrize("make,n", [("disk", 3000), ("orbits", 10000), ("clusters", 4892), ("plummer", 40000)])
@@ -384,7 +384,7 @@ def test_strict_mode_on_the_device_tree_is_still_the_oracle(rx, ob, make, n):
     fold that tree is the host tree bit for bit (or refused and built on the host), so three bit-exact steps on it are the
     oracle's three steps, bit for bit -- clusters of bodies within EPS included.  With exactly summed nodes (NBX_OPT_BH_FOLD = 0)
     the request is ignored: that tree is not the reference's."""
-    from rust_exp_amd.engine import NBX_OPT_BH_LAST_TREE
+    from rust_exp_amd.engine import NBX_STAT_BH_LAST_TREE
 
     if make == "disk":
         p = ob.random_disk(n, 45)
@@ -404,7 +404,7 @@ def test_strict_mode_on_the_device_tree_is_still_the_oracle(rx, ob, make, n):
     for k in range(3):
         e.step_barnes_hut(0.6, 0.01, 1)
         # (the clusters fall in on themselves: a later step may be one the device build hands to the host build)
-        assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1 or (make == "clusters" and k > 0)
+        assert e.get_stat(NBX_STAT_BH_LAST_TREE) == 1 or (make == "clusters" and k > 0)
         ob.step_barnes_hut(q, 0.6, 0.01, 1)
     st = e.get_particles()
     for k in ("px", "py", "vx", "vy"):
@@ -414,19 +414,19 @@ def test_strict_mode_on_the_device_tree_is_still_the_oracle(rx, ob, make, n):
     assert rc == 0 and np.array_equal(fx.view(np.uint32), ofx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), ofy.view(np.uint32))
     e.set_bh_fold("exact")
     e.step_barnes_hut(0.6, 0.01, 1)
-    assert e.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    assert e.get_stat(NBX_STAT_BH_LAST_TREE) == 0
     f = rx.NBodyEngine(mode="strict")        # default tree choice: the host build
     f.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     f.step_barnes_hut(0.6, 0.01, 1)
-    assert f.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    assert f.get_stat(NBX_STAT_BH_LAST_TREE) == 0
 
 
 def test_device_tree_node_pool_overflow_falls_back_to_host_build(rx, ob):
     """Thousands of pairs 2e-4 apart (farther than EPS in x, so nobody merges them: nbody.rs:249) force ~18-level chains,
     more than the 4 nodes per body the device pool holds: the device build reports pool exhaustion and the evaluation takes
-    the reference-faithful host build instead. Which build ran is ASSERTED (NBX_OPT_BH_FALLBACKS / NBX_OPT_BH_LAST_TREE),
+    the reference-faithful host build instead. Which build ran is ASSERTED (NBX_STAT_BH_FALLBACKS / NBX_STAT_BH_LAST_TREE),
     and the result is then the host-tree result bit for bit."""
-    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+    from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE
 
     rng = np.random.default_rng(8)
     x = rng.uniform(-20, 20, 4000).astype(np.float32)
@@ -439,21 +439,21 @@ def test_device_tree_node_pool_overflow_falls_back_to_host_build(rx, ob):
     a = rx.NBodyEngine(); a.set_bh_tree("host"); a.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     b = rx.NBodyEngine(); b.set_bh_tree("device"); b.set_bh_fold("exact"); b.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     fx, fy, _ = a.forces(0.5)
-    assert a.get_option(NBX_OPT_BH_LAST_TREE) == 0 and a.get_option(NBX_OPT_BH_FALLBACKS) == 0
+    assert a.get_stat(NBX_STAT_BH_LAST_TREE) == 0 and a.get_stat(NBX_STAT_BH_FALLBACKS) == 0
     gx, gy, _ = b.forces(0.5)
-    assert b.get_option(NBX_OPT_BH_FALLBACKS) == 1 and b.get_option(NBX_OPT_BH_LAST_TREE) == 0
-    from rust_exp_amd.engine import NBX_OPT_BH_REFUSAL
-    assert b.get_option(NBX_OPT_BH_REFUSAL) == 0x10000      # "the node pool overflowed"
+    assert b.get_stat(NBX_STAT_BH_FALLBACKS) == 1 and b.get_stat(NBX_STAT_BH_LAST_TREE) == 0
+    from rust_exp_amd.engine import NBX_STAT_BH_REFUSAL
+    assert b.get_stat(NBX_STAT_BH_REFUSAL) == 0x10000      # "the node pool overflowed"
     assert b.bh_host_timing()["nodes"] == a.bh_host_timing()["nodes"] > 4 * n
     assert np.array_equal(gx.view(np.uint32), fx.view(np.uint32)) and np.array_equal(gy.view(np.uint32), fy.view(np.uint32))
     b.step_barnes_hut(0.5, 0.01, 1)
-    assert b.get_option(NBX_OPT_BH_FALLBACKS) == 2
+    assert b.get_stat(NBX_STAT_BH_FALLBACKS) == 2
     assert np.isfinite(b.get_particles()["px"]).all()
     # a well-separated system of the same size stays on the device
     q = ob.random_disk(n, 5)
     b.set_particles(q["px"], q["py"], q["vx"], q["vy"], q["m"])
     b.forces(0.5)
-    assert b.get_option(NBX_OPT_BH_LAST_TREE) == 1 and b.get_option(NBX_OPT_BH_FALLBACKS) == 2
+    assert b.get_stat(NBX_STAT_BH_LAST_TREE) == 1 and b.get_stat(NBX_STAT_BH_FALLBACKS) == 2
 
 
 @pytest.mark.parametrize("walk", [1, 2, 0])
@@ -584,7 +584,7 @@ def test_steps_enqueued_without_waiting_for_the_build_verdict(rx, ob, fold):
     that needs the state.  Same state as the waiting form (NBX_OPT_BH_ASYNC = 0), bit for bit, over several back-to-back steps;
     and when the build must refuse (EPS triples under the reference fold, an exhausted node pool under either), the gated
     kernels leave the state alone and the step is redone on the host tree: the host-tree result, bit for bit."""
-    from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+    from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE
 
     p = ob.stable_orbits(12000, 0.5, 30.0, 51)
     outs = []
@@ -593,7 +593,7 @@ def test_steps_enqueued_without_waiting_for_the_build_verdict(rx, ob, fold):
         e.set_option(NBX_OPT_BH_ASYNC, async_)
         for _ in range(6):
             e.step_barnes_hut(0.7, 0.01, 1)
-        assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1 and e.get_option(NBX_OPT_BH_FALLBACKS) == 0
+        assert e.get_stat(NBX_STAT_BH_LAST_TREE) == 1 and e.get_stat(NBX_STAT_BH_FALLBACKS) == 0
         outs.append(e.get_particles())
     for k in ("px", "py", "vx", "vy"):
         assert np.array_equal(outs[0][k].view(np.uint32), outs[1][k].view(np.uint32)), k
@@ -614,51 +614,30 @@ def test_steps_enqueued_without_waiting_for_the_build_verdict(rx, ob, fold):
     # the bodies have moved apart by then, so the later builds succeed
     for _ in range(3):
         d.step_barnes_hut(0.5, 0.01, 1)
-    assert d.get_option(NBX_OPT_BH_FALLBACKS) >= 1
+    assert d.get_stat(NBX_STAT_BH_FALLBACKS) >= 1
     e1 = engines(rx, q, fold=fold); e1.set_bh_tree("device"); e1.set_option(NBX_OPT_BH_ASYNC, 0)
     e1.step_barnes_hut(0.5, 0.01, 1)
     a, b = h.get_particles(), e1.get_particles()
-    assert e1.get_option(NBX_OPT_BH_FALLBACKS) == 1 and e1.get_option(NBX_OPT_BH_LAST_TREE) == 0
+    assert e1.get_stat(NBX_STAT_BH_FALLBACKS) == 1 and e1.get_stat(NBX_STAT_BH_LAST_TREE) == 0
     for k in ("px", "py", "vx", "vy"):                       # the refused step == the host-tree step, bit for bit
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
     for _ in range(2):
         e1.step_barnes_hut(0.5, 0.01, 1)
     a, b = e1.get_particles(), d.get_particles()             # waiting form == pipelined form over the whole sequence
-    assert e1.get_option(NBX_OPT_BH_FALLBACKS) == d.get_option(NBX_OPT_BH_FALLBACKS)
+    assert e1.get_stat(NBX_STAT_BH_FALLBACKS) == d.get_stat(NBX_STAT_BH_FALLBACKS)
     for k in ("px", "py", "vx", "vy"):
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
-    fb = d.get_option(NBX_OPT_BH_FALLBACKS)
+    fb = d.get_stat(NBX_STAT_BH_FALLBACKS)
     # new state, new verdict: a well-separated system right behind it stays on the device, nothing is left pending
     d.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     d.step_barnes_hut(0.5, 0.01, 1)
     d.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])      # replaces the state while that step's verdict is still unread
     d.step_barnes_hut(0.5, 0.01, 1)
-    assert d.get_option(NBX_OPT_BH_LAST_TREE) == 1 and d.get_option(NBX_OPT_BH_FALLBACKS) == fb
+    assert d.get_stat(NBX_STAT_BH_LAST_TREE) == 1 and d.get_stat(NBX_STAT_BH_FALLBACKS) == fb
     ref = engines(rx, p, fold=fold); ref.set_option(NBX_OPT_BH_ASYNC, 0); ref.step_barnes_hut(0.5, 0.01, 1)
     a, b = ref.get_particles(), d.get_particles()
     for k in ("px", "py", "vx", "vy"):
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
-
-
-def test_compact_walk_records_are_bit_identical(rx, ob):
-    """NBX_OPT_BH_WALK_RECORDS = 16 (the round-3 A/B of the wave walk: 16-byte decision records + mass words, mass used one visit
-    late): every body's force and a step, bit for bit those of the 32-byte walk."""
-    from rust_exp_amd.engine import NBX_OPT_BH_WALK, NBX_OPT_BH_WALK_RECORDS
-
-    st = rx.plummer_sphere(100000, dim=2)
-    res = []
-    for rec in (32, 16):
-        e = rx.NBodyEngine()
-        e.set_bh_fold("exact")
-        e.set_option(NBX_OPT_BH_WALK, 0)   # the record size is a property of the node walk
-        e.set_option(NBX_OPT_BH_WALK_RECORDS, rec)
-        e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
-        for _ in range(3):
-            e.step_barnes_hut(0.5, 0.01, 1)
-        res.append(e.get_particles())
-    for k in ("px", "py", "vx", "vy"):
-        assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
-    assert np.abs(res[0]["px"] - st["px"]).max() > 0
 
 
 def test_reference_fold_merges_between_non_neighbouring_entities(rx, ob):
@@ -667,7 +646,7 @@ def test_reference_fold_merges_between_non_neighbouring_entities(rx, ob):
     between them -- and the reference still merges them when that third body arrived later; a neighbours-only merge misses it
     (10 nodes too many: the exact-sum class keeps that looser contract).  The reference-fold class must reproduce it (k_blobs
     replays the cluster, k_place moves the merged body next to its entity) or hand the step to the host build."""
-    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+    from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE
 
     rng = np.random.default_rng(5214)
     n = int(rng.choice([2, 3, 17, 255, 256, 257, 1000, 4097, 9000, 20000, 70000, 150000]))
@@ -685,10 +664,10 @@ def test_reference_fold_merges_between_non_neighbouring_entities(rx, ob):
     fx, fy, _ = h.forces(0.85)
     gx, gy, _ = d.forces(0.85)
     assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
-    if d.get_option(NBX_OPT_BH_LAST_TREE) == 1:          # since the replay of whole clusters (k_blobs): the device tree itself
+    if d.get_stat(NBX_STAT_BH_LAST_TREE) == 1:          # since the replay of whole clusters (k_blobs): the device tree itself
         _bit_equal_trees(d.bh_flat_dump(False), d.bh_flat_dump("device"))
     else:
-        assert d.get_option(NBX_OPT_BH_FALLBACKS) == 1
+        assert d.get_stat(NBX_STAT_BH_FALLBACKS) == 1
     # a step through the pipelined path gives the host-tree step too
     d.step_barnes_hut(0.85, 0.01, 1); h.step_barnes_hut(0.85, 0.01, 1)
     a, b = h.get_particles(), d.get_particles()
@@ -700,7 +679,7 @@ def test_refusals_in_a_row_back_off_to_the_host_build(rx, ob):
     """A system the device build refuses tends to stay that way for many steps: after the second refused build in a row the next 2, 4, 8 ..
     steps go straight to the host build, then one step tries the device again (engine_internal.h note_refusal).  Every step is
     the host-tree step, bit for bit; the number of device builds attempted is read from the profile; a new state resets it."""
-    from rust_exp_amd.engine import NBX_K_TREE_BUILD, NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+    from rust_exp_amd.engine import NBX_K_TREE_BUILD, NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE
 
     rng = np.random.default_rng(77)
     n0 = 4000
@@ -724,7 +703,7 @@ def test_refusals_in_a_row_back_off_to_the_host_build(rx, ob):
         b = d.get_particles()
         for k in ("px", "py", "vx", "vy"):
             assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
-        assert d.get_option(NBX_OPT_BH_FALLBACKS) == steps and d.get_option(NBX_OPT_BH_LAST_TREE) == 0
+        assert d.get_stat(NBX_STAT_BH_FALLBACKS) == steps and d.get_stat(NBX_STAT_BH_LAST_TREE) == 0
         # attempts: steps 1, 2 (refused twice -> 2 host steps), 5 (-> 4 host steps), 10 (-> 8 host steps); the pipelined form had
         # step 2's build in flight when step 1's verdict arrived (poisoned, enqueued again): one build more
         assert d.profile_read(NBX_K_TREE_BUILD)[1] == (5 if async_ else 4)
@@ -732,17 +711,17 @@ def test_refusals_in_a_row_back_off_to_the_host_build(rx, ob):
     p = ob.stable_orbits(6000, 0.5, 30.0, 3)
     d.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     d.step_barnes_hut(0.85, 0.01, 1)
-    assert d.get_option(NBX_OPT_BH_LAST_TREE) == 1 and d.get_option(NBX_OPT_BH_FALLBACKS) == steps
+    assert d.get_stat(NBX_STAT_BH_LAST_TREE) == 1 and d.get_stat(NBX_STAT_BH_FALLBACKS) == steps
 
 
 def test_strict_mode_on_the_device_tree_keeps_the_references_depth_panic(rx, ob):
     """The reference panics when its depth COUNTER passes 50 (nbody.rs:230-232) -- and the counter grows by two per level while a
     leaf is split down, so two bodies 1.5e-4 apart (not "too close") in a box 4e4 wide, 28 levels to separate, trip it although no
     node is deeper than 29.  The device build has no such counter: in the bit-exact mode it therefore leaves every tree with a
-    leaf below level 25 to the host build, which counts like the reference (NBX_OPT_BH_REFUSAL 0x200), and the caller gets the
+    leaf below level 25 to the host build, which counts like the reference (NBX_STAT_BH_REFUSAL 0x200), and the caller gets the
     reference's panic as NBX_ERR_TREE_DEPTH; found by tests/fuzz_strict.py seed 20206.  The fast mode documents that it has no
     depth panic and builds the tree."""
-    from rust_exp_amd.engine import NBX_OPT_BH_LAST_TREE, NBX_OPT_BH_REFUSAL
+    from rust_exp_amd.engine import NBX_STAT_BH_LAST_TREE, NBX_STAT_BH_REFUSAL
 
     rng = np.random.default_rng(5)
     n0 = 1500
@@ -757,7 +736,7 @@ def test_strict_mode_on_the_device_tree_keeps_the_references_depth_panic(rx, ob)
     e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     with pytest.raises(rx.NBodyError) as err:
         e.forces(0.5)
-    assert err.value.code == -4 and e.get_option(NBX_OPT_BH_REFUSAL) == 0x200
+    assert err.value.code == -4 and e.get_stat(NBX_STAT_BH_REFUSAL) == 0x200
     f = engines(rx, p); f.set_bh_tree("device")
     fx, fy, _ = f.forces(0.5)
-    assert f.get_option(NBX_OPT_BH_LAST_TREE) == 1 and np.isfinite(fx).all() and np.isfinite(fy).all()
+    assert f.get_stat(NBX_STAT_BH_LAST_TREE) == 1 and np.isfinite(fx).all() and np.isfinite(fy).all()

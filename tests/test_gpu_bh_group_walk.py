@@ -173,23 +173,28 @@ def test_group_walk_degenerate_trees(rx, ob):
                 assert max(np.abs(gx - ofx).max(), np.abs(gy - ofy).max()) <= 1e-5 * scale, (name, theta, tree)
 
 
-def test_launch_order_of_the_walks_changes_no_result(rx):
-    """NBX_OPT_BH_WALK_ORDER = 1 (opt-in A/B of round 4): more than 8 192 walks are launched longest-first by the previous step's
-    costs.  Which walk runs where and when must not change a bit of the state."""
-    from rust_exp_amd.engine import NBX_OPT_BH_WALK_ORDER
+def test_splitting_the_costliest_walks_changes_no_result(rx):
+    """NBX_WALK_SPLIT_PCT (the round-5 experiment, off by default): with more than 8 192 walks, the quarter that loaded the most
+    groups in the previous step runs as two halves of 32 bodies, Morton order kept.  Lanes masked out of a walk add nothing: which
+    bodies share a walk must not change a bit of the state (child process: the knob is read when an engine is created)."""
+    import os
+    import subprocess
+    import sys
 
-    st = rx.plummer_sphere(600000, dim=2)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import rust_exp_amd as rx\n"
+            "st = rx.plummer_sphere(600000, dim=2)\n"
+            "e = rx.NBodyEngine(); e.set_particles(st['px'], st['py'], st['vx'], st['vy'], st['m'])\n"
+            "for _ in range(4): e.step_barnes_hut(0.5, 0.01, 1)\n"
+            "q = e.get_particles(); np.save(sys.argv[1], np.stack([q['px'], q['py'], q['vx'], q['vy']]))\n" % root)
     res = []
-    for order in (0, 1):
-        e = rx.NBodyEngine()
-        e.set_option(NBX_OPT_BH_WALK_ORDER, order)
-        e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
-        for _ in range(4):
-            e.step_barnes_hut(0.5, 0.01, 1)
-        res.append(e.get_particles())
-    for k in ("px", "py", "vx", "vy"):
-        assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
-    assert np.abs(res[0]["px"] - st["px"]).max() > 0
+    for pct in ("0", "25"):
+        path = "/tmp/nbx_split_%s.npy" % pct
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, NBX_WALK_SPLIT_PCT=pct), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-500:]
+        res.append(np.load(path))
+    assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
 
 
 @pytest.mark.parametrize("n,async_,tree", [(300, 1, "device"), (3000, 1, "device"), (12000, 0, "device"), (12000, 1, "device"),
@@ -199,7 +204,7 @@ def test_kick_drift_folded_into_the_walk_changes_no_bit(rx, ob, n, async_, tree)
     and the velocity kill itself.  Same operations on the same acceleration: positions and velocities equal the separate
     kick-drift kernel's bit for bit, step after step -- bodies that cross the +-55 kill box included -- in the waiting and the
     pipelined form of the step, and when a refused device build hands the step to the host tree."""
-    from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_FUSE_KICK, NBX_OPT_BH_LAST_TREE
+    from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_STAT_BH_FALLBACKS, NBX_OPT_BH_FUSE_KICK, NBX_STAT_BH_LAST_TREE
 
     p = ob.stable_orbits(n, 0.5, 30.0, 77)
     rng = np.random.default_rng(n)
@@ -221,7 +226,7 @@ def test_kick_drift_folded_into_the_walk_changes_no_bit(rx, ob, n, async_, tree)
         for _ in range(4):
             e.step_barnes_hut(0.6, 0.01, 1)
         res.append(e.get_particles())
-        assert e.get_option(NBX_OPT_BH_LAST_TREE) == (1 if tree == "device" else 0) and e.get_option(NBX_OPT_BH_FALLBACKS) == 0
+        assert e.get_stat(NBX_STAT_BH_LAST_TREE) == (1 if tree == "device" else 0) and e.get_stat(NBX_STAT_BH_FALLBACKS) == 0
     for k in ("px", "py", "vx", "vy"):
         assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k
     assert np.abs(res[0]["px"] - p["px"]).max() > 0
@@ -232,7 +237,7 @@ def test_a_refused_build_stops_the_folded_kick_too(rx, ob, fold):
     """The gate of the pipelined step (bh_gate.h) in the kernel that now ends it: a device build that must refuse (node pool
     exhausted by thousands of 18-level chains; EPS triples under the reference fold) leaves the state alone, the step is redone on
     the host tree, the step enqueued behind it is enqueued again -- the same states as with the separate kick-drift kernel."""
-    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_FUSE_KICK
+    from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS, NBX_OPT_BH_FUSE_KICK
 
     rng = np.random.default_rng(8)
     x = rng.uniform(-20, 20, 4000).astype(np.float32); y = rng.uniform(-20, 20, 4000).astype(np.float32)
@@ -247,7 +252,7 @@ def test_a_refused_build_stops_the_folded_kick_too(rx, ob, fold):
         for _ in range(4):
             e.step_barnes_hut(0.5, 0.01, 1)
         res.append(e.get_particles())
-        fallbacks.append(e.get_option(NBX_OPT_BH_FALLBACKS))
+        fallbacks.append(e.get_stat(NBX_STAT_BH_FALLBACKS))
     assert fallbacks[0] >= 1 and fallbacks[0] == fallbacks[1]
     for k in ("px", "py", "vx", "vy"):
         assert np.array_equal(res[0][k].view(np.uint32), res[1][k].view(np.uint32)), k

@@ -34,21 +34,21 @@ def _state(rx, ob, make, n):
 @pytest.mark.parametrize("make,n,steps", [("orbits", 20000, 6), ("disk", 50000, 6), ("plummer", 65536, 4), ("orbits", 131072, 4),
                                           ("disk", 300000, 3)])
 def test_warm_sort_builds_the_host_tree_bit_for_bit_after_every_step(rx, ob, make, n, steps):
-    from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_LAST_TREE
+    from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE
 
     p = _state(rx, ob, make, n)
     e = rx.NBodyEngine()
     e.set_bh_fold("reference")                            # the class that promises the host tree node for node, at any size
     e.set_bh_tree("device")
     e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
-    fallbacks0 = e.get_option(NBX_OPT_BH_FALLBACKS)
+    fallbacks0 = e.get_stat(NBX_STAT_BH_FALLBACKS)
     for k in range(steps):
         e.step_barnes_hut(0.5, 0.01, 1)                   # build k is cold for k = 0, warm from then on
         e.synchronize()
         _bit_equal_trees(e.bh_flat_dump(False), e.bh_flat_dump("device"))   # (the dump builds once more: warm, same state)
     # the steps ran on the device tree, warm builds included (a refused build would have counted as a fallback)
-    assert e.get_option(NBX_OPT_BH_LAST_TREE) == 1
-    assert e.get_option(NBX_OPT_BH_FALLBACKS) == fallbacks0
+    assert e.get_stat(NBX_STAT_BH_LAST_TREE) == 1
+    assert e.get_stat(NBX_STAT_BH_FALLBACKS) == fallbacks0
 
 
 def test_warm_and_cold_sorts_step_to_the_same_bits(rx, ob):
@@ -62,7 +62,7 @@ def test_warm_and_cold_sorts_step_to_the_same_bits(rx, ob):
             "rng = np.random.default_rng(5); vx = rng.normal(0, 8, 200000).astype(np.float32); vy = rng.normal(0, 8, 200000).astype(np.float32)\n"
             "e = rx.NBodyEngine(); e.set_bh_tree('device'); e.set_particles(st['px'], st['py'], vx, vy, st['m'])\n"
             "for _ in range(8): e.step_barnes_hut(0.5, 0.01, 1)\n"
-            "q = e.get_particles(); print(e.get_option(rx.engine.NBX_OPT_BH_FALLBACKS)); np.save(sys.argv[1], np.stack([q['px'], q['py'], q['vx'], q['vy']]))\n"
+            "q = e.get_particles(); print(e.get_stat(rx.engine.NBX_STAT_BH_FALLBACKS)); np.save(sys.argv[1], np.stack([q['px'], q['py'], q['vx'], q['vy']]))\n"
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = []
     for flag in ("1", "0"):

@@ -6,7 +6,7 @@ independent, so atomics give exact counts."""
 import numpy as np
 import pytest
 
-from rust_exp_amd.engine import NBX_OPT_DRAW_AMBIGUOUS
+from rust_exp_amd.engine import NBX_STAT_DRAW_AMBIGUOUS
 
 pytestmark = pytest.mark.gpu
 
@@ -39,7 +39,7 @@ def test_device_draw_exact_on_octant_directions(rx, ob, shape):
     got = e.draw(w, h)
     assert np.array_equal(got, want), int((got != want).sum())
     n_diag = int(((np.abs(p["vx"]) == np.abs(p["vy"])) & (p["vx"] != 0)).sum())
-    assert e.get_option(NBX_OPT_DRAW_AMBIGUOUS) == n_diag > 1000
+    assert e.get_stat(NBX_STAT_DRAW_AMBIGUOUS) == n_diag > 1000
 
 
 def test_device_draw_adversarial_directions_near_every_octant_step(rx, ob):
@@ -73,7 +73,7 @@ def test_device_draw_adversarial_directions_near_every_octant_step(rx, ob):
     e = eng(rx, p)
     got = e.draw(256, 256)
     assert np.array_equal(got, want), int((got != want).sum())
-    amb = e.get_option(NBX_OPT_DRAW_AMBIGUOUS)
+    amb = e.get_stat(NBX_STAT_DRAW_AMBIGUOUS)
     assert 500 < amb < n                       # the band caught the near-step directions, and only part of the set is in it
 
 
@@ -100,11 +100,11 @@ def test_device_draw_equals_oracle_on_100000_random_bodies_and_is_the_default_fo
     d = rx.NBodyEngine()
     d.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
     d.step_brute_force(0.0)                      # state resident on the GPU (a zero-length step changes nothing)
-    assert np.array_equal(d.draw(512, 512), want) and d.get_option(NBX_OPT_DRAW_AMBIGUOUS) >= 0      # ran on the device
+    assert np.array_equal(d.draw(512, 512), want) and d.get_stat(NBX_STAT_DRAW_AMBIGUOUS) >= 0      # ran on the device
     small = rx.NBodyEngine()
     small.set_particles(p["px"][:4000], p["py"][:4000], p["vx"][:4000], p["vy"][:4000], p["m"][:4000])
     small.step_brute_force(0.0)
-    assert np.array_equal(small.draw(512, 512), ob.draw(p[:4000], 512, 512)) and small.get_option(NBX_OPT_DRAW_AMBIGUOUS) == -1
+    assert np.array_equal(small.draw(512, 512), ob.draw(p[:4000], 512, 512)) and small.get_stat(NBX_STAT_DRAW_AMBIGUOUS) == -1
     from rust_exp_amd.engine import NBX_OPT_DRAW_DEVICE
     assert d.get_option(NBX_OPT_DRAW_DEVICE) == -1
 

@@ -170,8 +170,8 @@ def test_config4_barnes_hut_1m_theta_half_against_the_oracle(rx, ob):
     d = rx.NBodyEngine(mode="fast")
     d.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
     dx, dy, _ = d.forces(theta)
-    from rust_exp_amd.engine import NBX_OPT_BH_LAST_TREE
-    assert d.get_option(NBX_OPT_BH_LAST_TREE) == 1
+    from rust_exp_amd.engine import NBX_STAT_BH_LAST_TREE
+    assert d.get_stat(NBX_STAT_BH_LAST_TREE) == 1
     dev_arb = np.maximum(np.abs(dx - ex), np.abs(dy - ey)) / scale
     orc_arb = np.maximum(np.abs(ofx - ex), np.abs(ofy - ey)) / scale
     dev_orc = np.maximum(np.abs(dx - ofx), np.abs(dy - ofy)) / scale

@@ -55,7 +55,7 @@ def main():
                 fx, fy, _ = e.forces(theta)
                 err = np.maximum(np.abs(fx - ofx), np.abs(fy - ofy)) / scale
                 r[where] = {"max": float(err.max()), "p999": float(np.percentile(err, 99.9)), "median": float(np.median(err)),
-                            "last_tree": e.get_option(rx.engine.NBX_OPT_BH_LAST_TREE), "fallbacks": e.get_option(rx.engine.NBX_OPT_BH_FALLBACKS)}
+                            "last_tree": e.get_stat(rx.engine.NBX_STAT_BH_LAST_TREE), "fallbacks": e.get_stat(rx.engine.NBX_STAT_BH_FALLBACKS)}
             rec[f"theta{theta}"] = r
         e = rx.NBodyEngine()
         e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])

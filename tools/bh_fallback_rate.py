@@ -9,7 +9,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import rust_exp_amd as rx  # noqa: E402
-from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS  # noqa: E402
+from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS  # noqa: E402
 
 CASES = (("stable_orbits", 10000), ("random_disk", 10000), ("random_disk", 2000), ("stable_orbits", 65536), ("random_disk", 65536))
 if len(sys.argv) > 1:   # e.g. random_disk:65536
@@ -29,5 +29,5 @@ for scene, n in CASES:
         if (k + 1) % (steps // 10) == 0:
             e.synchronize()
             marks.append(round((time.perf_counter() - t0) * 1e3 / (k + 1), 4))
-            fb.append(e.get_option(NBX_OPT_BH_FALLBACKS))
+            fb.append(e.get_stat(NBX_STAT_BH_FALLBACKS))
     print(json.dumps({"scene": scene, "n": n, "steps": steps, "fallbacks_cumulative_by_tenth": fb, "ms_per_step_cumulative": marks}), flush=True)

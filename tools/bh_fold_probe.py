@@ -39,7 +39,7 @@ def timed(st, theta, tree, fold, steps):
         e.step_barnes_hut(theta, 0.01, 1)
     e.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    return ms, e.get_option(rx.engine.NBX_OPT_BH_LAST_TREE), e.get_option(rx.engine.NBX_OPT_BH_FALLBACKS)
+    return ms, e.get_stat(rx.engine.NBX_STAT_BH_LAST_TREE), e.get_stat(rx.engine.NBX_STAT_BH_FALLBACKS)
 
 
 def main():

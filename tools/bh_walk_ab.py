@@ -20,9 +20,7 @@ def run(n, theta, walk, wave=1, steps=30, fold="exact"):
     e = rx.NBodyEngine(mode="fast")
     e.set_bh_fold(fold)
     e.set_option(NBX_OPT_BH_WALK, walk)
-    if os.environ.get("NBX_AB_WALK_ORDER"):
-        from rust_exp_amd.engine import NBX_OPT_BH_WALK_ORDER
-        e.set_option(NBX_OPT_BH_WALK_ORDER, int(os.environ["NBX_AB_WALK_ORDER"]))
+    # (round 4's NBX_AB_WALK_ORDER went with NBX_OPT_BH_WALK_ORDER; round 5's experiment is the env NBX_WALK_SPLIT_PCT, read by the engine)
     e.set_option(NBX_OPT_BH_WAVE, wave)
     if os.environ.get("NBX_AB_FUSE_KICK"):
         from rust_exp_amd.engine import NBX_OPT_BH_FUSE_KICK

@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import rust_exp_amd as rx
-from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS, NBX_OPT_BH_REFUSAL, NBX_OPT_BH_LAST_TREE
+from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_REFUSAL, NBX_STAT_BH_LAST_TREE
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1048576
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
@@ -21,5 +21,5 @@ for k in range(steps):
     t0 = time.perf_counter()
     e.step_barnes_hut(0.5, 0.01, 1)
     e.synchronize()
-    print(k, "ms %.3f" % ((time.perf_counter() - t0) * 1e3), "fallbacks", e.get_option(NBX_OPT_BH_FALLBACKS), "why 0x%x" % e.get_option(NBX_OPT_BH_REFUSAL),
-          "tree", e.get_option(NBX_OPT_BH_LAST_TREE))
+    print(k, "ms %.3f" % ((time.perf_counter() - t0) * 1e3), "fallbacks", e.get_stat(NBX_STAT_BH_FALLBACKS), "why 0x%x" % e.get_stat(NBX_STAT_BH_REFUSAL),
+          "tree", e.get_stat(NBX_STAT_BH_LAST_TREE))

@@ -10,7 +10,7 @@
 #   pmc     six rocprofv3 --pmc passes of the bench command (summarise locally with tools/pmc_summary.py TAG)
 #   power   tools/power_probe.py: board power during a >= 6 s K1 loop
 #   shapes  launch-shape sweeps (sweep_shapes.py, shard-of-8 shape)
-#   k1ab    K1 kernel variants 5/6/7 A/B (bench lines + board power)
+#   k1ab    K1 kernel variants 1/6/7 A/B (bench lines + board power)
 #   cfgs    bench.py on BASELINE configs #2 and #5 (one GPU), the 2-D kernel, the bit-exact mode
 #   fuzz    the four hand-run fuzz campaigns (tests/fuzz_*.py)
 #   ubench  instruction-issue microbenchmarks
@@ -55,17 +55,16 @@ for stage in "$@"; do
       done ;;
     power)
       timeout 300 python tools/power_probe.py 6 > $O/${TAG}_power_k1.json 2> $O/${TAG}_power_k1.err; echo "power rc=$?"; cut -c1-1500 $O/${TAG}_power_k1.json
-      timeout 300 python tools/power_probe.py 6 --variant 4 > $O/${TAG}_power_k1_variant4.json 2>> $O/${TAG}_power_k1.err
       timeout 300 python tools/power_probe.py 6 --variant 1 > $O/${TAG}_power_k1_variant1.json 2>> $O/${TAG}_power_k1.err
       ls /sys/class/drm/card*/device/hwmon/hwmon*/ > $O/${TAG}_hwmon_ls.txt 2>&1
       rocm-smi --showpower --showclocks --showmaxpower > $O/${TAG}_rocm_smi.txt 2>&1 ;;
     shapes)
       timeout 1200 python tools/sweep_shapes.py > $O/${TAG}_shapes.log 2>&1
-      for v in 5 ; do for s in 0 32 64 128; do
+      for v in 6 ; do for s in 0 32 64 128; do   # (round 1 swept variant 5 here; removed in round 5)
         timeout 300 python bench.py --shard-of 8 --variant $v --jsplit $s --no-cpu-baseline --no-traffic >> $O/${TAG}_shard_of_8.jsonl 2>> $O/${TAG}_shard.err
       done; done ;;
     k1ab)   # K1 variants A/B: bench line + board power per variant, at the headline size, config #2's size and the 8-way shard shape
-      for v in 5 6 7; do
+      for v in 1 6 7; do   # (variant 5 of the round-2 A/B was removed in round 5)
         timeout 300 python bench.py --variant $v --no-cpu-baseline --no-traffic >> $O/${TAG}_k1ab_n262144.jsonl 2>> $O/${TAG}_k1ab.err
         timeout 300 python bench.py --variant $v --n 65536 --no-cpu-baseline --no-traffic >> $O/${TAG}_k1ab_n65536.jsonl 2>> $O/${TAG}_k1ab.err
         timeout 300 python bench.py --variant $v --shard-of 8 --no-cpu-baseline --no-traffic >> $O/${TAG}_k1ab_shard_of_8.jsonl 2>> $O/${TAG}_k1ab.err

@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import rust_exp_amd as rx  # noqa: E402
-from rust_exp_amd.engine import NBX_OPT_BH_FALLBACKS  # noqa: E402
+from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 for scene, n in (("random_disk", 10000), ("stable_orbits", 10000), ("random_disk", 30000)):
@@ -32,5 +32,5 @@ for scene, n in (("random_disk", 10000), ("stable_orbits", 10000), ("random_disk
     ok = bool(np.isfinite(st["px"]).all() and np.isfinite(st["vx"]).all())
     rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     print(scene, n, "steps", k_steps, "finite", ok, "ms/step %.3f" % ((time.perf_counter() - t0) / k_steps * 1e3),
-          "handed over", e.get_option(NBX_OPT_BH_FALLBACKS), "maxrss growth KiB", rss1 - rss0, flush=True)
+          "handed over", e.get_stat(NBX_STAT_BH_FALLBACKS), "maxrss growth KiB", rss1 - rss0, flush=True)
     e.close()
