@@ -169,7 +169,7 @@ enum nbx_stat {
     NBX_STAT_DRAW_AMBIGUOUS = 2,   /* tails the last device draw left to the host; -1 = the last draw ran on the host */
     NBX_STAT_BH_REFUSAL = 3        /* why the last device tree build that handed its evaluation to the host build did so
                                     * (0: none has yet) -- 0x10000 = the node pool or the fold queue overflowed; 0x100000 = a bucket of the warm sort outgrew its
-                                    * slots (bh_build.hip, round 5); else bits of the
+                                    * slots (bh_sort.hip, round 5); else bits of the
                                     * cluster replay (NBX_OPT_BH_FOLD = 1): 1 more than 512 entities around one point, 4 a cluster
                                     * of more than 48 entities / 96 bodies, 8 a merge hinges on another cluster, 16 an outsider
                                     * within EPS of a blob's centre, 32 two entities in one level-31 cell that do not merge,

@@ -2,7 +2,7 @@
 //
 // Replaces Node::compute_force (nbody.rs:333-377), evaluated per body by the reference's worker
 // threads (nbody.rs:443-447).  The quadtree itself is built on the device (bh_build.hip: the fast mode's default from 1 024 bodies
-// on; up to 65 536 bodies bit-identical to the host tree) or on the host exactly as the reference builds it (host_ops.cpp;
+// on; up to 65 536 bodies bit-identical to the host tree) or on the host exactly as the reference builds it (host_tree.cpp;
 // nbody.rs:388-415: always in the bit-exact mode), and flattened in PRE-ORDER (children UL,UR,LL,LR,
 // empty exterior nodes dropped) with a skip pointer per node, so the recursive descent becomes a
 // stackless walk:  open a node -> next index;  accept / leaf -> skip[index].

@@ -318,15 +318,15 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
     return acc;
 }
 
-// order / cost (optional): the walks differ in length (a dense core's bodies sit deep in the tree), and 16 384 of them on 8 192
-// wave slots are two rounds and a tail whose length is the spread of those lengths.  Every walk leaves its cost (groups
-// loaded) in cost[]; order = the launch LIST k_walk_split_list makes of last step's costs (the costliest walks as two halves).
-// Which walk runs where, and with which of its bodies, changes no result.
+// The walks differ in length (a dense core's bodies sit deep in the tree), and 16 384 of them on 8 192 wave slots are two rounds and
+// a tail whose length is the spread of those lengths.  Measured and removed: launching them longest first (round 4: any departure
+// from Morton order costs the L2 more than the tail gains) and running the costliest p % as two halves of 32 bodies (round 5:
+// traversal 0.434 -> 0.482 / 0.499 / 0.543 / 0.635 ms with p = 10 / 25 / 50 / 100 at 1 M bodies -- half a walk costs 0.7 of a whole
+// one; docs/rounds/r05.md, profiles/r05_bh_walk_split_ab.jsonl).
 template <int BPW, bool ASM>
 __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* posm, const int lo, const int n_targets,
                                                        const BhGroup* __restrict__ groups, void* __restrict__ sink,
                                                        const unsigned* __restrict__ perm, const int xcd_order, const BuildGate gate,
-                                                       const int* __restrict__ order, int* __restrict__ cost,
                                                        unsigned long long* __restrict__ trace, float4* kick_posm, const float kick_dt)
 {
     // sink: float2 out[] (accelerations) -- or, with the kick folded in (kick_posm != nullptr), float4 vel[]: ONE pointer, because
@@ -339,19 +339,9 @@ __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* posm, const
     if (!gate_open(gate, n_nodes_unused, kick_posm != nullptr && blockIdx.x == 0 && threadIdx.x == 0)) return;
     const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;   // the 100 MHz clock all XCDs share
     // XCD-aware order (as the node walk, bh_eval.hip): XCD k walks the k-th contiguous eighth of the Morton-ordered bodies
-    // `entry` = walk | half << 28 is the ONE scalar that names this workgroup's work across the walk loop (the SGPR budget above)
-    int entry = xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if (BPW == 64 && order) {
-        // the launch list of a step whose long walks are split (k_walk_split_list): order[0] entries in Morton order, each a walk
-        // or one half of it (bits 28-29: 1 = its lanes 0-31, 2 = its lanes 32-63); XCD k takes the k-th eighth of the LIST
-        const int entries = order[0], per = (entries + 7) >> 3, j = (int)(blockIdx.x >> 3);
-        const int e = (int)(blockIdx.x & 7u) * per + j;
-        if (j >= per || e >= entries) return;
-        entry = order[1 + e];
-    }
-    const int t = (entry & 0x0FFFFFFF) * BPW + threadIdx.x;
-    bool valid = (int)threadIdx.x < BPW && t < n_targets;
-    if constexpr (BPW == 64) valid = valid && ((entry >> 28) == 0 || (int)(threadIdx.x >> 5) == (entry >> 28) - 1);   // (halves: 64-body walks only)
+    const int blk = xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int t = blk * BPW + threadIdx.x;
+    const bool valid = (int)threadIdx.x < BPW && t < n_targets;
     const u64 M = __ballot(valid);
     if (M == 0ull) return;
     const int it = valid ? (perm ? (int)perm[t] - lo : t) : 0;
@@ -361,16 +351,7 @@ __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* posm, const
     int overflow = ASM ? 0 : 1, turns = 0;
     if (ASM) acc = walk_groups_asm(groups, p, M, overflow, turns);
     if (__builtin_amdgcn_readfirstlane(overflow)) acc = walk_groups_compiled(groups, p, M, spill_mem);   // (uniform: the asm's output is an SGPR)
-    // who takes part, once more from `entry` (laundered: the compiler would otherwise carry the first evaluation's lane mask -- two
-    // more scalar registers -- across the loop; tests/test_kernel_resources.py holds the count)
-    bool valid2 = valid;
-    if constexpr (BPW == 64) {
-        int entry2 = entry;
-        asm volatile("" : "+s"(entry2));
-        valid2 = (int)threadIdx.x < BPW && (entry2 & 0x0FFFFFFF) * BPW + (int)threadIdx.x < n_targets &&
-                 ((entry2 >> 28) == 0 || (int)(threadIdx.x >> 5) == (entry2 >> 28) - 1);
-    }
-    if (valid2) {
+    if (valid) {
         if (kick_posm) {   // kick-drift with the acceleration just found: the operations and order of k_integrate_f2 (is_accel, killbox)
             float4* const vel = static_cast<float4*>(sink);
             float4 v = vel[it];
@@ -390,16 +371,12 @@ __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* posm, const
             static_cast<float2*>(sink)[it] = make_float2(acc.x, acc.y);
         }
     }
-    if (ASM && cost && threadIdx.x == 0) {   // (a half leaves 0.7 of its turns: what half a walk was measured to cost of a whole one)
-        const int tn = __builtin_amdgcn_readfirstlane(turns);
-        if (BPW != 64 || (entry >> 28) == 0) cost[entry] = tn; else atomicAdd(&cost[entry & 0x0FFFFFFF], (7 * tn) / 10);
-    }
     if (trace && threadIdx.x == 0) {   // tools/bh_walk_trace.py: when and where this walk ran (s_memrealtime: 10 ns ticks; HW_ID, XCC_ID)
         trace[4 * (size_t)blockIdx.x + 0] = t_start;
         trace[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         trace[4 * (size_t)blockIdx.x + 2] = (unsigned long long)((unsigned)__builtin_amdgcn_readfirstlane(turns) & 0x7FFFFFFFu) |
                                             ((ASM && __builtin_amdgcn_readfirstlane(overflow)) ? 0x80000000ull : 0ull) |   // redone with the LDS spill
-                                            ((unsigned long long)(unsigned)entry << 32);
+                                            ((unsigned long long)(unsigned)blk << 32);
         trace[4 * (size_t)blockIdx.x + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
                                             ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);
     }
@@ -519,73 +496,6 @@ hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta
     return hipGetLastError();
 }
 
-// EXPERIMENT of round 5 (NBX_WALK_SPLIT_PCT, default off): the launch list of the next step's walks from this
-// step's costs -- Morton order kept, but the `budget` walks that loaded the most groups are entered as TWO halves (32 bodies each),
-// so that the last round of walks is made of shorter units.  list[0] = entries, list[1 ..] = walk | half << 28.  Exec-masked lanes
-// add nothing: results are bit-identical.  cost_next is cleared for the walks of the next step (halves ADD their share).
-__global__ __launch_bounds__(1024) void k_walk_split_list(const int* __restrict__ cost, int* __restrict__ cost_next, const int walks,
-                                                          const int budget, int* __restrict__ list)
-{
-    constexpr int kBins = 4096;
-    __shared__ int hist[kBins];
-    __shared__ int threshold, wave_sum[16], carry;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int b = tid; b < kBins; b += 1024) hist[b] = 0;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int w = tid; w < walks; w += 1024) atomicAdd(&hist[min(max(cost[w], 0), kBins - 1)], 1);
-    __syncthreads();
-    {   // the smallest t with at most `budget` walks costlier than t: suffix sums of the histogram, four bins per thread
-        int c[4], sum = 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) { c[u] = hist[4 * tid + u]; sum += c[u]; }
-        int incl = sum;                                   // walks in this thread's bins and in those of the threads ABOVE it
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_down(incl, off); if (lane + off < 64) incl += o; }
-        if (lane == 0) wave_sum[wave] = incl;
-        __syncthreads();
-        for (int v = wave + 1; v < 16; v++) incl += wave_sum[v];
-        int above = incl - sum;                           // costlier than this thread's top bin
-        if (tid == 0) threshold = 0;
-        __syncthreads();
-#pragma unroll
-        for (int u = 3; u >= 0; u--) {
-            const int t = 4 * tid + u;
-            if (above <= budget && t > 0 && above + c[u] > budget) threshold = t;   // (one t at most: above grows as t falls)
-            above += c[u];
-        }
-    }
-    __syncthreads();
-    const int T = threshold;
-    for (int w0 = 0; w0 < walks; w0 += 1024) {
-        const int w = w0 + tid;
-        const int c = w < walks ? cost[w] : 0;
-        const int mine = w < walks ? (c > T ? 2 : 1) : 0;
-        int incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
-        if (lane == 63) wave_sum[wave] = incl;
-        __syncthreads();
-        int before = carry;
-        for (int v = 0; v < wave; v++) before += wave_sum[v];
-        const int pos = before + incl - mine;
-        if (mine == 1) list[1 + pos] = w;
-        else if (mine == 2) { list[1 + pos] = w | (1 << 28); list[2 + pos] = w | (2 << 28); }
-        if (w < walks) cost_next[w] = 0;
-        __syncthreads();
-        if (tid == 1023) carry = before + incl;
-        __syncthreads();
-    }
-    if (tid == 0) list[0] = carry;
-}
-
-hipError_t launch_walk_split_list(const int* cost, int* cost_next, int* list, int walks, int budget, hipStream_t stream)
-{
-    if (walks <= 0 || (walks & 7) || budget < 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_walk_split_list, dim3(1), dim3(1024), 0, stream, cost, cost_next, walks, budget, list);
-    return hipGetLastError();
-}
-
 // how many walks (workgroups) launch_bh_walk_groups starts for n_targets bodies in the wave form, and with how many bodies each
 int bh_walk_count(int n_targets, int* bodies_per_walk)
 {
@@ -602,12 +512,11 @@ int bh_walk_count(int n_targets, int* bodies_per_walk)
 
 template <bool ASM>
 static void launch_wave_walk(int bpw, dim3 g, hipStream_t stream, const float4* posm, int lo, int n_targets, const BhGroup* groups,
-                             float2* out, const unsigned* perm, BuildGate gate, const int* order, int* cost, unsigned long long* trace,
-                             BhKick kick)
+                             float2* out, const unsigned* perm, BuildGate gate, unsigned long long* trace, BhKick kick)
 {
     auto go = [&](auto kernel) {
         void* sink = kick.vel ? static_cast<void*>(kick.vel) : static_cast<void*>(out);
-        hipLaunchKernelGGL(kernel, g, dim3(64), 0, stream, posm, lo, n_targets, groups, sink, perm, 1, gate, order, cost, trace,
+        hipLaunchKernelGGL(kernel, g, dim3(64), 0, stream, posm, lo, n_targets, groups, sink, perm, 1, gate, trace,
                            kick.vel ? kick.posm : nullptr, kick.dt);
     };
     if (bpw == 64) go(k_bh_walk_groups<64, ASM>);
@@ -621,8 +530,7 @@ static void launch_wave_walk(int bpw, dim3 g, hipStream_t stream, const float4* 
 
 hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, float2* out, hipStream_t stream,
                                  const unsigned* perm, bool wave, bool hand_scheduled, int* gate_counters, int gate_node_cap,
-                                 int gate_crowd_limit, int gate_queue_limit, const int* order, int* cost, unsigned long long* trace,
-                                 const BhKick* kick, int split_budget)
+                                 int gate_crowd_limit, int gate_queue_limit, unsigned long long* trace, const BhKick* kick)
 {
     if (n_targets <= 0) return hipSuccess;
     const BhKick kd = kick ? *kick : BhKick{nullptr, nullptr, 0.0f, nullptr};
@@ -631,10 +539,9 @@ hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, cons
     if (wave && perm) {
         // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 4 and 64 bodies each (as the node walk)
         int bpw = 64;
-        const int walks = bh_walk_count(n_targets, &bpw);
-        const dim3 g((unsigned)(((order ? walks + split_budget : walks) + 7) / 8 * 8));
-        if (hand_scheduled) launch_wave_walk<true>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, order, cost, trace, kd);
-        else launch_wave_walk<false>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, nullptr, nullptr, trace, kd);
+        const dim3 g((unsigned)bh_walk_count(n_targets, &bpw));
+        if (hand_scheduled) launch_wave_walk<true>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, trace, kd);
+        else launch_wave_walk<false>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, trace, kd);
     } else {
         const int block = n_targets <= 65536 ? 64 : kTile;
         hipLaunchKernelGGL(k_bh_walk_groups_lane, dim3((unsigned)((n_targets + block - 1) / block)), dim3(block), 0, stream, posm, lo,

@@ -757,9 +757,7 @@ int32_t nbx_bh_walk_trace(nbx_engine* e, float theta, int32_t cap_walks, uint64_
     rc = resolve_pending(e);
     if (rc != NBX_OK) return rc;
     const int slab = e->slab();
-    int walks = nbx::bh_walk_count(slab);
-    if (walks > 8192 && e->walk_split_pct > 0)   // (the round-5 experiment: the costliest walks run as two workgroups)
-        walks = (walks + (int)((long long)walks * e->walk_split_pct / 100) + 7) / 8 * 8;
+    const int walks = nbx::bh_walk_count(slab);
     if (walks > cap_walks) return walks;
     HIP_TRY(hipSetDevice(e->device));
     unsigned long long* d = nullptr;

@@ -54,14 +54,6 @@ struct nbx_engine {
     nbx::BhGroup* d_groups = nullptr;
     size_t groups_cap = 0;
     // longest-first launch order of the walks: costs of the last walk, the order made from them, and what shape they belong to
-    // round-5 experiment (NBX_WALK_SPLIT_PCT): the costliest walks of the previous step run as two halves (engine.cpp launch_fast_walk)
-    int* d_walk_cost = nullptr;          // [2][walks]: groups every walk loaded, this step's and the next one's (halves add their share)
-    int* d_walk_list = nullptr;          // [1 + walks + budget]: the launch list made of the previous step's costs
-    size_t walk_cost_cap = 0, walk_list_cap = 0;
-    int walk_list_walks = 0;             // > 0: d_walk_list holds a list for that many walks (same slab, same bodies per walk)
-    int walk_list_slab = 0;
-    int walk_cost_flip = 0;
-    int walk_split_pct = [] { const char* v = std::getenv("NBX_WALK_SPLIT_PCT"); const int p = v ? std::atoi(v) : 0; return p < 0 ? 0 : (p > 100 ? 100 : p); }();
     unsigned long long* d_walk_trace = nullptr;   // nbx_bh_walk_trace: set for the one evaluation it traces
     bool walk_traced = false;                     // ... and whether the walk that ran was the shared (wave) form, the one that writes the trace
     int bh_fuse_kick = 1;                // NBX_OPT_BH_FUSE_KICK: 1 (default) = the child-group walk applies the kick-drift itself, 0 = separate kernel
@@ -343,6 +335,7 @@ int download_positions(nbx_engine* e);
 int download_velocities(nbx_engine* e);
 void choose_launch(const nbx_engine* e, int n_targets, int tiles_total, int* variant, int* bpt, int* jsplit, int* dim);
 int launch_forces_fast(nbx_engine* e);
+bool log_enabled();   // NBX_LOG=1
 nbx::MassExceptions exceptions_of(const nbx_engine* e);
 nbx::SelfImage self_image_of(const nbx_engine* e);
 int step_brute(nbx_engine* e, float dt);

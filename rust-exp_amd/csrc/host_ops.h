@@ -93,7 +93,7 @@ struct QuadTree {
     // levels it must fill, for the bodies warm .. n-1, pbucket[i - warm] = bucket of body i, `sorted` = their insert
     // events grouped by bucket with the index order kept inside every bucket (depth = level of the bucket root), and
     // offset[b] .. offset[b+1] = bucket b's range in `sorted`.  Returns false to make the build do it itself.
-    // (The engine routes and scatters on the GPU, where the positions already are: bh_build.hip.)
+    // (The engine routes and scatters on the GPU, where the positions already are: bh_front.hip.)
     struct TopView {
         const Node* top;            // nodes of the top levels; top[k].first_child >= 0 for pass-through nodes
         const int* bucket_of;       // per top node: bucket id, or -1 for a pass-through node

@@ -39,9 +39,6 @@ hipError_t launch_bh_groups(const BhNode* nodes, int n_nodes_or_cap, float theta
                             int* gate_counters = nullptr, int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0);
 // accelerations of the slab's bodies (fast mode).  wave && perm: one walk per wave (bodies in the spatial order perm; hand_scheduled:
 // the assembly loop, else the compiler's), else one per lane; bit-identical results whichever runs
-// order / cost (hand-scheduled wave form only; both optional): every walk leaves the number of groups it loaded in cost[]
-// (bh_walk_count(n_targets) ints); order = the launch list launch_walk_split_list makes of the previous step's costs (1 + walks +
-// split_budget ints: the costliest walks entered as two halves of 32 bodies; round-5 experiment, off by default).  No result changes.
 // kick (optional, wave form only): the kick-drift of the step (nbody.rs:453-471, what k_integrate_f2 does) applied by the walk itself
 // as soon as a body's acceleration is complete -- legitimate because a walk reads no other body's position from posm (the group
 // records hold copies) -- so a small system's step is one dependent kernel shorter.  out is not written then.  host_out: see BuildGate.
@@ -54,11 +51,9 @@ struct BhKick {
 hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, float2* out, hipStream_t stream,
                                  const unsigned* perm, bool wave, bool hand_scheduled, int* gate_counters = nullptr,
                                  int gate_node_cap = 0, int gate_crowd_limit = 0, int gate_queue_limit = 0,
-                                 const int* order = nullptr, int* cost = nullptr, unsigned long long* trace = nullptr,
-                                 const BhKick* kick = nullptr, int split_budget = 0);
+                                 unsigned long long* trace = nullptr, const BhKick* kick = nullptr);
 // trace (optional, 4 words per walk = workgroup): s_memrealtime (10 ns ticks) at its start and end, groups loaded (bit 31: redone with the LDS spill) | chunk << 32, HW_ID | XCC_ID << 32
 int bh_walk_count(int n_targets, int* bodies_per_walk = nullptr);   // walks (workgroups) of the wave form, a multiple of 8
-hipError_t launch_walk_split_list(const int* cost, int* cost_next, int* list, int walks, int budget, hipStream_t stream);
 hipError_t launch_bh_count_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, unsigned long long* totals,
                                   hipStream_t stream);   // totals[0] children visited, [1] pair laws, [2] opening tests (visits of
                                                          // interior nodes), [3] groups loaded (per body)
@@ -171,10 +166,10 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes);
 hipError_t device_tree_workspace_init(void* workspace, hipStream_t stream);
 // warm (round 5): the workspace still holds the order an earlier call (this one or device_tree_build_begin) left for the SAME n
 // bodies, give or take a step's motion -- the sort then starts from it (k_splitters / k_keys_scatter / k_bucket_sort) instead
-// of from scratch; a warm sort whose buckets overflow refuses the build (counters[1], see bh_build.hip)
+// of from scratch; a warm sort whose buckets overflow refuses the build (counters[1], see bh_sort.hip)
 hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size_t workspace_bytes, const unsigned** perm_dev,
                                 hipStream_t stream, bool warm = false);
-// Routing + stable scatter for the host quadtree build (see bh_build.hip): top_host = ntop records of (x1, y1, x2, y2,
+// Routing + stable scatter for the host quadtree build (see bh_front.hip): top_host = ntop records of (x1, y1, x2, y2,
 // first_child, bucket); pbucket_host / events_host / offset_host are pinned, device-visible host arrays of rest ints,
 // rest 16-byte insert events and nb + 1 64-bit offsets.  Enqueues on `stream`; the caller waits.
 size_t device_route_workspace_bytes(int rest, int ntop, int nb);

@@ -215,7 +215,7 @@ def test_threaded_quadtree_build_is_result_identical(rx, ob, threads, monkeypatc
 
 @pytest.mark.parametrize("case", ["limit5_random", "limit6_plummer", "corner_first", "sorted_x", "sparse_ring", "two_clumps"])
 def test_threaded_build_parallel_top_phase_is_result_identical(rx, ob, case, monkeypatch):
-    """The warm-up / freeze / route-fold-scatter scheme (host_ops.cpp) for every bucket depth, for orders that
+    """The warm-up / freeze / route-fold-scatter scheme (host_tree.cpp) for every bucket depth, for orders that
     leave many top nodes exterior at the freeze, and for very unbalanced buckets: node-for-node the oracle tree."""
     monkeypatch.setenv("NBX_HOST_THREADS", "12")
     rng = np.random.default_rng(11)

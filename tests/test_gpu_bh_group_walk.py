@@ -173,30 +173,6 @@ def test_group_walk_degenerate_trees(rx, ob):
                 assert max(np.abs(gx - ofx).max(), np.abs(gy - ofy).max()) <= 1e-5 * scale, (name, theta, tree)
 
 
-def test_splitting_the_costliest_walks_changes_no_result(rx):
-    """NBX_WALK_SPLIT_PCT (the round-5 experiment, off by default): with more than 8 192 walks, the quarter that loaded the most
-    groups in the previous step runs as two halves of 32 bodies, Morton order kept.  Lanes masked out of a walk add nothing: which
-    bodies share a walk must not change a bit of the state (child process: the knob is read when an engine is created)."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, numpy as np; sys.path.insert(0, %r); import rust_exp_amd as rx\n"
-            "st = rx.plummer_sphere(600000, dim=2)\n"
-            "e = rx.NBodyEngine(); e.set_particles(st['px'], st['py'], st['vx'], st['vy'], st['m'])\n"
-            "for _ in range(4): e.step_barnes_hut(0.5, 0.01, 1)\n"
-            "q = e.get_particles(); np.save(sys.argv[1], np.stack([q['px'], q['py'], q['vx'], q['vy']]))\n" % root)
-    res = []
-    for pct in ("0", "25"):
-        path = "/tmp/nbx_split_%s.npy" % pct
-        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, NBX_WALK_SPLIT_PCT=pct), stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-500:]
-        res.append(np.load(path))
-    assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
-
-
 @pytest.mark.parametrize("n,async_,tree", [(300, 1, "device"), (3000, 1, "device"), (12000, 0, "device"), (12000, 1, "device"),
                                           (100000, 1, "device"), (600000, 1, "device"), (70000, 1, "host")])
 def test_kick_drift_folded_into_the_walk_changes_no_bit(rx, ob, n, async_, tree):

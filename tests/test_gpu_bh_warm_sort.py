@@ -1,4 +1,4 @@
-"""GPU: the device tree build's sort that starts from last step's order (bh_build.hip, round 5: k_splitters / k_keys_scatter /
+"""GPU: the device tree build's sort that starts from last step's order (bh_sort.hip, round 5: k_sample_rank / k_keys_scatter /
 k_bucket_sort; replaces the serial insert loop nbody.rs:410-415 together with the rest of the build).
 
 (key, index) pairs are distinct, so the sorted order is unique and the tree must not depend on how it was reached: after EVERY

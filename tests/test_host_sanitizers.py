@@ -1,6 +1,6 @@
 """ThreadSanitizer and AddressSanitizer/UBSan over the host side of the library (worker pool, threaded quadtree
-build with its folds running beside everything else, pipelined flatten, threaded nb_draw): host_ops.cpp is compiled
-with g++ (it needs no device) together with tools/sanitize/host_main.cpp and must run without a single report."""
+build with its folds running beside everything else, pipelined flatten, threaded nb_draw): host_ops.cpp and host_tree.cpp
+are compiled with g++ (it needs no device) together with tools/sanitize/host_main.cpp and must run without a single report."""
 import os
 import shutil
 import subprocess
@@ -18,7 +18,7 @@ def test_host_code_is_sanitizer_clean(tmp_path, san, threads):
         pytest.skip("needs g++ and the HIP headers")
     exe = os.path.join(str(tmp_path), "host_san")
     cmd = [cxx, "-std=c++17", "-O1", "-g", "-fsanitize=" + san, "-ffp-contract=off", "-I/opt/rocm/include",
-           "-D__HIP_PLATFORM_AMD__", "-I" + CSRC, os.path.join(CSRC, "host_ops.cpp"),
+           "-D__HIP_PLATFORM_AMD__", "-I" + CSRC, os.path.join(CSRC, "host_ops.cpp"), os.path.join(CSRC, "host_tree.cpp"),
            os.path.join(ROOT, "tools", "sanitize", "host_main.cpp"), "-o", exe, "-pthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0 and "sanitize" in r.stderr:

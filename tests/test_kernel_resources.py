@@ -73,7 +73,7 @@ def test_fold_kernels_of_the_device_tree_build(tmp_path):
     CU (every queued node gets its own pair of waves at once)."""
     mk = open(os.path.join(CSRC, "Makefile")).read()
     strict = re.search(r"^STRICT\s*:=\s*(.*)$", mk, re.M).group(1).split()
-    k = _metadata(tmp_path, "bh_build.hip", strict)
+    k = _metadata(tmp_path, "bh_fold.hip", strict)
     folds = [v for n, v in k.items() if "k_fold_big" in n or "k_fold_root" in n]
     assert len(folds) == 2
     for v in folds:
@@ -88,7 +88,7 @@ def test_cluster_replay_kernels_of_the_device_tree_build(tmp_path):
     191 VGPRs and a scratch frame (measured slower)."""
     mk = open(os.path.join(CSRC, "Makefile")).read()
     strict = re.search(r"^STRICT\s*:=\s*(.*)$", mk, re.M).group(1).split()
-    k = _metadata(tmp_path, "bh_build.hip", strict)
+    k = _metadata(tmp_path, "bh_cluster.hip", strict)
     blobs = next(v for n, v in k.items() if "k_blobs" in n)
     # (a few SGPRs spill into VGPR lanes -- no memory traffic; nothing goes to scratch beyond the lambda bookkeeping)
     assert blobs["vgpr_spill_count"] == 0 and blobs["sgpr_spill_count"] <= 32 and blobs["private_segment_fixed_size"] <= 16, blobs
@@ -113,3 +113,19 @@ def test_hand_scheduled_walk_keeps_eight_waves_per_simd(tmp_path):
         assert v["vgpr_count"] <= 64, (n, v)
         if "ELb1E" in n:
             assert v["sgpr_count"] <= 80, (n, v)
+
+
+def test_warm_sort_kernels_of_the_device_tree_build(tmp_path):
+    """bh_sort.hip (round 5): no scratch anywhere; k_bucket_sort within the default 64 KB of dynamic LDS (no per-device opt-in) and
+    at most 128 VGPRs (four waves per SIMD); the scatter's four interleaved descents in at most 64."""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    strict = re.search(r"^STRICT\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    k = _metadata(tmp_path, "bh_sort.hip", strict)
+    names = ("k_sample_rank", "k_keys_scatter", "k_bucket_sort")
+    for name in names:
+        vs = [v for n, v in k.items() if name in n]
+        assert vs, name
+        for v in vs:
+            assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0, (name, v)
+    assert next(v for n, v in k.items() if "k_bucket_sort" in n)["vgpr_count"] <= 128
+    assert all(v["vgpr_count"] <= 64 for n, v in k.items() if "k_keys_scatter" in n)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Long runs on the device tree with the warm sort (bh_build.hip, round 5): how often is a build refused (bucket overflow of the
+"""Long runs on the device tree with the warm sort (bh_sort.hip, round 5): how often is a build refused (bucket overflow of the
 sort, EPS crowds, ...) and handed to the host tree over 1 000 steps of systems that collapse, orbit or fly apart?
 One JSON line per scene: fallbacks (cumulative, by tenth of the run), the last refusal's reasons, ms per step (cumulative)."""
 import json

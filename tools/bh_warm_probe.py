@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Probe of the warm sort (bh_build.hip, round 5): N steps of Barnes-Hut on the device tree, fallbacks and refusal reasons."""
+"""Probe of the warm sort (bh_sort.hip, round 5): N steps of Barnes-Hut on the device tree, fallbacks and refusal reasons."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
