@@ -682,7 +682,9 @@ def run(real_stdout):
             ev_s = max(per[0]["bh_eval_ms"], 1e-9) * 1e-3     # HIP events around the traversal: (tree -> child groups) + walk
             walk_kind = engine.get_option(rx.engine.NBX_OPT_BH_WALK) if args.mode == "fast" else 0
             # the kernels of one traversal, by name: the walk, and (child-group walks) the conversion of the tree before it
-            walk_kernel = "k_bh_walk_groups" if walk_kind else "k_bh_eval"
+            # (the wave form by its template brackets: "k_bh_walk_groups" alone also names k_bh_walk_groups_lane, the per-lane form --
+            #  round 4's host-tree line averaged one such launch, 6 GB, into the traffic of the wave walk)
+            walk_kernel = "k_bh_walk_groups<" if walk_kind else "k_bh_eval"
             trav_kernels = (walk_kernel, "k_bh_groups(") if walk_kind else (walk_kernel,)
             # ALGORITHMIC flops of one evaluation, counted from the reference as written (2-D, div and sqrt = 1 flop each):
             #   pair law  nbody.rs:164-184 + :358    2 sub, 2 mul + 1 add, 1 add eps, 1 mul, 1 div, 2 mul, 2 add          = 12
@@ -734,7 +736,7 @@ def run(real_stdout):
                 "roofline": {"bound": "valu_fp32",
                              "peak_definition": "fp32 vector FMA peak = CUs x clock x 256 flop/clk (157.3 TFLOP/s at 256 CUs, 2.4 GHz); "
                                                 "the contract's hbm|mfma classes do not fit: a tree walk is bound by instruction issue",
-                             "kernel": " + ".join(k.rstrip("(") for k in trav_kernels),
+                             "kernel": " + ".join(k.rstrip("(<") for k in trav_kernels),
                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                              "frac_definition": "algorithmic flops of one evaluation (12 per pair law + 7 per opening test, the reference's "
                                                 "expressions as written, nbody.rs:164-184, :341-345) / traversal time (HIP events: tree -> "

@@ -113,15 +113,27 @@ __global__ __launch_bounds__(kTile) void k_keys(const float4* __restrict__ posm,
     idx[i] = (unsigned)i;
 }
 
-size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
+// the library sort's temporary storage for n pairs (both shapes: which one runs depends on n alone, but n may shrink below the
+// switch).  The two size queries are host work inside the library: asked once per n, not on every step (a thread-local memo of
+// the last answer -- a step is ~0.1 ms of enqueueing)
+static size_t library_sort_tmp_bytes(int n)
 {
-    size_t tmp = 0;
-    size_t tmp_small = 0;   // (the workspace serves either shape: which one runs depends on n alone, but n may shrink below the switch)
+    thread_local int memo_n = -1;
+    thread_local size_t memo_bytes = 0;
+    if (n == memo_n) return memo_bytes;
+    size_t tmp = 0, tmp_small = 0;
     (void)rocprim::radix_sort_pairs<BuildSortConfig>(nullptr, tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                                      (unsigned*)nullptr, (unsigned*)nullptr, (size_t)n, 0, 2 * kLevels, (hipStream_t)0);
     (void)rocprim::radix_sort_pairs(nullptr, tmp_small, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
                                     (unsigned*)nullptr, (size_t)n, 0, 2 * kLevels, (hipStream_t)0);
-    if (tmp_small > tmp) tmp = tmp_small;
+    memo_n = n;
+    memo_bytes = tmp_small > tmp ? tmp_small : tmp;
+    return memo_bytes;
+}
+
+size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
+{
+    const size_t tmp = library_sort_tmp_bytes(n);   // (small systems too: the library sort is what a refused two-launch front falls back to)
     if (sort_tmp_bytes) *sort_tmp_bytes = tmp;
     const size_t nb = ((size_t)n + kScanBlock - 1) / kScanBlock;
     size_t bytes = 0;

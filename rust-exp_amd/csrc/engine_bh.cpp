@@ -400,7 +400,7 @@ static int resolve_slot(nbx_engine* e, int slot)
 {
     if (!e->pending[slot].active) return NBX_OK;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(wait_event(e->ev_step[slot]));
+    HIP_TRY(wait_event(e->ev_step[slot], e->n <= kSpinMaxBodies));
     const nbx_engine::PendingStep p = e->pending[slot];
     e->pending[slot].active = false;
     const int status = verdict_of(e, slot);

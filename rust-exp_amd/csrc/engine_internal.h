@@ -237,7 +237,10 @@ int grow(T** ptr, size_t* cap, size_t need)
 }
 
 // Host waits of the stepping path.  A 10 000-body step is ~0.1 ms of GPU work; the runtime's blocking wait adds its wake-up
-// latency to every such step, so poll first (NBX_SPIN_US microseconds, default 400; 0 = block at once) and block after that.
+// latency to every such step, so SHORT waits poll first (NBX_SPIN_US microseconds, default 400; 0 = block at once) and block
+// after that.  Only short ones: a system above kSpinMaxBodies bodies steps in several tenths of a millisecond and more -- polling
+// would burn a core per waiting thread (a group host has one per GPU) for nothing -- and blocks at once.
+constexpr int kSpinMaxBodies = 32768;
 inline int spin_budget_us()
 {
     static const int us = [] {
@@ -246,29 +249,34 @@ inline int spin_budget_us()
     }();
     return us;
 }
+// hipSuccess: done; hipErrorNotReady: the budget ran out (block now); anything else: the query's own error, handed on as it is
 template <typename Query>
-inline bool spin_until_done(Query query)
+inline hipError_t spin_until_done(Query query, bool short_work)
 {
-    const int budget = spin_budget_us();
-    if (budget <= 0) return false;
+    const int budget = short_work ? spin_budget_us() : 0;
+    if (budget <= 0) return hipErrorNotReady;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         for (int k = 0; k < 16; k++) {
             const hipError_t st = query();
-            if (st == hipSuccess) return true;
-            if (st != hipErrorNotReady) { (void)hipGetLastError(); return false; }   // let the blocking call report it
+            if (st != hipErrorNotReady) return st;
         }
-        if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= budget) return false;
+        (void)hipGetLastError();   // (hipErrorNotReady is sticky in hipGetLastError: it is not an error here)
+        if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= budget) return hipErrorNotReady;
     }
 }
-inline hipError_t wait_stream(hipStream_t s)
+inline hipError_t wait_stream(hipStream_t s, bool short_work)
 {
-    if (spin_until_done([&] { return hipStreamQuery(s); })) return hipSuccess;
+    const hipError_t st = spin_until_done([&] { return hipStreamQuery(s); }, short_work);
+    if (st != hipErrorNotReady) return st;
+    (void)hipGetLastError();
     return hipStreamSynchronize(s);
 }
-inline hipError_t wait_event(hipEvent_t ev)
+inline hipError_t wait_event(hipEvent_t ev, bool short_work)
 {
-    if (spin_until_done([&] { return hipEventQuery(ev); })) return hipSuccess;
+    const hipError_t st = spin_until_done([&] { return hipEventQuery(ev); }, short_work);
+    if (st != hipErrorNotReady) return st;
+    (void)hipGetLastError();
     return hipEventSynchronize(ev);
 }
 
