@@ -176,6 +176,7 @@ def companion_summary(key, line):
     if key.startswith("c4"):
         sp, acc = line.get("ms_split") or {}, cb.get("accuracy") or {}
         out.update({"build_ms": sp.get("tree_build"), "traversal_ms": sp.get("bh_eval_kernel"), "tree": (line.get("config") or {}).get("tree"),
+                    "fallbacks": line.get("bh_fallbacks"),
                     "valu_busy": r.get("valu_busy_frac"), "traffic_bytes": r.get("traffic"),
                     "algorithmic_bytes": r.get("hbm_algorithmic_bytes_per_launch"), "flops_per_launch": r.get("flops_per_launch"),
                     "cpu_ms_per_step": cb.get("ms_per_step"),
@@ -727,6 +728,10 @@ def run(real_stdout):
                            "tree": {0: "host (reference-faithful insertion build)", 1: "device (bh_build.hip)"}[engine.get_stat(rx.engine.NBX_STAT_BH_LAST_TREE)],
                            "walk": {0: "node by node (bh_eval.hip, rounds 1-3)", 1: "child groups, hand-scheduled loop (bh_walk.hip)",
                                     2: "child groups, compiled loop (bh_walk.hip)"}[walk_kind]},
+                # steps of this run that the device tree was selected for but the host tree served (a refused build: EPS crowds,
+                # an exhausted pool, a warm sort whose buckets overflowed) -- each costs ~20 ms at a million bodies
+                "bh_fallbacks": engine.get_stat(rx.engine.NBX_STAT_BH_FALLBACKS),
+                "bh_last_refusal": "0x%x" % engine.get_stat(rx.engine.NBX_STAT_BH_REFUSAL),
                 "ms_split": {"bh_eval_kernel": per[0]["bh_eval_ms"], "integrate_kernel": per[0]["integrate_ms"],
                              "host_download": ht["download_ms"],
                              # device tree: GPU time of the build, first launch to last (HIP events); host tree: host wall time

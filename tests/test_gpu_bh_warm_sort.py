@@ -94,3 +94,66 @@ def test_a_reshuffled_system_is_refused_not_wrong(rx, ob):
         assert np.isfinite(qa[k]).all()
         # exact-sum device tree vs host tree: the fast mode's tolerance class, not bits; a wrong sort would be off by O(1)
         assert np.abs(qa[k] - qb[k]).max() <= 2e-2 * max(1.0, np.abs(qb[k]).max()), k
+
+
+@pytest.mark.parametrize("n", [16385, 16640, 33000])
+def test_warm_sort_just_above_the_small_front(rx, ob, n):
+    """The first sizes that take the warm sort (26-52 buckets, fewer workgroups than CUs): the device tree equals the host tree bit
+    for bit after every step (reference fold)."""
+    from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS
+
+    p = ob.random_disk(n, 5)
+    e = rx.NBodyEngine()
+    e.set_bh_tree("device")
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    f0 = e.get_stat(NBX_STAT_BH_FALLBACKS)
+    kept = 0
+    for _ in range(4):
+        e.step_barnes_hut(0.85, 0.01, 1)
+        e.synchronize()
+        if e.get_stat(NBX_STAT_BH_FALLBACKS) == f0:          # (EPS clusters may hand a step of this class to the host build: its own test)
+            _bit_equal_trees(e.bh_flat_dump(False), e.bh_flat_dump("device"))
+            kept += 1
+        f0 = e.get_stat(NBX_STAT_BH_FALLBACKS)
+    assert kept >= 1
+
+
+def test_above_the_warm_sorts_range_the_library_sort_serves_every_step(rx, ob):
+    """More than 4 096 x 640 bodies: no warm sort (its splitter table ends there); the steps run on the device tree all the same
+    and leave a finite state."""
+    from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE
+
+    n = 4096 * 640 + 4096
+    st = rx.plummer_sphere(n, dim=2)
+    e = rx.NBodyEngine()
+    e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    for _ in range(3):
+        e.step_barnes_hut(0.5, 0.01, 1)
+    q = e.get_particles()
+    assert np.isfinite(q["px"]).all() and np.isfinite(q["vx"]).all()
+    assert e.get_stat(NBX_STAT_BH_LAST_TREE) == 1 and e.get_stat(NBX_STAT_BH_FALLBACKS) == 0
+
+
+def test_sharded_engines_take_the_warm_order_too(rx, ob, monkeypatch):
+    """world > 1 on one GPU (control flow): every engine sorts ALL bodies (tree replicas) and walks its slab in the Morton order
+    restricted to it; warm builds from the second step on.  Positions after four steps equal one plain engine's bit for bit
+    (exact-sum device tree: the same tree whichever sort made the order)."""
+    monkeypatch.setenv("NBX_GROUP_EXCHANGE", "copy")      # engines of one group may share the test GPU
+    n = 100000
+    st = rx.plummer_sphere(n, dim=2)
+    rng = np.random.default_rng(3)
+    vx = rng.normal(0, 5, n).astype(np.float32); vy = rng.normal(0, 5, n).astype(np.float32)
+    plain = rx.NBodyEngine()
+    plain.set_bh_tree("device")
+    plain.set_particles(st["px"], st["py"], vx, vy, st["m"])
+    g = rx.NBodyGroup([0, 0, 0])
+    from rust_exp_amd.engine import NBX_OPT_BH_TREE
+    g.set_option(NBX_OPT_BH_TREE, 1)
+    g.set_particles(st["px"], st["py"], vx, vy, st["m"])
+    for _ in range(4):
+        plain.step_barnes_hut(0.5, 0.01, 1)
+        g.step_barnes_hut(0.5, 0.01, 1)
+    a, b = plain.get_particles(), g.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    g.close()
