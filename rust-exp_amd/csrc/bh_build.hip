@@ -204,7 +204,9 @@ __device__ __forceinline__ ScanItem block_exclusive(const ScanItem mine, ScanIte
 __device__ __forceinline__ void scan_blocks(ScanItem* __restrict__ block_sums, const int nb);
 
 // Block sums, then -- in the LAST workgroup to finish (ticket) -- their exclusive scan: the fixed summation tree of round 2's
-// separate k_scan_blocks launch (same bits on every run), without the launch.
+// separate k_scan_blocks launch (same bits on every run), without the launch.  ticket == nullptr (round 5, big systems): no
+// hand-off in here, k_scan_blocks follows as a launch of its own -- a device-wide fence writes the L2 back on this chip, and a
+// thousand workgroups each paying one cost this kernel 15 of its 36 us at a million bodies; a launch costs 3.
 __global__ __launch_bounds__(kTile) void k_scan_reduce(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
                                                        const int n, ScanItem* __restrict__ block_sums, int* __restrict__ ticket,
                                                        unsigned char* __restrict__ cnt_cache)
@@ -218,13 +220,22 @@ __global__ __launch_bounds__(kTile) void k_scan_reduce(const float4* __restrict_
     __shared__ int last;
     if (threadIdx.x == 0) {
         block_sums[blockIdx.x] = total;
-        __threadfence();
-        last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+        if (ticket) {
+            __threadfence();
+            last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+        } else {
+            last = 0;
+        }
     }
     __syncthreads();
     if (!last) return;
     __threadfence();
     scan_blocks(block_sums, (int)gridDim.x);
+}
+
+__global__ __launch_bounds__(kTile) void k_scan_blocks(ScanItem* __restrict__ block_sums, const int nb)
+{
+    scan_blocks(block_sums, nb);
 }
 
 __device__ __forceinline__ void scan_blocks(ScanItem* __restrict__ block_sums, const int nb)
@@ -305,6 +316,7 @@ __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const u
 //       what sequential insertion leaves in every node, bit for bit.  Nodes of at most kFoldSmall bodies are folded right
 //       here (selection of the next index among <= kFoldSmall); bigger ones are queued for k_fold_big (one wave per node).
 constexpr int kFoldSmall = 8;
+constexpr int kTicketScanMax = 65536;   // up to here the scan of the block sums rides in k_scan_reduce's last workgroup (one launch less)
 
 __global__ __launch_bounds__(kTile) void k_emit(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
                                                 const unsigned* __restrict__ idx, const unsigned* __restrict__ box, const Prefix pre,
@@ -510,7 +522,12 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     // (for small systems the pair merge and the scan were tried as phases of ONE 1024-thread workgroup: 90 us against 22 for the
     //  four launches at 10 000 bodies -- per-body work here is chains of dependent loads that miss the L2 after every kernel
     //  boundary, and one CU hides far less of that than forty)
-    hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.counters + 3, k.pre.cnt);
+    if (n > kTicketScanMax) {   // big systems: the block sums' scan as a launch of its own (see k_scan_reduce)
+        hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, (int*)nullptr, k.pre.cnt);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kTile), 0, stream, k.block_sums, sb);
+    } else {
+        hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.counters + 3, k.pre.cnt);
+    }
     hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.pre, k.counters);
     // one thread per node; the node count is only known on the device, so the grid covers the whole pool (threads beyond
     // base[n] leave at once; the pool check is inside)

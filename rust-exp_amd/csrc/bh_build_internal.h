@@ -22,6 +22,35 @@ __device__ __forceinline__ float dec_f32(unsigned u)
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
+// The root box from k_bbox's partial boxes (at most 256: the launcher caps its grid), folded by EVERY workgroup of the first kernel
+// that needs it (k_keys cold, k_sample_rank warm) -- collective over a workgroup of kTile threads.  Round 5: k_bbox used to fold
+// them itself in its last workgroup, behind a ticket and two device-wide fences (each writes the L2 back on this chip): 11 us for
+// a pass over 16 MB; min and max are exact in any order, so who folds changes no bit.  publish: this workgroup also files the box
+// (encoded) for the kernels behind.
+__device__ __forceinline__ void fold_box_partials(const float4* __restrict__ part, const int parts, unsigned* __restrict__ box,
+                                                  const bool publish, float& x1, float& y1, float& x2, float& y2)
+{
+    __shared__ float red_box[kTile / 64][4];
+    x1 = 3.40282347e+38f; y1 = 3.40282347e+38f; x2 = -3.40282347e+38f; y2 = -3.40282347e+38f;
+    for (int b = threadIdx.x; b < parts; b += kTile) {
+        const float4 q = part[b];
+        x1 = fminf(x1, q.x); y1 = fminf(y1, q.y); x2 = fmaxf(x2, q.z); y2 = fmaxf(y2, q.w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x1 = fminf(x1, __shfl_xor(x1, off)); y1 = fminf(y1, __shfl_xor(y1, off));
+        x2 = fmaxf(x2, __shfl_xor(x2, off)); y2 = fmaxf(y2, __shfl_xor(y2, off));
+    }
+    if ((threadIdx.x & 63) == 0) { red_box[threadIdx.x >> 6][0] = x1; red_box[threadIdx.x >> 6][1] = y1; red_box[threadIdx.x >> 6][2] = x2; red_box[threadIdx.x >> 6][3] = y2; }
+    __syncthreads();
+    x1 = red_box[0][0]; y1 = red_box[0][1]; x2 = red_box[0][2]; y2 = red_box[0][3];
+#pragma unroll
+    for (int w = 1; w < kTile / 64; w++) {
+        x1 = fminf(x1, red_box[w][0]); y1 = fminf(y1, red_box[w][1]); x2 = fmaxf(x2, red_box[w][2]); y2 = fmaxf(y2, red_box[w][3]);
+    }
+    if (publish && threadIdx.x == 0) { box[0] = enc_f32(x1); box[1] = enc_f32(y1); box[2] = enc_f32(x2); box[3] = enc_f32(y2); }
+}
+
 // one step of quadrant_from_point + the child's AABB from create_children (unfused f32, nbody.rs:289-300,:324-331)
 __device__ __forceinline__ int descend(float& x1, float& y1, float& x2, float& y2, const float x, const float y)
 {
@@ -168,7 +197,7 @@ __device__ __forceinline__ void refuse(int* __restrict__ counters, const int why
 }
 
 // Workspace header (the first 4 KiB + 256 B): ints [0] node count, [1] bodies the pairs-only EPS merge left behind (or blobs whose
-// centre left their first member's cell), [2] nodes queued for k_fold_big, [3] ticket of k_scan_reduce -- all cleared by k_keys at every build -- [9] the "poison" flag of the gated steps (kernels.h), [8] ticket of k_bbox (self-clearing; zeroed once by device_tree_workspace_init),
+// centre left their first member's cell), [2] nodes queued for k_fold_big, [3] ticket of k_scan_reduce (systems up to kTicketScanMax bodies) -- all cleared by k_keys / k_bbox at every build -- [9] the "poison" flag of the gated steps (kernels.h; zeroed once by device_tree_workspace_init),
 // [12..15] the root box (encoded); then 256 float4 partial boxes of k_bbox.
 constexpr size_t kHeaderBytes = 256 + 256 * sizeof(float4);
 
@@ -216,8 +245,7 @@ struct Workspace {
     int* hv;
     unsigned hmask;
     int* ghosts;
-    unsigned long long* spl;      // round 5, warm sort: splitters, per-bucket counts, the buckets' slots
-    int* gcount;
+    int* gcount;                  // round 5, warm sort: per-bucket counts, the buckets' slots, the splitter candidates and their ranks
     ulonglong2* slots;            // kBucketCap (key, index) slots per bucket
     unsigned long long* skeys;
     int* srank;                   // [kMaxSamples] ranks of the splitter candidates
@@ -257,7 +285,6 @@ inline Workspace carve(void* workspace, int n, size_t sort_tmp, int node_cap)
     k.hv = reinterpret_cast<int*>(table + sizeof(unsigned long long) * slots);
     k.hmask = (unsigned)(slots - 1);
     k.ghosts = reinterpret_cast<int*>(take(sizeof(int) * kGhostCap));
-    k.spl = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * kMaxBuckets));
     k.gcount = reinterpret_cast<int*>(take(sizeof(int) * kMaxBuckets));
     k.skeys = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * kMaxSamples));
     k.srank = reinterpret_cast<int*>(take(sizeof(int) * (kMaxSamples + 64)));
@@ -268,7 +295,7 @@ inline Workspace carve(void* workspace, int n, size_t sort_tmp, int node_cap)
 
 
 // ---- between the units ------------------------------------------------------------------------------------------------------
-hipError_t launch_inc_sort(const float4* posm, int n, const unsigned* box, const unsigned* perm, unsigned long long* spl, int* gcount,
+hipError_t launch_inc_sort(const float4* posm, int n, unsigned* box, const float4* part, int parts, const unsigned* perm, int* gcount,
                            unsigned long long* skeys, int* srank, ulonglong2* slots, unsigned long long* keys_out,
                            unsigned* idx_out, int* counters, unsigned long long* cell_table, int cell_slots, hipStream_t stream);
 // root AABB -> path keys -> sorted (key, body) pairs in keys1 / idx1 (bh_front.hip)

@@ -18,23 +18,20 @@ constexpr int kBigSortFrom = 262144;   // (below: the library's own shape -- 65 
 using BuildSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<512, 512, 8, 128, 128, 4>,
                                                    rocprim::default_config, (size_t)1 << 20>;
 
-// box[0..3] = enc(min x), enc(min y), enc(max x), enc(max y).  One launch, no initialisation kernel: every workgroup leaves its
-// partial box in part[], takes a ticket, and the LAST one to finish folds the partials (fixed order) and publishes the box
-// (round 2: k_init_box + atomicMin/Max into a pre-initialised word).  The ticket word must be zero at launch: the last
-// workgroup clears it again (the engine zeroes it once when the workspace is allocated).
+// Partial boxes: workgroup b leaves (min x, min y, max x, max y) of its share of the bodies in part[b]; the first kernel behind
+// folds them (fold_box_partials) and files box[0..3] = enc(min x), enc(min y), enc(max x), enc(max y).
 // clear_*: words the kernels BEHIND this one add to (warm sort: the splitter candidates' ranks, the buckets' counts, the build's
 // counters -- which k_keys clears in the cold path), cleared here to save a launch
-__global__ __launch_bounds__(kTile) void k_bbox(const float4* __restrict__ posm, const int n, unsigned* __restrict__ box,
-                                                float4* __restrict__ part, int* __restrict__ ticket, int* __restrict__ clear_a,
-                                                const int count_a, int* __restrict__ clear_b, const int count_b, int* __restrict__ clear_c,
-                                                const int count_c)
+__global__ __launch_bounds__(kTile) void k_bbox(const float4* __restrict__ posm, const int n, float4* __restrict__ part,
+                                                int* __restrict__ clear_a, const int count_a, int* __restrict__ clear_b, const int count_b,
+                                                int* __restrict__ clear_c, const int count_c)
 {
     for (int i = blockIdx.x * kTile + threadIdx.x; i < count_a; i += (int)gridDim.x * kTile) clear_a[i] = 0;
     for (int i = blockIdx.x * kTile + threadIdx.x; i < count_b; i += (int)gridDim.x * kTile) clear_b[i] = 0;
     for (int i = blockIdx.x * kTile + threadIdx.x; i < count_c; i += (int)gridDim.x * kTile) clear_c[i] = 0;
     float x1 = 3.40282347e+38f, y1 = 3.40282347e+38f, x2 = -3.40282347e+38f, y2 = -3.40282347e+38f;
-    {   // eight independent loads in flight per thread (round 5: one at a time, a million bodies took 12 us -- sixteen dependent
-        // round trips per thread; min and max are exact in any order)
+    {   // eight independent loads in flight per thread (one at a time, a million bodies took 12 us -- sixteen dependent round
+        // trips per thread; min and max are exact in any order)
         constexpr int kFlight = 8;
         const int stride = (int)gridDim.x * kTile;
         for (int i0 = blockIdx.x * kTile + threadIdx.x; i0 < n; i0 += kFlight * stride) {
@@ -56,7 +53,6 @@ __global__ __launch_bounds__(kTile) void k_bbox(const float4* __restrict__ posm,
         x2 = fmaxf(x2, __shfl_xor(x2, off)); y2 = fmaxf(y2, __shfl_xor(y2, off));
     }
     __shared__ float red[4][4];
-    __shared__ int last;
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[wave][0] = x1; red[wave][1] = y1; red[wave][2] = x2; red[wave][3] = y2; }
     __syncthreads();
@@ -65,36 +61,11 @@ __global__ __launch_bounds__(kTile) void k_bbox(const float4* __restrict__ posm,
             x1 = fminf(x1, red[w][0]); y1 = fminf(y1, red[w][1]); x2 = fmaxf(x2, red[w][2]); y2 = fmaxf(y2, red[w][3]);
         }
         part[blockIdx.x] = make_float4(x1, y1, x2, y2);
-        __threadfence();
-        last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    x1 = 3.40282347e+38f; y1 = 3.40282347e+38f; x2 = -3.40282347e+38f; y2 = -3.40282347e+38f;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += kTile) {     // at most 256 partials (the launcher caps the grid)
-        const float4 q = part[b];
-        x1 = fminf(x1, q.x); y1 = fminf(y1, q.y); x2 = fmaxf(x2, q.z); y2 = fmaxf(y2, q.w);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        x1 = fminf(x1, __shfl_xor(x1, off)); y1 = fminf(y1, __shfl_xor(y1, off));
-        x2 = fmaxf(x2, __shfl_xor(x2, off)); y2 = fmaxf(y2, __shfl_xor(y2, off));
-    }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { red[wave][0] = x1; red[wave][1] = y1; red[wave][2] = x2; red[wave][3] = y2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) {
-            x1 = fminf(x1, red[w][0]); y1 = fminf(y1, red[w][1]); x2 = fmaxf(x2, red[w][2]); y2 = fmaxf(y2, red[w][3]);
-        }
-        box[0] = enc_f32(x1); box[1] = enc_f32(y1); box[2] = enc_f32(x2); box[3] = enc_f32(y2);
-        *ticket = 0;
     }
 }
 
-__global__ __launch_bounds__(kTile) void k_keys(const float4* __restrict__ posm, const int n,
-                                                const unsigned* __restrict__ box, unsigned long long* __restrict__ keys,
+__global__ __launch_bounds__(kTile) void k_keys(const float4* __restrict__ posm, const int n, const float4* __restrict__ part,
+                                                const int parts, unsigned* __restrict__ box, unsigned long long* __restrict__ keys,
                                                 unsigned* __restrict__ idx, int* __restrict__ counters,
                                                 unsigned long long* __restrict__ cell_table, const int cell_slots)
 {
@@ -103,8 +74,9 @@ __global__ __launch_bounds__(kTile) void k_keys(const float4* __restrict__ posm,
     if (i < 8) counters[i] = 0;
     // ... and the table of occupied grid cells that k_cells fills after the sort (reference fold only; at most 4 slots per body)
     for (int t = i; t < cell_slots; t += (int)gridDim.x * kTile) cell_table[t] = 0ull;
+    float x1, y1, x2, y2;
+    fold_box_partials(part, parts, box, blockIdx.x == 0, x1, y1, x2, y2);
     if (i >= n) return;
-    float x1 = dec_f32(box[0]), y1 = dec_f32(box[1]), x2 = dec_f32(box[2]), y2 = dec_f32(box[3]);
     const float4 p = posm[i];
     unsigned long long key = 0;
 #pragma unroll 1
@@ -157,8 +129,7 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     add((size_t)n);                                    // pmin in entity order
     add((sizeof(unsigned long long) + sizeof(int)) * cell_table_slots(n));
     add(sizeof(int) * kGhostCap);
-    add(sizeof(unsigned long long) * kMaxBuckets);     // warm sort (round 5): splitters
-    add(sizeof(int) * kMaxBuckets);                    // ... pairs per bucket
+    add(sizeof(int) * kMaxBuckets);                    // warm sort (round 5): pairs per bucket
     add(sizeof(unsigned long long) * kMaxSamples);     // ... splitter candidates
     add(sizeof(int) * (kMaxSamples + 64));             // ... their ranks, one ticket per row of the ranking
     const size_t slots_inc = inc_sort_enabled(n) ? (size_t)inc_buckets(n) * kBucketCap : 0;
@@ -383,15 +354,15 @@ hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sor
         (void)hipGetLastError();    // the LDS opt-in or a launch was refused (nothing ran): the general path below serves any size
     }
     const int nb = (n + kTile - 1) / kTile;
+    const int parts = nb < 256 ? nb : 256;
     if (warm && inc_sort_enabled(n)) {   // idx1 holds last step's order: sort from there (round 5)
-        hipLaunchKernelGGL(k_bbox, dim3(nb < 256 ? nb : 256), dim3(kTile), 0, stream, posm, n, k.box, k.part, k.counters + 8, k.srank,
-                           kOversample * inc_buckets(n), k.gcount, inc_buckets(n), k.counters, 8);
-        return launch_inc_sort(posm, n, k.box, k.idx1, k.spl, k.gcount, k.skeys, k.srank, k.slots, k.keys1, k.idx1, k.counters, k.hk,
+        hipLaunchKernelGGL(k_bbox, dim3(parts), dim3(kTile), 0, stream, posm, n, k.part, k.srank, kOversample * inc_buckets(n), k.gcount,
+                           inc_buckets(n), k.counters, 8);
+        return launch_inc_sort(posm, n, k.box, k.part, parts, k.idx1, k.gcount, k.skeys, k.srank, k.slots, k.keys1, k.idx1, k.counters, k.hk,
                                cell_table ? (int)(k.hmask + 1u) : 0, stream);
     }
-    hipLaunchKernelGGL(k_bbox, dim3(nb < 256 ? nb : 256), dim3(kTile), 0, stream, posm, n, k.box, k.part, k.counters + 8, (int*)nullptr, 0,
-                       (int*)nullptr, 0, (int*)nullptr, 0);
-    hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, k.box, k.keys0, k.idx0, k.counters, k.hk,
+    hipLaunchKernelGGL(k_bbox, dim3(parts), dim3(kTile), 0, stream, posm, n, k.part, (int*)nullptr, 0, (int*)nullptr, 0, (int*)nullptr, 0);
+    hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, k.part, parts, k.box, k.keys0, k.idx0, k.counters, k.hk,
                        cell_table ? (int)(k.hmask + 1u) : 0);
     if (n >= kBigSortFrom)
         return rocprim::radix_sort_pairs<BuildSortConfig>(k.sort_tmp, sort_tmp, k.keys0, k.keys1, k.idx0, k.idx1, (size_t)n, 0, 2 * kLevels, stream);

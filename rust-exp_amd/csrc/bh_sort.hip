@@ -65,7 +65,8 @@ __device__ __forceinline__ int sample_pos(const int i, const int n, const int sa
 // computes the keys of both its blocks itself (two descents per thread: cheaper than a launch of its own in front); the c = 0
 // column leaves block a's keys for k_keys_scatter.  No hand-off inside the kernel: a device-wide fence writes the L2 back on
 // this chip (k_sample_rank with a ticket and a last workgroup took 48 us, 40 of them fences).
-__global__ __launch_bounds__(kTile) void k_sample_rank(const float4* __restrict__ posm, const int n, const unsigned* __restrict__ box,
+__global__ __launch_bounds__(kTile) void k_sample_rank(const float4* __restrict__ posm, const int n, const float4* __restrict__ part,
+                                                       const int parts, unsigned* __restrict__ box,
                                                        const unsigned* __restrict__ perm, const int samples,
                                                        unsigned long long* __restrict__ skeys, int* __restrict__ srank)
 {
@@ -74,15 +75,24 @@ __global__ __launch_bounds__(kTile) void k_sample_rank(const float4* __restrict_
     const int a = blockIdx.x / sb, c = blockIdx.x - a * sb;
     const int tid = threadIdx.x;
     const int oc = c * kTile + tid, mine_i = a * kTile + tid;
+    // the bodies first (their two dependent loads fly while the box is folded out of k_bbox's partials; workgroup 0 files it)
+    const float4 p0 = posm[perm[sample_pos(mine_i < samples ? mine_i : 0, n, samples)]];
+    const float4 p1 = posm[perm[sample_pos(oc < samples ? oc : 0, n, samples)]];
+    float rx1, ry1, rx2, ry2;
+    fold_box_partials(part, parts, box, blockIdx.x == 0, rx1, ry1, rx2, ry2);
     unsigned long long ok = kPadKey, mine = kPadKey;
     if (a == c) {
-        if (mine_i < samples) mine = body_key(box, posm[perm[sample_pos(mine_i, n, samples)]]);
+        if (mine_i < samples) {
+            float ax1 = rx1, ay1 = ry1, ax2 = rx2, ay2 = ry2;
+            unsigned long long k0 = 0;
+#pragma unroll 1
+            for (int l = 0; l < kLevels; l++) k0 = (k0 << 2) | (unsigned long long)descend(ax1, ay1, ax2, ay2, p0.x, p0.y);
+            mine = k0;
+        }
         ok = mine;
     } else {
         // two descents, interleaved
-        const float4 p0 = posm[perm[sample_pos(mine_i < samples ? mine_i : 0, n, samples)]];
-        const float4 p1 = posm[perm[sample_pos(oc < samples ? oc : 0, n, samples)]];
-        float ax1 = dec_f32(box[0]), ay1 = dec_f32(box[1]), ax2 = dec_f32(box[2]), ay2 = dec_f32(box[3]);
+        float ax1 = rx1, ay1 = ry1, ax2 = rx2, ay2 = ry2;
         float bx1 = ax1, by1 = ay1, bx2 = ax2, by2 = ay2;
         unsigned long long k0 = 0, k1 = 0;
 #pragma unroll 1
@@ -440,7 +450,7 @@ __global__ __launch_bounds__(kTile) void k_bucket_sort(const ulonglong2* __restr
 
 // the sort of a warm build: bodies in last step's order (perm) -> sorted (key, body) pairs in keys_out / idx_out (perm == idx_out is fine:
 // it is read by the first three kernels and written by the last)
-hipError_t launch_inc_sort(const float4* posm, int n, const unsigned* box, const unsigned* perm, unsigned long long* spl, int* gcount,
+hipError_t launch_inc_sort(const float4* posm, int n, unsigned* box, const float4* part, int parts, const unsigned* perm, int* gcount,
                            unsigned long long* skeys, int* srank, ulonglong2* slots, unsigned long long* keys_out,
                            unsigned* idx_out, int* counters, unsigned long long* cell_table, int cell_slots, hipStream_t stream)
 {
@@ -448,7 +458,7 @@ hipError_t launch_inc_sort(const float4* posm, int n, const unsigned* box, const
     const int buckets = inc_buckets(n);
     const int samples = kOversample * buckets;
     const int sb = (samples + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_sample_rank, dim3((unsigned)(sb * sb)), dim3(kTile), 0, stream, posm, n, box, perm, samples, skeys, srank);
+    hipLaunchKernelGGL(k_sample_rank, dim3((unsigned)(sb * sb)), dim3(kTile), 0, stream, posm, n, part, parts, box, perm, samples, skeys, srank);
     const size_t shm = sizeof(unsigned long long) * (size_t)(buckets > 1 ? buckets - 1 : 1) + sizeof(int) * (size_t)buckets;
     if (n >= 262144)
         hipLaunchKernelGGL(k_keys_scatter<4>, dim3((unsigned)((n + 4 * kTile - 1) / (4 * kTile))), dim3(kTile), shm, stream, posm, n, box, perm,
