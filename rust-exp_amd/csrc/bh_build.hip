@@ -478,7 +478,7 @@ __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const u
 hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, size_t workspace_bytes, int node_cap, BhNode* out,
                                    int* host_counters /* pinned, >= 4 ints; null: the caller's gated kick-drift publishes them */,
                                    const unsigned** perm_dev, hipStream_t stream, int fold,
-                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, bool depth_panic_guard, bool warm)
+                                   hipStream_t side, hipEvent_t ev_go, hipEvent_t ev_done, bool depth_panic_guard, bool warm, const float4* sorted_pos)
 {
     *perm_dev = nullptr;
     if (n <= 0) return hipSuccess;
@@ -498,7 +498,7 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
         launch_fold_root(posm, n, out, side);
         if ((e = hipEventRecord(ev_done, side)) != hipSuccess) return e;
     }
-    e = sort_bodies(posm, n, k, sort_tmp, stream, fold == 1, warm);
+    e = sort_bodies(posm, n, k, sort_tmp, stream, fold == 1, warm, sorted_pos);
     if (e != hipSuccess) return e;
     *perm_dev = k.idx1;
     const int nb = (n + kTile - 1) / kTile;

@@ -295,11 +295,12 @@ inline Workspace carve(void* workspace, int n, size_t sort_tmp, int node_cap)
 
 
 // ---- between the units ------------------------------------------------------------------------------------------------------
-hipError_t launch_inc_sort(const float4* posm, int n, unsigned* box, const float4* part, int parts, const unsigned* perm, int* gcount,
+hipError_t launch_inc_sort(const float4* posm, const float4* sorted_pos, int n, unsigned* box, const float4* part, int parts, const unsigned* perm, int* gcount,
                            unsigned long long* skeys, int* srank, ulonglong2* slots, unsigned long long* keys_out,
                            unsigned* idx_out, int* counters, unsigned long long* cell_table, int cell_slots, hipStream_t stream);
 // root AABB -> path keys -> sorted (key, body) pairs in keys1 / idx1 (bh_front.hip)
-hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sort_tmp, hipStream_t stream, bool cell_table, bool warm);
+hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sort_tmp, hipStream_t stream, bool cell_table, bool warm,
+                       const float4* sorted_pos = nullptr);
 // the reference's EPS merge in full (bh_cluster.hip): entities in k.keys0 / k.idx0 / k.sb2 / k.pmin2
 hipError_t launch_cluster_replay(const float4* posm, int n, const Workspace& k, hipStream_t stream);
 // the reference's running fold (bh_fold.hip): the root on its own stream, the queued nodes behind k_emit

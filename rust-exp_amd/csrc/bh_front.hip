@@ -345,7 +345,8 @@ hipError_t launch_front_small(const float4* posm, int n, unsigned* box, unsigned
 }
 
 // root AABB -> path keys -> sorted (key, body) pairs in keys1 / idx1
-hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sort_tmp, hipStream_t stream, bool cell_table, bool warm)
+hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sort_tmp, hipStream_t stream, bool cell_table, bool warm,
+                       const float4* sorted_pos)
 {
     if (small_front_enabled(n)) {   // a small system (the reference's own 10 000 bodies): two launches instead of seven, no library sort
         const hipError_t e = launch_front_small(posm, n, k.box, k.keys0, k.idx0, k.keys1, k.idx1, k.counters, k.hk,
@@ -358,7 +359,7 @@ hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sor
     if (warm && inc_sort_enabled(n)) {   // idx1 holds last step's order: sort from there (round 5)
         hipLaunchKernelGGL(k_bbox, dim3(parts), dim3(kTile), 0, stream, posm, n, k.part, k.srank, kOversample * inc_buckets(n), k.gcount,
                            inc_buckets(n), k.counters, 8);
-        return launch_inc_sort(posm, n, k.box, k.part, parts, k.idx1, k.gcount, k.skeys, k.srank, k.slots, k.keys1, k.idx1, k.counters, k.hk,
+        return launch_inc_sort(posm, sorted_pos, n, k.box, k.part, parts, k.idx1, k.gcount, k.skeys, k.srank, k.slots, k.keys1, k.idx1, k.counters, k.hk,
                                cell_table ? (int)(k.hmask + 1u) : 0, stream);
     }
     hipLaunchKernelGGL(k_bbox, dim3(parts), dim3(kTile), 0, stream, posm, n, k.part, (int*)nullptr, 0, (int*)nullptr, 0, (int*)nullptr, 0);
@@ -372,14 +373,14 @@ hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sor
 // Spatial (Morton, reference quadrant order) permutation of the bodies only: bbox + path keys + radix sort.
 // Used to make the traversal of a HOST-built tree wave-coherent. *perm_dev points into the workspace.
 hipError_t device_spatial_order(const float4* posm, int n, void* workspace, size_t workspace_bytes, const unsigned** perm_dev,
-                                hipStream_t stream, bool warm)
+                                hipStream_t stream, bool warm, const float4* sorted_pos)
 {
     *perm_dev = nullptr;
     if (n <= 0) return hipSuccess;
     size_t sort_tmp = 0;
     if (device_tree_workspace_bytes(n, 1, &sort_tmp) > workspace_bytes) return hipErrorInvalidValue;
     const Workspace k = carve(workspace, n, sort_tmp, 1);
-    const hipError_t e = sort_bodies(posm, n, k, sort_tmp, stream, false, warm);
+    const hipError_t e = sort_bodies(posm, n, k, sort_tmp, stream, false, warm, sorted_pos);
     if (e != hipSuccess) return e;
     *perm_dev = k.idx1;
     return hipGetLastError();

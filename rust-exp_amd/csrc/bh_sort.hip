@@ -65,7 +65,8 @@ __device__ __forceinline__ int sample_pos(const int i, const int n, const int sa
 // computes the keys of both its blocks itself (two descents per thread: cheaper than a launch of its own in front); the c = 0
 // column leaves block a's keys for k_keys_scatter.  No hand-off inside the kernel: a device-wide fence writes the L2 back on
 // this chip (k_sample_rank with a ticket and a last workgroup took 48 us, 40 of them fences).
-__global__ __launch_bounds__(kTile) void k_sample_rank(const float4* __restrict__ posm, const int n, const float4* __restrict__ part,
+// (spos: the bodies in the order perm names, when the last kick-drift left them so -- BhKick::sorted -- else nullptr: gather)
+__global__ __launch_bounds__(kTile) void k_sample_rank(const float4* __restrict__ posm, const float4* __restrict__ spos, const int n, const float4* __restrict__ part,
                                                        const int parts, unsigned* __restrict__ box,
                                                        const unsigned* __restrict__ perm, const int samples,
                                                        unsigned long long* __restrict__ skeys, int* __restrict__ srank)
@@ -76,8 +77,9 @@ __global__ __launch_bounds__(kTile) void k_sample_rank(const float4* __restrict_
     const int tid = threadIdx.x;
     const int oc = c * kTile + tid, mine_i = a * kTile + tid;
     // the bodies first (their two dependent loads fly while the box is folded out of k_bbox's partials; workgroup 0 files it)
-    const float4 p0 = posm[perm[sample_pos(mine_i < samples ? mine_i : 0, n, samples)]];
-    const float4 p1 = posm[perm[sample_pos(oc < samples ? oc : 0, n, samples)]];
+    const int s0 = sample_pos(mine_i < samples ? mine_i : 0, n, samples), s1 = sample_pos(oc < samples ? oc : 0, n, samples);
+    const float4 p0 = spos ? spos[s0] : posm[perm[s0]];
+    const float4 p1 = spos ? spos[s1] : posm[perm[s1]];
     float rx1, ry1, rx2, ry2;
     fold_box_partials(part, parts, box, blockIdx.x == 0, rx1, ry1, rx2, ry2);
     unsigned long long ok = kPadKey, mine = kPadKey;
@@ -137,7 +139,7 @@ __device__ __forceinline__ int bucket_of(const unsigned long long* __restrict__ 
 }
 
 template <int EA>
-__global__ __launch_bounds__(kTile) void k_keys_scatter(const float4* __restrict__ posm, const int n, const unsigned* __restrict__ box,
+__global__ __launch_bounds__(kTile) void k_keys_scatter(const float4* __restrict__ posm, const float4* __restrict__ spos, const int n, const unsigned* __restrict__ box,
                                                         const unsigned* __restrict__ perm, const unsigned long long* __restrict__ skeys,
                                                         const int* __restrict__ srank, const int samples,
                                                         const int buckets, int* __restrict__ gcount,
@@ -162,7 +164,11 @@ __global__ __launch_bounds__(kTile) void k_keys_scatter(const float4* __restrict
         id[r] = perm[t < n ? t : n - 1];
     }
 #pragma unroll
-    for (int r = 0; r < EA; r++) { const float4 p = posm[id[r]]; px[r] = p.x; py[r] = p.y; }
+    for (int r = 0; r < EA; r++) {
+        const int t = t0 + r * kTile;
+        const float4 p = spos ? spos[t < n ? t : n - 1] : posm[id[r]];   // (coalesced when the last kick-drift left the bodies in this order)
+        px[r] = p.x; py[r] = p.y;
+    }
     {   // the splitters: of the S ranked candidates, those of rank q * (S / B) - 1, q = 1 .. B - 1, ascending
         const int per = samples / buckets;     // = kOversample (samples = kOversample * buckets)
         constexpr int kFlight = 8;             // ranks in flight per thread (one at a time: 26 dependent round trips, 11 us of this kernel)
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(kTile) void k_bucket_sort(const ulonglong2* __restr
 
 // the sort of a warm build: bodies in last step's order (perm) -> sorted (key, body) pairs in keys_out / idx_out (perm == idx_out is fine:
 // it is read by the first three kernels and written by the last)
-hipError_t launch_inc_sort(const float4* posm, int n, unsigned* box, const float4* part, int parts, const unsigned* perm, int* gcount,
+hipError_t launch_inc_sort(const float4* posm, const float4* sorted_pos, int n, unsigned* box, const float4* part, int parts, const unsigned* perm, int* gcount,
                            unsigned long long* skeys, int* srank, ulonglong2* slots, unsigned long long* keys_out,
                            unsigned* idx_out, int* counters, unsigned long long* cell_table, int cell_slots, hipStream_t stream)
 {
@@ -458,13 +464,13 @@ hipError_t launch_inc_sort(const float4* posm, int n, unsigned* box, const float
     const int buckets = inc_buckets(n);
     const int samples = kOversample * buckets;
     const int sb = (samples + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_sample_rank, dim3((unsigned)(sb * sb)), dim3(kTile), 0, stream, posm, n, part, parts, box, perm, samples, skeys, srank);
+    hipLaunchKernelGGL(k_sample_rank, dim3((unsigned)(sb * sb)), dim3(kTile), 0, stream, posm, sorted_pos, n, part, parts, box, perm, samples, skeys, srank);
     const size_t shm = sizeof(unsigned long long) * (size_t)(buckets > 1 ? buckets - 1 : 1) + sizeof(int) * (size_t)buckets;
     if (n >= 262144)
-        hipLaunchKernelGGL(k_keys_scatter<4>, dim3((unsigned)((n + 4 * kTile - 1) / (4 * kTile))), dim3(kTile), shm, stream, posm, n, box, perm,
+        hipLaunchKernelGGL(k_keys_scatter<4>, dim3((unsigned)((n + 4 * kTile - 1) / (4 * kTile))), dim3(kTile), shm, stream, posm, sorted_pos, n, box, perm,
                            skeys, srank, samples, buckets, gcount, slots, cell_table, cell_slots);
     else
-        hipLaunchKernelGGL(k_keys_scatter<1>, dim3((unsigned)((n + kTile - 1) / kTile)), dim3(kTile), shm, stream, posm, n, box, perm, skeys,
+        hipLaunchKernelGGL(k_keys_scatter<1>, dim3((unsigned)((n + kTile - 1) / kTile)), dim3(kTile), shm, stream, posm, sorted_pos, n, box, perm, skeys,
                            srank, samples, buckets, gcount, slots, cell_table, cell_slots);
     hipLaunchKernelGGL(k_bucket_sort, dim3((unsigned)buckets), dim3(kTile), kBucketSortLds, stream, slots, gcount, buckets, n,
                        keys_out, idx_out, counters);

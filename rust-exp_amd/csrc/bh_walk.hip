@@ -323,11 +323,14 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
 // from Morton order costs the L2 more than the tail gains) and running the costliest p % as two halves of 32 bodies (round 5:
 // traversal 0.434 -> 0.482 / 0.499 / 0.543 / 0.635 ms with p = 10 / 25 / 50 / 100 at 1 M bodies -- half a walk costs 0.7 of a whole
 // one; docs/rounds/r05.md, profiles/r05_bh_walk_split_ab.jsonl).
-template <int BPW, bool ASM>
+// TRACE: the timeline instrumentation (tools/bh_walk_trace.py) is a kernel of its own -- its pointer and the start time are four
+// scalar registers across the loop, which the plain kernel spends on `sorted` instead (BhKick: the new positions in walk order)
+template <int BPW, bool ASM, bool TRACE>
 __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* posm, const int lo, const int n_targets,
                                                        const BhGroup* __restrict__ groups, void* __restrict__ sink,
                                                        const unsigned* __restrict__ perm, const int xcd_order, const BuildGate gate,
-                                                       unsigned long long* __restrict__ trace, float4* kick_posm, const float kick_dt)
+                                                       unsigned long long* __restrict__ trace, float4* kick_posm, const float kick_dt,
+                                                       float4* __restrict__ sorted)
 {
     // sink: float2 out[] (accelerations) -- or, with the kick folded in (kick_posm != nullptr), float4 vel[]: ONE pointer, because
     // every scalar register that lives across the walk loop counts (80 SGPRs + the trap handler's 16 = 96 is the last allocation
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* posm, const
     // (with the kick folded in, this kernel is the last of a gated step: its first thread hands the build's counters to the host
     //  and raises the poison flag of a refused step, as k_integrate_f2 does otherwise)
     if (!gate_open(gate, n_nodes_unused, kick_posm != nullptr && blockIdx.x == 0 && threadIdx.x == 0)) return;
-    const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;   // the 100 MHz clock all XCDs share
+    const unsigned long long t_start = (TRACE && trace) ? __builtin_amdgcn_s_memrealtime() : 0ull;   // the 100 MHz clock all XCDs share
     // XCD-aware order (as the node walk, bh_eval.hip): XCD k walks the k-th contiguous eighth of the Morton-ordered bodies
     const int blk = xcd_order ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int t = blk * BPW + threadIdx.x;
@@ -367,11 +370,12 @@ __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* posm, const
             }
             vel[it] = v;
             kick_posm[lo + it] = q;
+            if (!TRACE && sorted) sorted[blk * BPW + (int)threadIdx.x] = q;
         } else {
             static_cast<float2*>(sink)[it] = make_float2(acc.x, acc.y);
         }
     }
-    if (trace && threadIdx.x == 0) {   // tools/bh_walk_trace.py: when and where this walk ran (s_memrealtime: 10 ns ticks; HW_ID, XCC_ID)
+    if (TRACE && trace && threadIdx.x == 0) {   // tools/bh_walk_trace.py: when and where this walk ran (s_memrealtime: 10 ns ticks; HW_ID, XCC_ID)
         trace[4 * (size_t)blockIdx.x + 0] = t_start;
         trace[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         trace[4 * (size_t)blockIdx.x + 2] = (unsigned long long)((unsigned)__builtin_amdgcn_readfirstlane(turns) & 0x7FFFFFFFu) |
@@ -517,15 +521,17 @@ static void launch_wave_walk(int bpw, dim3 g, hipStream_t stream, const float4* 
     auto go = [&](auto kernel) {
         void* sink = kick.vel ? static_cast<void*>(kick.vel) : static_cast<void*>(out);
         hipLaunchKernelGGL(kernel, g, dim3(64), 0, stream, posm, lo, n_targets, groups, sink, perm, 1, gate, trace,
-                           kick.vel ? kick.posm : nullptr, kick.dt);
+                           kick.vel ? kick.posm : nullptr, kick.dt, kick.vel ? kick.sorted : nullptr);
     };
-    if (bpw == 64) go(k_bh_walk_groups<64, ASM>);
-    else if (bpw == 32) go(k_bh_walk_groups<32, ASM>);
-    else if (bpw == 16) go(k_bh_walk_groups<16, ASM>);
-    else if (bpw == 8) go(k_bh_walk_groups<8, ASM>);
-    else if (bpw == 4) go(k_bh_walk_groups<4, ASM>);
-    else if (bpw == 2) go(k_bh_walk_groups<2, ASM>);
-    else go(k_bh_walk_groups<1, ASM>);
+#define NBX_WALK(B) do { if (trace) go(k_bh_walk_groups<B, ASM, true>); else go(k_bh_walk_groups<B, ASM, false>); } while (0)
+    if (bpw == 64) NBX_WALK(64);
+    else if (bpw == 32) NBX_WALK(32);
+    else if (bpw == 16) NBX_WALK(16);
+    else if (bpw == 8) NBX_WALK(8);
+    else if (bpw == 4) NBX_WALK(4);
+    else if (bpw == 2) NBX_WALK(2);
+    else NBX_WALK(1);
+#undef NBX_WALK
 }
 
 hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, const BhGroup* groups, float2* out, hipStream_t stream,
@@ -533,7 +539,7 @@ hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, cons
                                  int gate_crowd_limit, int gate_queue_limit, unsigned long long* trace, const BhKick* kick)
 {
     if (n_targets <= 0) return hipSuccess;
-    const BhKick kd = kick ? *kick : BhKick{nullptr, nullptr, 0.0f, nullptr};
+    const BhKick kd = kick ? *kick : BhKick{nullptr, nullptr, 0.0f, nullptr, nullptr};
     if (kd.vel && !(wave && perm && kd.posm)) return hipErrorInvalidValue;   // (the per-lane form has no kick)
     const BuildGate gate{gate_counters, gate_node_cap, gate_crowd_limit, gate_queue_limit, kd.vel ? kd.host_out : nullptr};
     if (wave && perm) {

@@ -122,6 +122,7 @@ int upload(nbx_engine* e)
     if (!(e->host_pos_valid && e->host_vel_valid)) return fail(NBX_ERR_STATE, "no valid state to upload");
     const int n = e->n;
     e->sort_warm_n = 0;   // new positions from the host: last step's order says nothing about them
+    e->positions_moved();
     e->n_pad = ((n + kTile - 1) / kTile) * kTile;
     if (e->n_pad == 0) e->n_pad = kTile;
     if (e->posm_external) {
@@ -309,6 +310,7 @@ bool log_enabled()
 
 int step_brute(nbx_engine* e, float dt)
 {
+    e->positions_moved();   // (an all-pairs step moves every body: the order-sorted copy of the positions is stale from here)
     int rc = upload(e);
     if (rc != NBX_OK) return rc;
     const int slab = e->slab();
@@ -382,6 +384,7 @@ void free_device(nbx_engine* e)
     if (e->d_acc) (void)hipFree(e->d_acc);
     if (e->d_f2) (void)hipFree(e->d_f2);
     if (e->d_out4) (void)hipFree(e->d_out4);
+    if (e->d_sorted_pos) (void)hipFree(e->d_sorted_pos);
     if (e->d_nodes) (void)hipFree(e->d_nodes);
     if (e->d_groups) (void)hipFree(e->d_groups);
     if (e->d_guard) (void)hipFree(e->d_guard);

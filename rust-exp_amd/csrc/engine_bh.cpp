@@ -198,7 +198,10 @@ int build_tree_on_device_begin(nbx_engine* e, int* host_counters, bool publish_b
     HIP_TRY(nbx::device_tree_build_begin(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes,
                                          publish_by_kernel ? nullptr : (host_counters ? host_counters : e->h_counters), &e->d_perm,
                                          e->stream, fold, e->side_stream, e->ev_side_go, e->ev_side_done,
-                                         /*depth_panic_guard=*/e->force_mode != 0, /*warm=*/e->sort_warm_n == e->n));
+                                         /*depth_panic_guard=*/e->force_mode != 0, /*warm=*/e->sort_warm_n == e->n,
+                                         e->sorted_positions()));
+    e->positions_moved();    // the workspace holds a NEW order now: the order-sorted copy of the positions belongs to the old one
+                             // (the fused kick-drift of the step this build serves, if there is one, leaves a current copy again)
     e->sort_warm_n = e->n;   // (a refusal -- of this build, or of one whose verdict is still in flight -- takes it back)
     return NBX_OK;
 }
@@ -264,7 +267,9 @@ int spatial_order(nbx_engine* e)
         e->sort_warm_n = 0;
         HIP_TRY(nbx::device_tree_workspace_init(e->d_tree_ws, e->stream));
     }
-    HIP_TRY(nbx::device_spatial_order(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, &e->d_perm, e->stream, e->sort_warm_n == e->n));
+    HIP_TRY(nbx::device_spatial_order(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, &e->d_perm, e->stream, e->sort_warm_n == e->n,
+                                      e->sorted_positions()));
+    e->positions_moved();    // (as in build_tree_on_device_begin: a new order)
     e->sort_warm_n = e->n;
     return NBX_OK;
 }
@@ -335,6 +340,7 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
     }
     const int slab = e->slab();
     if (slab == 0) return NBX_OK;
+    e->positions_moved();   // this step moves the slab's bodies; only a fused kick-drift below leaves the order-sorted copy current again
     int rc = grow(&e->d_f2, &e->f2_cap, (size_t)slab);
     if (rc != NBX_OK) return rc;
     const unsigned* perm = nullptr;
@@ -351,10 +357,18 @@ int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, 
     const bool wave = perm != nullptr && e->bh_wave;   // shared walk per wave, in both modes (same results as the per-lane walks)
     bool kicked = false;
     if (e->force_mode == 0) {
-        const nbx::BhKick kick{e->d_vel, e->d_posm, dt, gated ? gate_host_out : nullptr};
         kicked = walk_takes_kick(e, perm, wave, gate ? node_cap : (int)e->n_flat);
+        // the new positions once more in the walks' order, for the next build's sort: one GPU, engine-owned positions, the
+        // whole system in one slab, the order that of the tree workspace (d_perm)
+        const bool leave_sorted = kicked && e->world == 1 && !e->posm_external && slab == e->n && perm == e->d_perm && e->sort_warm_n == e->n;
+        if (leave_sorted) {
+            rc = grow(&e->d_sorted_pos, &e->sorted_pos_cap, (size_t)e->n);
+            if (rc != NBX_OK) return rc;
+        }
+        const nbx::BhKick kick{e->d_vel, e->d_posm, dt, gated ? gate_host_out : nullptr, leave_sorted ? e->d_sorted_pos : nullptr};
         rc = launch_fast_walk(e, theta, perm, wave, on_device, gate, node_cap, crowd_limit, queue_limit, kicked ? &kick : nullptr);
         if (rc != NBX_OK) return rc;
+        if (leave_sorted) e->sorted_pos_valid = true;
     } else {
         ProfScope ps(e, NBX_K_BH_EVAL);
         HIP_TRY(nbx::launch_bh_eval(e->d_posm, e->lo, slab, e->d_nodes, (int)e->n_flat, theta, wave ? 3 : e->force_mode, e->d_f2,

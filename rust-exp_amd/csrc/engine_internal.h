@@ -68,6 +68,13 @@ struct nbx_engine {
     hipEvent_t ev_side_go = nullptr, ev_side_done = nullptr;
     int* h_counters = nullptr;     // pinned: per-level node counters of the device build
     const unsigned* d_perm = nullptr;   // spatial body order produced by the device build
+    float4* d_sorted_pos = nullptr;     // the positions in the order d_perm names, as the last fused kick-drift left them (BhKick::sorted)
+    size_t sorted_pos_cap = 0;
+    bool sorted_pos_valid = false;      // ... and whether they still ARE the current positions in that order: set by the launch of a
+                                        // fused walk + kick-drift, taken back by everything else that moves bodies on the device or
+                                        // replaces the order (positions_moved()); never with a bound positions buffer or world > 1
+    void positions_moved() { sorted_pos_valid = false; }
+    const float4* sorted_positions() const { return (sorted_pos_valid && world == 1 && !posm_external && sort_warm_n == n) ? d_sorted_pos : nullptr; }
     int sort_warm_n = 0;                // > 0: the tree workspace holds the sorted order of this many bodies as of the last build /
                                         // spatial order of THIS state (one step old at most): the next sort starts from it (bh_build.hip,
                                         // round 5). 0 after an upload of host state, a refused build, a new workspace

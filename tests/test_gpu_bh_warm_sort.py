@@ -157,3 +157,43 @@ def test_sharded_engines_take_the_warm_order_too(rx, ob, monkeypatch):
     for k in ("px", "py", "vx", "vy"):
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
     g.close()
+
+
+def test_mixed_sequences_keep_the_order_sorted_copy_of_the_positions_honest(rx, ob):
+    """Round 5: the fused walk + kick-drift leaves the new positions once more in the walks' order, and the next build's sort reads
+    them from there instead of gathering.  Everything else that moves bodies or replaces the order must take that copy out of use:
+    all-pairs steps, force-only evaluations and tree dumps (a build without a kick-drift), new particles, bit-exact steps.
+    A sequence that interleaves them all equals the same sequence with the library sort every step (NBX_INC_SORT=0), bit for bit."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import rust_exp_amd as rx\n"
+            "n = 150000\n"
+            "st = rx.plummer_sphere(n, dim=2)\n"
+            "rng = np.random.default_rng(9); vx = rng.normal(0, 6, n).astype(np.float32); vy = rng.normal(0, 6, n).astype(np.float32)\n"
+            "e = rx.NBodyEngine(); e.set_bh_tree('device'); e.set_particles(st['px'], st['py'], vx, vy, st['m'])\n"
+            "out = []\n"
+            "def snap():\n"
+            "    q = e.get_particles(); out.append(np.stack([q['px'], q['py'], q['vx'], q['vy']]))\n"
+            "for _ in range(3): e.step_barnes_hut(0.5, 0.01, 1)\n"
+            "fx, fy, _ = e.forces(0.5); out.append(np.stack([fx, fy, fx, fy]))\n"       # a build without a kick-drift
+            "for _ in range(2): e.step_barnes_hut(0.5, 0.01, 1)\n"
+            "e.step_brute_force(0.01)\n"                                               # bodies move, the order does not
+            "for _ in range(2): e.step_barnes_hut(0.5, 0.01, 1)\n"
+            "snap()\n"
+            "d = e.bh_flat_dump('device'); out.append(np.stack([d['px'], d['py'], d['m'], d['s']])[:, :n])\n"
+            "e.step_barnes_hut(0.85, 0.01, 1); e.synchronize(); e.step_barnes_hut(0.5, 0.01, 1)\n"
+            "q = e.get_particles(); e.set_particles(q['py'], q['px'], q['vy'], q['vx'], q['m'])\n"   # new particles (mirrored)
+            "for _ in range(3): e.step_barnes_hut(0.5, 0.01, 1)\n"
+            "snap()\n"
+            "np.save(sys.argv[1], np.concatenate(out, axis=1))\n" % root)
+    res = []
+    for flag in ("1", "0"):
+        path = "/tmp/nbx_mixed_%s.npy" % flag
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, NBX_INC_SORT=flag), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-800:]
+        res.append(np.load(path))
+    assert res[0].shape == res[1].shape and np.isfinite(res[0]).all()
+    assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
