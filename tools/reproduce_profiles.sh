@@ -27,3 +27,17 @@ tools/ubench_sort_cfg > gpurun_out/${T}_ubench_sort_cfg.txt 2>&1
 NBX_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --dry-run --bodies 65536 > gpurun_out/${T}_bench_torch2_gloo_one_gpu_dry_run.json 2> /dev/null
 NBX_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 5 --warmup 1 --bodies 65536 --no-cpu-baseline > gpurun_out/${T}_bench_torch2_gloo_one_gpu.json 2> /dev/null
 python tools/bh_union_model.py 1048576 > gpurun_out/${T}_bh_walk_union_model_n1048576.json 2> /dev/null   # (CPU: needs no GPU)
+# round 5: the driver's line with its companions (configs #2, #4, #5), the Barnes-Hut line on the host tree (traffic of the wave walk
+# alone), kernel stats of the 1 M-body step, the bucket-sort shapes, long runs of the warm sort (fallback rates), the frame loops.
+# (The walk-split A/B -- profiles/r05_bh_walk_split_ab.jsonl, r05_bh_walk_trace_1m_split*.json -- was measured on a tree that still
+#  had the experiment: commit cc66460, `NBX_WALK_SPLIT_PCT=25 python tools/bh_walk_trace.py`, `bash tools/bh_walk_split_ab.sh`.)
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_n1_companions.json 2> gpurun_out/${T}_bench.err
+python bench.py --workload bh --bh-tree host --steps 10 --warmup 2 --steady-seconds 0 --no-accuracy > gpurun_out/${T}_bench_bh_host.json 2> /dev/null
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/nbx_bh_stats5 -o p --output-format csv -- python $OLDPWD/bench.py --workload bh --no-cpu-baseline --no-traffic --steps 40 --warmup 5 --steady-seconds 0 > /dev/null 2>&1); find /tmp/nbx_bh_stats5 -name '*kernel_stats.csv' -exec cp {} gpurun_out/${T}_bh_kernel_stats_1m.csv \;
+[ -x tools/ubench_bucket_sort ] || hipcc --offload-arch=gfx950 -O3 tools/ubench_bucket_sort.hip -o tools/ubench_bucket_sort
+(for a in "1048576 800 0" "1048576 640 4" "1048576 640 4 10" "262144 640 4"; do tools/ubench_bucket_sort $a; done) > gpurun_out/${T}_ubench_bucket_sort.txt 2>&1
+python tools/bh_warm_long_run.py > gpurun_out/${T}_bh_warm_long_run.jsonl 2>&1
+NBX_INC_SORT=0 python tools/bh_warm_long_run.py plummer:1048576 random_disk:262144 > gpurun_out/${T}_bh_cold_long_run.jsonl 2>&1
+NB_BH_FOLD=exact python tools/frame_loop.py > gpurun_out/${T}_frame_loop_level1_exact_fold.txt 2>&1
+NBX_GROUP_EXCHANGE=copy python bench.py --gpus 8 --dry-run > gpurun_out/${T}_bench_group8_dry_run.json 2> /dev/null
+bash tools/pmc_host_tree_walk.sh > gpurun_out/${T}_pmc_host_tree_walk.txt 2>&1
