@@ -197,3 +197,38 @@ def test_mixed_sequences_keep_the_order_sorted_copy_of_the_positions_honest(rx, 
         res.append(np.load(path))
     assert res[0].shape == res[1].shape and np.isfinite(res[0]).all()
     assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
+
+
+def test_clumped_keys_take_the_network_and_ties_go_by_index(rx, ob):
+    """Buckets whose keys clump -- EPS-scale clumps, six hundred bodies at ONE point (identical 62-bit keys: only the index orders
+    them; 600^2 > 48 x the bucket's pairs) -- leave the counting sort for the bitonic network over (key, index).  Warm and cold (library sort) runs must step to the
+    same bits, and the exact-sum device tree must stay within the fast mode's tolerance of the host tree's forces."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import rust_exp_amd as rx\n"
+            "rng = np.random.default_rng(21); n = 60000\n"
+            "x = rng.normal(0, 8, n).astype(np.float32); y = rng.normal(0, 8, n).astype(np.float32)\n"
+            "k = n // 4\n"                                                        # a quarter of the bodies in clumps ~3e-5 wide around others
+            "x[:k] = x[k:2 * k] + rng.normal(0, 3e-5, k).astype(np.float32); y[:k] = y[k:2 * k] + rng.normal(0, 3e-5, k).astype(np.float32)\n"
+            "x[-600:] = x[-601]; y[-600:] = y[-601]\n"                           # six hundred bodies at one point: one sub-bucket of 600
+            "m = rng.uniform(0.5, 1.5, n).astype(np.float32); v = np.zeros(n, np.float32)\n"
+            "e = rx.NBodyEngine(); e.set_bh_tree('device'); e.set_bh_fold('exact'); e.set_particles(x, y, v, v, m)\n"
+            "for _ in range(5): e.step_barnes_hut(0.5, 0.001, 1)\n"
+            "q = e.get_particles(); fx, fy, _ = e.forces(0.5)\n"
+            "h = rx.NBodyEngine(); h.set_bh_tree('host'); h.set_particles(q['px'], q['py'], q['vx'], q['vy'], q['m']); gx, gy, _ = h.forces(0.5)\n"
+            "err = max(np.abs(fx - gx).max(), np.abs(fy - gy).max()) / max(np.abs(gx).max(), np.abs(gy).max())\n"
+            "print(e.get_stat(rx.engine.NBX_STAT_BH_FALLBACKS), err)\n"
+            "np.save(sys.argv[1], np.stack([q['px'], q['py'], q['vx'], q['vy']]))\n" % root)
+    res = []
+    for flag in ("1", "0"):
+        path = "/tmp/nbx_clump_%s.npy" % flag
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, NBX_INC_SORT=flag), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-800:]
+        fallbacks, err = r.stdout.strip().splitlines()[-1].split()
+        res.append((np.load(path), int(fallbacks), float(err)))
+    assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+    assert res[0][1] == res[1][1] == 0                  # every step ran on the device tree, whichever sort made the order
+    assert res[0][2] <= 1e-2 and res[1][2] <= 1e-2, (res[0][2], res[1][2])
