@@ -42,9 +42,12 @@ extern "C" {
 /* Both levels: NBX_HOST_THREADS (workers of the host quadtree build / flatten / draw; default   */
 /* min(hardware threads, 32)), NBX_GROUP_EXCHANGE=copy (see nbx_group_*), NBX_LOG=1 (one stderr   */
 /* line per step; a device tree build that hands its step to the host build says why),            */
-/* NBX_TIMING=1 (host tree-build phases), NBX_BH_BACKOFF_MAX (see NBX_OPT_BH_FALLBACKS).          */
+/* NBX_TIMING=1 (host tree-build phases).                                                          */
 /* NBX_SPIN_US (default 400: a host wait of the stepping path -- nbx_synchronize, the verdict of a */
-/* pipelined Barnes-Hut step -- polls this many microseconds before it blocks; 0 = block at once). */
+/* pipelined Barnes-Hut step -- polls this many microseconds before it blocks; 0 = block at once;  */
+/* systems above 32 768 bodies block at once). NBX_INC_SORT=0: the device tree build sorts from     */
+/* scratch every step (the library sort) instead of from last step's order -- an A/B knob, the       */
+/* results are bit-identical.  NBX_BH_BACKOFF_MAX: see NBX_STAT_BH_FALLBACKS.                        */
 
 /* replaces nbody.rs:34-37   pub extern fn nb_num_particles() -> i32 */
 int32_t nb_num_particles(void);
