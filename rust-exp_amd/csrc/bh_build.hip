@@ -69,13 +69,16 @@ __device__ __forceinline__ int run_start(const unsigned long long* __restrict__ 
     return r;
 }
 
-// Also gathers the bodies into sorted order (sb[j] = posm[idx[j]]: round 2 had a kernel of its own for that).
+// Also gathers the bodies into sorted order (sb[j] = posm[idx[j]]: round 2 had a kernel of its own for that) -- unless the sort
+// delivered them already (sb_ready: the warm sort carries the records along, bh_sort.hip; the two gathers here fetched 239 MB for
+// 32 MB of records at a million bodies, a 128-byte line per 16-byte record, and made this kernel the build's most HBM-bound).
 __device__ __forceinline__ void merge_links_body(const int j, const float4* __restrict__ posm, float4* __restrict__ sb,
                                                  const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
-                                                 const int n, unsigned char* __restrict__ close, int* __restrict__ crowded)
+                                                 const int n, unsigned char* __restrict__ close, int* __restrict__ crowded,
+                                                 const bool sb_ready)
 {
-    const float4 b = posm[idx[j]];
-    sb[j] = b;
+    const float4 b = sb_ready ? sb[j] : posm[idx[j]];
+    if (!sb_ready) sb[j] = b;
     unsigned char out = 0;
     if (j + 1 < n && keys[j + 1] == keys[j] && !(j > 0 && keys[j - 1] == keys[j])) {
         // The first of several bodies of one level-31 cell: one leaf as long as every arrival is within EPS of the centre the
@@ -85,7 +88,7 @@ __device__ __forceinline__ void merge_links_body(const int j, const float4* __re
         float cx = 0.0f, cy = 0.0f, cm = 0.0f;
         int left = 0;
         for (int t = j; t < n && keys[t] == keys[j]; t++) {        // (the stable sort left them in index order)
-            const float4 q = posm[idx[t]];
+            const float4 q = sb_ready ? sb[t] : posm[idx[t]];
             if (t > j && !(fabsf(__fsub_rn(cx, q.x)) < kEps && fabsf(__fsub_rn(cy, q.y)) < kEps)) left++;
             fold_mass(cx, cy, cm, q.x, q.y, q.w);
         }
@@ -94,7 +97,7 @@ __device__ __forceinline__ void merge_links_body(const int j, const float4* __re
     if (j > 0 && keys[j - 1] != keys[j]) {
         // the entity's position is its first arrival's (later arrivals of the same cell are < 5e-8 of the box away)
         const int r = run_start(keys, j - 1);
-        const float4 a = posm[idx[r]];
+        const float4 a = sb_ready ? sb[r] : posm[idx[r]];
         if (fabsf(__fsub_rn(a.x, b.x)) < kEps && fabsf(__fsub_rn(a.y, b.y)) < kEps) {   // nbody.rs:249
             const int c = common_digits(keys[j - 1], keys[j]);
             const unsigned ia = idx[r], ib = idx[j];           // first arrival of either entity (stable sort: run start)
@@ -120,10 +123,10 @@ __device__ __forceinline__ void merge_links_body(const int j, const float4* __re
 __global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict__ posm, float4* __restrict__ sb,
                                                        const unsigned long long* __restrict__ keys,
                                                        const unsigned* __restrict__ idx, const int n,
-                                                       unsigned char* __restrict__ close, int* __restrict__ crowded)
+                                                       unsigned char* __restrict__ close, int* __restrict__ crowded, const int sb_ready)
 {
     const int j = blockIdx.x * kTile + threadIdx.x;
-    if (j < n) merge_links_body(j, posm, sb, keys, idx, n, close, crowded);
+    if (j < n) merge_links_body(j, posm, sb, keys, idx, n, close, crowded, sb_ready != 0);
 }
 
 // Pairs of entities only: of a chain of close boundaries every other one is dropped by the local rule "a boundary merges iff
@@ -498,7 +501,8 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
         launch_fold_root(posm, n, out, side);
         if ((e = hipEventRecord(ev_done, side)) != hipSuccess) return e;
     }
-    e = sort_bodies(posm, n, k, sort_tmp, stream, fold == 1, warm, sorted_pos);
+    bool sb_ready = false;   // did the sort deliver the bodies' records in sorted order (k.sb) already?
+    e = sort_bodies(posm, n, k, sort_tmp, stream, fold == 1, warm, sorted_pos, /*want_sb=*/true, &sb_ready);
     if (e != hipSuccess) return e;
     *perm_dev = k.idx1;
     const int nb = (n + kTile - 1) / kTile;
@@ -511,12 +515,12 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     const unsigned char* pmin = nullptr;
     if (fold == 1) {
         // blobs of any size, replayed (3c): the tree is then the reference's, node for node -- or the step is refused
-        if ((e = launch_cluster_replay(posm, n, k, stream)) != hipSuccess) return e;
+        if ((e = launch_cluster_replay(posm, n, k, stream, sb_ready)) != hipSuccess) return e;
         mi = k.idx0; ms = k.sb2; pmin = k.pmin2;
     } else {
         // pairs of neighbouring entities only (3b): links from the sorted keys + arrival order (this kernel also gathers the
         // bodies into sorted order), then both members of a pair share one key
-        hipLaunchKernelGGL(k_merge_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link, k.counters + 1);
+        hipLaunchKernelGGL(k_merge_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link, k.counters + 1, sb_ready ? 1 : 0);
         hipLaunchKernelGGL(k_merge_keys, dim3(nb), dim3(kTile), 0, stream, k.keys1, k.idx1, k.link, n, k.keys0, k.counters + 1);
     }
     // (for small systems the pair merge and the scan were tried as phases of ONE 1024-thread workgroup: 90 us against 22 for the

@@ -247,6 +247,7 @@ struct Workspace {
     int* ghosts;
     int* gcount;                  // round 5, warm sort: per-bucket counts, the buckets' slots, the splitter candidates and their ranks
     ulonglong2* slots;            // kBucketCap (key, index) slots per bucket
+    float4* slot_recs;            // ... and the bodies' records beside them (delivered to sb in sorted order by k_bucket_sort)
     unsigned long long* skeys;
     int* srank;                   // [kMaxSamples] ranks of the splitter candidates
 };
@@ -290,19 +291,22 @@ inline Workspace carve(void* workspace, int n, size_t sort_tmp, int node_cap)
     k.srank = reinterpret_cast<int*>(take(sizeof(int) * (kMaxSamples + 64)));
     const size_t slots_inc = inc_sort_enabled(n) ? (size_t)inc_buckets(n) * kBucketCap : 0;
     k.slots = reinterpret_cast<ulonglong2*>(take(sizeof(ulonglong2) * slots_inc));
+    k.slot_recs = reinterpret_cast<float4*>(take(sizeof(float4) * slots_inc));
     return k;
 }
 
 
 // ---- between the units ------------------------------------------------------------------------------------------------------
 hipError_t launch_inc_sort(const float4* posm, const float4* sorted_pos, int n, unsigned* box, const float4* part, int parts, const unsigned* perm, int* gcount,
-                           unsigned long long* skeys, int* srank, ulonglong2* slots, unsigned long long* keys_out,
-                           unsigned* idx_out, int* counters, unsigned long long* cell_table, int cell_slots, hipStream_t stream);
+                           unsigned long long* skeys, int* srank, ulonglong2* slots, float4* slot_recs, unsigned long long* keys_out,
+                           unsigned* idx_out, float4* sb_out, int* counters, unsigned long long* cell_table, int cell_slots, hipStream_t stream);
 // root AABB -> path keys -> sorted (key, body) pairs in keys1 / idx1 (bh_front.hip)
+// want_sb: also deliver the bodies' records in sorted order (k.sb[j] = posm[idx1[j]]) if the sort can do that on its way (the warm
+// sort can); *sb_ready says whether it did
 hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sort_tmp, hipStream_t stream, bool cell_table, bool warm,
-                       const float4* sorted_pos = nullptr);
+                       const float4* sorted_pos = nullptr, bool want_sb = false, bool* sb_ready = nullptr);
 // the reference's EPS merge in full (bh_cluster.hip): entities in k.keys0 / k.idx0 / k.sb2 / k.pmin2
-hipError_t launch_cluster_replay(const float4* posm, int n, const Workspace& k, hipStream_t stream);
+hipError_t launch_cluster_replay(const float4* posm, int n, const Workspace& k, hipStream_t stream, bool sb_ready);
 // the reference's running fold (bh_fold.hip): the root on its own stream, the queued nodes behind k_emit
 void launch_fold_root(const float4* posm, int n, BhNode* out, hipStream_t side);
 void launch_fold_big(const float4* posm, const float4* sb, const unsigned* idx, const int4* big, int big_cap, const int* counters, int n,

@@ -70,11 +70,11 @@ __global__ __launch_bounds__(kTile) void k_cells(const float4* __restrict__ posm
                                                  const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
                                                  const unsigned* __restrict__ box, const int n, unsigned long long* __restrict__ hk,
                                                  int* __restrict__ hv, const unsigned mask, unsigned long long* __restrict__ ekey,
-                                                 unsigned char* __restrict__ pmin)
+                                                 unsigned char* __restrict__ pmin, const int sb_ready)
 {
     const int j = blockIdx.x * kTile + threadIdx.x;
     if (j >= n) return;
-    sb[j] = posm[idx[j]];
+    if (!sb_ready) sb[j] = posm[idx[j]];      // (the warm sort delivers the records itself, bh_sort.hip)
     const unsigned long long k = keys[j];
     ekey[j] = k;
     pmin[j] = (unsigned char)kLevels;
@@ -447,10 +447,10 @@ __global__ __launch_bounds__(kTile) void k_place(const unsigned long long* __res
 }
 
 
-hipError_t launch_cluster_replay(const float4* posm, int n, const Workspace& k, hipStream_t stream)
+hipError_t launch_cluster_replay(const float4* posm, int n, const Workspace& k, hipStream_t stream, bool sb_ready)
 {
     const int nb = (n + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_cells, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, k.box, n, k.hk, k.hv, k.hmask, k.ekey, k.link);
+    hipLaunchKernelGGL(k_cells, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, k.box, n, k.hk, k.hv, k.hmask, k.ekey, k.link, sb_ready ? 1 : 0);
     hipLaunchKernelGGL(k_blobs, dim3(nb), dim3(kTile), 0, stream, k.sb, k.keys1, k.idx1, k.box, n, k.hk, k.hv, k.hmask, k.ekey, k.link,
                        k.ghosts, k.counters);
     hipLaunchKernelGGL(k_place, dim3(nb), dim3(kTile), 0, stream, k.keys1, k.ekey, k.idx1, k.sb, k.link, k.ghosts, k.counters, n,

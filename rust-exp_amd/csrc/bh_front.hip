@@ -134,6 +134,7 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     add(sizeof(int) * (kMaxSamples + 64));             // ... their ranks, one ticket per row of the ranking
     const size_t slots_inc = inc_sort_enabled(n) ? (size_t)inc_buckets(n) * kBucketCap : 0;
     add(sizeof(ulonglong2) * slots_inc);               // ... the buckets' slots
+    add(sizeof(float4) * slots_inc);                   // ... the records beside them
     return bytes;
 }
 
@@ -346,8 +347,9 @@ hipError_t launch_front_small(const float4* posm, int n, unsigned* box, unsigned
 
 // root AABB -> path keys -> sorted (key, body) pairs in keys1 / idx1
 hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sort_tmp, hipStream_t stream, bool cell_table, bool warm,
-                       const float4* sorted_pos)
+                       const float4* sorted_pos, bool want_sb, bool* sb_ready)
 {
+    if (sb_ready) *sb_ready = false;
     if (small_front_enabled(n)) {   // a small system (the reference's own 10 000 bodies): two launches instead of seven, no library sort
         const hipError_t e = launch_front_small(posm, n, k.box, k.keys0, k.idx0, k.keys1, k.idx1, k.counters, k.hk,
                                                 cell_table ? (int)(k.hmask + 1u) : 0, stream);
@@ -359,8 +361,9 @@ hipError_t sort_bodies(const float4* posm, int n, const Workspace& k, size_t sor
     if (warm && inc_sort_enabled(n)) {   // idx1 holds last step's order: sort from there (round 5)
         hipLaunchKernelGGL(k_bbox, dim3(parts), dim3(kTile), 0, stream, posm, n, k.part, k.srank, kOversample * inc_buckets(n), k.gcount,
                            inc_buckets(n), k.counters, 8);
-        return launch_inc_sort(posm, sorted_pos, n, k.box, k.part, parts, k.idx1, k.gcount, k.skeys, k.srank, k.slots, k.keys1, k.idx1, k.counters, k.hk,
-                               cell_table ? (int)(k.hmask + 1u) : 0, stream);
+        if (sb_ready) *sb_ready = want_sb;
+        return launch_inc_sort(posm, sorted_pos, n, k.box, k.part, parts, k.idx1, k.gcount, k.skeys, k.srank, k.slots, k.slot_recs, k.keys1, k.idx1,
+                               want_sb ? k.sb : nullptr, k.counters, k.hk, cell_table ? (int)(k.hmask + 1u) : 0, stream);
     }
     hipLaunchKernelGGL(k_bbox, dim3(parts), dim3(kTile), 0, stream, posm, n, k.part, (int*)nullptr, 0, (int*)nullptr, 0, (int*)nullptr, 0);
     hipLaunchKernelGGL(k_keys, dim3(nb), dim3(kTile), 0, stream, posm, n, k.part, parts, k.box, k.keys0, k.idx0, k.counters, k.hk,

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kTile) void k_keys_scatter(const float4* __restrict
                                                         const unsigned* __restrict__ perm, const unsigned long long* __restrict__ skeys,
                                                         const int* __restrict__ srank, const int samples,
                                                         const int buckets, int* __restrict__ gcount,
-                                                        ulonglong2* __restrict__ slots,
+                                                        ulonglong2* __restrict__ slots, float4* __restrict__ slot_recs,
                                                         unsigned long long* __restrict__ cell_table, const int cell_slots)
 {
     extern __shared__ unsigned long long sm[];
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(kTile) void k_keys_scatter(const float4* __restrict
     for (int t = blockIdx.x * kTile + tid; t < cell_slots; t += (int)gridDim.x * kTile) cell_table[t] = 0ull;   // (reference fold, as k_keys)
     // the bodies first (their loads fly while the splitters come in): EA per thread, their descents interleaved
     unsigned id[EA];
+    float4 rec[EA];                  // the bodies' records travel with their (key, index) pairs: k_bucket_sort delivers them sorted
     float px[EA], py[EA];
     const int t0 = blockIdx.x * (kTile * EA) + tid;
 #pragma unroll
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(kTile) void k_keys_scatter(const float4* __restrict
     for (int r = 0; r < EA; r++) {
         const int t = t0 + r * kTile;
         const float4 p = spos ? spos[t < n ? t : n - 1] : posm[id[r]];   // (coalesced when the last kick-drift left the bodies in this order)
+        rec[r] = p;
         px[r] = p.x; py[r] = p.y;
     }
     {   // the splitters: of the S ranked candidates, those of rank q * (S / B) - 1, q = 1 .. B - 1, ascending
@@ -221,7 +223,9 @@ __global__ __launch_bounds__(kTile) void k_keys_scatter(const float4* __restrict
         if (bk[r] < 0) continue;
         const int slot = hist[bk[r]] + off[r];
         if (slot < kBucketCap) {       // (a pair beyond the bucket's slots is dropped: gcount says so, k_bucket_sort refuses the build)
-            slots[(size_t)bk[r] * kBucketCap + (size_t)slot] = make_ulonglong2(key[r], (unsigned long long)id[r]);   // one 16-byte store
+            const size_t at = (size_t)bk[r] * kBucketCap + (size_t)slot;
+            slots[at] = make_ulonglong2(key[r], (unsigned long long)id[r]);   // one 16-byte store
+            if (slot_recs) slot_recs[at] = rec[r];
         }
     }
 }
@@ -236,7 +240,8 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(const unsigned long l
 template <int E>
 __device__ __forceinline__ void bucket_network(const ulonglong2* __restrict__ ps, const int cnt,
                                                unsigned long long* __restrict__ keys_out, unsigned* __restrict__ idx_out,
-                                               const int out_base, unsigned* __restrict__ lds)
+                                               const int out_base, unsigned* __restrict__ lds, const float4* __restrict__ posm,
+                                               float4* __restrict__ sb_out)
 {
     constexpr int P = kTile * E;
     const int tid = threadIdx.x;
@@ -303,7 +308,10 @@ __device__ __forceinline__ void bucket_network(const ulonglong2* __restrict__ ps
 #pragma unroll
     for (int r = 0; r < E; r++) {
         const int e = tid * E + r;
-        if (e < cnt) { keys_out[out_base + e] = k[r]; idx_out[out_base + e] = id[r]; }
+        if (e < cnt) {
+            keys_out[out_base + e] = k[r]; idx_out[out_base + e] = id[r];
+            if (sb_out) sb_out[out_base + e] = posm[id[r]];      // (the rare path gathers the records: they did not travel through the network)
+        }
     }
 }
 
@@ -314,7 +322,8 @@ constexpr int kClumpPerPair = 48;   // sum of squared sub-bucket counts per pair
 template <int E, class StartFn>
 __device__ __forceinline__ bool bucket_by_counting(const ulonglong2* __restrict__ ps, const int cnt,
                                                    unsigned long long* __restrict__ keys_out, unsigned* __restrict__ idx_out,
-                                                   unsigned* __restrict__ lds, StartFn start)
+                                                   unsigned* __restrict__ lds, StartFn start, const float4* __restrict__ precs,
+                                                   float4* __restrict__ sb_out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* hist = reinterpret_cast<int*>(lds);                                              // [kSub + 1]
@@ -391,6 +400,11 @@ __device__ __forceinline__ bool bucket_by_counting(const ulonglong2* __restrict_
         for (int t = s0; t < s1; t++) p += pair_less(skey[t], sidx[t], k[r], id[r]) ? 1 : 0;
         pos[r] = p;
     }
+    if (sb_out) {   // the records go straight from their slots to their places (16-byte stores inside the bucket's stretch of sb)
+#pragma unroll
+        for (int r = 0; r < E; r++)
+            if (pos[r] >= 0) sb_out[out_base + pos[r]] = precs[r * kTile + tid];
+    }
     __syncthreads();                                                 // every place is known: the staging arrays become the sorted bucket
 #pragma unroll
     for (int r = 0; r < E; r++)
@@ -401,9 +415,10 @@ __device__ __forceinline__ bool bucket_by_counting(const ulonglong2* __restrict_
 }
 
 constexpr size_t kBucketSortLds = sizeof(unsigned) * (kSub + 2) + 12 * (size_t)kBucketCap;
-__global__ __launch_bounds__(kTile) void k_bucket_sort(const ulonglong2* __restrict__ slots, const int* __restrict__ gcount, const int buckets,
+__global__ __launch_bounds__(kTile) void k_bucket_sort(const ulonglong2* __restrict__ slots, const float4* __restrict__ slot_recs,
+                                                       const float4* __restrict__ posm, const int* __restrict__ gcount, const int buckets,
                                                        const int n, unsigned long long* __restrict__ keys_out, unsigned* __restrict__ idx_out,
-                                                       int* __restrict__ counters)
+                                                       float4* __restrict__ sb_out, int* __restrict__ counters)
 {
     extern __shared__ unsigned lds_sort[];
     __shared__ int red[2][kTile / 64];
@@ -429,7 +444,10 @@ __global__ __launch_bounds__(kTile) void k_bucket_sort(const ulonglong2* __restr
             // some bucket outgrew its slots: refuse the build (gate / device_tree_build_end read counters[1]) and leave a well-formed
             // tail -- largest key, a valid index -- so that the kernels behind this one stay inside their arrays
             if (tid == 0) { atomicAdd(&counters[1], 0x20000000); atomicOr(&counters[5], kWhySortOverflow); }
-            for (int t = total + tid; t < n; t += kTile) { keys_out[t] = (1ull << (2 * kLevels)) - 1ull; idx_out[t] = 0u; }
+            for (int t = total + tid; t < n; t += kTile) {
+                keys_out[t] = (1ull << (2 * kLevels)) - 1ull; idx_out[t] = 0u;
+                if (sb_out) sb_out[t] = posm[0];
+            }
         }
         return before;
     };
@@ -437,28 +455,29 @@ __global__ __launch_bounds__(kTile) void k_bucket_sort(const ulonglong2* __restr
     cnt = cnt > kBucketCap ? kBucketCap : cnt;
     if (cnt == 0) { (void)start(); return; }
     const ulonglong2* ps = slots + (size_t)b * kBucketCap;
+    const float4* precs = slot_recs + (size_t)b * kBucketCap;
     bool done;
-    if (cnt <= kTile) done = bucket_by_counting<1>(ps, cnt, keys_out, idx_out, lds_sort, start);
-    else if (cnt <= 2 * kTile) done = bucket_by_counting<2>(ps, cnt, keys_out, idx_out, lds_sort, start);
-    else if (cnt <= 4 * kTile) done = bucket_by_counting<4>(ps, cnt, keys_out, idx_out, lds_sort, start);
-    else if (cnt <= 8 * kTile) done = bucket_by_counting<8>(ps, cnt, keys_out, idx_out, lds_sort, start);
-    else done = bucket_by_counting<16>(ps, cnt, keys_out, idx_out, lds_sort, start);
+    if (cnt <= kTile) done = bucket_by_counting<1>(ps, cnt, keys_out, idx_out, lds_sort, start, precs, sb_out);
+    else if (cnt <= 2 * kTile) done = bucket_by_counting<2>(ps, cnt, keys_out, idx_out, lds_sort, start, precs, sb_out);
+    else if (cnt <= 4 * kTile) done = bucket_by_counting<4>(ps, cnt, keys_out, idx_out, lds_sort, start, precs, sb_out);
+    else if (cnt <= 8 * kTile) done = bucket_by_counting<8>(ps, cnt, keys_out, idx_out, lds_sort, start, precs, sb_out);
+    else done = bucket_by_counting<16>(ps, cnt, keys_out, idx_out, lds_sort, start, precs, sb_out);
     if (done) return;
     __syncthreads();
     const int before = start();
     __syncthreads();
-    if (cnt <= kTile) bucket_network<1>(ps, cnt, keys_out, idx_out, before, lds_sort);
-    else if (cnt <= 2 * kTile) bucket_network<2>(ps, cnt, keys_out, idx_out, before, lds_sort);
-    else if (cnt <= 4 * kTile) bucket_network<4>(ps, cnt, keys_out, idx_out, before, lds_sort);
-    else if (cnt <= 8 * kTile) bucket_network<8>(ps, cnt, keys_out, idx_out, before, lds_sort);
-    else bucket_network<16>(ps, cnt, keys_out, idx_out, before, lds_sort);
+    if (cnt <= kTile) bucket_network<1>(ps, cnt, keys_out, idx_out, before, lds_sort, posm, sb_out);
+    else if (cnt <= 2 * kTile) bucket_network<2>(ps, cnt, keys_out, idx_out, before, lds_sort, posm, sb_out);
+    else if (cnt <= 4 * kTile) bucket_network<4>(ps, cnt, keys_out, idx_out, before, lds_sort, posm, sb_out);
+    else if (cnt <= 8 * kTile) bucket_network<8>(ps, cnt, keys_out, idx_out, before, lds_sort, posm, sb_out);
+    else bucket_network<16>(ps, cnt, keys_out, idx_out, before, lds_sort, posm, sb_out);
 }
 
 // the sort of a warm build: bodies in last step's order (perm) -> sorted (key, body) pairs in keys_out / idx_out (perm == idx_out is fine:
 // it is read by the first three kernels and written by the last)
 hipError_t launch_inc_sort(const float4* posm, const float4* sorted_pos, int n, unsigned* box, const float4* part, int parts, const unsigned* perm, int* gcount,
-                           unsigned long long* skeys, int* srank, ulonglong2* slots, unsigned long long* keys_out,
-                           unsigned* idx_out, int* counters, unsigned long long* cell_table, int cell_slots, hipStream_t stream)
+                           unsigned long long* skeys, int* srank, ulonglong2* slots, float4* slot_recs, unsigned long long* keys_out,
+                           unsigned* idx_out, float4* sb_out, int* counters, unsigned long long* cell_table, int cell_slots, hipStream_t stream)
 {
     static_assert(kBucketSortLds <= 64 * 1024, "k_bucket_sort's LDS must stay within the default limit (no per-device opt-in)");
     const int buckets = inc_buckets(n);
@@ -468,12 +487,12 @@ hipError_t launch_inc_sort(const float4* posm, const float4* sorted_pos, int n, 
     const size_t shm = sizeof(unsigned long long) * (size_t)(buckets > 1 ? buckets - 1 : 1) + sizeof(int) * (size_t)buckets;
     if (n >= 262144)
         hipLaunchKernelGGL(k_keys_scatter<4>, dim3((unsigned)((n + 4 * kTile - 1) / (4 * kTile))), dim3(kTile), shm, stream, posm, sorted_pos, n, box, perm,
-                           skeys, srank, samples, buckets, gcount, slots, cell_table, cell_slots);
+                           skeys, srank, samples, buckets, gcount, slots, sb_out ? slot_recs : nullptr, cell_table, cell_slots);
     else
         hipLaunchKernelGGL(k_keys_scatter<1>, dim3((unsigned)((n + kTile - 1) / kTile)), dim3(kTile), shm, stream, posm, sorted_pos, n, box, perm, skeys,
-                           srank, samples, buckets, gcount, slots, cell_table, cell_slots);
-    hipLaunchKernelGGL(k_bucket_sort, dim3((unsigned)buckets), dim3(kTile), kBucketSortLds, stream, slots, gcount, buckets, n,
-                       keys_out, idx_out, counters);
+                           srank, samples, buckets, gcount, slots, sb_out ? slot_recs : nullptr, cell_table, cell_slots);
+    hipLaunchKernelGGL(k_bucket_sort, dim3((unsigned)buckets), dim3(kTile), kBucketSortLds, stream, slots, slot_recs, posm, gcount, buckets, n,
+                       keys_out, idx_out, sb_out, counters);
     return hipGetLastError();
 }
 
