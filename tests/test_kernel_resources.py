@@ -107,17 +107,17 @@ def test_hand_scheduled_walk_keeps_eight_waves_per_simd(tmp_path):
     strict = re.search(r"^STRICT\s*:=\s*(.*)$", mk, re.M).group(1).split()
     k = _metadata(tmp_path, "bh_walk.hip", strict + ["-Wno-inline-asm"])
     walks = {n: v for n, v in k.items() if "k_bh_walk_groupsILi" in n}
-    assert len(walks) == 14                                                # 64 ... 1 bodies per walk, hand-scheduled and compiled
+    assert len(walks) == 28                # 64 ... 1 bodies per walk x hand-scheduled / compiled x with / without the timeline (round 5)
     for n, v in walks.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0, (n, v)
         assert v["vgpr_count"] <= 64, (n, v)
-        if "ELb1E" in n:
+        if re.search(r"ILi\d+ELb1ELb[01]E", n):                            # <BPW, ASM = true, TRACE>: the hand-scheduled loop, either variant
             assert v["sgpr_count"] <= 80, (n, v)
 
 
 def test_warm_sort_kernels_of_the_device_tree_build(tmp_path):
     """bh_sort.hip (round 5): no scratch anywhere; k_bucket_sort within the default 64 KB of dynamic LDS (no per-device opt-in) and
-    at most 128 VGPRs (four waves per SIMD); the scatter's four interleaved descents in at most 64."""
+    at most 128 VGPRs (four waves per SIMD); the scatter with its four interleaved descents and records in at most 80."""
     mk = open(os.path.join(CSRC, "Makefile")).read()
     strict = re.search(r"^STRICT\s*:=\s*(.*)$", mk, re.M).group(1).split()
     k = _metadata(tmp_path, "bh_sort.hip", strict)
@@ -128,4 +128,4 @@ def test_warm_sort_kernels_of_the_device_tree_build(tmp_path):
         for v in vs:
             assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0, (name, v)
     assert next(v for n, v in k.items() if "k_bucket_sort" in n)["vgpr_count"] <= 128
-    assert all(v["vgpr_count"] <= 64 for n, v in k.items() if "k_keys_scatter" in n)
+    assert all(v["vgpr_count"] <= 80 for n, v in k.items() if "k_keys_scatter" in n)   # (four bodies per thread with their records: six waves per SIMD)
