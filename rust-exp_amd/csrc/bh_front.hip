@@ -138,7 +138,7 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     return bytes;
 }
 
-// once per (re)allocation of the workspace: the self-clearing ticket of k_bbox starts at zero
+// once per (re)allocation of the workspace: the poison flag of the gated steps and the scan's ticket start at zero
 hipError_t device_tree_workspace_init(void* workspace, hipStream_t stream)
 {
     return hipMemsetAsync(workspace, 0, 256, stream);

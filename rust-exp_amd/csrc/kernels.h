@@ -168,7 +168,7 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes);
 // call once after every (re)allocation of the workspace, before its first use (clears the header's self-clearing ticket)
 hipError_t device_tree_workspace_init(void* workspace, hipStream_t stream);
 // warm (round 5): the workspace still holds the order an earlier call (this one or device_tree_build_begin) left for the SAME n
-// bodies, give or take a step's motion -- the sort then starts from it (k_splitters / k_keys_scatter / k_bucket_sort) instead
+// bodies, give or take a step's motion -- the sort then starts from it (bh_sort.hip: k_sample_rank / k_keys_scatter / k_bucket_sort) instead
 // of from scratch; a warm sort whose buckets overflow refuses the build (counters[1], see bh_sort.hip)
 // sorted_pos (optional, warm only): posm in the order the workspace holds (entry t = posm[order[t]], as the last fused kick-drift
 // left it, BhKick::sorted): the warm sort then reads the bodies from there, coalesced, instead of gathering them

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Barnes-Hut step, traversal and build times of the shipped path (child-group walk, device tree) over sizes; both tree classes
+where they apply.  One JSON line per (bodies, fold).  Usage: bh_sizes.py [n:theta ...]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bh_walk_ab import run  # noqa: E402
+
+cases = [a.split(":") for a in sys.argv[1:]] or [("2000", "0.85"), ("10000", "0.85"), ("16384", "0.85"), ("20000", "0.5"), ("32768", "0.5"),
+                                                  ("65536", "0.5"), ("131072", "0.5"), ("262144", "0.5"), ("524288", "0.5"),
+                                                  ("1048576", "0.5"), ("2097152", "0.5")]
+for n, theta in cases:
+    print(json.dumps(run(int(n), float(theta), 1)), flush=True)
+    if int(n) <= 65536:
+        print(json.dumps(run(int(n), float(theta), 1, fold="reference")), flush=True)

@@ -20,7 +20,6 @@ def run(n, theta, walk, wave=1, steps=30, fold="exact"):
     e = rx.NBodyEngine(mode="fast")
     e.set_bh_fold(fold)
     e.set_option(NBX_OPT_BH_WALK, walk)
-    # (round 4's NBX_AB_WALK_ORDER went with NBX_OPT_BH_WALK_ORDER; round 5's experiment is the env NBX_WALK_SPLIT_PCT, read by the engine)
     e.set_option(NBX_OPT_BH_WAVE, wave)
     if os.environ.get("NBX_AB_FUSE_KICK"):
         from rust_exp_amd.engine import NBX_OPT_BH_FUSE_KICK

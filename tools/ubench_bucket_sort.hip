@@ -169,13 +169,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_v1(const u64* pkeys, const unsig
 // sub-bucket's start (scan) and an arrival number; its place inside the sub-bucket = the number of smaller (key, index) pairs among
 // the sub-bucket's members (1-3 reads).  A bucket with a crowded sub-bucket (> kCrowd pairs: clustered keys) takes the bitonic network.
 constexpr int kD = 2048, kCrowd = 24;
-template <int E>
+template <int E, int STAGE>
 __device__ __forceinline__ bool v2_body(const u64* pk, const unsigned* pi, int cnt, u64* ko, unsigned* io, int base, unsigned* lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* hist = reinterpret_cast<int*>(lds);                       // [kD + 1]
     u64* skey = reinterpret_cast<u64*>(lds + kD + 2);              // [kCap]  (8-byte aligned: kD + 2 words in front)
-    unsigned* sidx = reinterpret_cast<unsigned*>(skey + kCap);     // [kCap]
+    unsigned* sidx = reinterpret_cast<unsigned*>(skey + STAGE);    // [STAGE]
     __shared__ u64 red[2][kTile / 64];
     __shared__ int wsum[kTile / 64];
     __shared__ int crowded;
@@ -239,6 +239,7 @@ __device__ __forceinline__ bool v2_body(const u64* pk, const unsigned* pi, int c
     }
     return true;
 }
+template <int STAGE>
 __global__ __launch_bounds__(kTile) void k_v2(const u64* pkeys, const unsigned* pidx, const int* gcount, const int* start, u64* ko, unsigned* io)
 {
     extern __shared__ unsigned lds_sort[];
@@ -246,11 +247,11 @@ __global__ __launch_bounds__(kTile) void k_v2(const u64* pkeys, const unsigned* 
     const int cnt = gcount[b], base = start[b];
     const u64* pk = pkeys + (size_t)b * kCap; const unsigned* pi = pidx + (size_t)b * kCap;
     bool done;
-    if (cnt <= kTile) done = v2_body<1>(pk, pi, cnt, ko, io, base, lds_sort);
-    else if (cnt <= 2 * kTile) done = v2_body<2>(pk, pi, cnt, ko, io, base, lds_sort);
-    else if (cnt <= 4 * kTile) done = v2_body<4>(pk, pi, cnt, ko, io, base, lds_sort);
-    else if (cnt <= 8 * kTile) done = v2_body<8>(pk, pi, cnt, ko, io, base, lds_sort);
-    else done = v2_body<16>(pk, pi, cnt, ko, io, base, lds_sort);
+    if (cnt <= kTile) done = v2_body<1, STAGE>(pk, pi, cnt, ko, io, base, lds_sort);
+    else if (cnt <= 2 * kTile) done = v2_body<2, STAGE>(pk, pi, cnt, ko, io, base, lds_sort);
+    else if (cnt <= 4 * kTile) done = v2_body<4, STAGE>(pk, pi, cnt, ko, io, base, lds_sort);
+    else if (cnt <= 8 * kTile) done = v2_body<8, STAGE>(pk, pi, cnt, ko, io, base, lds_sort);
+    else done = v2_body<16, STAGE>(pk, pi, cnt, ko, io, base, lds_sort);
     if (done) return;
     __syncthreads();
     if (cnt <= kTile) v0_body<1>(pk, pi, cnt, ko, io, base, lds_sort);
@@ -319,8 +320,9 @@ int main(int argc, char** argv)
     };
     time_it("v0 256 threads / bucket, bpermute + LDS", [&] { hipLaunchKernelGGL(k_v0, dim3(B), dim3(kTile), 12 * kCap, 0, d_pk, d_pi, d_cnt, d_start, d_ko, d_io); });
     time_it("v0 same, 24 KB LDS claimed (buckets <= 2048)", [&] { hipLaunchKernelGGL(k_v0, dim3(B), dim3(kTile), maxc <= 2048 ? 12 * 2048 : 12 * kCap, 0, d_pk, d_pi, d_cnt, d_start, d_ko, d_io); });
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_v2), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (kD + 2) + 12 * kCap));
-    time_it("v2 interpolation + counting (bitonic if crowded)", [&] { hipLaunchKernelGGL(k_v2, dim3(B), dim3(kTile), 4 * (kD + 2) + 12 * kCap, 0, d_pk, d_pi, d_cnt, d_start, d_ko, d_io); });
+    time_it("v2 interpolation + counting (bitonic if crowded)", [&] { hipLaunchKernelGGL(k_v2<kCap>, dim3(B), dim3(kTile), 4 * (kD + 2) + 12 * kCap, 0, d_pk, d_pi, d_cnt, d_start, d_ko, d_io); });
+    if (maxc <= 2048 && !clustered)   // (the network of a crowded bucket needs the full staging area)
+        time_it("v2 same, staging for 2 048 pairs (32 KB LDS)", [&] { hipLaunchKernelGGL(k_v2<2048>, dim3(B), dim3(kTile), 4 * (kD + 2) + 12 * 2048, 0, d_pk, d_pi, d_cnt, d_start, d_ko, d_io); });
     time_it("v1 one wave / bucket, bpermute, 4 waves/wg", [&] { hipLaunchKernelGGL((k_v1<0, 4>), dim3((B + 3) / 4), dim3(256), 0, 0, d_pk, d_pi, d_cnt, d_start, B, d_ko, d_io); });
     time_it("v1 one wave / bucket, dpp/swizzle, 4 waves/wg", [&] { hipLaunchKernelGGL((k_v1<1, 4>), dim3((B + 3) / 4), dim3(256), 0, 0, d_pk, d_pi, d_cnt, d_start, B, d_ko, d_io); });
     time_it("v1 one wave / bucket, dpp/swizzle, 1 wave/wg", [&] { hipLaunchKernelGGL((k_v1<1, 1>), dim3(B), dim3(64), 0, 0, d_pk, d_pi, d_cnt, d_start, B, d_ko, d_io); });
