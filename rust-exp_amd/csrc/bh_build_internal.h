@@ -267,8 +267,9 @@ inline Workspace carve(void* workspace, int n, size_t sort_tmp, int node_cap)
     k.idx1 = k.idx0 + n;
     k.sort_tmp = take(sort_tmp);
     k.sb = reinterpret_cast<float4*>(take(sizeof(float4) * (size_t)n));
-    double* d = reinterpret_cast<double*>(take(sizeof(double) * ((size_t)n + 1) * 3));
-    k.pre.m = d; k.pre.mx = d + (size_t)n + 1; k.pre.my = d + 2 * ((size_t)n + 1);
+    const size_t pstride = ((size_t)n + 2) & ~(size_t)1;   // (even: every prefix array starts 16-byte aligned for k_scan_write's vector stores)
+    double* d = reinterpret_cast<double*>(take(sizeof(double) * pstride * 3));
+    k.pre.m = d; k.pre.mx = d + pstride; k.pre.my = d + 2 * pstride;
     k.pre.base = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)n + 1)));
     k.pre.ent = reinterpret_cast<int*>(take(sizeof(int) * ((size_t)n + 1)));
     k.pre.cnt = reinterpret_cast<unsigned char*>(take((size_t)n));

@@ -115,7 +115,7 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     add(sizeof(unsigned) * (size_t)n * 2);             // idx in/out
     add(tmp);
     add(sizeof(float4) * (size_t)n);                   // sorted bodies
-    add(sizeof(double) * ((size_t)n + 1) * 3);         // prefix sums m, m*x, m*y
+    add(sizeof(double) * (((size_t)n + 2) & ~(size_t)1) * 3);   // prefix sums m, m*x, m*y (each 16-byte aligned)
     add(sizeof(int) * ((size_t)n + 1));                // pre-order base
     add(sizeof(int) * ((size_t)n + 1));                // entities before every body
     add((size_t)n);                                    // nodes starting at every body (cache between the two scan kernels)
