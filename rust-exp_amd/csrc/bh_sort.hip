@@ -270,21 +270,27 @@ __device__ __forceinline__ void bucket_network(const ulonglong2* __restrict__ ps
                     if (mine_less != keep_min) { k[r] = ok; id[r] = oi; }
                 }
             } else {
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < E; r++) {
-                    lds[r * kTile + tid] = (unsigned)k[r];
-                    lds[P + r * kTile + tid] = (unsigned)(k[r] >> 32);
-                    lds[2 * P + r * kTile + tid] = id[r];
-                }
-                __syncthreads();
+                // partners in other waves: through LDS, at most eight pairs per thread at a time (the network of a 4 096-pair
+                // bucket trades in two halves: the staging area holds kStage pairs)
+                constexpr int H = E > 8 ? E / 8 : 1, EH = E / H, PH = kTile * EH;
                 const int pt = tid ^ tj;
 #pragma unroll
-                for (int r = 0; r < E; r++) {
-                    const unsigned long long ok = (unsigned long long)lds[r * kTile + pt] | ((unsigned long long)lds[P + r * kTile + pt] << 32);
-                    const unsigned oi = lds[2 * P + r * kTile + pt];
-                    const bool mine_less = pair_less(k[r], id[r], ok, oi);
-                    if (mine_less != keep_min) { k[r] = ok; id[r] = oi; }
+                for (int h = 0; h < H; h++) {
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < EH; r++) {
+                        lds[r * kTile + tid] = (unsigned)k[h * EH + r];
+                        lds[PH + r * kTile + tid] = (unsigned)(k[h * EH + r] >> 32);
+                        lds[2 * PH + r * kTile + tid] = id[h * EH + r];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < EH; r++) {
+                        const unsigned long long ok = (unsigned long long)lds[r * kTile + pt] | ((unsigned long long)lds[PH + r * kTile + pt] << 32);
+                        const unsigned oi = lds[2 * PH + r * kTile + pt];
+                        const bool mine_less = pair_less(k[h * EH + r], id[h * EH + r], ok, oi);
+                        if (mine_less != keep_min) { k[h * EH + r] = ok; id[h * EH + r] = oi; }
+                    }
                 }
             }
         }
@@ -318,6 +324,9 @@ __device__ __forceinline__ void bucket_network(const ulonglong2* __restrict__ ps
 // the common case: sub-buckets by interpolation, place inside a sub-bucket by counting.  false: the keys clump, nothing was written
 // (and start() has not been called).  start() -- collective, called once -- returns where the bucket's pairs go in the output.
 constexpr int kSub = 2048;          // sub-buckets per bucket
+constexpr int kStage = 2560;        // pairs the LDS staging area holds: 4 x the bucket target (P(an Erlang-4 bucket is bigger) = 9e-5;
+                                    // those take the network) -- 38 KB of LDS per workgroup, four workgroups per CU instead of two
+                                    // (tools/ubench_bucket_sort.hip: 23 -> 17 us for the kernel alone)
 constexpr int kClumpPerPair = 48;   // sum of squared sub-bucket counts per pair beyond which the network is cheaper
 template <int E, class StartFn>
 __device__ __forceinline__ bool bucket_by_counting(const ulonglong2* __restrict__ ps, const int cnt,
@@ -327,8 +336,9 @@ __device__ __forceinline__ bool bucket_by_counting(const ulonglong2* __restrict_
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* hist = reinterpret_cast<int*>(lds);                                              // [kSub + 1]
-    unsigned long long* skey = reinterpret_cast<unsigned long long*>(lds + kSub + 2);     // [kBucketCap]
-    unsigned* sidx = reinterpret_cast<unsigned*>(skey + kBucketCap);                      // [kBucketCap]
+    unsigned long long* skey = reinterpret_cast<unsigned long long*>(lds + kSub + 2);     // [kStage]
+    unsigned* sidx = reinterpret_cast<unsigned*>(skey + kStage);                          // [kStage]
+    if (cnt > kStage) return false;                                                       // (uniform; start() not called)
     __shared__ unsigned long long red[2][kTile / 64];
     __shared__ int wsum[kTile / 64];
     __shared__ unsigned long long wsq[kTile / 64];
@@ -414,7 +424,8 @@ __device__ __forceinline__ bool bucket_by_counting(const ulonglong2* __restrict_
     return true;
 }
 
-constexpr size_t kBucketSortLds = sizeof(unsigned) * (kSub + 2) + 12 * (size_t)kBucketCap;
+constexpr size_t kBucketSortLds = sizeof(unsigned) * (kSub + 2) + 12 * (size_t)kStage;
+static_assert(12 * (size_t)kStage >= 12 * (size_t)kTile * 8, "the network trades eight pairs per thread at a time through the staging area");
 __global__ __launch_bounds__(kTile) void k_bucket_sort(const ulonglong2* __restrict__ slots, const float4* __restrict__ slot_recs,
                                                        const float4* __restrict__ posm, const int* __restrict__ gcount, const int buckets,
                                                        const int n, unsigned long long* __restrict__ keys_out, unsigned* __restrict__ idx_out,

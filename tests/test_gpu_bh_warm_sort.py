@@ -201,7 +201,8 @@ def test_mixed_sequences_keep_the_order_sorted_copy_of_the_positions_honest(rx, 
 
 def test_clumped_keys_take_the_network_and_ties_go_by_index(rx, ob):
     """Buckets whose keys clump -- EPS-scale clumps, six hundred bodies at ONE point (identical 62-bit keys: only the index orders
-    them; 600^2 > 48 x the bucket's pairs) -- leave the counting sort for the bitonic network over (key, index).  Warm and cold (library sort) runs must step to the
+    them; 600^2 > 48 x the bucket's pairs; the second clump of 3 000 fills a bucket beyond the LDS staging area: the network's
+    two-halves exchange) -- leave the counting sort for the bitonic network over (key, index).  Warm and cold (library sort) runs must step to the
     same bits, and the exact-sum device tree must stay within the fast mode's tolerance of the host tree's forces."""
     import subprocess
     import sys
@@ -213,6 +214,7 @@ def test_clumped_keys_take_the_network_and_ties_go_by_index(rx, ob):
             "k = n // 4\n"                                                        # a quarter of the bodies in clumps ~3e-5 wide around others
             "x[:k] = x[k:2 * k] + rng.normal(0, 3e-5, k).astype(np.float32); y[:k] = y[k:2 * k] + rng.normal(0, 3e-5, k).astype(np.float32)\n"
             "x[-600:] = x[-601]; y[-600:] = y[-601]\n"                           # six hundred bodies at one point: one sub-bucket of 600
+            "x[100:3100] = x[99]; y[100:3100] = y[99]\n"                         # three thousand at another: a bucket beyond the staging area
             "m = rng.uniform(0.5, 1.5, n).astype(np.float32); v = np.zeros(n, np.float32)\n"
             "e = rx.NBodyEngine(); e.set_bh_tree('device'); e.set_bh_fold('exact'); e.set_particles(x, y, v, v, m)\n"
             "for _ in range(5): e.step_barnes_hut(0.5, 0.001, 1)\n"
