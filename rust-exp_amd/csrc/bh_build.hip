@@ -369,10 +369,15 @@ __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const u
     const int l = top + (k - first);
     const float4 p = sb[a];
     // node size: the path replayed with the reference's f32 midpoints (nbody.rs:289-300), by the key's digits -- the quadrant
-    // choices of the body that opened the entity
-    float x1 = dec_f32(box[0]), y1 = dec_f32(box[1]), x2 = dec_f32(box[2]), y2 = dec_f32(box[3]);
+    // choices of the body that opened the entity.  Only the x extent goes into the record (nbody.rs:341), and the two axes halve
+    // independently: the y half of the replay is left to the one check below that needs it (round 5: a sixth of this kernel's
+    // vector instructions, profiles/r05_bh_step_issue_counters.json)
+    float x1 = dec_f32(box[0]), x2 = dec_f32(box[2]);
 #pragma unroll 1
-    for (int d = 0; d < l; d++) descend_digit(x1, y1, x2, y2, (int)(ka >> (2 * (kLevels - 1 - d))) & 3);
+    for (int d = 0; d < l; d++) {
+        const float cx = __fmul_rn(__fadd_rn(x1, x2), 0.5f);
+        if ((ka >> (2 * (kLevels - 1 - d))) & 1ull) x1 = cx; else x2 = cx;
+    }
     BhNode o;
     o.s = __fsub_rn(x2, x1);                        // nbody.rs:341
     // interior nodes before this one in pre-order (meaningful for an interior node: where the fast walk files its child group,
@@ -432,8 +437,13 @@ __device__ __forceinline__ void emit_node(const float4* __restrict__ sb, const u
             // replay files a blob under its centre's path; one it never saw -- bodies of ONE level-31 cell without company --
             // sits on the path of its first member.  The same leaf unless the centre left that cell:
             float u1 = dec_f32(box[0]), v1 = dec_f32(box[1]), u2 = dec_f32(box[2]), v2 = dec_f32(box[3]);
+            float y1 = v1, y2 = v2;                 // (the y half of this leaf's own path)
 #pragma unroll 1
-            for (int d = 0; d < l; d++) descend(u1, v1, u2, v2, px, py);
+            for (int d = 0; d < l; d++) {
+                descend(u1, v1, u2, v2, px, py);
+                const float cy = __fmul_rn(__fadd_rn(y1, y2), 0.5f);
+                if ((ka >> (2 * (kLevels - 1 - d))) & 2ull) y2 = cy; else y1 = cy;
+            }
             if (u1 != x1 || v1 != y1 || u2 != x2 || v2 != y2) refuse(counters, kWhyCentrePath);   // counted as "crowded": host build
         }
     } else if (fold == 1) {
