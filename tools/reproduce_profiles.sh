@@ -41,3 +41,6 @@ NBX_INC_SORT=0 python tools/bh_warm_long_run.py plummer:1048576 random_disk:2621
 NB_BH_FOLD=exact python tools/frame_loop.py > gpurun_out/${T}_frame_loop_level1_exact_fold.txt 2>&1
 NBX_GROUP_EXCHANGE=copy python bench.py --gpus 8 --dry-run > gpurun_out/${T}_bench_group8_dry_run.json 2> /dev/null
 bash tools/pmc_host_tree_walk.sh > gpurun_out/${T}_pmc_host_tree_walk.txt 2>&1
+python tools/bh_dense_probe.py > gpurun_out/${T}_bh_dense_handover.jsonl 2>&1
+bash tools/bh_build_valu.sh > gpurun_out/${T}_bh_step_issue_counters.json 2> /dev/null
+(timeout 1500 python tests/fuzz_fast.py 700000 20000 2>&1 | tail -1; timeout 700 python tests/fuzz_strict.py 70000 400 2>&1 | tail -1; timeout 300 python tests/fuzz_group.py 70000 3000 2>&1 | tail -1; timeout 600 python tests/fuzz_api.py 70000 150 2>&1 | tail -1) > gpurun_out/${T}_fuzz_long2.txt 2>&1
