@@ -37,7 +37,7 @@ extern "C" {
 /* single-process multi-GPU group, see nbx_group_*), NB_SEED (u64,                               */
 /* default: OS entropy, as the reference's thread_rng), NB_FORCE_MODE=fast|strict,                */
 /* NB_DRAW=host|device, NB_BH_TREE=host|device (both default: by size), NB_BH_FOLD=reference|exact  */
-/* (NBX_OPT_BH_FOLD; default: reference up to 65 536 bodies), NB_SOURCE_BITS=16 (fp16               */
+/* (NBX_OPT_BH_FOLD; default: by cost -- exact sums in the fast mode), NB_SOURCE_BITS=16 (fp16      */
 /* source copy for the all-pairs sweep, BASELINE config #5; default 32).                          */
 /* Both levels: NBX_HOST_THREADS (workers of the host quadtree build / flatten / draw; default   */
 /* min(hardware threads, 32)), NBX_GROUP_EXCHANGE=copy (see nbx_group_*), NBX_LOG=1 (one stderr   */
@@ -121,11 +121,11 @@ enum nbx_option {
                                     * Default (-1): host below 4096 bodies or while the state is not on the GPU, device otherwise */
     NBX_OPT_BH_TREE = 8,           /* Barnes-Hut tree: 0 = built on the host exactly like the reference (the bit-exact mode's
                                     * default), 1 = built on the device (bh_build.hip: same node set and leaf records incl. the
-                                    * reference's EPS merge; interior centres of mass are the reference's running f32 fold up to
-                                    * 65 536 bodies, roundings of the exact mean above: NBX_OPT_BH_FOLD).  The bit-exact mode
+                                    * reference's EPS merge; interior centres of mass are roundings of the exact mean, or -- on
+                                    * request, and in the bit-exact mode -- the reference's running f32 fold: NBX_OPT_BH_FOLD).  The bit-exact mode
                                     * honours 1 only while the device tree carries the reference fold (that tree IS the host
                                     * tree bit for bit, or the build refuses and the host builds: the same results at a third of
-                                    * the step time at 10 000 bodies).  -1 (default) = device in the fast mode from 1 024 bodies on (512 with NBX_OPT_BH_FOLD = 0),
+                                    * the step time at 10 000 bodies).  -1 (default) = device in the fast mode from 512 bodies on (1 024 with NBX_OPT_BH_FOLD = 1),
                                     * else host */
     NBX_OPT_BH_WAVE = 9,           /* 1 (default): with the device-built tree, walk the tree once per WAVE (node
                                     * records through the scalar cache, lanes park on accepted subtrees); 0: one
@@ -136,9 +136,17 @@ enum nbx_option {
     NBX_OPT_BH_FOLD = 14,          /* device-built tree, interior nodes: 1 = the reference's own f32 running fold of masses and
                                     * centres in ARRIVAL order (nbody.rs:303-320) and its EPS merge (nbody.rs:249-260: blobs of any
                                     * size, grown in arrival order) replayed on the device -- the host tree's records bit for bit;
-                                    * systems the replay cannot reproduce node for node go to the host build (NBX_LOG says why);
+                                    * what the replay cannot reproduce node for node is refused (NBX_LOG says why): the fast mode
+                                    * then serves the step from the exact-sum DEVICE build (NBX_STAT_BH_CLASS_SWITCHES; round 6 --
+                                    * the host build only if that refuses too), the bit-exact mode from the host build;
                                     * 0 = roundings of the exact sums (own tolerance class);
-                                    * -1 (default) = 1 up to 65 536 bodies (the root's fold is n serial steps), 0 above */
+                                    * -1 (default) = BY COST (round 6): the fast mode takes 1 only while its build costs at most
+                                    * 1.5 x the exact-sum build's -- at no size the device build serves (2.6 x at 2 000 bodies,
+                                    * 12.7 x at 65 536: the root's fold is n serial f32 steps; profiles/r06_bh_sizes.jsonl), so the
+                                    * fast mode's default is 0 at every size; the bit-exact mode (which only 1 can serve, and only
+                                    * with NBX_OPT_BH_TREE = 1) keeps 1 up to 65 536 bodies.  Rounds 3-5 defaulted to 1 up to
+                                    * 65 536 bodies in both modes: the reference's own 10 000-body scene then stepped in 0.22 ms
+                                    * against 0.09, and nb_random_disk(65536) spent 63 % of its steps on the host tree */
     NBX_OPT_BH_ASYNC = 15,         /* 1 (default): a Barnes-Hut step on the device-built tree is enqueued without waiting for the
                                     * build's verdict (node count, EPS clusters); walk and kick-drift check it on the device, the
                                     * host at the next call that needs the state (nbx_synchronize, get, draw, the next step) and
@@ -164,13 +172,16 @@ enum nbx_option {
 /* What an engine has done so far (read only; nbx_get_stat).  Rounds 1-4 carried these among the options (10, 11, 12, 17). */
 enum nbx_stat {
     NBX_STAT_BH_FALLBACKS = 0,     /* Barnes-Hut evaluations since the engine was created that the
-                                    * device tree was selected for but the host tree served: builds the device refused (node
-                                    * pool exhausted; a warm sort whose buckets overflowed; EPS clusters it cannot reproduce under NBX_OPT_BH_FOLD = 1) plus the steps
-                                    * sent straight to the host build after refusals in a row (2, 4 .. 32 steps, then the
-                                    * device is tried again; env NBX_BH_BACKOFF_MAX = longest run, 0 = always try the device) */
+                                    * device tree was selected for but the HOST tree served: builds the device refused (node
+                                    * pool exhausted; a warm sort whose buckets overflowed; more unmerged EPS-chain bodies than the
+                                    * exact-sum class tolerates; in the bit-exact mode: EPS clusters the reference-fold replay cannot
+                                    * reproduce) plus the steps sent straight to the host build after refusals in a row (2, 4 .. 32
+                                    * steps, then the device is tried again; env NBX_BH_BACKOFF_MAX = longest run, 0 = always try
+                                    * the device).  A fast-mode refusal of the reference-fold class is NOT one of these: see
+                                    * NBX_STAT_BH_CLASS_SWITCHES */
     NBX_STAT_BH_LAST_TREE = 1,     /* where the tree of the last Barnes-Hut evaluation was built: 0 host, 1 device */
     NBX_STAT_DRAW_AMBIGUOUS = 2,   /* tails the last device draw left to the host; -1 = the last draw ran on the host */
-    NBX_STAT_BH_REFUSAL = 3        /* why the last device tree build that handed its evaluation to the host build did so
+    NBX_STAT_BH_REFUSAL = 3,       /* why the last device tree build that was refused (its evaluation served by another class) was
                                     * (0: none has yet) -- 0x10000 = the node pool or the fold queue overflowed; 0x100000 = a bucket of the warm sort outgrew its
                                     * slots (bh_sort.hip, round 5); else bits of the
                                     * cluster replay (NBX_OPT_BH_FOLD = 1): 1 more than 512 entities around one point, 4 a cluster
@@ -179,6 +190,14 @@ enum nbx_stat {
                                     * 64 more than 4 096 bodies to move, 128 a blob's successive centres part ways above its
                                     * leaf, 512 (bit-exact mode) a leaf deeper than 25 levels, where the reference may panic, 256 a leaf of more bodies than the leaf fold orders; exact-sum class: 0x20000 = more
                                     * bodies left unmerged than it tolerates */
+    NBX_STAT_BH_CLASS_SWITCHES = 4, /* fast mode, NBX_OPT_BH_FOLD = 1 (round 6): evaluations the reference-fold device build was
+                                    * selected for but the exact-sum DEVICE build served -- a refused build redone there, and the
+                                    * back-off run (2, 4 .. 32 steps) behind refusals in a row.  Such a step stays on the GPU and
+                                    * inside the fast mode's stated tolerance (the exact-sum class's) */
+    NBX_STAT_BH_COLD_RESORTS = 5   /* device builds whose warm sort overflowed a bucket (NBX_STAT_BH_REFUSAL 0x100000: more than 4 096
+                                    * bodies on one 62-bit key, or a reshuffled system) and that were redone at once from a cold sort,
+                                    * same class, on the device (round 6; round 5 sent such a step to the host build); the next
+                                    * 2, 4 .. 32 builds then sort cold as well */
 };
 
 enum nbx_kernel_id {
@@ -214,10 +233,13 @@ void nbx_destroy(nbx_engine *e);
 
 int32_t nbx_set_option(nbx_engine *e, int32_t option, int64_t value);
 int64_t nbx_get_option(const nbx_engine *e, int32_t option);
-/* as nbx_get_option with the status apart from the value: -1 is a legitimate value of some options ("by size" of
- * NBX_OPT_DRAW_DEVICE / NBX_OPT_BH_TREE, "the last draw ran on the host" of NBX_OPT_DRAW_AMBIGUOUS) and also NBX_ERR_INVALID */
+/* as nbx_get_option with the status apart from the value: -1 is a legitimate value of some options ("by size" / "by cost" of
+ * NBX_OPT_DRAW_DEVICE / NBX_OPT_BH_TREE / NBX_OPT_BH_FOLD) and also NBX_ERR_INVALID */
 int32_t nbx_query_option(const nbx_engine *e, int32_t option, int64_t *value);
-int64_t nbx_get_stat(const nbx_engine *e, int32_t stat); /* enum nbx_stat; -1 for an unknown one */
+/* enum nbx_stat.  INT64_MIN for an unknown stat or a null engine (-1 is a legitimate value: NBX_STAT_DRAW_AMBIGUOUS, "the last
+ * draw ran on the host"), and INT64_MIN as well when reading the verdict of a step still in flight failed (a refused step's redo
+ * hit an error: nbx_last_error() has the text) -- the counters would be stale */
+int64_t nbx_get_stat(const nbx_engine *e, int32_t stat);
 
 /* Presets: same sampling as nbody.rs:39-104, but from a seedable generator (splitmix64 -> top 24
  * bits -> [0,1) f32, the rand 0.3 `next_f32` construction). */
@@ -290,7 +312,9 @@ int32_t nbx_bind_positions(nbx_engine *e, void *device_ptr, size_t bytes);
  * all-gather moves (half the bytes); bind a caller-owned device buffer of >= nbx_half_sources_bytes(). */
 size_t nbx_half_sources_bytes(const nbx_engine *e); /* n_padded * 8 */
 int32_t nbx_bind_half_sources(nbx_engine *e, void *device_ptr, size_t bytes);
-void *nbx_positions_device(nbx_engine *e); /* device pointer of the float4 (x,y,z,m) array */
+/* device pointer of the float4 (x,y,z,m) array.  The caller may WRITE through it (sharded runs: the per-step all-gather lands
+ * here); the engine therefore treats every call as "positions may have moved" (anything it derived from them is rebuilt) */
+void *nbx_positions_device(nbx_engine *e);
 size_t nbx_positions_bytes(const nbx_engine *e); /* n_padded * 16 */
 int32_t nbx_set_stream(nbx_engine *e, void *hip_stream); /* run on a caller-owned hipStream_t */
 /* force + integrate for this rank's slab only, writing the new positions into the slab's slot of

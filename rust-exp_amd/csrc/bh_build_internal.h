@@ -210,7 +210,7 @@ constexpr int kOversample = 4;                   // splitter candidates per buck
                                                  // Erlang-4 around the target, P(size > kBucketCap = 6.4 x target) = 2e-8 per bucket
 constexpr int kMaxSamples = kOversample * kMaxBuckets;
 constexpr int kIncMaxBodies = kMaxBuckets * kBucketTarget;
-constexpr int kWhySortOverflow = 1 << 20;
+// (kWhySortOverflow = 1 << 20: kernels.h -- the host layer reads it too)
 
 constexpr unsigned long long kPadKey = ~0ull;   // (real keys occupy 62 bits)
 __device__ __forceinline__ bool pair_less(const unsigned long long ka, const unsigned ia, const unsigned long long kb, const unsigned ib)

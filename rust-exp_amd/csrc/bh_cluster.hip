@@ -241,6 +241,11 @@ __device__ int replay_component(BlobShared& s, const int nruns, const ReplayView
         }
     int ne = 0;
     for (int t = 0; t < k; t++) {
+        // somebody has refused this build already (this class tolerates nothing: device_tree_limits): whatever is replayed from here
+        // on is thrown away.  In a collapsed core -- where refusals come from -- the replays left are the expensive ones (rival scans
+        // of a thousand slots, 3 x 3 cell visits of hundreds of entities, per member): round 6 measured 0.3-0.7 s for one refused
+        // build of a collapsing 65 536-body disc (profiles/r06_bh_sizes.jsonl, first run) against ~1 ms for a kept one
+        if (__hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 0;
         const int slot = s.mem_slot[t];
         const unsigned long long kb = v.keys[slot];
         const float4 pb = v.sb[slot];
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(kTile) void k_blobs(const float4* __restrict__ sb, 
     BlobShared& s = bs[threadIdx.x >> 6];
     unsigned long long todo = __ballot(root);
     while (todo) {
+        if (__hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;   // refused already (see replay_component)
         const int lane = __ffsll((long long)todo) - 1;
         todo &= todo - 1ull;
         if ((int)(threadIdx.x & 63) != lane) continue;

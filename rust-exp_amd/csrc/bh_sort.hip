@@ -69,8 +69,10 @@ __device__ __forceinline__ int sample_pos(const int i, const int n, const int sa
 __global__ __launch_bounds__(kTile) void k_sample_rank(const float4* __restrict__ posm, const float4* __restrict__ spos, const int n, const float4* __restrict__ part,
                                                        const int parts, unsigned* __restrict__ box,
                                                        const unsigned* __restrict__ perm, const int samples,
-                                                       unsigned long long* __restrict__ skeys, int* __restrict__ srank)
+                                                       unsigned long long* __restrict__ skeys, int* __restrict__ srank,
+                                                       const int* __restrict__ poison)
 {
+    if (*poison) return;   // see launch_inc_sort: the order in `perm` is not to be trusted
     __shared__ __attribute__((aligned(16))) unsigned long long other[kTile];
     const int sb = (samples + kTile - 1) / kTile;
     const int a = blockIdx.x / sb, c = blockIdx.x - a * sb;
@@ -144,8 +146,10 @@ __global__ __launch_bounds__(kTile) void k_keys_scatter(const float4* __restrict
                                                         const int* __restrict__ srank, const int samples,
                                                         const int buckets, int* __restrict__ gcount,
                                                         ulonglong2* __restrict__ slots, float4* __restrict__ slot_recs,
-                                                        unsigned long long* __restrict__ cell_table, const int cell_slots)
+                                                        unsigned long long* __restrict__ cell_table, const int cell_slots,
+                                                        const int* __restrict__ poison)
 {
+    if (*poison) return;
     extern __shared__ unsigned long long sm[];
     const int ns = buckets - 1;
     int P2 = 1;
@@ -431,6 +435,7 @@ __global__ __launch_bounds__(kTile) void k_bucket_sort(const ulonglong2* __restr
                                                        const int n, unsigned long long* __restrict__ keys_out, unsigned* __restrict__ idx_out,
                                                        float4* __restrict__ sb_out, int* __restrict__ counters)
 {
+    if (counters[kTreePoisonWord]) return;
     extern __shared__ unsigned lds_sort[];
     __shared__ int red[2][kTile / 64];
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -486,6 +491,11 @@ __global__ __launch_bounds__(kTile) void k_bucket_sort(const ulonglong2* __restr
 
 // the sort of a warm build: bodies in last step's order (perm) -> sorted (key, body) pairs in keys_out / idx_out (perm == idx_out is fine:
 // it is read by the first three kernels and written by the last)
+// The poison word (kTreePoisonWord, kernels.h): a step enqueued behind a REFUSED one starts from what that one left -- after
+// an overflow an idx that is no permutation (valid indices, some twice, some missing), and an order-sorted copy of the positions that the
+// refused, gated walk never rewrote.  Every consumer of such a build is gated on the poison word and does nothing, and the host enqueues the
+// step again from a cold sort; the three kernels here check the word themselves and leave the arrays as the refused build left them (in
+// bounds: its own later kernels ran on them), instead of sorting garbage into a tree nobody may read.
 hipError_t launch_inc_sort(const float4* posm, const float4* sorted_pos, int n, unsigned* box, const float4* part, int parts, const unsigned* perm, int* gcount,
                            unsigned long long* skeys, int* srank, ulonglong2* slots, float4* slot_recs, unsigned long long* keys_out,
                            unsigned* idx_out, float4* sb_out, int* counters, unsigned long long* cell_table, int cell_slots, hipStream_t stream)
@@ -494,14 +504,15 @@ hipError_t launch_inc_sort(const float4* posm, const float4* sorted_pos, int n, 
     const int buckets = inc_buckets(n);
     const int samples = kOversample * buckets;
     const int sb = (samples + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_sample_rank, dim3((unsigned)(sb * sb)), dim3(kTile), 0, stream, posm, sorted_pos, n, part, parts, box, perm, samples, skeys, srank);
+    hipLaunchKernelGGL(k_sample_rank, dim3((unsigned)(sb * sb)), dim3(kTile), 0, stream, posm, sorted_pos, n, part, parts, box, perm, samples, skeys, srank,
+                       counters + kTreePoisonWord);
     const size_t shm = sizeof(unsigned long long) * (size_t)(buckets > 1 ? buckets - 1 : 1) + sizeof(int) * (size_t)buckets;
     if (n >= 262144)
         hipLaunchKernelGGL(k_keys_scatter<4>, dim3((unsigned)((n + 4 * kTile - 1) / (4 * kTile))), dim3(kTile), shm, stream, posm, sorted_pos, n, box, perm,
-                           skeys, srank, samples, buckets, gcount, slots, sb_out ? slot_recs : nullptr, cell_table, cell_slots);
+                           skeys, srank, samples, buckets, gcount, slots, sb_out ? slot_recs : nullptr, cell_table, cell_slots, counters + kTreePoisonWord);
     else
         hipLaunchKernelGGL(k_keys_scatter<1>, dim3((unsigned)((n + kTile - 1) / kTile)), dim3(kTile), shm, stream, posm, sorted_pos, n, box, perm, skeys,
-                           srank, samples, buckets, gcount, slots, sb_out ? slot_recs : nullptr, cell_table, cell_slots);
+                           srank, samples, buckets, gcount, slots, sb_out ? slot_recs : nullptr, cell_table, cell_slots, counters + kTreePoisonWord);
     hipLaunchKernelGGL(k_bucket_sort, dim3((unsigned)buckets), dim3(kTile), kBucketSortLds, stream, slots, slot_recs, posm, gcount, buckets, n,
                        keys_out, idx_out, sb_out, counters);
     return hipGetLastError();

@@ -179,9 +179,14 @@ int64_t nbx_get_option(const nbx_engine* e, int32_t option)
 int64_t nbx_get_stat(const nbx_engine* e, int32_t stat)
 {
     if (!e) return INT64_MIN;
-    if (e->any_pending() && (stat == NBX_STAT_BH_FALLBACKS || stat == NBX_STAT_BH_LAST_TREE || stat == NBX_STAT_BH_REFUSAL))
-        (void)resolve_pending(const_cast<nbx_engine*>(e));   // what the last step ran on is known once its build's verdict is read
+    if (e->any_pending() && (stat == NBX_STAT_BH_FALLBACKS || stat == NBX_STAT_BH_LAST_TREE || stat == NBX_STAT_BH_REFUSAL ||
+                             stat == NBX_STAT_BH_CLASS_SWITCHES || stat == NBX_STAT_BH_COLD_RESORTS)) {
+        // what the last step ran on is known once its build's verdict is read; a redo that fails leaves the counters stale
+        if (resolve_pending(const_cast<nbx_engine*>(e)) != NBX_OK) return INT64_MIN;
+    }
     switch (stat) {
+        case NBX_STAT_BH_CLASS_SWITCHES: return e->bh_class_switches;
+        case NBX_STAT_BH_COLD_RESORTS: return e->bh_cold_resorts;
         case NBX_STAT_BH_FALLBACKS: return e->bh_fallbacks;
         case NBX_STAT_BH_LAST_TREE: return e->bh_last_tree_device;
         case NBX_STAT_BH_REFUSAL: return e->bh_last_refusal;
@@ -525,9 +530,9 @@ int32_t nbx_bh_flat_dump(nbx_engine* e, void* rows, int32_t cap, int32_t threade
         int rc0 = upload(e);
         if (rc0 != NBX_OK) return rc0;
         bool done = false;
-        rc0 = build_tree_on_device(e, &done);
+        rc0 = build_tree_on_device(e, &done, /*may_demote=*/false);   // (the class asked for, or nothing)
         if (rc0 != NBX_OK) return rc0;
-        if (!done) return fail(NBX_ERR_STATE, "device tree build fell back (node pool exhausted)");
+        if (!done) return fail(NBX_ERR_STATE, "device tree build refused (NBX_STAT_BH_REFUSAL says why)");
         if ((size_t)cap >= e->n_flat && rows && e->n_flat) {
             HIP_TRY(hipMemcpyAsync(rows, e->d_nodes, sizeof(nbx::BhNode) * e->n_flat, hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream));
@@ -668,6 +673,9 @@ void* nbx_positions_device(nbx_engine* e)
 {
     if (!e) return nullptr;
     if (upload(e) != NBX_OK) return nullptr;
+    // the pointer is mutable and the caller may write positions through it (with world == 1 too): nothing derived from the old
+    // positions -- the order-sorted copy the warm sort reads its keys from -- may be trusted any more
+    e->positions_moved();
     return e->d_posm;
 }
 
@@ -680,6 +688,7 @@ int32_t nbx_set_stream(nbx_engine* e, void* hip_stream)
     if (e->own_stream && e->stream) HIP_TRY(hipStreamDestroy(e->stream));
     e->stream = static_cast<hipStream_t>(hip_stream);
     e->own_stream = false;
+    e->positions_moved();   // (a caller with its own stream orders its own writes to the positions on it)
     return NBX_OK;
 }
 

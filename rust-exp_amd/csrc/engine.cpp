@@ -428,7 +428,7 @@ void after_host_state_change(nbx_engine* e)
         e->pending[0].active = e->pending[1].active = false;
     }
     e->n = e->host.n();
-    e->bh_refusal_streak = e->bh_host_steps_left = 0;
+    e->reset_backoff();
     compute_slab(e);
     e->host_pos_valid = e->host_vel_valid = true;
     e->dev_valid = false;

@@ -164,7 +164,7 @@ int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also, int n_also, bo
 
 // node slots are 32-bit and a body can own up to 32 nodes: beyond this size the host build is used
 static constexpr int kDeviceTreeMaxBodies = 1 << 25;
-static constexpr int kBackoffMaxSteps = 32;   // see nbx_engine::note_refusal
+static constexpr int kBackoffMaxSteps = 32;   // see nbx_engine::note_refusal (both ladders)
 
 // quadtree on the device (bh_build.hip), in two halves so that a group can start every device's build before it waits
 // for any: begin enqueues the build, end waits for it. *done = false when the node pool overflowed (the caller falls
@@ -195,11 +195,12 @@ int build_tree_on_device_begin(nbx_engine* e, int* host_counters, bool publish_b
         HIP_TRY(hipEventCreateWithFlags(&e->ev_side_done, hipEventDisableTiming));
     }
     ProfScope ps(e, NBX_K_TREE_BUILD);
+    const bool warm = e->sort_warm_n == e->n && e->warm_holdoff == 0;   // (hold-off: cold sorts behind an overflowed warm one, engine_internal.h)
+    if (e->warm_holdoff > 0) e->warm_holdoff--;
     HIP_TRY(nbx::device_tree_build_begin(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, node_cap, e->d_nodes,
                                          publish_by_kernel ? nullptr : (host_counters ? host_counters : e->h_counters), &e->d_perm,
                                          e->stream, fold, e->side_stream, e->ev_side_go, e->ev_side_done,
-                                         /*depth_panic_guard=*/e->force_mode != 0, /*warm=*/e->sort_warm_n == e->n,
-                                         e->sorted_positions()));
+                                         /*depth_panic_guard=*/e->force_mode != 0, warm, warm ? e->sorted_positions() : nullptr));
     e->positions_moved();    // the workspace holds a NEW order now: the order-sorted copy of the positions belongs to the old one
                              // (the fused kick-drift of the step this build serves, if there is one, leaves a current copy again)
     e->sort_warm_n = e->n;   // (a refusal -- of this build, or of one whose verdict is still in flight -- takes it back)
@@ -222,21 +223,22 @@ int build_tree_on_device_end(nbx_engine* e, bool* done)
     *done = false;
     HIP_TRY(hipSetDevice(e->device));
     const int node_cap = 4 * e->n + 1024;
+    const int fold = e->effective_fold();
     int n_nodes = 0, status = 0;
-    HIP_TRY(nbx::device_tree_build_end(e->n, node_cap, e->h_counters, &n_nodes, &status, e->stream, e->effective_fold()));
+    HIP_TRY(nbx::device_tree_build_end(e->n, node_cap, e->h_counters, &n_nodes, &status, e->stream, fold));
     if (status != 0) {
-        e->bh_fallbacks++;
-        e->note_refusal(backoff_max_steps());
+        // (who serves the step instead -- the exact-sum device build or the host build -- and which counter that is, is the caller's)
+        e->note_refusal(fold, backoff_max_steps());
         e->note_why(status, e->h_counters[5]);
         e->d_perm = nullptr;
         e->sort_warm_n = 0;
         if (std::getenv("NBX_LOG"))
-            std::fprintf(stderr, "[nbx] device tree build of %d bodies handed over to the host build: status %d (1 = pool / queue overflow, 2 = EPS "
-                                 "clusters), nodes %d of %d, left-behind bodies %d (why 0x%x), queued folds %d\n", e->n, status, e->h_counters[0], node_cap,
-                         e->h_counters[1], (unsigned)e->h_counters[5], e->h_counters[2]);
-        return NBX_OK;   // caller takes the host path
+            std::fprintf(stderr, "[nbx] device tree build of %d bodies (%s) refused: status %d (1 = pool / queue overflow, 2 = EPS "
+                                 "clusters), nodes %d of %d, left-behind bodies %d (why 0x%x), queued folds %d\n", e->n, fold == 1 ? "reference fold" : "exact sums",
+                         status, e->h_counters[0], node_cap, e->h_counters[1], (unsigned)e->h_counters[5], e->h_counters[2]);
+        return NBX_OK;   // caller takes the class below
     }
-    e->note_accepted();
+    e->note_accepted(fold);
     e->n_flat = (size_t)n_nodes;
     e->host_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - e->tree_t0).count();
     e->host_steps++;
@@ -244,13 +246,37 @@ int build_tree_on_device_end(nbx_engine* e, bool* done)
     return NBX_OK;
 }
 
-int build_tree_on_device(nbx_engine* e, bool* done)
+// The device build of the class the engine is set to, waited for.  *done = false: the caller builds on the host (counted here).
+// may_demote (round 6): a FAST-mode build of the reference-fold class that refuses is tried once more as an exact-sum build --
+// the class the fast mode defaults to anyway, 8 x faster than the host build at 65 536 bodies and inside the fast mode's stated
+// tolerance -- before the host is asked; the bit-exact mode, and a refusal of the exact-sum class itself, go to the host build.
+int build_tree_on_device(nbx_engine* e, bool* done, bool may_demote)
 {
     *done = false;
     if (e->n > kDeviceTreeMaxBodies) return NBX_OK;   // caller takes the host path
-    const int rc = build_tree_on_device_begin(e);
+    int rc = build_tree_on_device_begin(e);
     if (rc != NBX_OK) return rc;
-    return build_tree_on_device_end(e, done);
+    rc = build_tree_on_device_end(e, done);
+    if (rc != NBX_OK || *done) return rc;
+    if (e->sort_overflowed()) {   // the warm sort's order failed, not the tree: once more from a cold sort (the refusal took the order back)
+        e->bh_cold_resorts++;
+        rc = build_tree_on_device_begin(e);
+        if (rc != NBX_OK) return rc;
+        rc = build_tree_on_device_end(e, done);
+        if (rc != NBX_OK || *done) return rc;
+    }
+    if (may_demote && e->demotes_on_device(e->effective_fold())) {
+        e->bh_class_switches++;
+        const int first = e->bh_last_refusal;
+        FoldForce down(e, 0);
+        rc = build_tree_on_device_begin(e);
+        if (rc != NBX_OK) return rc;
+        rc = build_tree_on_device_end(e, done);
+        if (rc != NBX_OK || *done) return rc;
+        e->bh_last_refusal |= first;   // both classes refused: the reasons of the class asked for stay on record
+    }
+    e->bh_fallbacks++;
+    return NBX_OK;
 }
 
 // Morton permutation of the bodies on the device (for the traversal of a host-built tree)
@@ -267,8 +293,11 @@ int spatial_order(nbx_engine* e)
         e->sort_warm_n = 0;
         HIP_TRY(nbx::device_tree_workspace_init(e->d_tree_ws, e->stream));
     }
-    HIP_TRY(nbx::device_spatial_order(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, &e->d_perm, e->stream, e->sort_warm_n == e->n,
-                                      e->sorted_positions()));
+    // ALWAYS the library sort here: the warm sort may overflow a bucket (more than kBucketCap bodies on one 62-bit key --
+    // coincident positions, exactly what sends a step to the host tree -- or, at 2e-8 per bucket and step, a reshuffled system) and then
+    // leaves a non-permutation; the device build's gate catches that, this path has no gate.  The sort overlaps the host build
+    // (milliseconds), so nothing is lost; its order is still a good sampling frame for the next warm DEVICE build.
+    HIP_TRY(nbx::device_spatial_order(e->d_posm, e->n, e->d_tree_ws, e->tree_ws_bytes, &e->d_perm, e->stream, /*warm=*/false, nullptr));
     e->positions_moved();    // (as in build_tree_on_device_begin: a new order)
     e->sort_warm_n = e->n;
     return NBX_OK;
@@ -419,15 +448,14 @@ static int resolve_slot(nbx_engine* e, int slot)
     e->pending[slot].active = false;
     const int status = verdict_of(e, slot);
     if (status == 0) {
-        e->note_accepted();
+        e->note_accepted(p.fold);
         e->n_flat = (size_t)e->h_verdict[slot][0];
         e->bh_last_tree_device = 1;
         e->host_steps++;
         return NBX_OK;
     }
     // refused: this step's gated kernels did nothing and poisoned the step behind it (if one is in flight)
-    e->bh_fallbacks++;
-    e->note_refusal(backoff_max_steps());
+    e->note_refusal(p.fold, backoff_max_steps());
     e->note_why(status, e->h_verdict[slot][5]);
     e->d_perm = nullptr;
     e->sort_warm_n = 0;
@@ -436,15 +464,38 @@ static int resolve_slot(nbx_engine* e, int slot)
     const nbx_engine::PendingStep later = e->pending[other];
     e->pending[other].active = false;
     HIP_TRY(hipStreamSynchronize(e->stream));
+    const bool on_device_first = e->demotes_on_device(p.fold);   // fast mode, reference fold refused: the exact-sum DEVICE build first
     if (std::getenv("NBX_LOG"))
-        std::fprintf(stderr, "[nbx] device tree build of %d bodies refused (status %d: nodes %d of %d, left-behind bodies %d (why 0x%x), queued folds %d): "
-                             "step redone on the host tree%s\n", e->n, status, e->h_verdict[slot][0], p.node_cap, e->h_verdict[slot][1],
-                     (unsigned)e->h_verdict[slot][5], e->h_verdict[slot][2], redo_later ? ", the step behind it enqueued again" : "");
+        std::fprintf(stderr, "[nbx] device tree build of %d bodies (%s) refused (status %d: nodes %d of %d, left-behind bodies %d (why 0x%x), queued folds %d): "
+                             "step redone on the %s%s\n", e->n, p.fold == 1 ? "reference fold" : "exact sums", status, e->h_verdict[slot][0], p.node_cap,
+                     e->h_verdict[slot][1], (unsigned)e->h_verdict[slot][5], e->h_verdict[slot][2],
+                     e->sort_overflowed() ? "device tree, cold sort" : on_device_first ? "exact-sum device tree" : "host tree", redo_later ? ", the step behind it enqueued again" : "");
     HIP_TRY(hipMemsetAsync(nbx::device_tree_counters(e->d_tree_ws) + nbx::kTreePoisonWord, 0, sizeof(int), e->stream));
-    const bool want_order = e->bh_wave && e->n >= 65536;
-    int rc = build_and_upload_tree(e, nullptr, 0, want_order);
-    if (rc != NBX_OK) return rc;
-    rc = bh_eval_and_integrate(e, p.theta, p.dt, false, want_order && e->d_perm != nullptr);
+    int rc = NBX_OK;
+    bool on_device = false;
+    if (e->sort_overflowed()) {   // only the warm sort's order failed: the same class once more, from a cold sort, on the device
+        e->bh_cold_resorts++;
+        FoldForce same(e, p.fold);
+        rc = build_tree_on_device(e, &on_device);   // (demotes / counts the fallback itself if the tree is refused as well)
+        if (rc != NBX_OK) return rc;
+    } else if (on_device_first) {
+        e->bh_class_switches++;
+        const int first = e->bh_last_refusal;
+        FoldForce down(e, 0);
+        rc = build_tree_on_device(e, &on_device, /*may_demote=*/false);   // (counts the fallback itself if this class refuses too)
+        if (rc != NBX_OK) return rc;
+        if (!on_device) e->bh_last_refusal |= first;
+    } else {
+        e->bh_fallbacks++;
+    }
+    bool have_perm = on_device;
+    if (!on_device) {
+        const bool want_order = e->bh_wave && e->n >= 65536;
+        rc = build_and_upload_tree(e, nullptr, 0, want_order);
+        if (rc != NBX_OK) return rc;
+        have_perm = want_order && e->d_perm != nullptr;
+    }
+    rc = bh_eval_and_integrate(e, p.theta, p.dt, on_device, have_perm);
     if (rc != NBX_OK) return rc;
     return redo_later ? step_bh(e, later.theta, later.dt) : NBX_OK;
 }
@@ -485,16 +536,30 @@ static int step_bh_async(nbx_engine* e, float theta, float dt)
 int step_bh(nbx_engine* e, float theta, float dt)
 {
     int rc = NBX_OK;
-    if (e->any_pending() && e->bh_refusal_streak > 0) {   // a verdict that may start a back-off: read it before choosing the path
+    if (e->any_pending() && (e->bh_refusal_streak[0] > 0 || e->bh_refusal_streak[1] > 0)) {   // a verdict that may start a back-off: read it before choosing the path
         rc = resolve_pending(e);
         if (rc != NBX_OK) return rc;
     }
+    // the tree class of this step: the one the options name, or -- while a back-off run lasts (engine_internal.h) -- the class below
+    // (a step re-enqueued from inside another step's redo chooses for itself: the outer step's class is not this one's)
+    FoldForce this_step(e, -1);
+    this_step.set(-1);
     bool device_tree = e->use_device_tree() && e->n <= kDeviceTreeMaxBodies;
-    if (device_tree && e->bh_host_steps_left > 0) {       // back-off after refusals in a row (engine_internal.h)
-        e->bh_host_steps_left--;
-        e->bh_fallbacks++;
-        device_tree = false;
+    int forced = -1;
+    if (device_tree) {
+        int fold = e->effective_fold();
+        if (fold == 1 && e->bh_demoted_steps_left[1] > 0) {
+            e->bh_demoted_steps_left[1]--;
+            if (e->force_mode == 0) { forced = fold = 0; e->bh_class_switches++; }   // fast mode: the exact-sum DEVICE build serves the run
+            else { device_tree = false; e->bh_fallbacks++; }                        // bit-exact mode: only the host build can
+        }
+        if (device_tree && fold == 0 && e->bh_demoted_steps_left[0] > 0) {
+            e->bh_demoted_steps_left[0]--;
+            e->bh_fallbacks++;
+            device_tree = false;
+        }
     }
+    this_step.set(forced);
     const bool async_ok = e->bh_async && e->world == 1 && !e->source_half && device_tree && e->force_mode == 0;
     if (!(async_ok && e->dev_ready && e->dev_valid && e->n > 0)) {   // (a live device state needs no upload, and no verdict read)
         rc = upload(e);
@@ -542,7 +607,7 @@ int step_bh_group(nbx_engine* const* eng, int count, float theta, float dt)
             bool done = false;
             const int rc = build_tree_on_device_end(eng[d], &done);
             if (rc != NBX_OK) return rc;
-            if (!done) on_device = false;   // same bodies, same tree: if one pool overflows, all do
+            if (!done) { on_device = false; eng[d]->bh_fallbacks++; }   // same bodies, same tree: if one build refuses, all do (the group goes to the host build)
         }
     }
     if (!on_device) {

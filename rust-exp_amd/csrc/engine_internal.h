@@ -101,9 +101,19 @@ struct nbx_engine {
         return bh_tree_device == 1 || (bh_tree_device < 0 && n >= (effective_fold() == 1 ? 2 * kDeviceTreeFrom : kDeviceTreeFrom));
     }
     // NBX_OPT_BH_FOLD: interior nodes of the DEVICE-built tree: 1 = the reference's f32 running fold in arrival order (the host
-    // tree's records bit for bit), 0 = roundings of exact sums (round 2), -1 (default) = faithful up to kFoldFaithfulMax bodies
+    // tree's records bit for bit), 0 = roundings of exact sums (round 2), -1 (default) = BY COST (round 6): the fast mode takes the
+    // reference fold only while its build costs at most 1.5 x the exact-sum build's -- up to kFoldCostMax bodies (kernels.h: at no
+    // size the device build serves, measured) -- the bit-exact mode, which only the reference fold can serve, up to kFoldFaithfulMax
     int bh_fold = -1;
-    int effective_fold() const { return bh_fold >= 0 ? bh_fold : (n <= nbx::kFoldFaithfulMax ? 1 : 0); }
+    // >= 0 while a step (or force evaluation) runs on another class than the option names: a fast-mode step whose reference-fold
+    // build refused is redone on the exact-sum DEVICE build (class 0), and so is the back-off run behind refusals in a row
+    int fold_forced = -1;
+    int effective_fold() const
+    {
+        if (fold_forced >= 0) return fold_forced;
+        if (bh_fold >= 0) return bh_fold;
+        return n <= (force_mode != 0 ? nbx::kFoldFaithfulMax : nbx::kFoldCostMax) ? 1 : 0;
+    }
     int bh_wave = 1;               // wave-uniform traversal when a spatial body order is available
     // A Barnes-Hut step on the device tree is enqueued WITHOUT waiting for the build's verdict (node count, EPS clusters): walk
     // and kick-drift are gated on the device by the build's own counters.  The host reads the verdict at the next call that
@@ -121,20 +131,44 @@ struct nbx_engine {
     int bh_async = 1;
     int bh_last_tree_device = 0;   // where the last evaluated tree was built
     int bh_fallbacks = 0;          // steps / evaluations the device tree was selected for but the host tree served
+    int bh_class_switches = 0;     // NBX_STAT_BH_CLASS_SWITCHES: fast-mode steps / evaluations the reference-fold device build was selected
+                                   // for but the exact-sum DEVICE build served (a refusal redone there, or its back-off run)
     // Consecutive refused device builds (a dense core keeps its EPS clusters for many steps): from the second refusal in a row
-    // the next 2, 4, .. kBackoffMaxSteps steps go straight to the host build -- counted in bh_fallbacks like the refusals -- and
-    // then ONE step tries the device again.  Any replaced state (after_host_state_change) and any accepted build reset it.
-    int bh_refusal_streak = 0, bh_host_steps_left = 0;
+    // the next 2, 4, .. kBackoffMaxSteps steps go straight to the class below -- and then ONE step tries the refused class again.
+    // Two ladders (round 6): [1] the reference-fold build's refusals, whose class below is the exact-sum DEVICE build in the
+    // fast mode (counted in bh_class_switches) and the host build in the bit-exact mode; [0] the exact-sum build's, whose class
+    // below is the host build (counted in bh_fallbacks like the refusals).  Any replaced state (after_host_state_change) resets
+    // both, an accepted build its own.
+    int bh_refusal_streak[2] = {0, 0}, bh_demoted_steps_left[2] = {0, 0};
     int bh_last_refusal = 0;       // NBX_STAT_BH_REFUSAL: reasons of the last refused device build (status and counter word 5)
-    void note_why(int status, int why) { bh_last_refusal = status == 1 ? 0x10000 : (why ? why : 0x20000); }
-    void note_refusal(int max_steps)
+    void note_why(int status, int why)
     {
-        if (++bh_refusal_streak >= 2 && max_steps > 0) {
-            const int k = bh_refusal_streak - 1;
-            bh_host_steps_left = k >= 30 || (1 << k) > max_steps ? max_steps : (1 << k);
+        bh_last_refusal = status == 1 ? 0x10000 : (why ? why : 0x20000);
+        if (status != 1 && (why & nbx::kWhySortOverflow)) {   // the warm sort overflowed: the next builds sort from scratch (below)
+            warm_holdoff = warm_holdoff_next;
+            warm_holdoff_next = std::min(32, 2 * warm_holdoff_next);
         }
     }
-    void note_accepted() { bh_refusal_streak = 0; }
+    // A warm sort whose bucket overflows (more than 4 096 bodies on one 62-bit key: coincident positions; or, at 2e-8 per bucket and
+    // step, bad luck) says nothing against the TREE: that build is redone at once from a cold sort, same class, on the device
+    // (NBX_STAT_BH_COLD_RESORTS; round 6 -- rounds 5 sent the step to the host build), and the next 2, 4 .. 32 builds sort cold
+    // too (a clump of coincident bodies stays one for many steps and would overflow every warm sort).
+    int bh_cold_resorts = 0;
+    int warm_holdoff = 0, warm_holdoff_next = 2;
+    bool sort_overflowed() const { return bh_last_refusal != 0x10000 && (bh_last_refusal & nbx::kWhySortOverflow) != 0; }
+    void note_refusal(int fold, int max_steps)
+    {
+        const int c = fold == 1 ? 1 : 0;
+        if (++bh_refusal_streak[c] >= 2 && max_steps > 0) {
+            const int k = bh_refusal_streak[c] - 1;
+            bh_demoted_steps_left[c] = k >= 30 || (1 << k) > max_steps ? max_steps : (1 << k);
+        }
+    }
+    // (an accepted reference-fold build ends both streaks: that class is the stricter one)
+    void note_accepted(int fold) { bh_refusal_streak[0] = 0; if (fold == 1) bh_refusal_streak[1] = 0; }
+    void reset_backoff() { bh_refusal_streak[0] = bh_refusal_streak[1] = bh_demoted_steps_left[0] = bh_demoted_steps_left[1] = 0; warm_holdoff = 0; warm_holdoff_next = 2; }
+    // a fast-mode build of the reference-fold class that refuses is redone one class down on the device, not on the host
+    bool demotes_on_device(int fold) const { return fold == 1 && force_mode == 0; }
     void* d_counts = nullptr;      // device draw: uint2 hit counters per pixel
     size_t counts_cap = 0;         // pixels
     unsigned* d_fb = nullptr;
@@ -196,6 +230,17 @@ struct nbx_engine {
     int host_steps = 0;
 
     int slab() const { return hi - lo; }
+};
+
+// a class of device tree build forced for the duration of a scope (fold < 0: nothing forced)
+struct FoldForce {
+    nbx_engine* e;
+    int saved;
+    FoldForce(nbx_engine* eng, int fold) : e(eng), saved(eng->fold_forced) { if (fold >= 0) e->fold_forced = fold; }
+    void set(int fold) { e->fold_forced = fold; }   // (-1: the options decide again)
+    ~FoldForce() { e->fold_forced = saved; }
+    FoldForce(const FoldForce&) = delete;
+    FoldForce& operator=(const FoldForce&) = delete;
 };
 
 struct GroupWorkers;   // group.cpp: one persistent enqueue thread per engine (optional)
@@ -357,7 +402,7 @@ int step_brute(nbx_engine* e, float dt);
 int build_and_upload_tree(nbx_engine* e, nbx_engine* const* also = nullptr, int n_also = 0, bool order_bodies = false);
 int build_tree_on_device_begin(nbx_engine* e, int* host_counters = nullptr, bool publish_by_kernel = false);
 int build_tree_on_device_end(nbx_engine* e, bool* done);
-int build_tree_on_device(nbx_engine* e, bool* done);
+int build_tree_on_device(nbx_engine* e, bool* done, bool may_demote = true);
 int bh_eval_and_integrate(nbx_engine* e, float theta, float dt, bool on_device, bool have_perm, bool gated = false,
                           int* gate_host_out = nullptr);
 // the fast traversal of e->d_nodes for this engine's slab into e->d_f2 (accelerations): child-group walk or node walk (NBX_OPT_BH_WALK)

@@ -188,7 +188,13 @@ hipError_t device_slab_order(const unsigned* perm, int n, int lo, int hi, void* 
 // fold: 0 = interior masses / centres are roundings of exact fp64 sums (own tolerance class); 1 = the reference's f32 running
 // fold in arrival order (nbody.rs:303-320), EPS clusters of any size replayed in arrival order: the host tree bit for bit; what
 // the replay cannot reproduce reports status 2 (caller builds on the host; the reasons are in the build's counter word 5).
-constexpr int kFoldFaithfulMax = 65536;   // default: faithful fold up to this many bodies (the root's chain is n serial steps)
+constexpr int kFoldFaithfulMax = 65536;   // bit-exact mode (only this class serves it): faithful fold up to this many bodies (the root's chain is n serial steps)
+// Fast mode, default class BY COST (round 6): the reference fold only while its build takes at most 1.5 x the
+// exact-sum build's.  Measured (profiles/r06_bh_sizes.jsonl, build ms reference / exact): 2 000 bodies 0.114 / 0.044, 10 000
+// 0.19 / 0.057, 65 536 1.09 / 0.086 -- 2.6 x at the smallest size listed and growing (the root's fold is n serial f32 steps), and
+// below 1 024 bodies this class is served by the host build anyway: at NO size the device build serves.  0 = never by default;
+// NBX_OPT_BH_FOLD = 1 still asks for it at any size.
+constexpr int kFoldCostMax = 0;
 // side / ev_go / ev_done (optional, fold = 1): a second stream and two events of the same device -- the root's fold then runs
 // on `side` from the start of the build, beside everything else (it is the longest chain and needs only the bodies);
 // host_counters: pinned words the build's counters are copied to at the end; null = the caller's gated kick-drift
@@ -202,6 +208,7 @@ hipError_t device_tree_build_end(int n, int node_cap, const int* host_counters, 
 // the device-side view of the same verdict: where the build's counters live (for launch_bh_eval / launch_integrate_f2 gates)
 // and the limits device_tree_build_end applies to counters[1] (left-behind bodies) and counters[2] (queued folds)
 int* device_tree_counters(void* workspace);
+constexpr int kWhySortOverflow = 1 << 20;   // refusal reason (counter word 5): a bucket of the warm sort outgrew its slots -- the ORDER failed, not the tree
 constexpr int kTreePoisonWord = 9;   // device_tree_counters()[9]: set by a gated kick-drift whose build was refused; while it is set
                                      // every gated kernel is a no-op (the host clears it when it redoes the refused step)
 void device_tree_limits(int n, int fold, int* crowd_limit, int* queue_limit);

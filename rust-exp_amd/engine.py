@@ -45,6 +45,8 @@ NBX_STAT_BH_FALLBACKS = 0
 NBX_STAT_BH_LAST_TREE = 1
 NBX_STAT_DRAW_AMBIGUOUS = 2
 NBX_STAT_BH_REFUSAL = 3
+NBX_STAT_BH_CLASS_SWITCHES = 4
+NBX_STAT_BH_COLD_RESORTS = 5
 
 NBX_GROUP_INFO_EXCHANGE = 0
 NBX_GROUP_INFO_RCCL_RANKS = 1

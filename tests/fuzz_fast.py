@@ -8,8 +8,9 @@ walk: 99.9 % of the bodies within 2e-4 max|F| (4e-4 above 100 000 bodies: the re
 the device's sums are exact -- and a handful of opening decisions flip), everyone within 5e-3 max|F| (1e-2 at theta = 0.85: a
 flipped decision costs one node's approximation error, which grows with theta; seed 41296 reached 5.2e-3).
 Round 3: a third of the cases have ONE common mass plus 0 / 1 / 5 / 30 exceptions (the unit-mass sweep + K2 correction from
-16 384 bodies on); up to 65 536 bodies the device tree carries the reference's running fold, so whenever it is kept (no EPS
-cluster handed to the host build) its forces must equal the host tree's BIT FOR BIT; and four Barnes-Hut steps enqueued back to
+16 384 bodies on); from 1 024 to 65 536 bodies a third engine asks for the reference's running fold (the default class of rounds 3-5; on
+request since round 6): whenever that build is kept its forces must equal the host tree's BIT FOR BIT, and when it refuses the exact-sum
+DEVICE build must have served the evaluation (bit for bit the exact-sum engine's forces), not the host; and four Barnes-Hut steps enqueued back to
 back (the two-slot pipeline without a host wait) must leave the state of four waited-for steps, bit for bit.
 Late round 3: 40 % of the cases get 5 / 50 / 300 clusters of 2 .. 6 bodies around EPS wide in shuffled arrival order (the device
 build replays whole clusters: k_blobs)."""
@@ -68,6 +69,7 @@ def main():
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     bad = 0
     kept = [[0, 0], [0, 0]]     # [clumps added?][device tree kept?]
+    kept_ref = [0, 0, 0]        # reference-fold class asked for: kept / served by the exact-sum device build / by the host build
     t0 = time.time()
     for seed in range(first, first + count):
         x, y, vx, vy, m, theta, mk, clumps, scale = make_case(seed)
@@ -106,8 +108,8 @@ def main():
                 err = np.maximum(np.abs(dx_ - bfx), np.abs(dy_ - bfy)) / bsc
                 if not np.isfinite(dx_).all():
                     why.append("device tree not finite")
-                elif clumps and n > 65536:
-                    # above 65 536 bodies the default is the exact-sum class: pairs only, up to max(16, n/2000) bodies of bigger
+                elif clumps:
+                    # the default is the exact-sum class (round 6: at every size; rounds 3-5: above 65 536 bodies): pairs only, up to max(16, n/2000) bodies of bigger
                     # clusters left unmerged by contract -- they and their blob-mates (up to 7 each) then feel O(1) different
                     # forces, more than the 0.1 % the percentile below allows.  Still quantitative: everybody else is
                     # held to the unclustered bounds -- the 99th percentile instead of the 99.9th, and no more bodies beyond the
@@ -121,9 +123,22 @@ def main():
                     why.append("device tree p99.9 %.2e max %.2e" % (np.percentile(err, 99.9), err.max()))
                 from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_STAT_BH_LAST_TREE
                 kept[int(clumps > 0)][int(fd.get_stat(NBX_STAT_BH_LAST_TREE) == 1)] += 1
-                if 512 <= n <= 65536 and fd.get_stat(NBX_STAT_BH_LAST_TREE) == 1:   # reference fold kept: the host tree, bit for bit
-                    if not (np.array_equal(dx_.view(np.uint32), bfx.view(np.uint32)) and np.array_equal(dy_.view(np.uint32), bfy.view(np.uint32))):
-                        why.append("reference-fold device tree != host tree (%d words)" % int((dx_.view(np.uint32) != bfx.view(np.uint32)).sum()))
+                if 1024 <= n <= 65536:
+                    # the reference-fold class (on request since round 6): kept -> the host tree, bit for bit; refused -> served by the
+                    # exact-sum DEVICE build (NBX_STAT_BH_CLASS_SWITCHES), i.e. fd's forces bit for bit -- never by the host build
+                    # unless the exact-sum class refuses as well
+                    from rust_exp_amd.engine import NBX_STAT_BH_CLASS_SWITCHES, NBX_STAT_BH_FALLBACKS
+                    fr = rx.NBodyEngine(mode="fast"); fr.set_bh_tree("device"); fr.set_bh_fold("reference"); fr.set_particles(x, y, vx, vy, m)
+                    rx_, ry_, _ = fr.forces(theta)
+                    sw, fb = fr.get_stat(NBX_STAT_BH_CLASS_SWITCHES), fr.get_stat(NBX_STAT_BH_FALLBACKS)
+                    same = lambda a, b: np.array_equal(a.view(np.uint32), b.view(np.uint32))   # noqa: E731
+                    if sw == 0 and fb == 0:
+                        if not (same(rx_, bfx) and same(ry_, bfy)):
+                            why.append("reference-fold device tree != host tree (%d words)" % int((rx_.view(np.uint32) != bfx.view(np.uint32)).sum()))
+                    elif fb == 0 and fd.get_stat(NBX_STAT_BH_LAST_TREE) == 1:
+                        if not (same(rx_, dx_) and same(ry_, dy_)):
+                            why.append("refused reference-fold build not served by the exact-sum device build's forces")
+                    kept_ref[0 if sw == 0 and fb == 0 else (1 if fb == 0 else 2)] += 1
                 # (once the bodies have moved a tree may be one the reference panics on -- two bodies an ulp apart at |x| ~ 3000
                 #  need cells no f32 midpoint can make: the library then reports the reference's panic, seed 91685 -- not a failure)
                 try:
@@ -148,8 +163,9 @@ def main():
         if why:
             bad += 1
             print("FAIL seed", seed, "n", n, "scale", scale, "masses", mk, "theta", theta, why)
-    print("fuzz fast: %d cases, %d failures, %.1f s; device tree kept / handed over: %d / %d without added clusters, %d / %d with"
-          % (count, bad, time.time() - t0, kept[0][1], kept[0][0], kept[1][1], kept[1][0]))
+    print("fuzz fast: %d cases, %d failures, %.1f s; device tree kept / handed over: %d / %d without added clusters, %d / %d with; "
+          "reference-fold class asked for (1 024 .. 65 536 bodies): %d kept, %d served by the exact-sum device build, %d by the host build"
+          % (count, bad, time.time() - t0, kept[0][1], kept[0][0], kept[1][1], kept[1][0], kept_ref[0], kept_ref[1], kept_ref[2]))
 
 
 if __name__ == "__main__":

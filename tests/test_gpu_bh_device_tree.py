@@ -1,9 +1,9 @@
 """GPU: quadtree built ON THE DEVICE (bh_build.hip; the fast mode's default from 1 024 bodies on) against the host build,
 which is node-for-node the oracle's tree.  Two classes (NBX_OPT_BH_FOLD):
-  * fold = reference (round 3; the default up to 65 536 bodies): interior masses and centres are the reference's own f32 running
+  * fold = reference (round 3; on request in the fast mode since round 6): interior masses and centres are the reference's own f32 running
     fold in arrival order (nbody.rs:303-320) -> the flattened tree equals the host tree BIT FOR BIT, or the build reports EPS
     clusters it cannot reproduce node for node and the step runs on the host tree;
-  * fold = exact (round 2; the default above): same node set / skip pointers / node sizes / leaf records -- including the
+  * fold = exact (round 2; the fast mode's default at every size since round 6 -- by cost): same node set / skip pointers / node sizes / leaf records -- including the
     reference's EPS merge of close pairs -- with interior records that are roundings of the EXACT sums (the reference's fold
     drifts, 6e-4 at a million bodies), so forces are compared with the oracle AND with the fp64 arbiter
     (oracle/nbody_oracle.c orc_bh_forces_exact)."""
@@ -46,8 +46,8 @@ def test_device_tree_with_the_reference_fold_equals_the_host_tree_bit_for_bit(rx
     else:
         st = rx.plummer_sphere(n, dim=2)
         p = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
-    e = engines(rx, p, fold="reference" if n > 65536 else None)
-    assert e.query_option(NBX_OPT_BH_FOLD) == (1 if n > 65536 else -1)
+    e = engines(rx, p, fold="reference")
+    assert e.query_option(NBX_OPT_BH_FOLD) == 1
     _bit_equal_trees(e.bh_flat_dump(False), e.bh_flat_dump("device"))
     # and the forces through it are the host-tree forces bit for bit (same walk over the same records), hence within the
     # fast mode's 2e-5 of the oracle for EVERY body
@@ -81,7 +81,7 @@ def test_device_tree_reference_fold_replays_eps_clusters(rx, ob):
     n = len(x)
     p = ob.particles(x, y, np.zeros(n), np.zeros(n), rng.uniform(0.5, 2.0, n))
     a = engines(rx, p); a.set_bh_tree("host")
-    b = engines(rx, p)                                   # default: device tree, reference fold
+    b = engines(rx, p, fold="reference")                 # device tree, reference fold (rounds 3-5: the default up to 65 536 bodies)
     c = engines(rx, p, fold="exact")
     fx, fy, _ = a.forces(0.5)
     gx, gy, _ = b.forces(0.5)
@@ -118,8 +118,9 @@ def test_device_tree_reference_fold_clusters_in_random_arrival_order(rx, ob, see
     of other bodies; clusters that straddle cell boundaries of every level).  Tight clusters (every member within EPS of the
     moving centre) the device build replays and files under their centre's path: the host tree bit for bit.  Looser ones leave
     unmerged bodies a fraction of EPS beside a blob of several bodies, its leaf is then ~18 levels deep and the blob's successive
-    centres often sit in different cells at that depth: the build says so (NBX_STAT_BH_REFUSAL: 0x80) and the step runs on the host tree.  Either
-    way the forces are the host tree's, bit for bit; a system made of nothing but clusters (the last case: more bodies to move
+    centres often sit in different cells at that depth: the build says so (NBX_STAT_BH_REFUSAL: 0x80) and the evaluation runs on the class
+    below -- since round 6 the exact-sum DEVICE build in the fast mode, the host tree only when that refuses as well (more
+    unmerged bodies than it tolerates).  Kept or handed to the host, the forces are the host tree's, bit for bit; a system made of nothing but clusters (the last case: more bodies to move
     than the build lists, more nodes than its pool holds) goes to the host build as a whole."""
     from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE
 
@@ -127,16 +128,30 @@ def test_device_tree_reference_fold_clusters_in_random_arrival_order(rx, ob, see
     x, y, m = _clumps(rng, n_base, n_clumps, spread)
     n = len(x)
     p = ob.particles(x, y, np.zeros(n), np.zeros(n), m)
+    from rust_exp_amd.engine import NBX_STAT_BH_CLASS_SWITCHES, NBX_STAT_BH_REFUSAL
+
     h = engines(rx, p); h.set_bh_tree("host")
-    d = engines(rx, p)
+    d = engines(rx, p, fold="reference"); d.set_bh_tree("device")   # (rounds 3-5: the default class up to 65 536 bodies)
     fx, fy, _ = h.forces(0.85)
     gx, gy, _ = d.forces(0.85)
-    assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
-    device = d.get_stat(NBX_STAT_BH_LAST_TREE) == 1
-    assert d.get_stat(NBX_STAT_BH_FALLBACKS) == (0 if device else 1)
-    from rust_exp_amd.engine import NBX_STAT_BH_REFUSAL
-    why = d.get_stat(NBX_STAT_BH_REFUSAL)                  # the build says why it handed the system over
-    assert (why == 0) == device and (device or why & (0x10000 | 8 | 16 | 32 | 64 | 128))
+    sw, fb = d.get_stat(NBX_STAT_BH_CLASS_SWITCHES), d.get_stat(NBX_STAT_BH_FALLBACKS)
+    device = sw == 0 and fb == 0                           # the reference-fold build was kept
+    assert (d.get_stat(NBX_STAT_BH_LAST_TREE) == 1) == (fb == 0)
+    why = d.get_stat(NBX_STAT_BH_REFUSAL)                  # the build says why it handed the system on (the reasons of the class asked for
+    assert (why == 0) == device and (device or why & (0x10000 | 1 | 4 | 8 | 16 | 32 | 64 | 128))   # stay on record when the class below refuses too)
+    same = np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
+    if device or fb == 1:
+        assert same                                        # the host tree's forces bit for bit: its own records, or its own build
+    else:
+        # round 6: refused in the fast mode -> served by the exact-sum DEVICE build: that engine's forces bit for bit (its class:
+        # pairs merged, a few bodies of bigger clusters left unmerged)
+        assert sw == 1
+        x_ = engines(rx, p, fold="exact"); x_.set_bh_tree("device")
+        ex, ey, _ = x_.forces(0.85)
+        assert x_.get_stat(NBX_STAT_BH_LAST_TREE) == 1
+        assert np.array_equal(ex.view(np.uint32), gx.view(np.uint32)) and np.array_equal(ey.view(np.uint32), gy.view(np.uint32))
+        err = np.maximum(np.abs(gx - fx), np.abs(gy - fy)) / max(np.abs(fx).max(), np.abs(fy).max())
+        assert np.percentile(err, 99.0) <= 4e-4, np.percentile(err, 99.0)
     if on_device is not None:
         assert device == on_device
     if device:
@@ -192,7 +207,7 @@ def test_device_tree_has_the_host_trees_structure(rx, ob, make, n):
 @pytest.mark.parametrize("theta", [0.5, 0.85])
 def test_device_tree_forces_and_step_match_host_tree(rx, ob, theta):
     p = ob.stable_orbits(50000, 0.5, 30.0, 44)
-    a, b = engines(rx, p), engines(rx, p, fold="exact")
+    a, b = engines(rx, p), engines(rx, p)                # (b: the fast mode's default class since round 6 -- exact sums)
     a.set_bh_tree("host")
     b.set_bh_tree("device")
     fx, fy, _ = a.forces(theta)
@@ -257,7 +272,7 @@ def test_device_tree_reproduces_the_reference_eps_merge_in_arrival_order(rx, ob,
     try:
         _bit_equal_trees(host, r.bh_flat_dump("device"))
     except rx.NBodyError as ex:
-        assert "fell back" in str(ex)
+        assert "refused" in str(ex)
     rc, ofx, ofy = ob.bh_forces(p, 0.5, nthreads=8)
     e.set_bh_tree("device")
     fx, fy, _ = e.forces(0.5)
@@ -330,13 +345,15 @@ def test_device_tree_exact_sums_are_at_least_as_close_to_exact_arithmetic_as_the
     rc, ofx, ofy = ob.bh_forces(p, theta, nthreads=16)
     rc2, ex, ey = ob.bh_forces_exact(p, theta, nthreads=16)
     assert rc == 0 and rc2 == 0
-    e = engines(rx, p, fold="exact")         # fast mode, n >= 512 -> device tree; exact sums (the default only above 65 536)
+    e = engines(rx, p)                       # fast mode, n >= 512 -> device tree; exact sums (round 6: the default at every size)
+    from rust_exp_amd.engine import NBX_OPT_BH_FOLD
+    assert e.query_option(NBX_OPT_BH_FOLD) == -1
     fx, fy, _ = e.forces(theta)
     assert e.get_stat(NBX_STAT_BH_LAST_TREE) == 1
     scale = max(np.abs(ex).max(), np.abs(ey).max())
     if n <= 65536:
-        # the DEFAULT at this size (reference fold): within the fast mode's 2e-5 of the oracle for every single body
-        d = engines(rx, p)
+        # the reference fold (on request since round 6): within the fast mode's 2e-5 of the oracle for every single body
+        d = engines(rx, p, fold="reference")
         dx, dy, _ = d.forces(theta)
         assert d.get_stat(NBX_STAT_BH_LAST_TREE) == 1
         assert max(np.abs(dx - ofx).max(), np.abs(dy - ofy).max()) <= 2e-5 * max(np.abs(ofx).max(), np.abs(ofy).max())
@@ -349,11 +366,11 @@ def test_device_tree_exact_sums_are_at_least_as_close_to_exact_arithmetic_as_the
 
 
 def test_tree_choice_by_mode_and_size(rx, ob):
-    """NBX_OPT_BH_TREE = -1 (default): device build in the fast mode from 1 024 bodies on (512 with exactly summed nodes), host
-    build below and in the bit-exact mode; 0 / 1 force one or the other."""
+    """NBX_OPT_BH_TREE = -1 (default): device build in the fast mode from 512 bodies on (exactly summed nodes: that mode's default class
+    since round 6; 1 024 when the reference fold is asked for), host build below and in the bit-exact mode; 0 / 1 force one or the other."""
     from rust_exp_amd.engine import NBX_STAT_BH_LAST_TREE, NBX_OPT_BH_TREE
 
-    for n, mode, want in ((4096, "fast", 1), (1024, "fast", 1), (1023, "fast", 0), (20000, "strict", 0)):
+    for n, mode, want in ((4096, "fast", 1), (512, "fast", 1), (511, "fast", 0), (20000, "strict", 0)):
         p = ob.random_disk(n, 3)
         e = rx.NBodyEngine(mode=mode)
         assert e.get_option(NBX_OPT_BH_TREE) == -1
@@ -660,17 +677,24 @@ def test_reference_fold_merges_between_non_neighbouring_entities(rx, ob):
     y[:k] = y[k:2 * k] + (rng.normal(0, 1e-3, k) * scale).astype(np.float32)
     p = ob.particles(x, y, np.zeros(n), np.zeros(n), np.full(n, 0.37))
     h = engines(rx, p); h.set_bh_tree("host")
-    d = engines(rx, p); d.set_bh_tree("device")         # device tree, reference fold (below 1 024 bodies the default is the host build)
+    d = engines(rx, p, fold="reference"); d.set_bh_tree("device")   # device tree, reference fold (below 1 024 bodies that class defaults to the host build)
+    from rust_exp_amd.engine import NBX_STAT_BH_CLASS_SWITCHES
+
     fx, fy, _ = h.forces(0.85)
     gx, gy, _ = d.forces(0.85)
-    assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
-    if d.get_stat(NBX_STAT_BH_LAST_TREE) == 1:          # since the replay of whole clusters (k_blobs): the device tree itself
+    kept = d.get_stat(NBX_STAT_BH_CLASS_SWITCHES) == 0 and d.get_stat(NBX_STAT_BH_FALLBACKS) == 0
+    if kept:                                            # since the replay of whole clusters (k_blobs): the device tree itself
+        assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
         _bit_equal_trees(d.bh_flat_dump(False), d.bh_flat_dump("device"))
-    else:
-        assert d.get_stat(NBX_STAT_BH_FALLBACKS) == 1
-    # a step through the pipelined path gives the host-tree step too
-    d.step_barnes_hut(0.85, 0.01, 1); h.step_barnes_hut(0.85, 0.01, 1)
-    a, b = h.get_particles(), d.get_particles()
+    # the same build asked for by the BIT-EXACT mode (its only device class): kept -> that tree, refused -> the host build; a step
+    # through either gives the host-tree step bit for bit
+    s_, hs = rx.NBodyEngine(mode="strict"), rx.NBodyEngine(mode="strict")
+    s_.set_bh_tree("device"); s_.set_bh_fold("reference"); hs.set_bh_tree("host")
+    for e in (s_, hs):
+        e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+        e.step_barnes_hut(0.85, 0.01, 1)
+    assert (s_.get_stat(NBX_STAT_BH_LAST_TREE) == 1) == kept and s_.get_stat(NBX_STAT_BH_FALLBACKS) == (0 if kept else 1)
+    a, b = hs.get_particles(), s_.get_particles()
     for kk in ("px", "py", "vx", "vy"):
         assert np.array_equal(a[kk].view(np.uint32), b[kk].view(np.uint32)), kk
 
@@ -740,3 +764,89 @@ def test_strict_mode_on_the_device_tree_keeps_the_references_depth_panic(rx, ob)
     f = engines(rx, p); f.set_bh_tree("device")
     fx, fy, _ = f.forces(0.5)
     assert f.get_stat(NBX_STAT_BH_LAST_TREE) == 1 and np.isfinite(fx).all() and np.isfinite(fy).all()
+
+
+def _disk_with_a_long_eps_chain(ob, n_disk, chain, seed):
+    """A random disk + `chain` bodies on a line, 1.5 EPS apart: every link is shorter than 2 EPS (one connected component for the
+    reference-fold replay: more than its 96 bodies -> that class must refuse, NBX_STAT_BH_REFUSAL bit 4) and longer than EPS
+    (nothing merges, nbody.rs:249: the exact-sum class builds the reference's node set without leaving anybody behind)."""
+    rng = np.random.default_rng(seed)
+    d = ob.random_disk(n_disk, seed)
+    cx = np.float32(3.0) + np.arange(chain, dtype=np.float32) * np.float32(1.5e-4)
+    cy = np.full(chain, 2.0, np.float32)
+    order = rng.permutation(n_disk + chain)                 # the chain's bodies arrive anywhere in the sequence
+    cat = lambda a, b: np.concatenate([np.asarray(a, np.float32), np.asarray(b, np.float32)])[order]   # noqa: E731
+    zero = np.zeros(chain, np.float32)
+    # (masses of the chain small: it stays a chain for the steps below)
+    return ob.particles(cat(d["px"], cx), cat(d["py"], cy), cat(d["vx"], zero), cat(d["vy"], zero), cat(d["m"], np.full(chain, 1e-3)))
+
+
+@pytest.mark.parametrize("async_", [1, 0])
+def test_a_refused_reference_fold_build_is_served_by_the_exact_sum_device_build(rx, ob, async_):
+    """Round 6: in the FAST mode a reference-fold device build that refuses (nbody.rs:249-260's merge, :303-320's
+    fold: what the replay cannot reproduce node for node) is redone on the exact-sum DEVICE build -- 8 x faster than the host build
+    at 65 536 bodies and inside the fast mode's stated tolerance -- and so is the back-off run behind refusals in a row; the host
+    build serves only the bit-exact mode and refusals of the exact-sum class itself.  The step is then the exact-sum engine's
+    step bit for bit, its forces within the exact-sum class's bounds of the oracle's fp64 arbiter (orc_bh_forces_exact)."""
+    from rust_exp_amd.engine import (NBX_OPT_BH_ASYNC, NBX_STAT_BH_CLASS_SWITCHES, NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE,
+                                     NBX_STAT_BH_REFUSAL)
+
+    p = _disk_with_a_long_eps_chain(ob, 20000, 130, 77)
+    theta = 0.5
+    r = engines(rx, p, fold="reference"); r.set_option(NBX_OPT_BH_ASYNC, async_)
+    x = engines(rx, p, fold="exact"); x.set_option(NBX_OPT_BH_ASYNC, async_)
+    # forces: refused -> exact-sum device tree, never the host
+    fx, fy, _ = r.forces(theta)
+    assert r.get_stat(NBX_STAT_BH_CLASS_SWITCHES) == 1 and r.get_stat(NBX_STAT_BH_FALLBACKS) == 0
+    assert r.get_stat(NBX_STAT_BH_LAST_TREE) == 1 and r.get_stat(NBX_STAT_BH_REFUSAL) & 4
+    gx, gy, _ = x.forces(theta)
+    assert x.get_stat(NBX_STAT_BH_CLASS_SWITCHES) == 0 and x.get_stat(NBX_STAT_BH_FALLBACKS) == 0
+    assert np.array_equal(fx.view(np.uint32), gx.view(np.uint32)) and np.array_equal(fy.view(np.uint32), gy.view(np.uint32))
+    rc, ex, ey = ob.bh_forces_exact(p, theta, nthreads=16)
+    assert rc == 0
+    scale = max(np.abs(ex).max(), np.abs(ey).max())
+    err = np.maximum(np.abs(fx - ex), np.abs(fy - ey)) / scale
+    assert np.percentile(err, 99.9) <= 2e-5 and err.max() <= 2e-3, (np.percentile(err, 99.9), err.max())
+    # steps: six in a row, every one refused by the reference-fold class or inside its back-off run (refusals 1, 2 -> run of 2 ->
+    # refusal 3 -> run of 4 ...): all six served by the exact-sum device build, none by the host
+    for _ in range(6):
+        r.step_barnes_hut(theta, 0.01, 1)
+        x.step_barnes_hut(theta, 0.01, 1)
+    a, b = r.get_particles(), x.get_particles()
+    assert r.get_stat(NBX_STAT_BH_CLASS_SWITCHES) == 1 + 6 and r.get_stat(NBX_STAT_BH_FALLBACKS) == 0
+    assert r.get_stat(NBX_STAT_BH_LAST_TREE) == 1
+    for k in ("px", "py", "vx", "vy"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    # the bit-exact mode on the same system: only the reference fold serves it, so the refusal goes to the HOST build -- the
+    # host-tree step bit for bit
+    s = rx.NBodyEngine(mode="strict"); s.set_bh_tree("device"); s.set_bh_fold("reference"); s.set_option(NBX_OPT_BH_ASYNC, async_)
+    h = rx.NBodyEngine(mode="strict"); h.set_bh_tree("host")
+    for e in (s, h):
+        e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+        e.step_barnes_hut(theta, 0.01, 1)
+    assert s.get_stat(NBX_STAT_BH_FALLBACKS) == 1 and s.get_stat(NBX_STAT_BH_CLASS_SWITCHES) == 0 and s.get_stat(NBX_STAT_BH_LAST_TREE) == 0
+    a, b = s.get_particles(), h.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+
+
+def test_the_fast_modes_default_tree_class_is_chosen_by_cost(rx, ob):
+    """NBX_OPT_BH_FOLD = -1 (round 6): the fast mode builds exact sums on the device from 512 bodies on at EVERY size (the
+    reference fold's build is 2.6 x .. 12.7 x the exact-sum build's between 2 000 and 65 536 bodies, profiles/r06_bh_sizes.jsonl:
+    never within the 1.5 x of the cost rule) -- the default engine's forces are the exact-sum engine's bit for bit, not the
+    reference-fold engine's; the bit-exact mode keeps the host build."""
+    from rust_exp_amd.engine import NBX_STAT_BH_LAST_TREE
+
+    for n in (600, 10000, 65536):
+        p = ob.stable_orbits(n, 0.5, 30.0, 5)
+        d, x, r = engines(rx, p), engines(rx, p, fold="exact"), engines(rx, p, fold="reference")
+        r.set_bh_tree("device")
+        fd, fx, fr = d.forces(0.85), x.forces(0.85), r.forces(0.85)
+        assert d.get_stat(NBX_STAT_BH_LAST_TREE) == 1 and x.get_stat(NBX_STAT_BH_LAST_TREE) == 1
+        assert np.array_equal(fd[0].view(np.uint32), fx[0].view(np.uint32)) and np.array_equal(fd[1].view(np.uint32), fx[1].view(np.uint32))
+        if n >= 10000:
+            assert not np.array_equal(fd[0].view(np.uint32), fr[0].view(np.uint32))   # (the classes do differ: the sun's chain of 10^4 terms)
+    s = rx.NBodyEngine(mode="strict")
+    s.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    s.forces(0.85)
+    assert s.get_stat(NBX_STAT_BH_LAST_TREE) == 0

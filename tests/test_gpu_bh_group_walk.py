@@ -164,10 +164,12 @@ def test_group_walk_degenerate_trees(rx, ob):
     }
     for name, p in cases.items():
         for theta in (0.5, 1e-6, -0.25):
-            for tree in ("host", "device"):
-                e = _engine(rx, p, 1, tree=tree)
+            for tree, fold in (("host", None), ("device", "reference"), ("device", "exact")):
+                e = _engine(rx, p, 1, tree=tree, fold=fold)
                 gx, gy, _ = e.forces(theta)
-                rc, ofx, ofy = ob.bh_forces(p, theta)
+                # (the exact-sum class against the oracle's traversal with exactly summed nodes: 300 bodies on a line take the ROOT at
+                #  theta 0.5 -- s = 0 -- and the reference's running f32 fold of its centre is 4e-5 of max|F| off the exact one)
+                rc, ofx, ofy = ob.bh_forces_exact(p, theta) if fold == "exact" else ob.bh_forces(p, theta)
                 assert rc == 0
                 scale = max(np.abs(ofx).max(), np.abs(ofy).max(), 1e-30)
                 assert max(np.abs(gx - ofx).max(), np.abs(gy - ofy).max()) <= 1e-5 * scale, (name, theta, tree)

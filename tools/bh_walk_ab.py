@@ -13,12 +13,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import rust_exp_amd as rx  # noqa: E402
-from rust_exp_amd.engine import NBX_OPT_BH_WALK, NBX_OPT_BH_WAVE  # noqa: E402
+from rust_exp_amd.engine import (NBX_OPT_BH_WALK, NBX_OPT_BH_WAVE, NBX_STAT_BH_CLASS_SWITCHES, NBX_STAT_BH_FALLBACKS,  # noqa: E402
+                                 NBX_STAT_BH_LAST_TREE)
 
 
-def run(n, theta, walk, wave=1, steps=30, fold="exact"):
+def run(n, theta, walk, wave=1, steps=30, fold="exact", tree=None):
     e = rx.NBodyEngine(mode="fast")
     e.set_bh_fold(fold)
+    if tree:
+        e.set_bh_tree(tree)
     e.set_option(NBX_OPT_BH_WALK, walk)
     e.set_option(NBX_OPT_BH_WAVE, wave)
     if os.environ.get("NBX_AB_FUSE_KICK"):
@@ -52,7 +55,9 @@ def run(n, theta, walk, wave=1, steps=30, fold="exact"):
            "tree_build_ms": round(tb / max(tcnt, 1), 4), "kick_drift_ms": round(ki / max(kcnt, 1), 4), "nodes": e.bh_host_timing()["nodes"],
            "visits_per_body": wk["node_visits"] / n, "pairs_per_body": wk["pair_evals"] / n,
            "opening_tests_per_body": wk["opening_tests"] / n, "group_loads_per_body": wk["group_loads"] / n,
-           "force_checksum": float(np.abs(fx).sum() + np.abs(fy).sum())}
+           "force_checksum": float(np.abs(fx).sum() + np.abs(fy).sum()),
+           "last_tree": "device" if e.get_stat(NBX_STAT_BH_LAST_TREE) == 1 else "host", "host_hand_overs": e.get_stat(NBX_STAT_BH_FALLBACKS),
+           "class_switches": e.get_stat(NBX_STAT_BH_CLASS_SWITCHES)}
     e.close()
     return out
 

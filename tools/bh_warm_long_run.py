@@ -10,7 +10,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import rust_exp_amd as rx  # noqa: E402
-from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_REFUSAL  # noqa: E402
+from rust_exp_amd.engine import NBX_STAT_BH_CLASS_SWITCHES, NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_REFUSAL  # noqa: E402
 
 CASES = (("plummer", 1048576), ("random_disk", 262144), ("stable_orbits", 262144), ("stable_orbits", 1048576), ("two_galaxies", 524288),
          ("random_disk", 65536))
@@ -19,6 +19,8 @@ if len(sys.argv) > 1:   # e.g. plummer:1048576
 STEPS = int(os.environ.get("NBX_LONG_STEPS", "1000"))
 for scene, n in CASES:
     e = rx.NBodyEngine()
+    if os.environ.get("NBX_LONG_FOLD"):     # reference | exact (default: the engine's own choice, by cost)
+        e.set_bh_fold(os.environ["NBX_LONG_FOLD"])
     e.seed(11)
     if scene == "stable_orbits":
         e.stable_orbits(n, 0.5, 30.0)
@@ -41,6 +43,7 @@ for scene, n in CASES:
     st = e.get_particles()
     import numpy as np
     print(json.dumps({"scene": scene, "n": n, "steps": STEPS, "theta": 0.5, "fallbacks_cumulative_by_tenth": fb,
-                      "fallback_rate": fb[-1] / STEPS, "last_refusal_why": "0x%x" % e.get_stat(NBX_STAT_BH_REFUSAL),
+                      "fallback_rate": fb[-1] / STEPS, "class_switches": e.get_stat(NBX_STAT_BH_CLASS_SWITCHES),
+                      "fold": os.environ.get("NBX_LONG_FOLD", "default"), "last_refusal_why": "0x%x" % e.get_stat(NBX_STAT_BH_REFUSAL),
                       "ms_per_step_cumulative": marks, "finite": bool(np.isfinite(st["px"]).all() and np.isfinite(st["vx"]).all()),
                       "inc_sort": os.environ.get("NBX_INC_SORT", "1")}), flush=True)
