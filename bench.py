@@ -37,36 +37,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from bench_support import (DT, GroupHost, SingleHost, TorchHost, measure_counters, measure_traffic,  # noqa: E402
-                           steady_state)
+                           steady_state, effective_cores, cpu_facts, CPU_LAW, GPU_LAW_2D, GPU_LAW_3D)
 
 FLOPS_PER_INTERACTION = 17   # 3 sub, 3 mul + 2 add, 1 add eps, 1 mul, 1 div, 3 mul, 3 add
 
 KERNEL_NAMES = {1: "k_force_tile_pk", 6: "k_force_smem_pkw<unit_mass=0>", 7: "k_force_smem_pkw<unit_mass=1>", 16: "k_force_tile_pk_h",
                 17: "k_force_smem_pkw<unit_mass=0,self_image=1> on the widened fp16 copy", 18: "k_force_smem_pkw<unit_mass=1,self_image=1> on the widened fp16 copy",
                 -1: "k_force_strict", -8: "k_force_strict_pc<8,8>", -16: "k_force_strict_pc<16,4>"}
-
-
-def effective_cores():
-    """Cores this process may actually use: scheduler affinity, capped by a cgroup CPU quota if there is one."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
-            else:
-                q = int(txt[0])
-                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                if q > 0:
-                    n = min(n, max(1, int(q / p + 0.5)))
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    return max(1, n)
 
 
 def cpu_baseline(st, seconds):
@@ -90,7 +67,7 @@ def cpu_baseline(st, seconds):
     t0 = time.perf_counter(); ob.brute_forces(p, 0, n1, nthreads=1); t2 = time.perf_counter()
     st1 = n1 * (n - 1) / (t2 - t0)
     return {
-        "value": mt, "unit": "interactions/s", "cores": cores, "kind": "port", "logical_cpus": os.cpu_count(),
+        "value": mt, "unit": "interactions/s", "cores": cores, "kind": "port", **cpu_facts(cores), "law": CPU_LAW,
         "sample": f"first {ni} targets x {n} sources (2-D reference law), {cores} threads, reference slab split",
         "single_thread_value": st1,
         "single_thread_sample": f"first {n1} targets x {n} sources, 1 thread (the reference's brute force is single-threaded)",
@@ -144,6 +121,72 @@ def bh_accuracy(st, theta, engine, threads):
             "oracle_seconds": t1 - t0, "threads": threads}
 
 
+REFERENCE_PUBLISHED_MS = 30.75   # screenshot.png, top-middle panel (2016 desktop, 1 thread)
+
+
+def reference_scene_line(no_cpu_baseline=False, frames=90):
+    """BASELINE.md section 1, the one number the reference publishes, measured the way its caller measures it
+    (hs-src/RustNBodyExperiment.hs): withExperiment -> nb_stable_orbits 10000 0.5 30.0 (:42); every frame timeIt(nb_step_barnes_hut
+    0.85 0.01 1) (:55-57) then nb_draw 512 512 (:58-60); the status line shows the MEDIAN of the last 30 step times (:44, :62,
+    :65).  All through the SIX level-1 symbols -- the process-global engine, the drop-in's everyday path.  Beside it (cpu_baseline
+    leg): BASELINE.md section 3 row CB -- the oracle's nb_step_barnes_hut on the same seeded scene, 1 thread, median of 30 -- and
+    the force error of an engine in the level-1 configuration against the oracle's own traversal (orc_bh_forces, nbody.rs:333-377)."""
+    os.environ.setdefault("NB_SEED", "1")
+    import rust_exp_amd as rx
+
+    theta, dt, nthreads, n = 0.85, 0.01, 1, 10000
+    rx.nb_stable_orbits(n, 0.5, 30.0)
+    times, draws = [], []
+    for _ in range(frames):
+        t0 = time.perf_counter()
+        rx.nb_step_barnes_hut(theta, dt, nthreads)
+        t1 = time.perf_counter()
+        rx.nb_draw(512, 512)
+        t2 = time.perf_counter()
+        times.append(t1 - t0); draws.append(t2 - t1)
+    ms = float(np.median(times[-30:])) * 1e3
+    # an engine in the same (default) configuration, same seed: which tree served the steps, and the checker's state
+    e = rx.NBodyEngine()
+    e.seed(1)
+    e.stable_orbits(n, 0.5, 30.0)
+    st = e.get_particles()
+    for _ in range(5):
+        e.step_barnes_hut(theta, dt, nthreads)
+    e.synchronize()
+    tree = {0: "host (reference-faithful insertion build)", 1: "device (bh_build.hip), exact sums"}[e.get_stat(rx.engine.NBX_STAT_BH_LAST_TREE)]
+    out = {"metric": "ms per nb_step_barnes_hut call, reference default scene (10 000-body nb_stable_orbits, theta 0.85, dt 0.01, 1 thread), "
+                     "median of the last 30 wall-clocked calls", "value": ms, "unit": "ms", "higher_is_better": False, "n_gpus": 1,
+           "steps": frames, "warmup": frames - 30, "ms_per_step": ms, "draw_ms": float(np.median(draws[-30:])) * 1e3, "dtype": "f32",
+           "data": "synthetic (seeded preset, NB_SEED=1)", "published_ms_per_step": REFERENCE_PUBLISHED_MS,
+           "vs_baseline": REFERENCE_PUBLISHED_MS / ms,
+           "vs_baseline_note": "published figure / this figure: other hardware (a 2016 desktop CPU), read off screenshot.png +-1 in the last digit",
+           "config": {"workload": "reference_default_scene_nb_stable_orbits_N10000_theta0.85_dt0.01_level1_symbols", "bodies": n,
+                      "tree": tree, "how": "RustNBodyExperiment.hs:42-65: timeIt around the FFI call, nb_draw 512x512 between calls, median of 30"},
+           "bh_fallbacks": e.get_stat(rx.engine.NBX_STAT_BH_FALLBACKS)}
+    if not no_cpu_baseline:
+        from oracle import binding as ob
+
+        p = ob.particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+        q = p.copy()
+        ts = []
+        for _ in range(30):
+            t0 = time.perf_counter(); rc = ob.step_barnes_hut(q, theta, dt, 1); ts.append(time.perf_counter() - t0)
+        rc2, ofx, ofy = ob.bh_forces(p, theta, nthreads=effective_cores())
+        e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+        gx, gy, _ = e.forces(theta)
+        scale = float(max(np.abs(ofx).max(), np.abs(ofy).max()))
+        err = np.maximum(np.abs(gx - ofx), np.abs(gy - ofy)) / scale
+        out["cpu_baseline"] = {"value": float(np.median(ts)) * 1e3, "unit": "ms per step", "ms_per_step": float(np.median(ts)) * 1e3, "cores": 1,
+                               "kind": "port", **cpu_facts(effective_cores()), "rc": rc,
+                               "law": "nb_step_barnes_hut as written (nbody.rs:186-480), 1 thread like the published figure",
+                               "sample": "BASELINE.md section 3 row CB: the oracle on the same seeded scene, 30 consecutive steps, median",
+                               "accuracy": {"vs": "orc_bh_forces (the oracle's own f32 tree and traversal), initial state, all bodies, relative to max|F|",
+                                            "p50": float(np.percentile(err, 50)), "p999": float(np.percentile(err, 99.9)), "max": float(err.max()),
+                                            "rc": rc2}}
+    e.close()
+    return out
+
+
 def _claim_stdout():
     """RCCL (and other C libraries) print banners to the C stdout ("RCCL version : ..." at communicator
     creation, flushed at exit). The contract is ONE JSON line on stdout, so keep a private handle to the real
@@ -157,6 +200,9 @@ def _claim_stdout():
 # ---- companions: the other BASELINE configs, timed by the same driver-run command ----------------------
 COMPANIONS = (
     # key, BASELINE config, argv of the child run
+    ("c0_reference_scene", "the reference's own default scene and the ONE number it publishes (BASELINE.md section 1): nb_stable_orbits(10000, 0.5, "
+                           "30.0), nb_step_barnes_hut(0.85, 0.01, 1) through the six level-1 symbols, median of the last 30 wall-clocked calls",
+     ["--workload", "reference_scene"]),
     ("c2_brute_65536", "65 536-body Plummer sphere, brute-force fp32 on 1 MI355X",
      ["--bodies", "65536", "--steps", "300", "--warmup", "60", "--steady-seconds", "0", "--no-general-masses", "--no-traffic",
       "--cpu-seconds", "2"]),
@@ -173,6 +219,12 @@ def companion_summary(key, line):
     r, cb = line.get("roofline") or {}, line.get("cpu_baseline") or {}
     out = {"value": line.get("value"), "unit": line.get("unit"), "ms_per_step": line.get("ms_per_step"), "steps": line.get("steps"),
            "frac": r.get("frac"), "kernel_avg_ms": r.get("kernel_avg_ms"), "cpu_value": cb.get("value"), "cpu_cores": cb.get("cores")}
+    if key.startswith("c0"):
+        acc = cb.get("accuracy") or {}
+        return {"ms_per_step": line.get("value"), "cpu_ms_per_step": cb.get("ms_per_step"), "cpu_cores": cb.get("cores"),
+                "published_ms_per_step": line.get("published_ms_per_step"), "draw_ms": line.get("draw_ms"), "frames": line.get("steps"),
+                "tree": (line.get("config") or {}).get("tree"), "host_hand_overs": line.get("bh_fallbacks"),
+                "err_p999": acc.get("p999"), "err_max": acc.get("max"), "err_vs": acc.get("vs")}
     if key.startswith("c4"):
         sp, acc = line.get("ms_split") or {}, cb.get("accuracy") or {}
         out.update({"build_ms": sp.get("tree_build"), "traversal_ms": sp.get("bh_eval_kernel"), "tree": (line.get("config") or {}).get("tree"),
@@ -216,7 +268,7 @@ def flatten_companions(comp):
     for key, row in comp.items():
         short = key.split("_")[0]
         for k, v in row.items():
-            if k in ("config", "argv", "wall_s", "unit", "steps", "kernel", "tree", "err_vs", "cpu_cores", "flops_per_interaction"):
+            if k in ("config", "argv", "wall_s", "unit", "steps", "kernel", "tree", "err_vs", "cpu_cores", "flops_per_interaction", "frames"):
                 continue
             if isinstance(v, (int, float, str)) or v is None:
                 flat[f"{short}_{k}"] = v
@@ -240,8 +292,9 @@ def parse_args():
                     help="bit-exact mode: 0 = by size; 16 / 8 = waves per 64-target workgroup; 1 = one thread per body")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="plummer", choices=["plummer", "two_galaxies", "stable_orbits", "bh"],
-                    help="stable_orbits = the reference's own preset (nb_stable_orbits n 0.5 30, seed 1; 2-D: unit planets + a 1000-mass sun)")
+    ap.add_argument("--workload", default="plummer", choices=["plummer", "two_galaxies", "stable_orbits", "bh", "reference_scene"],
+                    help="stable_orbits = the reference's own preset (nb_stable_orbits n 0.5 30, seed 1; 2-D: unit planets + a 1000-mass sun); "
+                         "reference_scene = the reference's default scene through the six nb_* symbols, timed as its caller times it")
     ap.add_argument("--theta", type=float, default=0.5, help="--workload bh: opening angle")
     ap.add_argument("--bh-tree", default="default", choices=["default", "host", "device"])
     ap.add_argument("--bh-walk", type=int, default=-1, choices=[-1, 0, 1, 2],
@@ -453,6 +506,9 @@ def run(real_stdout):
     # multi-process GPU work on this stack needs dmabuf IPC (exported by the driver; harmless to restate)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse_args()
+    if args.workload == "reference_scene":   # companion c0: its own line, nothing of the all-pairs machinery
+        os.write(real_stdout, (json.dumps(reference_scene_line(args.no_cpu_baseline)) + "\n").encode())
+        return
     if args.n <= 0:
         args.n = 1048576 if args.workload == "bh" else 262144
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -652,8 +708,10 @@ def run(real_stdout):
                              "ceiling_frac": ceiling, "frac_of_ceiling": (achieved / peak / ceiling) if ceiling else None,
                              "ceiling_note": ("what this kernel's own instruction mix allows at the nominal 2.4 GHz: 17 (12) flop x 128 "
                                               "interactions / (packed ops x 3.85 + 2 v_rcp_f32 x 8.7 issue cycles) / 64 flop per cycle and "
-                                              "SIMD; the sweep runs with the VALU 97 % busy at the board's power cap (clock ~2.3 of 2.4 GHz): "
-                                              "what is left between frac and ceiling_frac is that clock, not idle issue slots") if ceiling else
+                                              "SIMD; the sweep runs with the VALU 97 % busy at the board's power cap -- valu_busy_frac 0.971 (equal masses) / 0.974 "
+                                              "(general masses), effective clock 2.23 of 2.4 GHz under the profiler: this round's counters, "
+                                              "profiles/r06_pmc_summary.json (tools/gpu_session.sh k1pmc) -- so what is left between frac and "
+                                              "ceiling_frac is that clock, not idle issue slots") if ceiling else
                                              ("no mix ceiling is quoted for the bit-exact kernels: frac counts the reference's 17 (12) flops "
                                               "per interaction against the plain fp32 peak, while the kernel executes the reference's "
                                               "arithmetic as written -- unfused multiplies and adds, an IEEE-correct sqrt and divide "
@@ -773,11 +831,16 @@ def run(real_stdout):
                 if not args.no_accuracy and host_kind == "single" and args.mode == "fast":
                     acc = bh_accuracy(st, args.theta, engine, cores)
                 out["cpu_baseline"] = {"value": n / (ms1 * 1e-3), "unit": "body-steps/s", "cores": cores, "kind": "port",
+                                       **cpu_facts(effective_cores()),
+                                       "law": "nb_step_barnes_hut as written (nbody.rs:186-480): serial f32 insertion build, recursive traversal "
+                                              "with sqrt + divide per opening test, the 2-D pair law with an IEEE divide",
                                        "ms_per_step": ms1, "rc": rc, "accuracy": acc,
                                        "sample": f"oracle nb_step_barnes_hut on the same {n} bodies: serial tree build + {cores} traversal "
                                                  f"threads (the caller's maximum is 16, hs:94-97), median of {3 if n > 200000 else 15} steps"}
             else:
                 out["cpu_baseline"] = cpu_baseline(st, args.cpu_seconds)
+                # the two rates are NOT the same work per interaction: say what each side computes
+                out["cpu_baseline"]["gpu_law"] = GPU_LAW_3D if out["config"]["launch"]["dim"] == 3 else GPU_LAW_2D
         comp_ok = (host_kind == "single" and world == 1 and not is_bh and args.workload == "plummer" and n == 262144
                    and args.mode == "fast" and args.variant < 0 and args.source_bits == 32 and args.shard_of <= 1
                    and args.jsplit == 0 and args.bpt == 0 and not args.no_companions)

@@ -356,3 +356,54 @@ class TorchHost:
     def close(self):
         if self.world > 1:
             self.dist.destroy_process_group()
+
+
+# ---- who ran the CPU leg, and what each side computes (bench.py's cpu_baseline block) -----------------------------------------
+def effective_cores():
+    """Cores this process may actually use: scheduler affinity, capped by a cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / p + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def cpu_model():
+    """The host CPU's model string (/proc/cpuinfo "model name"; BASELINE.md section 3: "state T and CPU model")."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine() or "unknown"
+
+
+def cpu_facts(cores):
+    """Who ran the CPU leg: model, and how many of the host's logical CPUs this process may use (cgroup quota / affinity)."""
+    logical = os.cpu_count() or cores
+    return {"model": cpu_model(), "logical_cpus": logical,
+            "quota": f"{cores} of {logical} logical CPUs (cgroup CPU quota / scheduler affinity)"}
+
+
+# what the CPU leg computes, beside what the GPU sweep computes: NOT the same work per interaction (VERDICT r05 #4)
+CPU_LAW = ("2-D reference law as written (nbody.rs:174-183 + :141-142): 12 flops per interaction, one IEEE divide, f32, "
+           "ascending-j sequential sum, self skipped by index")
+GPU_LAW_3D = "3-D float4 sweep: 17 algorithmic flops per interaction (z terms added), v_rcp_f32 for the divide, packed FMA, tiled sums"
+GPU_LAW_2D = "2-D sweep: 12 algorithmic flops per interaction, v_rcp_f32 for the divide, packed FMA, tiled sums"

@@ -81,7 +81,7 @@ def test_companions_block_is_flat_scalars_and_survives_a_failed_child():
     """BASELINE configs #2, #4, #5 ride on the driver-run line. The block is assembled from the children's
     own JSON lines; what goes into `roofline` must be scalars (the driver's parser keeps scalars one level deep); a child that
     fails leaves an `error`, not an exception."""
-    assert [k for k, _, _ in bench.COMPANIONS] == ["c2_brute_65536", "c4_barnes_hut_1048576", "c5_fp16_sources_524288"]
+    assert [k for k, _, _ in bench.COMPANIONS] == ["c0_reference_scene", "c2_brute_65536", "c4_barnes_hut_1048576", "c5_fp16_sources_524288"]
     argv = {k: a for k, _, a in bench.COMPANIONS}
     assert argv["c4_barnes_hut_1048576"][:6] == ["--workload", "bh", "--bodies", "1048576", "--theta", "0.5"]
     assert "--source-bits" in argv["c5_fp16_sources_524288"] and "524288" in argv["c5_fp16_sources_524288"]
@@ -104,3 +104,33 @@ def test_companions_block_is_flat_scalars_and_survives_a_failed_child():
     assert flat["c2_value"] == 5.4e12 and flat["c2_frac"] == 0.6 and flat["c4_build_ms"] == 0.36 and flat["c5_error"] == "rc 1: boom"
     assert all(v is None or isinstance(v, (int, float, str)) for v in flat.values())
     json.dumps(flat)
+    # round 6: the reference's one published number rides on the line as c0_* -- ms per nb_step_barnes_hut call of
+    # its default scene, the oracle's 1-thread median beside it (BASELINE.md section 3 row CB), the error against the oracle's traversal
+    assert argv["c0_reference_scene"] == ["--workload", "reference_scene"]
+    c0_line = {"value": 0.101, "unit": "ms", "steps": 90, "draw_ms": 0.12, "published_ms_per_step": 30.75, "bh_fallbacks": 0,
+               "config": {"tree": "device (bh_build.hip), exact sums"},
+               "cpu_baseline": {"value": 7.9, "ms_per_step": 7.9, "cores": 1, "accuracy": {"p999": 3e-6, "max": 2e-5, "vs": "orc_bh_forces"}}}
+    c0 = bench.companion_summary("c0_reference_scene", c0_line)
+    f0 = bench.flatten_companions({"c0_reference_scene": dict(c0, config="x", argv="y", wall_s=3.0)})
+    assert f0["c0_ms_per_step"] == 0.101 and f0["c0_cpu_ms_per_step"] == 7.9 and f0["c0_published_ms_per_step"] == 30.75
+    assert f0["c0_err_p999"] == 3e-6 and f0["c0_err_max"] == 2e-5 and f0["c0_host_hand_overs"] == 0
+    assert all(v is None or isinstance(v, (int, float, str)) for v in f0.values())
+
+
+def test_cpu_baseline_says_who_ran_it_and_what_it_computes():
+    """VERDICT r05 #4 / BASELINE.md section 3 ("state T and CPU model"): the cpu_baseline block names the CPU model, the share of
+    the host's logical CPUs the process may use, and the LAW each side computes -- the CPU leg is the 2-D 12-flop reference law
+    with an IEEE divide, the GPU sweep the 3-D 17-flop one: the two rates are not the same work per interaction."""
+    import numpy as np
+
+    facts = bench.cpu_facts(bench.effective_cores())
+    assert isinstance(facts["model"], str) and facts["model"] and facts["logical_cpus"] >= 1
+    assert str(bench.effective_cores()) in facts["quota"] and "logical CPUs" in facts["quota"]
+    assert "12 flops" in bench.CPU_LAW and "divide" in bench.CPU_LAW and "17" in bench.GPU_LAW_3D and "12" in bench.GPU_LAW_2D
+    rng = np.random.default_rng(0)
+    st = {k: rng.normal(0, 1, 600).astype(np.float32) for k in ("px", "py", "vx", "vy")}
+    st["m"] = np.ones(600, np.float32)
+    cb = bench.cpu_baseline(st, 0.05)          # (the oracle on the host cores: the cpu_baseline leg itself, tiny)
+    for k in ("value", "unit", "cores", "kind", "sample", "model", "quota", "logical_cpus", "law"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] == bench.effective_cores() and cb["law"] == bench.CPU_LAW and cb["value"] > 0

@@ -53,6 +53,17 @@ for stage in "$@"; do
         (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp -d $OLDPWD/$O/pmc_$name -o p --output-format csv -- python $OLDPWD/bench.py --no-cpu-baseline --no-traffic --steps 5 --warmup 1 > /dev/null 2> $OLDPWD/$O/pmc_$name.err)
         f=$(find $O/pmc_$name -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp "$f" $O/pmc_$name/p_counter_collection.csv
       done ;;
+    k1pmc)  # round 6: K1's counters in the round they are quoted -- both sweeps of the default bench line
+      # (k_force_smem_pkw<3,8,true> = the headline, <3,8,false> = general masses), one counter group per pass, no child runs
+      i=0
+      for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+        name=$(echo fetch write sq1 grbm | cut -d' ' -f$((i+1))); i=$((i+1))
+        rm -rf $O/pmc_$name
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp -d $OLDPWD/$O/pmc_$name -o p --output-format csv -- python $OLDPWD/bench.py --no-cpu-baseline --no-traffic --no-companions --steady-seconds 0 --steps 5 --warmup 1 > /dev/null 2> $OLDPWD/$O/pmc_$name.err)
+        f=$(find $O/pmc_$name -name '*counter_collection.csv' | head -1); [ -n "$f" ] && { cp -f "$f" $O/pmc_$name/p_counter_collection.csv 2>/dev/null; cp -f "$f" $O/${TAG}_pmc_${name}_counter_collection.csv; }
+      done
+      rm -rf $O/pmc_sq2 $O/pmc_tcc
+      python tools/pmc_summary.py $TAG > $O/${TAG}_pmc_summary.log 2>&1; cp profiles/${TAG}_pmc_summary.json $O/ 2>/dev/null; tail -5 $O/${TAG}_pmc_summary.log ;;
     power)
       timeout 300 python tools/power_probe.py 6 > $O/${TAG}_power_k1.json 2> $O/${TAG}_power_k1.err; echo "power rc=$?"; cut -c1-1500 $O/${TAG}_power_k1.json
       timeout 300 python tools/power_probe.py 6 --variant 1 > $O/${TAG}_power_k1_variant1.json 2>> $O/${TAG}_power_k1.err
