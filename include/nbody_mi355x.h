@@ -189,15 +189,24 @@ enum nbx_stat {
                                     * within EPS of a blob's centre, 32 two entities in one level-31 cell that do not merge,
                                     * 64 more than 4 096 bodies to move, 128 a blob's successive centres part ways above its
                                     * leaf, 512 (bit-exact mode) a leaf deeper than 25 levels, where the reference may panic, 256 a leaf of more bodies than the leaf fold orders; exact-sum class: 0x20000 = more
-                                    * bodies left unmerged than it tolerates */
+                                    * bodies than it tolerates in chains of close bodies that its replay only approximates (NBX_STAT_BH_CHAIN_APPROX; rounds 2-5:
+                                    * bodies left unmerged by the pairs-only merge) */
     NBX_STAT_BH_CLASS_SWITCHES = 4, /* fast mode, NBX_OPT_BH_FOLD = 1 (round 6): evaluations the reference-fold device build was
                                     * selected for but the exact-sum DEVICE build served -- a refused build redone there, and the
                                     * back-off run (2, 4 .. 32 steps) behind refusals in a row.  Such a step stays on the GPU and
                                     * inside the fast mode's stated tolerance (the exact-sum class's) */
-    NBX_STAT_BH_COLD_RESORTS = 5   /* device builds whose warm sort overflowed a bucket (NBX_STAT_BH_REFUSAL 0x100000: more than 4 096
+    NBX_STAT_BH_COLD_RESORTS = 5,  /* device builds whose warm sort overflowed a bucket (NBX_STAT_BH_REFUSAL 0x100000: more than 4 096
                                     * bodies on one 62-bit key, or a reshuffled system) and that were redone at once from a cold sort,
                                     * same class, on the device (round 6; round 5 sent such a step to the host build); the next
                                     * 2, 4 .. 32 builds then sort cold as well */
+    NBX_STAT_BH_CHAIN_MERGED = 6,  /* exact-sum device build (round 6): bodies the last accepted build merged into another body's leaf
+                                    * by replaying chains of bodies within EPS in arrival order (nbody.rs:249-260; rounds 2-5 merged
+                                    * pairs only and handed crowded systems to the host build) */
+    NBX_STAT_BH_CHAIN_APPROX = 7   /* ... and what of that build was approximate: bodies of blobs that end at a cut of a chain of more than 60
+                                    * linked bodies (such chains are replayed in pieces) + merges decided with the search for an earlier arrival deeper in
+                                    * the newcomer's path cut short (more than 256 sorted neighbours share the cell: taken as merges).
+                                    * At most max(16, n/2000) in a build that was accepted: beyond that the step goes to the host build
+                                    * (NBX_STAT_BH_REFUSAL 0x20000) */
 };
 
 enum nbx_kernel_id {

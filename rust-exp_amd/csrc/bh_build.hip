@@ -12,8 +12,9 @@
 //   3. sort of (key, body index): from last step's order when there is one (bh_sort.hip, round 5: four launches instead of the
 //      library's seventeen), in two launches up to 16 384 bodies (bh_front.hip), rocPRIM's radix sort on a cold build
 //   3b. the reference's EPS merge (nbody.rs:249-260) -- reference fold: whole clusters of close bodies replayed in arrival order
-//       (k_cells / k_blobs / k_place: bh_cluster.hip); exact-sum class: close PAIRS decided from the sorted keys and the arrival
-//       order (k_merge_links / k_merge_keys, section 3b below)
+//       (k_cells / k_blobs / k_place: bh_cluster.hip); exact-sum class (round 6): every CHAIN of close sorted neighbours replayed in
+//       arrival order by one wave (k_chain_links / k_chain_heads / k_chain, section 3b below); only chains of more than 60 bodies,
+//       beyond a limit, are refused
 //   4. nodes straight from the sorted keys: every node is (first body a, depth l); how many nodes start at each body
 //      follows from the digits it shares with its two neighbours, an exclusive scan of those counts gives every node's
 //      PRE-ORDER slot, and a node's skip pointer is the slot of the first node after its bodies (see "the tree from
@@ -29,62 +30,129 @@
 //      Node sizes: the first body's path replayed with the reference's f32 midpoints.
 //
 // fold = 0 is its own tolerance class.  Same node set, same s = x2-x1 per node, same leaf records as the
-// host build + flatten, INCLUDING the reference's EPS merge for pairs (nbody.rs:249-260); what differs there:
+// host build + flatten, INCLUDING the reference's EPS merge (nbody.rs:249-260) of chains of any length; what differs there:
 //   * interior centres of mass are the f32 rounding of the exact weighted mean instead of the reference's
 //     particle-by-particle f32 running fold (which drifts by up to ~6e-4 relative at 100 k bodies);
-//   * a merged pair's leaf sits on the path of its FIRST-arrived member, the reference's on the path of the blob's centre
-//     (different only when a third body shares the pair's last common cell, <= EPS-sized);
-//   * clusters of three or more bodies within EPS: the reference folds arrivals into one blob while each stays within EPS
-//     of the blob's current centre; here only the first two of a run of mutually-close sorted neighbours merge (bodies whose
-//     62-bit keys are identical -- the same level-31 cell, 4.7e-8 of the box -- always share one leaf, any number of them);
-//     more than max(16, n/2000) such bodies send the step to the host build;
+//   * bodies the reference merges although more than two others lie between them in key order (close in space, far apart on the
+//     Z-curve: a cluster astride a coarse cell boundary) stay apart -- 10-65 of 40 000 blobs of the collapsed 2 M-body model;
+//   * a merged blob whose centre's path lies outside its chain's place in the sorted order is filed under the member's path that
+//     follows the centre's deepest;
+//   * a chain of more than 60 linked bodies is replayed in pieces (cuts at multiples of 32 sorted places); the bodies of a blob that ends
+//     at a cut count as left behind: more than max(16, n/2000) of them send the step to the host build (as chains of three did before);
 //   * no depth-50 panic (nbody.rs:230-232): keys stop at level 31.
-// A pair within EPS whose members are not neighbours in key order (a third body of their common cell between them) merges in the
-// reference when every body between them arrived later: the neighbours-only merge misses it.  fold = 1 replays it like every
-// other cluster (3c); fold = 0 lives with it (its own tolerance class).
+// fold = 1 replays whole clusters through a grid of cells (3c) and refuses what it cannot reproduce.
 #include <cstdlib>
 
 #include "bh_build_internal.h"
 
 namespace nbx {
 
-// ---- 3b. the reference's EPS merge, for pairs ----------------------------------------------------------------------------
-// nbody.rs:249-260: a body B arriving at a non-empty exterior node merges into it when the node's content A is closer than
-// EPS in both axes.  B arrives at A's leaf iff that leaf -- one level below the deepest cell A shares with any body inserted
-// BEFORE B -- still contains B, i.e. iff no earlier body C shares at least as many leading digits with A as B does:
-//     merge(A, B)  <=>  |dx| < EPS and |dy| < EPS  and  there is no C with idx(C) < idx(B), C != A, common(A, C) >= common(A, B)
-// (A = the earlier of the two).  Candidates for C are contiguous around the pair in the sorted order (everything sharing
-// >= common(A, B) digits with A), so the test is a short outward scan from the pair.
-// The unit of all this is an ENTITY: a maximal run of bodies with identical keys (one level-31 cell: they always end up in one
-// leaf, in index order thanks to the stable sort) -- usually a single body.  close[j] = 1 marks a boundary j between two
-// different entities (the one ending at j-1 and the one starting at j) that the reference merges.
-constexpr int kMergeScanCap = 4096;   // per side; undecided after that many neighbours -> merge (needs an early, crowded pair)
-constexpr int kRunCap = 4096;         // longest identical-key run walked back to its start (longer: treated as starting there)
+// ---- 3b. the reference's EPS merge, exact-sum class: chains of close bodies replayed in arrival order (round 6) ------------
+// nbody.rs:249-260: a body B arriving at a non-empty exterior node merges into it when the node's content -- a body, or the
+// running centre of the bodies merged there so far -- is closer than EPS in both axes; otherwise the node splits until the two
+// part ways (the blob travels by its CENTRE, :271-281).  B arrives at the leaf of an earlier entity X iff X is the ONE earlier
+// entity whose path shares the most leading digits with B's: a tie means B's cell below their common node is still empty.
+//     merge(X, B)  <=>  X = the unique argmax of common(path(X's centre now), key(B)) over the entities that arrived before B
+//                       and  |dx| < EPS and |dy| < EPS against X's centre
+// Rounds 2-5 decided that for PAIRS of sorted neighbours and left longer chains alone (counted; beyond max(16, n/2000) bodies the
+// step went to the host build: every few steps of a collapsing system from 1.5 M bodies on, 50-85 ms each).  Now every CHAIN is
+// replayed:
+//   k_chain_links   boundary b (between sorted bodies b-1 and b) is linked when some pair (j, t), j < b <= t <= j + 3, lies within
+//                   2 EPS in both axes -- sorted neighbours that could meet in one leaf, with up to two strangers between them in
+//                   key order.  (2 EPS, three ahead: measured on chains of 2-6 bodies in random arrival order and on the 2 M-body
+//                   model of the benchmarks 5 to 40 steps into its collapse -- 1 EPS / neighbours only misses 2 % / 0.3 % of the
+//                   reference's blobs, this none of the injected ones and 10-65 of 40 000 in the collapsed model: pairs that are
+//                   close in space and far apart on the Z-curve.)  Bodies of one level-31 cell beyond kRunLink of them stay out
+//                   (they share a leaf anyway, any number of them).
+//   k_chain_heads   lists the bodies at which a maximal run of linked boundaries starts (a SEGMENT: at most 60 bodies -- a longer chain
+//                   is cut at multiples of 32 that have 14 linked boundaries on either side)
+//   k_chain         one wave per segment, one lane per body: the wave replays the reference's insertion in arrival order: the live entities compare their
+//                   centre's path with the newcomer's key (the deepest of them: five ballots),
+//                   the unique winner tests EPS against its centre, and nobody OUTSIDE the segment who arrived earlier may sit
+//                   at least as deep in the newcomer's path (64 sorted neighbours per probe, at most 256 on either side) --
+//                   then the winner folds the newcomer in (add_mass, f32) and re-derives its path.  Output: the segment's
+//                   bodies regrouped blob by blob, each blob in arrival order (what emit_node's leaf fold wants), every member
+//                   under ONE key -- the path of the blob's centre, where the reference files it -- written to a second set of
+//                   arrays (keys0 / idx0 / sb2) so that neighbouring waves' probes read the sort's own output; everybody else is
+//                   copied.
+// Same leaves, same node set as the host tree wherever a blob's bodies are that close on the Z-curve (tests: trees with injected
+// chains, the 2 M-body model before and during its collapse: chains of at most 36 bodies there).  What the replay only approximates
+// -- in a chain of more than 60 the blobs that end at a cut which a pair within EPS spans (measured: forces up to 1.7e-2 of max|F|
+// off the reference's tree on 777 bodies 0.26 EPS apart with masses over six decades), a merge behind a probe that hit its cap -- is
+// counted (counters[6]) and counts as left behind like the chains of rounds 2-5 did: beyond max(16, n/2000) such bodies the step goes to the host build, so
+// the class's bounds hold for every tree it serves.  counters[7]: the bodies merged.
+constexpr int kRunLink = 8;          // bodies of one level-31 cell that still take part in a replay as individuals
+constexpr int kLinkLook = 3;         // a body links boundaries up to this many sorted places ahead
+constexpr float kLinkEps = 2.0e-4f;  // 2 EPS
+constexpr float kTightEps = 1.0001e-4f;   // EPS, and a rounding of the difference (the merge test itself is exact, in k_chain)
+constexpr int kCutEvery = 32, kCutSpan = 14;   // segments stay <= 2 * kCutSpan + kCutEvery = 60 bodies
+constexpr int kRivalProbes = 4;      // 64 neighbours each, per side
+constexpr int kTallySlots = 256;     // slots the replay's tallies are spread over (2 words each: approximate, merged),
+constexpr int kTallyStride = 16;     // 64 bytes apart (kTallySlots * kTallyStride = kGhostCap words: the other class's list)
+static_assert(kTallySlots * kTallyStride <= kGhostCap, "the tallies live in the ghost list");
 
-__device__ __forceinline__ int run_start(const unsigned long long* __restrict__ keys, const int j)
+__device__ __forceinline__ bool in_long_run(const unsigned long long* __restrict__ keys, const int j, const int n)
 {
     const unsigned long long k = keys[j];
-    int r = j;
-    for (int t = 0; r > 0 && t < kRunCap && keys[r - 1] == k; t++) r--;
-    return r;
+    const bool l = j > 0 && keys[j - 1] == k, r = j + 1 < n && keys[j + 1] == k;
+    if (!l && !r) return false;
+    int len = 1;
+    for (int t = j - 1; t >= 0 && len <= kRunLink && keys[t] == k; t--) len++;
+    for (int t = j + 1; t < n && len <= kRunLink && keys[t] == k; t++) len++;
+    return len > kRunLink;
 }
 
 // Also gathers the bodies into sorted order (sb[j] = posm[idx[j]]: round 2 had a kernel of its own for that) -- unless the sort
-// delivered them already (sb_ready: the warm sort carries the records along, bh_sort.hip; the two gathers here fetched 239 MB for
-// 32 MB of records at a million bodies, a 128-byte line per 16-byte record, and made this kernel the build's most HBM-bound).
-__device__ __forceinline__ void merge_links_body(const int j, const float4* __restrict__ posm, float4* __restrict__ sb,
-                                                 const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
-                                                 const int n, unsigned char* __restrict__ close, int* __restrict__ crowded,
-                                                 const bool sb_ready)
+// delivered them already (sb_ready: the warm sort carries the records along, bh_sort.hip; the two gathers of round 4 fetched
+// 239 MB for 32 MB of records at a million bodies, a 128-byte line per 16-byte record).  The neighbours' records come out of LDS.
+__global__ __launch_bounds__(kTile) void k_chain_links(const float4* __restrict__ posm, float4* __restrict__ sb,
+                                                       const unsigned long long* __restrict__ keys,
+                                                       const unsigned* __restrict__ idx, const int n,
+                                                       unsigned char* __restrict__ link, int* __restrict__ crowded, const int sb_ready,
+                                                       unsigned long long* __restrict__ out_keys, unsigned* __restrict__ out_idx,
+                                                       float4* __restrict__ out_sb)
 {
-    const float4 b = sb_ready ? sb[j] : posm[idx[j]];
-    if (!sb_ready) sb[j] = b;
+    __shared__ float2 tile[kTile + 2 * kLinkLook];
+    const int j0 = blockIdx.x * kTile - kLinkLook;
+    for (int t = threadIdx.x; t < kTile + 2 * kLinkLook; t += kTile) {
+        const int j = j0 + t;
+        float4 b = make_float4(3.0e38f, 3.0e38f, 0.0f, 0.0f);    // (outside the array: close to nobody)
+        if (j >= 0 && j < n) {
+            const unsigned i = idx[j];
+            b = sb_ready ? sb[j] : posm[i];
+            if (t >= kLinkLook && t < kTile + kLinkLook) {
+                // everybody as the sort left them, into the arrays the scans and k_emit read: k_chain rewrites the segments it replays
+                // (this kernel has the records in hand; as k_chain's own first act the copy ran at 1 TB/s, half-empty waves of 32)
+                if (!sb_ready) sb[j] = b;
+                out_keys[j] = keys[j]; out_idx[j] = i; out_sb[j] = b;
+            }
+        }
+        tile[t] = make_float2(b.x, b.y);
+    }
+    __syncthreads();
+    const int j = blockIdx.x * kTile + threadIdx.x;          // boundary j: between bodies j - 1 and j
+    if (j >= n) return;
+    const int c = threadIdx.x + kLinkLook;                   // body j in the tile
+    bool covered = false, tight = false;
+#pragma unroll
+    for (int u = 1; u <= kLinkLook; u++)                     // left end j - u, right ends j .. j - u + kLinkLook
+#pragma unroll
+        for (int v = 0; v + u <= kLinkLook; v++) {
+            const float2 p = tile[c - u], q = tile[c + v];
+            const float dx = fabsf(p.x - q.x), dy = fabsf(p.y - q.y);
+            covered |= dx < kLinkEps && dy < kLinkEps;
+            tight |= dx < kTightEps && dy < kTightEps;
+        }
+    // bit 0: linked; bit 1: a pair within EPS spans this boundary -- a segment without one cannot merge anybody (the first merge of a
+    // replay is between two BODIES) and is not replayed: two thirds of the segments of the collapsing 1 M-body model
     unsigned char out = 0;
-    if (j + 1 < n && keys[j + 1] == keys[j] && !(j > 0 && keys[j - 1] == keys[j])) {
-        // The first of several bodies of one level-31 cell: one leaf as long as every arrival is within EPS of the centre the
+    if (j > 0 && covered && !in_long_run(keys, j - 1, n) && !in_long_run(keys, j, n)) out = tight ? 3 : 1;
+    link[j] = out;
+    if (j + 1 < n && keys[j + 1] == keys[j] && !(j > 0 && keys[j - 1] == keys[j]) && in_long_run(keys, j, n)) {
+        // The first of MANY bodies of one level-31 cell: one leaf as long as every arrival is within EPS of the centre the
         // earlier ones have folded to.  Where an ulp of the coordinates is no longer small against EPS (|x| in the thousands) the
         // folded centre of even identical positions can sit more than EPS away (nbody.rs:315-317 round three times) and the
-        // reference splits: such bodies are counted as left behind.
+        // reference splits: such bodies are counted as left behind (counters[1]; shorter runs are replayed body by body).
         float cx = 0.0f, cy = 0.0f, cm = 0.0f;
         int left = 0;
         for (int t = j; t < n && keys[t] == keys[j]; t++) {        // (the stable sort left them in index order)
@@ -94,69 +162,253 @@ __device__ __forceinline__ void merge_links_body(const int j, const float4* __re
         }
         if (left) atomicAdd(crowded, left);
     }
-    if (j > 0 && keys[j - 1] != keys[j]) {
-        // the entity's position is its first arrival's (later arrivals of the same cell are < 5e-8 of the box away)
-        const int r = run_start(keys, j - 1);
-        const float4 a = sb_ready ? sb[r] : posm[idx[r]];
-        if (fabsf(__fsub_rn(a.x, b.x)) < kEps && fabsf(__fsub_rn(a.y, b.y)) < kEps) {   // nbody.rs:249
-            const int c = common_digits(keys[j - 1], keys[j]);
-            const unsigned ia = idx[r], ib = idx[j];           // first arrival of either entity (stable sort: run start)
-            const unsigned second = ia > ib ? ia : ib;
-            const unsigned long long kf = ia < ib ? keys[j - 1] : keys[j];   // the earlier entity's path
-            bool earlier_rival = false;
-            for (int x = r - 1, t = 0; x >= 0 && t < kMergeScanCap && !earlier_rival; x--, t++) {
-                if (common_digits(kf, keys[x]) < c) break;
-                earlier_rival = idx[x] < second;
-            }
-            const unsigned long long kj = keys[j];
-            for (int x = j + 1, t = 0; x < n && t < kMergeScanCap && !earlier_rival; x++, t++) {
-                if (keys[x] == kj) continue;                   // the right entity's own later arrivals
-                if (common_digits(kf, keys[x]) < c) break;
-                earlier_rival = idx[x] < second;
-            }
-            out = earlier_rival ? 0 : 1;
+}
+
+// is boundary b (between sorted bodies b - 1 and b) linked, cuts of long chains taken out.  The 14 links on either side of a multiple
+// of 32 are two aligned 16-byte loads (link[] holds 0 / 1 and is 256-byte aligned): as 28 dependent byte loads this test WAS the two
+// kernels below wherever the system is dense.
+__device__ __forceinline__ bool chain_linked(const unsigned char* __restrict__ link, const int b, const int n)
+{
+    if (b <= 0 || b >= n || !(link[b] & 1)) return false;
+    if (b % kCutEvery != 0 || b - kCutSpan < 1 || b + kCutSpan > n - 1) return true;
+    static_assert(kCutEvery % 16 == 0 && kCutSpan == 14, "the two loads below cover link[b - 16 .. b + 15]");
+    uint4 lo = *reinterpret_cast<const uint4*>(link + b - 16);   // (b + 15 <= n: the array is padded, carve)
+    uint4 hi = *reinterpret_cast<const uint4*>(link + b);
+    lo.x &= 0x01010101u; lo.y &= 0x01010101u; lo.z &= 0x01010101u; lo.w &= 0x01010101u;   // (bit 0 of every byte: linked)
+    hi.x &= 0x01010101u; hi.y &= 0x01010101u; hi.z &= 0x01010101u; hi.w &= 0x01010101u;
+    const bool all = (lo.x & 0xFFFF0000u) == 0x01010000u && lo.y == 0x01010101u && lo.z == 0x01010101u && lo.w == 0x01010101u &&
+                     (hi.x & 0xFFFFFF00u) == 0x01010100u && hi.y == 0x01010101u && hi.z == 0x01010101u && (hi.w & 0x00FFFFFFu) == 0x00010101u;
+    return !all;   // deep inside a long chain: cut here
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
+    return v;
+}
+// lane `src`'s value, src the same in every lane (a ballot's first bit, a loop counter): v_readlane, a few cycles -- __shfl goes
+// through the LDS crossbar (ds_bpermute) whatever the index is, and the replay's serial loop is made of these
+__device__ __forceinline__ int bcast_i32(const int v, const int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ unsigned bcast_u32(const unsigned v, const int src) { return (unsigned)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ float bcast_f32(const float v, const int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ unsigned long long shfl_u64(const unsigned long long v, const int src)
+{
+    const unsigned lo = bcast_u32((unsigned)v, src), hi = bcast_u32((unsigned)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// earlier arrivals OUTSIDE the segment [p0, p0 + t) that sit at least `depth` digits deep in the path kb: 1 = there is one,
+// 0 = none, -1 = none among the neighbours probed but the probes ran out (counted as approximate by the caller).  The first 64
+// neighbours on either side are in registers (nk / ni: lane l holds the l-th neighbour to the left and to the right, loaded once
+// per segment -- a probe from memory inside the replay's serial loop made one long segment the kernel's duration: 56 us at a
+// million bodies for 4 500 merges); only a cell more crowded than that goes back to memory.
+struct ChainNeighbours {
+    unsigned long long kl, kr;
+    unsigned il, ir;      // 0xFFFFFFFF: outside the array
+};
+__device__ __forceinline__ int chain_rival(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx, const int n,
+                                           const int p0, const int t, const unsigned long long kb, const unsigned ib, const int depth,
+                                           const int lane, const ChainNeighbours nb)
+{
+    const bool deep_l = nb.il != 0xFFFFFFFFu && common_digits(nb.kl, kb) >= depth;
+    const bool deep_r = nb.ir != 0xFFFFFFFFu && common_digits(nb.kr, kb) >= depth;
+    if (__ballot((deep_l && nb.il < ib) || (deep_r && nb.ir < ib)) != 0ull) return 1;
+    int out = 0;
+    for (int side = 0; side < 2; side++) {
+        if (__ballot(side == 0 ? deep_l : deep_r) != ~0ull) continue;   // the end of that cell (or of the array) was in sight
+        for (int probe = 1; probe < kRivalProbes; probe++) {
+            const int q = side == 0 ? p0 - 1 - probe * 64 - lane : p0 + t + probe * 64 + lane;
+            const bool in = q >= 0 && q < n;
+            const bool deep = in && common_digits(keys[in ? q : 0], kb) >= depth;
+            const bool rival = deep && idx[q] < ib;
+            if (__ballot(rival) != 0ull) return 1;
+            if (__ballot(deep) != ~0ull) break;
+            if (probe == kRivalProbes - 1) out = -1;
         }
     }
-    close[j] = out;
+    return out;
 }
 
-__global__ __launch_bounds__(kTile) void k_merge_links(const float4* __restrict__ posm, float4* __restrict__ sb,
-                                                       const unsigned long long* __restrict__ keys,
-                                                       const unsigned* __restrict__ idx, const int n,
-                                                       unsigned char* __restrict__ close, int* __restrict__ crowded, const int sb_ready)
+// the bodies that start a segment, in any order (head_list; their number in *head_count).  One atomic per 1 024 bodies: one per wave
+// -- 16 384 on one address at a million bodies once the system is dense -- took 6 .. 90 us.
+constexpr int kHeadsBlock = 1024;
+__global__ __launch_bounds__(kHeadsBlock) void k_chain_heads(const unsigned char* __restrict__ link, const int n, int* __restrict__ head_list,
+                                                             int* __restrict__ head_count, int* __restrict__ tally)
 {
-    const int j = blockIdx.x * kTile + threadIdx.x;
-    if (j < n) merge_links_body(j, posm, sb, keys, idx, n, close, crowded, sb_ready != 0);
-}
-
-// Pairs of entities only: of a chain of close boundaries every other one is dropped by the local rule "a boundary merges iff
-// the boundary at the start of its left entity does not" (deterministic, no scan, merges stay disjoint).  All members of a
-// merged pair of entities take the key of the entity that arrived first; the array stays sorted (the new key lies between the
-// old ones).  Bodies left behind by the rule -- third and later entities of a chain, where the reference would have grown a
-// bigger blob -- are counted in *crowded.
-__device__ __forceinline__ void merge_keys_body(const int j, const unsigned long long* __restrict__ keys,
-                                                const unsigned* __restrict__ idx, const unsigned char* __restrict__ close,
-                                                const int n, unsigned long long* __restrict__ out, int* __restrict__ crowded)
-{
-    const int r = run_start(keys, j);             // this body's entity is [r, e)
-    const int e = run_end(keys, j, n);
-    unsigned long long k = keys[j];
-    if (r > 0 && close[r]) {
-        const int rl = run_start(keys, r - 1);    // left neighbour entity [rl, r)
-        if (!(rl > 0 && close[rl])) k = idx[rl] < idx[r] ? keys[rl] : keys[r];   // merges with it
-        else atomicAdd(crowded, 1);               // its left neighbour is already taken
-    } else if (e < n && close[e]) {
-        k = idx[r] < idx[e] ? keys[r] : keys[e];  // the entity starting at e merges with this one (close[r] is 0 here)
+    __shared__ int wave_base[kHeadsBlock / 64 + 1];
+    if (blockIdx.x == 0 && threadIdx.x < kTallySlots) { tally[kTallyStride * threadIdx.x] = 0; tally[kTallyStride * threadIdx.x + 1] = 0; }   // (k_chain's, launched behind this kernel)
+    const int p = blockIdx.x * kHeadsBlock + threadIdx.x;
+    const bool head = p < n && !chain_linked(link, p, n) && chain_linked(link, p + 1, n);
+    const unsigned long long hm = __ballot(head);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_base[wave + 1] = __popcll(hm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int w = 0; w < kHeadsBlock / 64; w++) { const int c = wave_base[w + 1]; wave_base[w + 1] = total; total += c; }
+        wave_base[0] = total ? atomicAdd(head_count, total) : 0;
     }
-    out[j] = k;
+    __syncthreads();
+    if (head) head_list[wave_base[0] + wave_base[wave + 1] + __popcll(hm & ((1ull << lane) - 1ull))] = p;
 }
 
-__global__ __launch_bounds__(kTile) void k_merge_keys(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
-                                                      const unsigned char* __restrict__ close, const int n,
-                                                      unsigned long long* __restrict__ out, int* __restrict__ crowded)
+// One wave per segment, taken off the list in strides of the grid (a wave per 32 sorted places that replayed the segments starting there
+// one after the other took 49-56 us at a million bodies for 2 000 segments: they sit side by side in the sorted order wherever the system
+// is dense, so a few waves did most of them).
+__global__ __launch_bounds__(64) void k_chain(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
+                                              const float4* __restrict__ sb, const unsigned char* __restrict__ link, const int n,
+                                              const unsigned* __restrict__ box, unsigned long long* __restrict__ out_keys,
+                                              unsigned* __restrict__ out_idx, float4* __restrict__ out_sb, int* __restrict__ counters,
+                                              const int* __restrict__ head_list, const int* __restrict__ head_count, int* __restrict__ tally)
 {
-    const int j = blockIdx.x * kTile + threadIdx.x;
-    if (j < n) merge_keys_body(j, keys, idx, close, n, out, crowded);
+    const int lane = threadIdx.x;
+    const int count = *head_count;
+    int merged_total = 0, approx_total = 0;
+    for (int h = blockIdx.x; h < count; h += (int)gridDim.x) {
+        const int p0 = head_list[h];
+        // the segment: lanes 0 .. t - 1 <-> sorted bodies p0 .. p0 + t - 1
+        const unsigned long long lw = __ballot(lane >= 1 && chain_linked(link, p0 + lane, n)) | 1ull;
+        const int t = ~lw == 0ull ? 64 : __builtin_ctzll(~lw);               // (<= 60 by the cut rule)
+        if (__ballot(lane >= 1 && lane < t && (link[p0 + lane] & 2)) == 0ull) continue;   // nobody within EPS of anybody: as copied
+        const bool member = lane < t;
+        const int p = member ? p0 + lane : p0;
+        const unsigned long long key = keys[p];
+        const unsigned my_idx = idx[p];
+        const float4 rec = sb[p];
+        ChainNeighbours nb;                                  // the 64 sorted neighbours on either side of the segment
+        {
+            const int ql = p0 - 1 - lane, qr = p0 + t + lane;
+            nb.kl = ql >= 0 ? keys[ql] : 0ull; nb.il = ql >= 0 ? idx[ql] : 0xFFFFFFFFu;
+            nb.kr = qr < n ? keys[qr] : 0ull; nb.ir = qr < n ? idx[qr] : 0xFFFFFFFFu;
+        }
+        bool live = false;
+        int blob = lane;                                     // the lane that heads my blob
+        float cx = rec.x, cy = rec.y, cm = rec.w;            // (head lanes) the blob's running centre and mass, nbody.rs:303-320
+        unsigned long long rep = key;                        // (head lanes) the path of that centre
+        // The cell all members share (their keys' common digits: the first and the last suffice, the keys are sorted), replayed once:
+        // a blob's centre lies in it, so its path is these digits + the rest of the descent -- a third of path_key's 31 levels
+        const unsigned long long k_first = shfl_u64(key, 0), k_last = shfl_u64(key, t - 1);
+        const int d0 = common_digits(k_first, k_last);
+        float bx1 = dec_f32(box[0]), by1 = dec_f32(box[1]), bx2 = dec_f32(box[2]), by2 = dec_f32(box[3]);
+#pragma unroll 1
+        for (int l = 0; l < d0; l++) descend_digit(bx1, by1, bx2, by2, (int)((k_first >> (2 * (kLevels - 1 - l))) & 3ull));
+        // arrival order: a body's place among the segment's indices (one pass of broadcasts; a wave minimum per step -- six dependent
+        // cross-lane exchanges -- was a third of the loop)
+        int place = 0;
+        for (int l = 0; l < t; l++) place += (bcast_u32(my_idx, l) < my_idx) ? 1 : 0;
+        // (exact: is the path in `rep` the centre's own down to level 31?  Inside the loop a path is only followed until it has parted
+        //  from the keys of everybody still to come -- all that common(rep, key of an arrival) can ever see, a third of the levels;
+        //  the blobs' full paths, which file them in the tree, are made once after the loop, all of them side by side)
+        bool exact = true;
+        for (int step = 0; step < t; step++) {
+            const int j = __builtin_ctzll(__ballot(member && place == step));
+            const float xb = bcast_f32(rec.x, j), yb = bcast_f32(rec.y, j);
+            // nbody.rs:249 against every live entity's centre: nobody that close -> a new entity, whatever leaf it arrives at
+            const bool close = live && fabsf(__fsub_rn(cx, xb)) < kEps && fabsf(__fsub_rn(cy, yb)) < kEps;
+            const unsigned long long closem = __ballot(close);
+            bool merged = false;
+            if (closem) {
+                const unsigned ib = bcast_u32(my_idx, j);
+                const unsigned long long kb = shfl_u64(key, j);
+                const int c = live ? common_digits(rep, kb) : -1;
+                // the live entities deepest in the newcomer's path: the maximum of c (0 .. 31) bit by bit, five ballots
+                unsigned long long who = __ballot(live);
+                int cmax = 0;
+#pragma unroll
+                for (int bit = 4; bit >= 0; bit--) {
+                    const unsigned long long m = __ballot(live && ((c >> bit) & 1)) & who;
+                    if (m) { who = m; cmax |= 1 << bit; }
+                }
+                // the one entity whose leaf the newcomer arrives at, if there is one, and if it is close
+                const int rival = __popcll(who) == 1 && (who & closem) ? chain_rival(keys, idx, n, p0, t, kb, ib, cmax, lane, nb) : 1;
+                if (rival <= 0) {
+                    if (rival < 0) approx_total++;
+                    const int x = __builtin_ctzll(who);
+                    const float mb = bcast_f32(rec.w, j);
+                    if (lane == x) { fold_mass(cx, cy, cm, xb, yb, mb); exact = false; }
+                    if (lane == j) blob = x;
+                    merged = true;
+                    merged_total++;
+                    // the new centre's path from the segment's common cell down, every lane alongside: lane l holds it against its own
+                    // key while its body is still to come (place > step), and the descent ends when nobody does any more
+                    const float ncx = bcast_f32(cx, x), ncy = bcast_f32(cy, x);
+                    unsigned long long kc;
+                    if (d0 < kLevels && ncx >= bx1 && ncx < bx2 && ncy >= by1 && ncy < by2) {   // (half-open like quadrant_from_point)
+                        float x1 = bx1, y1 = by1, x2 = bx2, y2 = by2;
+                        kc = d0 ? k_first >> (2 * (kLevels - d0)) : 0ull;
+                        bool follows = member && place > step;
+                        int l = d0;
+#pragma unroll 1
+                        for (; l < kLevels && __ballot(follows) != 0ull; l++) {
+                            const int q = descend(x1, y1, x2, y2, ncx, ncy);
+                            kc = (kc << 2) | (unsigned long long)q;
+                            follows = follows && (int)((key >> (2 * (kLevels - 1 - l))) & 3ull) == q;
+                        }
+                        kc <<= 2 * (kLevels - l);
+                    } else {
+                        kc = path_key(box, ncx, ncy);   // (a centre rounded out of the common cell, or one level-31 cell: from the root)
+                    }
+                    if (lane == x) rep = kc;
+                }
+            }
+            if (lane == j) live = !merged;
+        }
+        // A piece of a longer chain: the blob at a cut that a pair within EPS spans may be one of the reference's cut in two -- its bodies
+        // count as approximate (and, through counters[6], as left behind: beyond the class's limit the step goes to the host build)
+        if (p0 > 0 && (link[p0] & 2)) approx_total += __popcll(__ballot(member && blob == bcast_i32(blob, 0)));
+        if (p0 + t < n && (link[p0 + t] & 2)) approx_total += __popcll(__ballot(member && blob == bcast_i32(blob, t - 1)));
+        // the blobs' exact paths (heads whose centre moved), side by side
+        {
+            const bool redo = member && live && !exact;
+            if (__ballot(redo)) {
+                const bool inside = redo && d0 < kLevels && cx >= bx1 && cx < bx2 && cy >= by1 && cy < by2;
+                if (__ballot(redo && !inside)) {
+                    if (redo) rep = path_key(box, cx, cy);
+                } else if (redo) {
+                    float x1 = bx1, y1 = by1, x2 = bx2, y2 = by2;
+                    unsigned long long kc = d0 ? k_first >> (2 * (kLevels - d0)) : 0ull;
+#pragma unroll 1
+                    for (int l = d0; l < kLevels; l++) kc = (kc << 2) | (unsigned long long)descend(x1, y1, x2, y2, cx, cy);
+                    rep = kc;
+                }
+            }
+        }
+        // One key per blob: the path of its CENTRE -- the reference files a blob where its centre is (nbody.rs:271-281); every centre
+        // since the blob's last split lies in its leaf's cell, so the last one's path is as good as any -- unless that path lies
+        // outside the segment's place in the sorted order (the centre has left the cells of all members, and their neighbours'):
+        // then the member's whose path follows the centre's deepest (first of them in key order).
+        const unsigned long long k_prev = p0 > 0 ? keys[p0 - 1] : 0ull, k_next = p0 + t < n ? keys[p0 + t] : ~0ull;
+        unsigned long long out_key = key;
+        unsigned long long multi = __ballot(member && blob != lane);
+        while (multi) {
+            const int x = bcast_i32(blob, __builtin_ctzll(multi));
+            const bool mine = member && blob == x;
+            multi &= ~__ballot(mine);
+            const unsigned long long rx = shfl_u64(rep, x);
+            unsigned long long k = rx;
+            if (!((p0 == 0 || k_prev < rx) && (p0 + t >= n || rx < k_next))) {
+                const int c = mine ? common_digits(rx, key) : -1;
+                const int best = wave_max_i32(c);
+                k = shfl_u64(key, __builtin_ctzll(__ballot(mine && c == best)));
+            }
+            if (mine) out_key = k;
+        }
+        // blobs in key order, a blob's bodies in arrival order
+        int rank = 0;
+        for (int l = 0; l < t; l++) {
+            const unsigned long long ko = shfl_u64(out_key, l);
+            const unsigned io = bcast_u32(my_idx, l);
+            rank += (ko < out_key || (ko == out_key && io < my_idx)) ? 1 : 0;
+        }
+        if (member) { out_keys[p0 + rank] = out_key; out_idx[p0 + rank] = my_idx; out_sb[p0 + rank] = rec; }
+    }
+    // the tallies: over kTallySlots words each, summed into counters[6] / [7] by k_scan_write's last workgroup -- as one atomic per wave on
+    // ONE word they were this kernel: 37 us for 2 600 of them at a million bodies (6 700 replay steps in all), 100 us for 8 000
+    if (lane == 0) {
+        if (merged_total) atomicAdd(&tally[(blockIdx.x % kTallySlots) * kTallyStride + 1], merged_total);
+        if (approx_total) atomicAdd(&tally[(blockIdx.x % kTallySlots) * kTallyStride], approx_total);
+    }
 }
 
 __device__ __forceinline__ ScanItem scan_item(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
@@ -259,8 +511,23 @@ __device__ __forceinline__ void scan_blocks(ScanItem* __restrict__ block_sums, c
 
 __global__ __launch_bounds__(kTile) void k_scan_write(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
                                                       const int n, const ScanItem* __restrict__ block_sums, Prefix p,
-                                                      int* __restrict__ counters)
+                                                      int* __restrict__ counters, const int* __restrict__ tally)
 {
+    if (tally && blockIdx.x == gridDim.x - 1) {   // the chain replay's tallies (k_chain), one slot per thread -> counters[6], [7]
+        static_assert(kTallySlots == kTile, "one slot per thread");
+        __shared__ int tsum[2][kTile / 64];
+        int a = tally[kTallyStride * threadIdx.x], m = tally[kTallyStride * threadIdx.x + 1];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); m += __shfl_xor(m, off); }
+        if ((threadIdx.x & 63) == 0) { tsum[0][threadIdx.x >> 6] = a; tsum[1][threadIdx.x >> 6] = m; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int ta = 0, tm = 0;
+            for (int w = 0; w < kTile / 64; w++) { ta += tsum[0][w]; tm += tsum[1][w]; }
+            counters[6] = ta; counters[7] = tm;
+            if (ta) atomicAdd(&counters[1], ta);   // what the replay only approximated counts as left behind: beyond the class's limit -> host build
+        }
+    }
     const int j0 = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
     ScanItem it[kScanPerThread];
     ScanItem s{0.0, 0.0, 0.0, 0, 0};
@@ -543,15 +810,23 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     const unsigned* mi = k.idx1;
     const float4* ms = k.sb;
     const unsigned char* pmin = nullptr;
+    const int* tally = nullptr;
     if (fold == 1) {
         // blobs of any size, replayed (3c): the tree is then the reference's, node for node -- or the step is refused
         if ((e = launch_cluster_replay(posm, n, k, stream, sb_ready)) != hipSuccess) return e;
         mi = k.idx0; ms = k.sb2; pmin = k.pmin2;
     } else {
-        // pairs of neighbouring entities only (3b): links from the sorted keys + arrival order (this kernel also gathers the
-        // bodies into sorted order), then both members of a pair share one key
-        hipLaunchKernelGGL(k_merge_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link, k.counters + 1, sb_ready ? 1 : 0);
-        hipLaunchKernelGGL(k_merge_keys, dim3(nb), dim3(kTile), 0, stream, k.keys1, k.idx1, k.link, n, k.keys0, k.counters + 1);
+        // chains of close bodies replayed in arrival order (3b): links from the sorted bodies (this kernel also gathers them into
+        // sorted order), then one wave per 32 sorted places regroups what the reference merges
+        hipLaunchKernelGGL(k_chain_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link, k.counters + 1, sb_ready ? 1 : 0,
+                           k.keys0, k.idx0, k.sb2);
+        int* const head_list = reinterpret_cast<int*>(k.big);          // (k_fold_big's queue: the other class's)
+        hipLaunchKernelGGL(k_chain_heads, dim3((unsigned)((n + kHeadsBlock - 1) / kHeadsBlock)), dim3(kHeadsBlock), 0, stream, k.link, n, head_list, k.counters + 4, k.ghosts);
+        const int waves = n / 128 < 64 ? 64 : (n / 128 > 16384 ? 16384 : n / 128);
+        hipLaunchKernelGGL(k_chain, dim3((unsigned)waves), dim3(64), 0, stream, k.keys1, k.idx1, k.sb, k.link, n, k.box, k.keys0, k.idx0, k.sb2,
+                           k.counters, head_list, k.counters + 4, k.ghosts);
+        tally = k.ghosts;
+        mi = k.idx0; ms = k.sb2;
     }
     // (for small systems the pair merge and the scan were tried as phases of ONE 1024-thread workgroup: 90 us against 22 for the
     //  four launches at 10 000 bodies -- per-body work here is chains of dependent loads that miss the L2 after every kernel
@@ -562,7 +837,7 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
     } else {
         hipLaunchKernelGGL(k_scan_reduce, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.counters + 3, k.pre.cnt);
     }
-    hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.pre, k.counters);
+    hipLaunchKernelGGL(k_scan_write, dim3(sb), dim3(kTile), 0, stream, ms, mk, n, k.block_sums, k.pre, k.counters, tally);
     // one thread per node; the node count is only known on the device, so the grid covers the whole pool (threads beyond
     // base[n] leave at once; the pool check is inside)
     const int eb = n <= 65536 ? 64 : kTile;   // spread a small system's few waves over the CUs

@@ -276,7 +276,7 @@ inline Workspace carve(void* workspace, int n, size_t sort_tmp, int node_cap)
     k.pre.owner = reinterpret_cast<int*>(take(sizeof(int) * (size_t)node_cap));
     k.pre.owner_cap = node_cap;
     k.block_sums = reinterpret_cast<ScanItem*>(take(sizeof(ScanItem) * (nb + 1)));
-    k.link = reinterpret_cast<unsigned char*>(take((size_t)n));
+    k.link = reinterpret_cast<unsigned char*>(take((size_t)n + 16));   // (+ 16: chain_linked reads 16 bytes at a time, bh_build.hip)
     k.big = reinterpret_cast<int4*>(take(sizeof(int4) * (size_t)n));
     k.sb2 = reinterpret_cast<float4*>(take(sizeof(float4) * (size_t)n));
     k.ekey = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * (size_t)n));

@@ -121,7 +121,7 @@ size_t device_tree_workspace_bytes(int n, int node_cap, size_t* sort_tmp_bytes)
     add((size_t)n);                                    // nodes starting at every body (cache between the two scan kernels)
     add(sizeof(int) * (size_t)node_cap);               // owner body of every node slot
     add(sizeof(ScanItem) * (nb + 1));                  // block sums
-    add((size_t)n);                                    // EPS-merge links / pmin
+    add((size_t)n + 16);                               // EPS-merge links / pmin
     add(sizeof(int4) * (size_t)n);                     // nodes queued for k_fold_big (more than n of them -> host build)
     // reference fold: the EPS blobs (k_cells / k_blobs / k_place)
     add(sizeof(float4) * (size_t)n);                   // bodies in entity order

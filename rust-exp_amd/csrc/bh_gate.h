@@ -21,6 +21,7 @@ __device__ __forceinline__ bool gate_open(const BuildGate g, int& n_nodes, const
     if (mark && g.host_out) {
         g.host_out[0] = g.counters[0]; g.host_out[1] = g.counters[1]; g.host_out[2] = g.counters[2];
         g.host_out[5] = g.counters[5];   // why the build refused, if it did (bh_build.hip kWhy..)
+        g.host_out[6] = g.counters[6]; g.host_out[7] = g.counters[7];   // the chain replay's tallies (bh_build.hip 3b)
         __threadfence_system();
     }
     if (g.counters[kTreePoisonWord] != 0) return false;

@@ -180,13 +180,16 @@ int64_t nbx_get_stat(const nbx_engine* e, int32_t stat)
 {
     if (!e) return INT64_MIN;
     if (e->any_pending() && (stat == NBX_STAT_BH_FALLBACKS || stat == NBX_STAT_BH_LAST_TREE || stat == NBX_STAT_BH_REFUSAL ||
-                             stat == NBX_STAT_BH_CLASS_SWITCHES || stat == NBX_STAT_BH_COLD_RESORTS)) {
+                             stat == NBX_STAT_BH_CLASS_SWITCHES || stat == NBX_STAT_BH_COLD_RESORTS || stat == NBX_STAT_BH_CHAIN_MERGED ||
+                             stat == NBX_STAT_BH_CHAIN_APPROX)) {
         // what the last step ran on is known once its build's verdict is read; a redo that fails leaves the counters stale
         if (resolve_pending(const_cast<nbx_engine*>(e)) != NBX_OK) return INT64_MIN;
     }
     switch (stat) {
         case NBX_STAT_BH_CLASS_SWITCHES: return e->bh_class_switches;
         case NBX_STAT_BH_COLD_RESORTS: return e->bh_cold_resorts;
+        case NBX_STAT_BH_CHAIN_MERGED: return e->bh_chain_merged;
+        case NBX_STAT_BH_CHAIN_APPROX: return e->bh_chain_approx;
         case NBX_STAT_BH_FALLBACKS: return e->bh_fallbacks;
         case NBX_STAT_BH_LAST_TREE: return e->bh_last_tree_device;
         case NBX_STAT_BH_REFUSAL: return e->bh_last_refusal;

@@ -239,6 +239,9 @@ int build_tree_on_device_end(nbx_engine* e, bool* done)
         return NBX_OK;   // caller takes the class below
     }
     e->note_accepted(fold);
+    e->note_chains(e->h_counters);
+    if (fold == 0 && std::getenv("NBX_LOG_CHAINS"))   // (waited-for builds only: the pipelined steps hand over fewer words)
+        std::fprintf(stderr, "[nbx] chain replay, %d bodies: %d segments listed, %d bodies merged, %d approximate\n", e->n, e->h_counters[4], e->h_counters[7], e->h_counters[6]);
     e->n_flat = (size_t)n_nodes;
     e->host_ms[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - e->tree_t0).count();
     e->host_steps++;
@@ -449,6 +452,7 @@ static int resolve_slot(nbx_engine* e, int slot)
     const int status = verdict_of(e, slot);
     if (status == 0) {
         e->note_accepted(p.fold);
+        e->note_chains(e->h_verdict[slot]);
         e->n_flat = (size_t)e->h_verdict[slot][0];
         e->bh_last_tree_device = 1;
         e->host_steps++;

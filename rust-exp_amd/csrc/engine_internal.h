@@ -154,6 +154,8 @@ struct nbx_engine {
     // (NBX_STAT_BH_COLD_RESORTS; round 6 -- rounds 5 sent the step to the host build), and the next 2, 4 .. 32 builds sort cold
     // too (a clump of coincident bodies stays one for many steps and would overflow every warm sort).
     int bh_cold_resorts = 0;
+    int bh_chain_merged = 0, bh_chain_approx = 0;   // NBX_STAT_BH_CHAIN_*: the chain replay's tallies of the last accepted exact-sum build
+    void note_chains(const int* c) { bh_chain_approx = c[6]; bh_chain_merged = c[7]; }
     int warm_holdoff = 0, warm_holdoff_next = 2;
     bool sort_overflowed() const { return bh_last_refusal != 0x10000 && (bh_last_refusal & nbx::kWhySortOverflow) != 0; }
     void note_refusal(int fold, int max_steps)

@@ -47,6 +47,8 @@ NBX_STAT_DRAW_AMBIGUOUS = 2
 NBX_STAT_BH_REFUSAL = 3
 NBX_STAT_BH_CLASS_SWITCHES = 4
 NBX_STAT_BH_COLD_RESORTS = 5
+NBX_STAT_BH_CHAIN_MERGED = 6
+NBX_STAT_BH_CHAIN_APPROX = 7
 
 NBX_GROUP_INFO_EXCHANGE = 0
 NBX_GROUP_INFO_RCCL_RANKS = 1

@@ -3,7 +3,7 @@
     python tests/fuzz_fast.py [first_seed] [count]
 Random sizes / scales / mass ranges / clumps as in fuzz_strict.py. Per case: everything finite; fast all-pairs forces
 within 5e-5 max|F| sqrt(N)/64 of the bit-exact kernel's; fast Barnes-Hut (host tree) within 1e-4 max|F| of the bit-exact walk;
-device-built tree (EPS merge of pairs reproduced; crowded systems fall back to the host build) vs host tree through the same
+device-built tree (EPS merge reproduced: pairs since round 2, chains of any length since round 6) vs host tree through the same
 walk: 99.9 % of the bodies within 2e-4 max|F| (4e-4 above 100 000 bodies: the reference's own f32 node folds drift by 2e-4 .. 3e-4 at 150 000 bodies --
 the device's sums are exact -- and a handful of opening decisions flip), everyone within 5e-3 max|F| (1e-2 at theta = 0.85: a
 flipped decision costs one node's approximation error, which grows with theta; seed 41296 reached 5.2e-3).
@@ -108,17 +108,9 @@ def main():
                 err = np.maximum(np.abs(dx_ - bfx), np.abs(dy_ - bfy)) / bsc
                 if not np.isfinite(dx_).all():
                     why.append("device tree not finite")
-                elif clumps:
-                    # the default is the exact-sum class (round 6: at every size; rounds 3-5: above 65 536 bodies): pairs only, up to max(16, n/2000) bodies of bigger
-                    # clusters left unmerged by contract -- they and their blob-mates (up to 7 each) then feel O(1) different
-                    # forces, more than the 0.1 % the percentile below allows.  Still quantitative: everybody else is
-                    # held to the unclustered bounds -- the 99th percentile instead of the 99.9th, and no more bodies beyond the
-                    # max-error bound than the contract's left-behind bodies and their mates
-                    allowed = 8 * max(16, n // 2000)
-                    beyond = int((err > (1e-2 if theta > 0.8 else 5e-3)).sum())
-                    if np.percentile(err, 99.0) > 4e-4 or beyond > allowed:
-                        why.append("device tree (clustered, exact sums) p99 %.2e, %d bodies beyond the max-error bound (%d allowed)"
-                                   % (np.percentile(err, 99.0), beyond, allowed))
+                # (round 6: chains of close bodies are replayed in arrival order by the exact-sum class too -- bh_build.hip 3b -- so systems
+                #  with injected clusters are held to the SAME bounds as everybody else; rounds 3-5 allowed them the 99th percentile and
+                #  8 * max(16, n/2000) bodies beyond the max-error bound: the bodies the pairs-only merge left behind and their mates)
                 elif np.percentile(err, 99.9) > (4e-4 if n > 100000 else 2e-4) or err.max() > (1e-2 if theta > 0.8 else 5e-3):
                     why.append("device tree p99.9 %.2e max %.2e" % (np.percentile(err, 99.9), err.max()))
                 from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_STAT_BH_LAST_TREE

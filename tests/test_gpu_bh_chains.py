@@ -1,0 +1,202 @@
+"""GPU: the exact-sum device build replays CHAINS of bodies within EPS in arrival order (bh_build.hip section 3b, round 6;
+VERDICT r05 #2).  nbody.rs:249-260: an arriving body merges into the leaf it arrives at when that leaf's content -- a body, or the
+running centre of the bodies merged there so far -- is closer than EPS in both axes; otherwise the leaf splits (:262-283) and the
+blob travels on by its centre.  Rounds 2-5 reproduced that for PAIRS of sorted neighbours and sent systems with more than
+max(16, n/2000) bodies in longer chains to the host build (every few steps of the collapsing 2 M-body model, 50-85 ms each).
+Now: same node set, same skip pointers, same node sizes and every leaf record -- merged blobs folded in arrival order -- equal to
+the host (= oracle) tree bit for bit wherever the merged bodies are near one another on the Z-curve; only chains of more than 60
+linked bodies (replayed in pieces, approximately) still count as left behind, and beyond max(16, n/2000) of them go to the host build."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(rx, p, fold="exact"):
+    e = rx.NBodyEngine()
+    e.set_bh_fold(fold)
+    e.set_particles(p["px"], p["py"], p["vx"], p["vy"], p["m"])
+    return e
+
+
+def _structure_equal(host, dev):
+    assert len(host) == len(dev), (len(host), len(dev))
+    assert np.array_equal(host["skip"], dev["skip"]) and np.array_equal(host["interior"], dev["interior"])
+    assert np.array_equal(host["s"].view(np.uint32), dev["s"].view(np.uint32))
+    leaf = host["interior"] == 0
+    for k in ("px", "py", "m"):
+        assert np.array_equal(host[k][leaf].view(np.uint32), dev[k][leaf].view(np.uint32)), k
+    return int(leaf.sum())
+
+
+def _leaf_set(t):
+    leaf = t[t["interior"] == 0]
+    a = np.ascontiguousarray(np.stack([leaf["px"], leaf["py"], leaf["m"]], 1).astype(np.float32))
+    return set(map(bytes, a.view(np.uint8).reshape(len(a), 12)))
+
+
+def _structure_close(host, dev, stray):
+    """Equal but for at most `stray` leaves of the host tree (blobs whose bodies are close in space and far apart on the Z-curve:
+    the replay works on sorted neighbours) -- each costs a few nodes around it."""
+    if len(host) == len(dev):
+        try:
+            return _structure_equal(host, dev), 0
+        except AssertionError:
+            pass
+    h, d = _leaf_set(host), _leaf_set(dev)
+    missing = len(h - d)
+    assert missing <= stray and len(d - h) <= 3 * stray and abs(len(host) - len(dev)) <= 8 * stray, (missing, len(d - h), len(host), len(dev))
+    return int((dev["interior"] == 0).sum()), missing
+
+
+def _chains(rng, n0, seeds, longest, step=9e-5, box=20.0):
+    """n0 bodies uniform in a box + `seeds` chains grown from some of them: 1 .. longest further bodies, each within `step` (< EPS)
+    of the one before in both axes -- so a chain's ends may be several EPS apart -- everything in random arrival order."""
+    x = rng.uniform(-box, box, n0).astype(np.float32)
+    y = rng.uniform(-box, box, n0).astype(np.float32)
+    xs, ys = [x], [y]
+    for s in rng.choice(n0, seeds, replace=False):
+        cx, cy = x[s], y[s]
+        for _ in range(int(rng.integers(1, longest + 1))):
+            cx = np.float32(cx + rng.uniform(-step, step))
+            cy = np.float32(cy + rng.uniform(-step, step))
+            xs.append(np.array([cx], np.float32))
+            ys.append(np.array([cy], np.float32))
+    x, y = np.concatenate(xs), np.concatenate(ys)
+    order = rng.permutation(len(x))
+    return x[order], y[order]
+
+
+@pytest.mark.parametrize("seed,n0,seeds,longest,stray", [(1, 2500, 400, 5, 0), (2, 20000, 600, 5, 0), (3, 20000, 3000, 8, 3),
+                                                          (4, 200000, 20000, 4, 6), (5, 600, 300, 12, 0), (6, 70000, 2000, 6, 0)])
+def test_chains_of_close_bodies_merge_as_in_the_reference(rx, ob, seed, n0, seeds, longest, stray):
+    from rust_exp_amd.engine import NBX_STAT_BH_CHAIN_APPROX, NBX_STAT_BH_CHAIN_MERGED, NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE
+
+    rng = np.random.default_rng(seed)
+    x, y = _chains(rng, n0, seeds, longest)
+    n = len(x)
+    p = ob.particles(x, y, np.zeros(n), np.zeros(n), rng.uniform(0.5, 2.0, n))
+    e = _engine(rx, p)
+    host, dev = e.bh_flat_dump(False), e.bh_flat_dump("device")
+    leaves, missed = _structure_close(host, dev, stray)   # (seeds 3, 4: one chain in a thousand straddles a coarse cell edge)
+    assert leaves < n - seeds // 2                         # blobs did form ...
+    e.set_bh_tree("device")
+    fx, fy, _ = e.forces(0.5)
+    assert e.get_stat(NBX_STAT_BH_FALLBACKS) == 0 and e.get_stat(NBX_STAT_BH_LAST_TREE) == 1
+    assert e.get_stat(NBX_STAT_BH_CHAIN_MERGED) == n - leaves and e.get_stat(NBX_STAT_BH_CHAIN_APPROX) == 0   # ... and are counted
+    assert missed <= stray
+    rc, ox, oy = ob.bh_forces_exact(p, 0.5, nthreads=16)
+    scale = max(np.abs(ox).max(), np.abs(oy).max())
+    err = np.maximum(np.abs(fx - ox), np.abs(fy - oy)) / scale
+    # (the exact-sum class's allowance, DESIGN.md section 4: 0.1 % of the bodies on a flipped opening decision -- of 2 581 bodies
+    #  that is the worst two: the percentile is taken where it means something)
+    bulk = np.percentile(err, 99.9 if n >= 20000 else 99.0)
+    assert rc == 0 and bulk <= 2e-5 and err.max() <= 2e-3, (bulk, err.max())
+
+
+def test_a_blob_travels_by_its_centre_and_leaves_a_member_behind_in_key_order(rx, ob):
+    """Two far bodies span the root box [-30, 30]^2; its upper-left quadrant is empty until A and B arrive 8e-5 apart astride that
+    quadrant's vertical midline x = -15 and merge (B three times as heavy: the centre lies on B's side).  Then C -- straight below
+    A, more than EPS from the centre -- splits the leaf: the reference files the blob where its CENTRE is (nbody.rs:271-281), in
+    B's cell, so in key order A now sits on the far side of C from its blob.  The replay regroups the segment accordingly."""
+    for a_first in (True, False):
+        a, b = (-15.0 - 3.0e-5, 1.0, 1.0), (-15.0 + 5.0e-5, 1.0, 3.0)
+        pts = [(-30.0, -30.0, 1.0), (30.0, 30.0, 1.0)] + ([a, b] if a_first else [b, a]) + [(-15.0 - 3.0e-5, 1.0 - 1.5e-4, 1.0)]
+        x = np.array([q[0] for q in pts], np.float32)
+        y = np.array([q[1] for q in pts], np.float32)
+        p = ob.particles(x, y, np.zeros(len(x)), np.zeros(len(x)), np.array([q[2] for q in pts], np.float32))
+        e = _engine(rx, p)
+        host = e.bh_flat_dump(False)
+        assert _structure_equal(host, e.bh_flat_dump("device")) == 4
+        assert float(host["m"][host["interior"] == 0].max()) == 4.0
+
+
+def test_chains_beyond_the_replays_reach_go_to_the_host_build(rx, ob):
+    """A chain of more than 60 linked bodies is replayed in pieces: its blobs end where the pieces end, which is not the reference's
+    tree (measured: forces up to 3e-4 of max|F| off it on clumps of 750 bodies 2 EPS wide, 1.7e-2 on 777 bodies 0.26 EPS apart with
+    masses over six decades -- tests/test_gpu_randomized.py seed 3).  The bodies of a blob at such a cut are counted
+    (NBX_STAT_BH_CHAIN_APPROX) and count as left behind: a few are tolerated -- here a line of 100 bodies in a system of 300 000: inside the exact-sum class's bounds -- and
+    beyond max(16, n/2000) of them the build is refused and the step runs on the host tree, bit for bit, as it did in rounds 2-5."""
+    from rust_exp_amd.engine import (NBX_STAT_BH_CHAIN_APPROX, NBX_STAT_BH_CHAIN_MERGED, NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE,
+                                     NBX_STAT_BH_REFUSAL)
+
+    rng = np.random.default_rng(7)
+    c = rng.normal(0, 8, (40, 2)).astype(np.float32)
+    pts = (c[rng.integers(0, 40, 30000)] + rng.normal(0, 2e-4, (30000, 2))).astype(np.float32)      # 40 clumps ~2 EPS wide
+    n = len(pts)
+    p = ob.particles(pts[:, 0], pts[:, 1], np.zeros(n), np.zeros(n), np.ones(n))
+    a = _engine(rx, p); a.set_bh_tree("host")
+    b = _engine(rx, p); b.set_bh_tree("device")
+    fx, fy, _ = a.forces(0.3)
+    gx, gy, _ = b.forces(0.3)
+    assert b.get_stat(NBX_STAT_BH_FALLBACKS) == 1 and b.get_stat(NBX_STAT_BH_LAST_TREE) == 0 and b.get_stat(NBX_STAT_BH_REFUSAL) == 0x20000
+    assert np.array_equal(gx.view(np.uint32), fx.view(np.uint32)) and np.array_equal(gy.view(np.uint32), fy.view(np.uint32))
+    for _ in range(3):                                       # steps: enqueued without a verdict read, redone on the host tree
+        a.step_barnes_hut(0.5, 0.01, 1); b.step_barnes_hut(0.5, 0.01, 1)
+    sa, sb = a.get_particles(), b.get_particles()
+    for k in ("px", "py", "vx", "vy"):
+        assert np.array_equal(sa[k].view(np.uint32), sb[k].view(np.uint32)), k
+    # a few such bodies among many: tolerated, and inside the class's bounds
+    d = ob.random_disk(300000, 5)
+    line = np.float32(3.0) + np.arange(100, dtype=np.float32) * np.float32(5e-5)
+    order = rng.permutation(300100)
+    cat = lambda u, v: np.concatenate([np.asarray(u, np.float32), np.asarray(v, np.float32)])[order]   # noqa: E731
+    q = ob.particles(cat(d["px"], line), cat(d["py"], np.full(100, 2.0)), np.zeros(300100), np.zeros(300100), cat(d["m"], np.full(100, 0.5)))
+    e = _engine(rx, q); e.set_bh_tree("device")
+    gx, gy, _ = e.forces(0.5)
+    assert e.get_stat(NBX_STAT_BH_FALLBACKS) == 0 and e.get_stat(NBX_STAT_BH_LAST_TREE) == 1
+    assert 2 <= e.get_stat(NBX_STAT_BH_CHAIN_APPROX) <= 16 and e.get_stat(NBX_STAT_BH_CHAIN_MERGED) >= 50    # (one cut: the blobs on either side)
+    rc, ox, oy = ob.bh_forces_exact(q, 0.5, nthreads=16)
+    scale = max(np.abs(ox).max(), np.abs(oy).max())
+    err = np.maximum(np.abs(gx - ox), np.abs(gy - oy)) / scale
+    assert rc == 0 and np.percentile(err, 99.9) <= 2e-5 and err.max() <= 2e-3, (np.percentile(err, 99.9), err.max())
+
+
+def test_short_runs_of_one_level_31_cell_take_part_and_long_ones_stay_whole(rx, ob):
+    """Exact duplicates: up to 8 of them are replayed body by body with their close neighbours (the tree is the host's); 3 000 at
+    one point are one leaf of their own (any number of bodies of one level-31 cell share a leaf), a partner within EPS stays
+    apart -- a valid tree, the mass is all there."""
+    rng = np.random.default_rng(17)
+    x = rng.uniform(-20, 20, 3000).astype(np.float32)
+    y = rng.uniform(-20, 20, 3000).astype(np.float32)
+    xs = np.concatenate([x, x[:500] + np.float32(3e-5), x[:100], x[:100], x[100:200], x[100:140] - np.float32(4e-5)])
+    ys = np.concatenate([y, y[:500], y[:100], y[:100], y[100:200] + np.float32(2e-5), y[100:140]])
+    order = rng.permutation(len(xs))
+    xs, ys = xs[order], ys[order]
+    n = len(xs)
+    p = ob.particles(xs, ys, np.zeros(n), np.zeros(n), rng.uniform(0.5, 2.0, n))
+    e = _engine(rx, p)
+    assert 3000 <= _structure_equal(e.bh_flat_dump(False), e.bh_flat_dump("device")) <= 3010   # (a cluster astride a coarse cell edge stays apart)
+    # (at a position whose multiples are exact in f32: the folded centre of a pile drifts by an ulp per fold otherwise, nbody.rs:315-317,
+    #  past EPS after a few thousand folds -- the reference then SPLITS bodies of one position, which no key order can express: such
+    #  builds are refused as before, tests/test_gpu_bh_warm_sort.py)
+    xs = np.concatenate([x, np.full(3000, 1.5, np.float32), [np.float32(1.5) + np.float32(5e-5)]])
+    ys = np.concatenate([y, np.full(3000, -2.25, np.float32), [np.float32(-2.25)]])
+    n = len(xs)
+    p = ob.particles(xs, ys, np.zeros(n), np.zeros(n), np.ones(n))
+    e = _engine(rx, p)
+    dev = e.bh_flat_dump("device")
+    leaf = dev["interior"] == 0
+    assert int(leaf.sum()) == 3002 and float(dev["m"][leaf].max()) == 3000.0 and float(dev["m"][0]) == float(n)
+
+
+@pytest.mark.parametrize("steps,stray", [(0, 0), (6, 0), (22, 100)])
+def test_two_million_bodies_the_device_tree_is_the_host_tree(rx, ob, steps, stray):
+    """The benchmark's 2-D Plummer model at twice config #4's size, as generated and a few steps into its collapse (from ~1.5 M
+    bodies on rounds 2-5 handed steps of this run to the host build): node set, skip pointers, sizes and every leaf record of the
+    exact-sum device tree equal the host tree's.  22 steps in -- the densest moment: 40 000 blobs, 230 000 bodies in chains -- all but
+    a few dozen of 2 050 000 leaves (tools/bh_chain_model.py counted 65 on the oracle's run of the same model)."""
+    from rust_exp_amd.engine import NBX_STAT_BH_CHAIN_MERGED, NBX_STAT_BH_FALLBACKS
+
+    st = rx.plummer_sphere(2097152, dim=2)
+    e = rx.NBodyEngine()
+    e.set_bh_fold("exact")
+    e.set_particles(st["px"], st["py"], st["vx"], st["vy"], st["m"])
+    for _ in range(steps):
+        e.step_barnes_hut(0.5, 0.01, 1)
+    assert e.get_stat(NBX_STAT_BH_FALLBACKS) == 0
+    host, dev = e.bh_flat_dump(True), e.bh_flat_dump("device")
+    leaves, missed = _structure_close(host, dev, stray)
+    assert leaves < 2097152 and missed <= stray
+    e.forces(0.5)
+    assert e.get_stat(NBX_STAT_BH_CHAIN_MERGED) == 2097152 - leaves

@@ -4,7 +4,7 @@ which is node-for-node the oracle's tree.  Two classes (NBX_OPT_BH_FOLD, DESIGN.
     fold in arrival order (nbody.rs:303-320) -> the flattened tree equals the host tree BIT FOR BIT, or the build reports EPS
     clusters it cannot reproduce node for node and the step runs on the host tree;
   * fold = exact (round 2; the fast mode's default at every size since round 6 -- by cost): same node set / skip pointers / node sizes / leaf records -- including the
-    reference's EPS merge of close pairs -- with interior records that are roundings of the EXACT sums (the reference's fold
+    reference's EPS merge (round 6: chains of any length, tests/test_gpu_bh_chains.py) -- with interior records that are roundings of the EXACT sums (the reference's fold
     drifts, 6e-4 at a million bodies), so forces are compared with the oracle AND with the fp64 arbiter
     (oracle/nbody_oracle.c orc_bh_forces_exact)."""
 import numpy as np
@@ -284,12 +284,10 @@ def test_device_tree_reproduces_the_reference_eps_merge_in_arrival_order(rx, ob,
     assert rc == 0 and np.percentile(err, 99.9) <= 2e-5 and err.max() <= 2e-3, (np.percentile(err, 99.9), err.max())
 
 
-def test_device_tree_duplicates_with_partners_and_crowded_clusters(rx, ob):
-    """Bodies of one level-31 cell (exact duplicates) are one entity: they share a leaf in arrival order, and a close
-    partner merges with the whole entity exactly like the reference does (nbody.rs:249-260) -- same tree as the host's.
-    Clusters of three or more DISTINCT positions within EPS are another matter: the reference grows multi-body blobs in arrival
-    order, which the pairs-only merge does not reproduce.  A few such bodies (<= max(16, n/2000)) are tolerated; a system
-    full of them -- dense clumps -- is detected by the device build and redone on the host: the host-tree result bit for bit."""
+def test_device_tree_duplicates_with_partners(rx, ob):
+    """Bodies of one level-31 cell (exact duplicates) share a leaf in arrival order, and a close partner merges with them exactly
+    like the reference does (nbody.rs:249-260) -- same tree as the host's.  (Clusters of three or more DISTINCT positions within
+    EPS, which rounds 2-5 left to the host build when there were many: tests/test_gpu_bh_chains.py.)"""
     from rust_exp_amd.engine import NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE
 
     rng = np.random.default_rng(7)
@@ -308,19 +306,6 @@ def test_device_tree_duplicates_with_partners_and_crowded_clusters(rx, ob):
     rc, ofx, ofy = ob.bh_forces(p, 0.3, nthreads=8)
     err = np.maximum(np.abs(gx - ofx), np.abs(gy - ofy)) / max(np.abs(ofx).max(), np.abs(ofy).max())
     assert rc == 0 and np.percentile(err, 99.9) <= 2e-5 and err.max() <= 2e-3
-
-    c = rng.normal(0, 8, (40, 2)).astype(np.float32)
-    pts = (c[rng.integers(0, 40, 30000)] + rng.normal(0, 2e-4, (30000, 2))).astype(np.float32)      # 40 clumps ~ 2 EPS wide
-    p = ob.particles(pts[:, 0], pts[:, 1], np.zeros(30000), np.zeros(30000), np.ones(30000))
-    a = engines(rx, p); a.set_bh_tree("host")
-    b = engines(rx, p, fold="exact"); b.set_bh_tree("device")
-    fx, fy, _ = a.forces(0.3)
-    gx, gy, _ = b.forces(0.3)
-    assert b.get_stat(NBX_STAT_BH_FALLBACKS) == 1 and b.get_stat(NBX_STAT_BH_LAST_TREE) == 0
-    assert np.array_equal(gx.view(np.uint32), fx.view(np.uint32)) and np.array_equal(gy.view(np.uint32), fy.view(np.uint32))
-    rc, ofx, ofy = ob.bh_forces(p, 0.3, nthreads=8)
-    scale = max(np.abs(ofx).max(), np.abs(ofy).max())
-    assert rc == 0 and np.abs(gx - ofx).max() <= 2e-5 * scale and np.abs(gy - ofy).max() <= 2e-5 * scale
 
 
 @pytest.mark.parametrize("make,n", [("orbits", 50000), ("disk", 20000), ("plummer", 262144)])
@@ -767,18 +752,20 @@ def test_strict_mode_on_the_device_tree_keeps_the_references_depth_panic(rx, ob)
 
 
 def _disk_with_a_long_eps_chain(ob, n_disk, chain, seed):
-    """A random disk + `chain` bodies on a line, 1.5 EPS apart: every link is shorter than 2 EPS (one connected component for the
+    """A random disk + `chain` bodies on a line, 1.9 EPS apart: every link is shorter than 2 EPS (one connected component for the
     reference-fold replay: more than its 96 bodies -> that class must refuse, NBX_STAT_BH_REFUSAL bit 4) and longer than EPS
-    (nothing merges, nbody.rs:249: the exact-sum class builds the reference's node set without leaving anybody behind)."""
+    (nothing merges, nbody.rs:249: the exact-sum class builds the reference's node set without leaving anybody behind -- it replays a
+    chain this long in pieces, and blobs at the cuts would count as left behind: at 1.5 EPS the disk's tide had pushed 25 of 130
+    bodies within EPS of a neighbour after four steps, 26 of them at cuts, 16 are tolerated at this size)."""
     rng = np.random.default_rng(seed)
     d = ob.random_disk(n_disk, seed)
-    cx = np.float32(3.0) + np.arange(chain, dtype=np.float32) * np.float32(1.5e-4)
+    cx = np.float32(3.0) + np.arange(chain, dtype=np.float32) * np.float32(1.9e-4)
     cy = np.full(chain, 2.0, np.float32)
     order = rng.permutation(n_disk + chain)                 # the chain's bodies arrive anywhere in the sequence
     cat = lambda a, b: np.concatenate([np.asarray(a, np.float32), np.asarray(b, np.float32)])[order]   # noqa: E731
     zero = np.zeros(chain, np.float32)
     # (masses of the chain small: it stays a chain for the steps below)
-    return ob.particles(cat(d["px"], cx), cat(d["py"], cy), cat(d["vx"], zero), cat(d["vy"], zero), cat(d["m"], np.full(chain, 1e-3)))
+    return ob.particles(cat(d["px"], cx), cat(d["py"], cy), cat(d["vx"], zero), cat(d["vy"], zero), cat(d["m"], np.full(chain, 1e-6)))
 
 
 @pytest.mark.parametrize("async_", [1, 0])
@@ -791,7 +778,7 @@ def test_a_refused_reference_fold_build_is_served_by_the_exact_sum_device_build(
     from rust_exp_amd.engine import (NBX_OPT_BH_ASYNC, NBX_STAT_BH_CLASS_SWITCHES, NBX_STAT_BH_FALLBACKS, NBX_STAT_BH_LAST_TREE,
                                      NBX_STAT_BH_REFUSAL)
 
-    p = _disk_with_a_long_eps_chain(ob, 20000, 130, 77)
+    p = _disk_with_a_long_eps_chain(ob, 20000, 110, 77)
     theta = 0.5
     r = engines(rx, p, fold="reference"); r.set_option(NBX_OPT_BH_ASYNC, async_)
     x = engines(rx, p, fold="exact"); x.set_option(NBX_OPT_BH_ASYNC, async_)
