@@ -394,13 +394,19 @@ __global__ __launch_bounds__(64) void k_chain(const unsigned long long* __restri
             }
             if (mine) out_key = k;
         }
-        // blobs in key order, a blob's bodies in arrival order
+        // blobs in key order, a blob's bodies in arrival order.  Two blobs under ONE key -- both filed under a member's path, and the
+        // members share a level-31 cell: bodies of one position whose folded centre drifted an ulp, which where an ulp is no longer
+        // small against EPS (|x| in the thousands) makes the reference split them, nbody.rs:315-317 -- become one leaf here: counted
+        // as approximate
         int rank = 0;
+        bool collides = false;
         for (int l = 0; l < t; l++) {
             const unsigned long long ko = shfl_u64(out_key, l);
             const unsigned io = bcast_u32(my_idx, l);
             rank += (ko < out_key || (ko == out_key && io < my_idx)) ? 1 : 0;
+            collides = collides || (ko == out_key && bcast_i32(blob, l) != blob);
         }
+        approx_total += __popcll(__ballot(member && collides));
         if (member) { out_keys[p0 + rank] = out_key; out_idx[p0 + rank] = my_idx; out_sb[p0 + rank] = rec; }
     }
     // the tallies: over kTallySlots words each, summed into counters[6] / [7] by k_scan_write's last workgroup -- as one atomic per wave on

@@ -70,8 +70,9 @@ __global__ __launch_bounds__(kTile) void k_cells(const float4* __restrict__ posm
                                                  const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
                                                  const unsigned* __restrict__ box, const int n, unsigned long long* __restrict__ hk,
                                                  int* __restrict__ hv, const unsigned mask, unsigned long long* __restrict__ ekey,
-                                                 unsigned char* __restrict__ pmin, const int sb_ready)
+                                                 unsigned char* __restrict__ pmin, const int sb_ready, const int* __restrict__ poison)
 {
+    if (*poison) return;   // (see launch_cluster_replay)
     const int j = blockIdx.x * kTile + threadIdx.x;
     if (j >= n) return;
     if (!sb_ready) sb[j] = posm[idx[j]];      // (the warm sort delivers the records itself, bh_sort.hip)
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(kTile) void k_blobs(const float4* __restrict__ sb, 
                                                  unsigned char* __restrict__ pmin, int* __restrict__ ghosts, int* __restrict__ counters)
 {
     __shared__ BlobShared bs[kTile / 64];             // one component at a time per wave
+    if (counters[kTreePoisonWord]) return;            // (see launch_cluster_replay)
     const int j = blockIdx.x * kTile + threadIdx.x;
     const CellGrid g = make_grid(box, hk, hv, mask);
     bool root = false;
@@ -413,6 +415,7 @@ __global__ __launch_bounds__(kTile) void k_place(const unsigned long long* __res
 {
     __shared__ int gslot[kGhostCap];
     __shared__ unsigned long long gkey[kGhostCap];
+    if (counters[kTreePoisonWord]) return;            // (see launch_cluster_replay)
     int G = counters[4];
     const bool overflow = G > kGhostCap;              // the step is refused then: everybody stays where it is, under its own
     if (overflow) G = 0;                              // key (the arrays below must hold a permutation whatever happens)
@@ -453,10 +456,15 @@ __global__ __launch_bounds__(kTile) void k_place(const unsigned long long* __res
 }
 
 
+// The poison word (kernels.h kTreePoisonWord): a build enqueued BEHIND a refused step starts from what that step left -- the warm sort's
+// kernels then do nothing (bh_sort.hip launch_inc_sort), and with them the clearing of the cell table; a replay on a table still full of the
+// refused build's cells took 33-49 ms (k_cells) + 270-380 ms (k_blobs) at 65 536 bodies (every refusal of a run of pipelined steps:
+// profiles/r06_bh_sizes.jsonl, 38.8 ms per step) for a tree nobody may read: the three kernels leave at once, like the sort's.
 hipError_t launch_cluster_replay(const float4* posm, int n, const Workspace& k, hipStream_t stream, bool sb_ready)
 {
     const int nb = (n + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_cells, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, k.box, n, k.hk, k.hv, k.hmask, k.ekey, k.link, sb_ready ? 1 : 0);
+    hipLaunchKernelGGL(k_cells, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, k.box, n, k.hk, k.hv, k.hmask, k.ekey, k.link, sb_ready ? 1 : 0,
+                       k.counters + kTreePoisonWord);
     hipLaunchKernelGGL(k_blobs, dim3(nb), dim3(kTile), 0, stream, k.sb, k.keys1, k.idx1, k.box, n, k.hk, k.hv, k.hmask, k.ekey, k.link,
                        k.ghosts, k.counters);
     hipLaunchKernelGGL(k_place, dim3(nb), dim3(kTile), 0, stream, k.keys1, k.ekey, k.idx1, k.sb, k.link, k.ghosts, k.counters, n,

@@ -318,6 +318,116 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
     return acc;
 }
 
+// ---- the same loop with the distance of the NEXT child formed while the current one is tested (round 6) ---------
+// v_pk_add -> v_pk_mul -> v_add are each other's operands, and gfx950 wants a wait state behind a packed result (the two s_nop 0 of
+// NBX_ASM_CHILD): here the next child's v_pk_add / v_pk_mul sit in those slots -- two register sets, A = v[14:17] for children 3 and 1,
+// B = v[26:29] for 2 and 0 -- so a group of k children spends 1 wait state on distances instead of 2 k.  A group enters at its first
+// present child through a prologue (one child: the plain block); the order of the sums is the same, the results bit for bit.
+// Measured (profiles/r06_bh_walk_pipelined_ab.txt, three alternating runs at 1 M bodies): traversal 0.4378 / 0.4374 / 0.4401 ->
+// 0.4335 / 0.4333 / 0.4343 ms, -1.0 %; 10 000 bodies 0.0417 -> 0.0412.  Shipped (NBX_BH_WALK_PIPE=0: the loop of rounds 4-5); the 4 %
+// the instruction count promised is not there -- 2.5 issue slots of a turn's ~62 are not what a resident walk waits for.
+#define NBX_ASM_PRO(x, D, SQ)                                                                              \
+    " v_pk_add_f32 " D ", " x ", v[10:11] neg_lo:[0,1] neg_hi:[0,1]\n"                                     \
+    " s_nop 0\n"                                                                                           \
+    " v_pk_mul_f32 " SQ ", " D ", " D "\n"
+#define NBX_ASM_TAIL(m, D, c)                                                                              \
+    " v_add_f32 v20, 0x38d1b717, v18\n"                                                                    \
+    " s_andn2_b64 s[42:43], s[40:41], exec\n"                                                              \
+    " s_cbranch_execz Lskip" #c "_%=\n"                                                                    \
+    " v_rcp_f32 v20, v20\n"                                                                                \
+    " s_nop 0\n"                                                                                           \
+    " v_mul_f32 v20, " m ", v20\n"                                                                         \
+    " v_pk_fma_f32 v[12:13], v[20:21], " D ", v[12:13] op_sel_hi:[0,1,1]\n"                                \
+    "Lskip" #c "_%=:\n"                                                                                    \
+    " s_mov_b64 exec, s[40:41]\n"                                                                          \
+    " s_cbranch_scc1 Lpush" #c "_%=\n"                                                                     \
+    "Lback" #c "_%=:\n"
+// child c (distance in D / SQlo, SQhi), the next child's distance into Dn / SQn
+#define NBX_ASM_BODY(m, T, D, SQlo, SQhi, xn, Dn, SQn, c)                                                  \
+    "Lb" #c "_%=:\n"                                                                                       \
+    " v_pk_add_f32 " Dn ", " xn ", v[10:11] neg_lo:[0,1] neg_hi:[0,1]\n"                                   \
+    " v_add_f32 v18, " SQlo ", " SQhi "\n"                                                                 \
+    " v_pk_mul_f32 " SQn ", " Dn ", " Dn "\n"                                                              \
+    " v_cmpx_nge_f32 vcc, " T ", v18\n"                                                                    \
+    NBX_ASM_TAIL(m, D, c)
+#define NBX_ASM_BODY_LAST(m, T, D, SQlo, SQhi, c)                                                          \
+    "Lb" #c "_%=:\n"                                                                                       \
+    " v_add_f32 v18, " SQlo ", " SQhi "\n"                                                                 \
+    " v_cmpx_nge_f32 vcc, " T ", v18\n"                                                                    \
+    NBX_ASM_TAIL(m, D, c)
+
+__device__ __forceinline__ v2f walk_groups_asm_pipelined(const BhGroup* __restrict__ groups, const v2f p, u64 M, int& overflow, int& turns)
+{
+    v2f acc = {0.0f, 0.0f};
+    const char* base = reinterpret_cast<const char*>(groups);
+    asm volatile(
+        " s_mov_b64 s[46:47], exec\n"
+        " s_mov_b32 s44, 0\n"
+        " s_mov_b32 s45, 0\n"
+        " s_mov_b32 s52, 0\n"
+        " s_mov_b32 s53, -1\n"
+        " s_mov_b32 s56, 0\n"
+        " s_branch Lload_%=\n"
+        "Lpop_%=:\n"
+        " s_cmp_lt_i32 s53, 0\n"
+        " s_cbranch_scc1 Lpopv_%=\n"
+        " s_mov_b32 s45, s53\n"
+        " s_mov_b64 s[40:41], s[54:55]\n"
+        " s_mov_b32 s53, -1\n"
+        " s_branch Lload_%=\n"
+        "Lpopv_%=:\n"
+        " s_cmp_eq_u32 s44, 0\n"
+        " s_cbranch_scc1 Ldone_%=\n"
+        " s_add_u32 s44, s44, -1\n"
+        " v_readlane_b32 s45, v22, s44\n"
+        " v_readlane_b32 s40, v23, s44\n"
+        " v_readlane_b32 s41, v24, s44\n"
+        "Lload_%=:\n"
+        " s_add_u32 s56, s56, 1\n"
+        " s_load_dwordx16 s[20:35], s[48:49], s45\n"
+        " s_load_dwordx4 s[36:39], s[50:51], s45\n"
+        " s_mov_b64 exec, s[40:41]\n"
+        " s_waitcnt lgkmcnt(0)\n"
+        " s_cmp_eq_u32 s38, -2\n"                 // slot 2 absent: one or two children
+        " s_cbranch_scc1 Lle2_%=\n"
+        " s_cmp_eq_u32 s39, -2\n"
+        " s_cbranch_scc1 Le2_%=\n"
+        NBX_ASM_PRO("s[32:33]", "v[14:15]", "v[16:17]")
+        NBX_ASM_BODY("s34", "s35", "v[14:15]", "v16", "v17", "s[28:29]", "v[26:27]", "v[28:29]", 3)
+        NBX_ASM_BODY("s30", "s31", "v[26:27]", "v28", "v29", "s[24:25]", "v[14:15]", "v[16:17]", 2)
+        NBX_ASM_BODY("s26", "s27", "v[14:15]", "v16", "v17", "s[20:21]", "v[26:27]", "v[28:29]", 1)
+        NBX_ASM_BODY_LAST("s22", "s23", "v[26:27]", "v28", "v29", 0)
+        " s_branch Lpop_%=\n"
+        "Le2_%=:\n"                               // three children: in at child 2
+        NBX_ASM_PRO("s[28:29]", "v[26:27]", "v[28:29]")
+        " s_branch Lb2_%=\n"
+        "Lle2_%=:\n"
+        " s_cmp_eq_u32 s37, -2\n"
+        " s_cbranch_scc1 Lc0_%=\n"
+        NBX_ASM_PRO("s[24:25]", "v[14:15]", "v[16:17]")   // two children: in at child 1
+        " s_branch Lb1_%=\n"
+        "Lc0_%=:\n"                               // one child: the plain block (nothing to overlap with)
+        " v_pk_add_f32 v[26:27], s[20:21], v[10:11] neg_lo:[0,1] neg_hi:[0,1]\n"
+        " s_nop 0\n"
+        " v_pk_mul_f32 v[28:29], v[26:27], v[26:27]\n"
+        " s_nop 0\n"
+        " s_branch Lb0_%=\n"
+        NBX_ASM_PUSH("s39", 3)
+        NBX_ASM_PUSH("s38", 2)
+        NBX_ASM_PUSH("s37", 1)
+        NBX_ASM_PUSH("s36", 0)
+        "Lovf_%=:\n"
+        " s_mov_b32 s52, 1\n"
+        "Ldone_%=:\n"
+        " s_mov_b64 exec, s[46:47]\n"
+        : "+{v[12:13]}"(acc), "={s52}"(overflow), "+{s[40:41]}"(M), "={s56}"(turns)
+        : "{s[48:49]}"(base), "{s[50:51]}"(base + 64), "{v[10:11]}"(p)
+        : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37",
+          "s38", "s39", "s42", "s43", "s44", "s45", "s46", "s47", "s54", "s55", "s53", "v14", "v15", "v16", "v17", "v18", "v20", "v21", "v22", "v23", "v24",
+          "v26", "v27", "v28", "v29", "vcc", "scc", "m0");
+    return acc;
+}
+
 // The walks differ in length (a dense core's bodies sit deep in the tree), and 16 384 of them on 8 192 wave slots are two rounds and
 // a tail whose length is the spread of those lengths.  Measured and removed: launching them longest first (round 4: any departure
 // from Morton order costs the L2 more than the tail gains) and running the costliest p % as two halves of 32 bodies (round 5:
@@ -325,7 +435,7 @@ __device__ __forceinline__ v2f walk_groups_asm(const BhGroup* __restrict__ group
 // one; docs/rounds/r05.md, profiles/r05_bh_walk_split_ab.jsonl).
 // TRACE: the timeline instrumentation (tools/bh_walk_trace.py) is a kernel of its own -- its pointer and the start time are four
 // scalar registers across the loop, which the plain kernel spends on `sorted` instead (BhKick: the new positions in walk order)
-template <int BPW, bool ASM, bool TRACE>
+template <int BPW, int ASM, bool TRACE>   // ASM: 0 compiled loop, 1 hand-scheduled, 2 hand-scheduled with the next child's distance overlapped
 __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* posm, const int lo, const int n_targets,
                                                        const BhGroup* __restrict__ groups, void* __restrict__ sink,
                                                        const unsigned* __restrict__ perm, const int xcd_order, const BuildGate gate,
@@ -352,7 +462,8 @@ __global__ __launch_bounds__(64) void k_bh_walk_groups(const float4* posm, const
     const v2f p = {pi.x, pi.y};
     v2f acc;
     int overflow = ASM ? 0 : 1, turns = 0;
-    if (ASM) acc = walk_groups_asm(groups, p, M, overflow, turns);
+    if (ASM == 2) acc = walk_groups_asm_pipelined(groups, p, M, overflow, turns);
+    else if (ASM) acc = walk_groups_asm(groups, p, M, overflow, turns);
     if (__builtin_amdgcn_readfirstlane(overflow)) acc = walk_groups_compiled(groups, p, M, spill_mem);   // (uniform: the asm's output is an SGPR)
     if (valid) {
         if (kick_posm) {   // kick-drift with the acceleration just found: the operations and order of k_integrate_f2 (is_accel, killbox)
@@ -514,7 +625,7 @@ int bh_walk_count(int n_targets, int* bodies_per_walk)
     return (nblk + 7) / 8 * 8;
 }
 
-template <bool ASM>
+template <int ASM>
 static void launch_wave_walk(int bpw, dim3 g, hipStream_t stream, const float4* posm, int lo, int n_targets, const BhGroup* groups,
                              float2* out, const unsigned* perm, BuildGate gate, unsigned long long* trace, BhKick kick)
 {
@@ -546,8 +657,10 @@ hipError_t launch_bh_walk_groups(const float4* posm, int lo, int n_targets, cons
         // bodies per wave: aim at >= 4 walks per SIMD (4096 waves), between 4 and 64 bodies each (as the node walk)
         int bpw = 64;
         const dim3 g((unsigned)bh_walk_count(n_targets, &bpw));
-        if (hand_scheduled) launch_wave_walk<true>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, trace, kd);
-        else launch_wave_walk<false>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, trace, kd);
+        static const int pipe = [] { const char* v = std::getenv("NBX_BH_WALK_PIPE"); return v ? std::atoi(v) : 1; }();   // (0: the loop of rounds 4-5, for the A/B)
+        if (hand_scheduled && pipe) launch_wave_walk<2>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, trace, kd);
+        else if (hand_scheduled) launch_wave_walk<1>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, trace, kd);
+        else launch_wave_walk<0>(bpw, g, stream, posm, lo, n_targets, groups, out, perm, gate, trace, kd);
     } else {
         const int block = n_targets <= 65536 ? 64 : kTile;
         hipLaunchKernelGGL(k_bh_walk_groups_lane, dim3((unsigned)((n_targets + block - 1) / block)), dim3(block), 0, stream, posm, lo,

@@ -1,4 +1,13 @@
-"""CPU model of the chain merge for the exact-sum class (prototype for k_chain)."""
+#!/usr/bin/env python3
+"""CPU model of the exact-sum device build's chain replay (bh_build.hip section 3b: k_chain_links / k_chain_heads / k_chain), the way the
+rule was found and its parameters fixed in round 6 -- numpy for the keys and the links, plain Python for the replay of a segment -- and
+compared with the ORACLE's tree (diagnostic tool: the oracle is the checker here, as in tools/bh_device_tree_probe.py):
+    python tools/bh_chain_model.py [seed]          20 000 bodies + 600 chains of 2-6 bodies within EPS, random arrival order
+    from bh_chain_model import compare; compare(particles, W=1 << 30, K=3, LINK=np.float32(2e-4))
+`compare` returns how many leaves / nodes the model's tree and the oracle's differ by, and the segment statistics.  Parameters: K = how many
+sorted places ahead a body links boundaries, LINK = the link distance (2 EPS shipped), CUTW / MCUT = where chains longer than CUTW + 2 MCUT are
+cut (32 / 14 shipped), LOOSECUT = also cut chains longer than this at boundaries no pair within EPS spans (0 = off: shipped).
+Results that fixed them: docs/rounds/r06.md section 2."""
 import sys, numpy as np
 sys.path.insert(0, "/root/repo")
 from oracle import binding as ob
@@ -199,5 +208,6 @@ if __name__ == "__main__":
     perm = rng.permutation(len(x)); x, y = x[perm], y[perm]
     n = len(x)
     p = ob.particles(x, y, np.zeros(n), np.zeros(n), rng.uniform(0.5, 2.0, n))
-    print(compare(p))
-    print("2xEPS links:", compare(p, LINK=f32(2e-4)))
+    print("links at 1 EPS, sorted neighbours only:", compare(p))
+    print("links at 2 EPS, sorted neighbours only:", compare(p, LINK=f32(2e-4)))
+    print("links at 2 EPS, three places ahead (shipped):", compare(p, LINK=f32(2e-4), K=3))

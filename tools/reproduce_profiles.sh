@@ -44,3 +44,14 @@ bash tools/pmc_host_tree_walk.sh > gpurun_out/${T}_pmc_host_tree_walk.txt 2>&1
 python tools/bh_dense_probe.py > gpurun_out/${T}_bh_dense_handover.jsonl 2>&1
 bash tools/bh_build_valu.sh > gpurun_out/${T}_bh_step_issue_counters.json 2> /dev/null
 (timeout 1500 python tests/fuzz_fast.py 700000 20000 2>&1 | tail -1; timeout 700 python tests/fuzz_strict.py 70000 400 2>&1 | tail -1; timeout 300 python tests/fuzz_group.py 70000 3000 2>&1 | tail -1; timeout 600 python tests/fuzz_api.py 70000 150 2>&1 | tail -1) > gpurun_out/${T}_fuzz_long2.txt 2>&1
+# round 6: the default tree class by cost and its done-criteria (sizes, long runs, frame loop), the chain replay (dense models with the
+# force error after 35 steps, the reference-fold class with pipelined steps), K1's counters of the round, the walk loop A/B, the fuzz
+# campaigns (chains injected), the first-contact rehearsals once more
+python tools/bh_sizes.py > gpurun_out/${T}_bh_sizes.jsonl 2> /dev/null
+NBX_LONG_STEPS=1000 python tools/bh_warm_long_run.py random_disk:65536 stable_orbits:10000 random_disk:10000 > gpurun_out/${T}_bh_warm_long_run.jsonl 2> /dev/null
+python tools/bh_dense_probe.py --accuracy 1048576 2097152 4194304 > gpurun_out/${T}_bh_dense_probe.jsonl 2> /dev/null
+python tools/bh_reference_fold_async_probe.py > gpurun_out/${T}_bh_reference_fold_async_probe.txt 2>&1
+bash tools/gpu_session.sh k1pmc
+for r in 1 2 3; do for pipe in 0 1; do echo -n "pipe $pipe "; NBX_BH_WALK_PIPE=$pipe python bench.py --workload bh --no-cpu-baseline --no-traffic --steps 40 --warmup 5 --steady-seconds 0 2> /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms/step %.4f traversal_ms %.4f' % (d['ms_per_step'], d['roofline']['kernel_avg_ms']))"; done; done > gpurun_out/${T}_bh_walk_pipelined_ab.txt
+python tests/fuzz_fast.py 60000 3000 > gpurun_out/${T}_fuzz_fast.txt 2>&1; python tests/fuzz_strict.py 60000 300 > gpurun_out/${T}_fuzz_strict.txt 2>&1
+python tests/fuzz_api.py 60000 100 > gpurun_out/${T}_fuzz_api.txt 2>&1; python tests/fuzz_group.py 60000 500 > gpurun_out/${T}_fuzz_group.txt 2>&1
