@@ -211,6 +211,10 @@ COMPANIONS = (
     ("c5_fp16_sources_524288", "524 288-body two-galaxy collision, fp16 positions / fp32 accumulators (1 of its 8 GPUs' worth: whole system on 1 GPU)",
      ["--workload", "two_galaxies", "--bodies", "524288", "--source-bits", "16", "--dim", "2", "--steps", "10", "--warmup", "2",
       "--steady-seconds", "0", "--no-general-masses", "--no-traffic", "--cpu-seconds", "2"]),
+    # not a BASELINE config (round 6): config #4's model at twice its size, 35 steps into its collapse -- where rounds 2-5
+    # handed every few steps to a 50-85 ms host build (chains of bodies within EPS, nbody.rs:249-260); c6_fallbacks counts such steps
+    ("c6_barnes_hut_2097152", "2 097 152 bodies Barnes-Hut theta=0.5 on 1 GPU (beyond BASELINE: config #4's model at twice the size, through its collapse)",
+     ["--workload", "bh", "--bodies", "2097152", "--theta", "0.5", "--steps", "30", "--warmup", "5", "--steady-seconds", "0", "--no-traffic"]),
 )
 
 
@@ -225,7 +229,7 @@ def companion_summary(key, line):
                 "published_ms_per_step": line.get("published_ms_per_step"), "draw_ms": line.get("draw_ms"), "frames": line.get("steps"),
                 "tree": (line.get("config") or {}).get("tree"), "host_hand_overs": line.get("bh_fallbacks"),
                 "err_p999": acc.get("p999"), "err_max": acc.get("max"), "err_vs": acc.get("vs")}
-    if key.startswith("c4"):
+    if key.startswith(("c4", "c6")):
         sp, acc = line.get("ms_split") or {}, cb.get("accuracy") or {}
         out.update({"build_ms": sp.get("tree_build"), "traversal_ms": sp.get("bh_eval_kernel"), "tree": (line.get("config") or {}).get("tree"),
                     "fallbacks": line.get("bh_fallbacks"),

@@ -64,23 +64,24 @@ namespace nbx {
 //                   reference's blobs, this none of the injected ones and 10-65 of 40 000 in the collapsed model: pairs that are
 //                   close in space and far apart on the Z-curve.)  Bodies of one level-31 cell beyond kRunLink of them stay out
 //                   (they share a leaf anyway, any number of them).
-//   k_chain_heads   lists the bodies at which a maximal run of linked boundaries starts (a SEGMENT: at most 60 bodies -- a longer chain
-//                   is cut at multiples of 32 that have 14 linked boundaries on either side)
-//   k_chain         one wave per segment, one lane per body: the wave replays the reference's insertion in arrival order: the live entities compare their
-//                   centre's path with the newcomer's key (the deepest of them: five ballots),
-//                   the unique winner tests EPS against its centre, and nobody OUTSIDE the segment who arrived earlier may sit
-//                   at least as deep in the newcomer's path (64 sorted neighbours per probe, at most 256 on either side) --
-//                   then the winner folds the newcomer in (add_mass, f32) and re-derives its path.  Output: the segment's
-//                   bodies regrouped blob by blob, each blob in arrival order (what emit_node's leaf fold wants), every member
-//                   under ONE key -- the path of the blob's centre, where the reference files it -- written to a second set of
-//                   arrays (keys0 / idx0 / sb2) so that neighbouring waves' probes read the sort's own output; everybody else is
-//                   copied.
+//   k_chain_heads   lists the bodies at which a maximal run of linked boundaries starts (a SEGMENT: at most 60 bodies -- a longer
+//                   chain is cut at multiples of 32 that have 14 linked boundaries on either side)
+//   k_chain         one wave per segment that holds a pair within EPS, one lane per body.  The wave replays the reference's insertion
+//                   in arrival order: the live entities compare their centre's path with the newcomer's key (the deepest of them:
+//                   five ballots), the unique winner tests EPS against its centre, and nobody OUTSIDE the segment who arrived
+//                   earlier may sit at least as deep in the newcomer's path (the 64 sorted neighbours on either side, held in
+//                   registers; up to 256 where a cell is that crowded) -- then the winner folds the newcomer in (add_mass, f32) and
+//                   follows its new centre down from the segment's common cell until it has parted from everybody still to come.
+//                   Output: the segment's bodies regrouped blob by blob, each blob in arrival order (what emit_node's leaf fold
+//                   wants), every member under ONE key -- the path of the blob's centre, where the reference files it -- written to
+//                   a second set of arrays (keys0 / idx0 / sb2) so that neighbouring waves' probes read the sort's own output;
+//                   everybody else is as k_chain_links copied them.
 // Same leaves, same node set as the host tree wherever a blob's bodies are that close on the Z-curve (tests: trees with injected
 // chains, the 2 M-body model before and during its collapse: chains of at most 36 bodies there).  What the replay only approximates
 // -- in a chain of more than 60 the blobs that end at a cut which a pair within EPS spans (measured: forces up to 1.7e-2 of max|F|
 // off the reference's tree on 777 bodies 0.26 EPS apart with masses over six decades), a merge behind a probe that hit its cap -- is
-// counted (counters[6]) and counts as left behind like the chains of rounds 2-5 did: beyond max(16, n/2000) such bodies the step goes to the host build, so
-// the class's bounds hold for every tree it serves.  counters[7]: the bodies merged.
+// counted (counters[6]) and counts as left behind like the chains of rounds 2-5 did: beyond max(16, n/2000) such bodies the step
+// goes to the host build, so the class's bounds hold for every tree it serves.  counters[7]: bodies merged.
 constexpr int kRunLink = 8;          // bodies of one level-31 cell that still take part in a replay as individuals
 constexpr int kLinkLook = 3;         // a body links boundaries up to this many sorted places ahead
 constexpr float kLinkEps = 2.0e-4f;  // 2 EPS
@@ -253,9 +254,9 @@ __global__ __launch_bounds__(kHeadsBlock) void k_chain_heads(const unsigned char
     if (head) head_list[wave_base[0] + wave_base[wave + 1] + __popcll(hm & ((1ull << lane) - 1ull))] = p;
 }
 
-// One wave per segment, taken off the list in strides of the grid (a wave per 32 sorted places that replayed the segments starting there
-// one after the other took 49-56 us at a million bodies for 2 000 segments: they sit side by side in the sorted order wherever the system
-// is dense, so a few waves did most of them).
+// One wave per segment, taken off the list in strides of the grid: segments sit side by side in the sorted order wherever the system is
+// dense (30 000 of them in the core of the collapsing 1 M-body model), and a wave per 32 sorted places that replays the ones starting
+// there one after the other leaves those stretches to a few waves.
 __global__ __launch_bounds__(64) void k_chain(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
                                               const float4* __restrict__ sb, const unsigned char* __restrict__ link, const int n,
                                               const unsigned* __restrict__ box, unsigned long long* __restrict__ out_keys,

@@ -81,7 +81,8 @@ def test_companions_block_is_flat_scalars_and_survives_a_failed_child():
     """BASELINE configs #2, #4, #5 ride on the driver-run line. The block is assembled from the children's
     own JSON lines; what goes into `roofline` must be scalars (the driver's parser keeps scalars one level deep); a child that
     fails leaves an `error`, not an exception."""
-    assert [k for k, _, _ in bench.COMPANIONS] == ["c0_reference_scene", "c2_brute_65536", "c4_barnes_hut_1048576", "c5_fp16_sources_524288"]
+    assert [k for k, _, _ in bench.COMPANIONS] == ["c0_reference_scene", "c2_brute_65536", "c4_barnes_hut_1048576", "c5_fp16_sources_524288",
+                                                   "c6_barnes_hut_2097152"]   # (c6, round 6: config #4's model at twice the size -- hand-overs to the host build)
     argv = {k: a for k, _, a in bench.COMPANIONS}
     assert argv["c4_barnes_hut_1048576"][:6] == ["--workload", "bh", "--bodies", "1048576", "--theta", "0.5"]
     assert "--source-bits" in argv["c5_fp16_sources_524288"] and "524288" in argv["c5_fp16_sources_524288"]
