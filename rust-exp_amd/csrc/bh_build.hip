@@ -111,9 +111,11 @@ __global__ __launch_bounds__(kTile) void k_chain_links(const float4* __restrict_
                                                        const unsigned* __restrict__ idx, const int n,
                                                        unsigned char* __restrict__ link, int* __restrict__ crowded, const int sb_ready,
                                                        unsigned long long* __restrict__ out_keys, unsigned* __restrict__ out_idx,
-                                                       float4* __restrict__ out_sb)
+                                                       float4* __restrict__ out_sb, int* __restrict__ tally)
 {
     __shared__ float2 tile[kTile + 2 * kLinkLook];
+    static_assert(kTallySlots <= kTile, "one thread per slot");
+    if (blockIdx.x == 0 && threadIdx.x < kTallySlots) { tally[kTallyStride * threadIdx.x] = 0; tally[kTallyStride * threadIdx.x + 1] = 0; }   // (the replay's, two launches on)
     const int j0 = blockIdx.x * kTile - kLinkLook;
     for (int t = threadIdx.x; t < kTile + 2 * kLinkLook; t += kTile) {
         const int j = j0 + t;
@@ -235,10 +237,9 @@ __device__ __forceinline__ int chain_rival(const unsigned long long* __restrict_
 // -- 16 384 on one address at a million bodies once the system is dense -- took 6 .. 90 us.
 constexpr int kHeadsBlock = 1024;
 __global__ __launch_bounds__(kHeadsBlock) void k_chain_heads(const unsigned char* __restrict__ link, const int n, int* __restrict__ head_list,
-                                                             int* __restrict__ head_count, int* __restrict__ tally)
+                                                             int* __restrict__ head_count)
 {
     __shared__ int wave_base[kHeadsBlock / 64 + 1];
-    if (blockIdx.x == 0 && threadIdx.x < kTallySlots) { tally[kTallyStride * threadIdx.x] = 0; tally[kTallyStride * threadIdx.x + 1] = 0; }   // (k_chain's, launched behind this kernel)
     const int p = blockIdx.x * kHeadsBlock + threadIdx.x;
     const bool head = p < n && !chain_linked(link, p, n) && chain_linked(link, p + 1, n);
     const unsigned long long hm = __ballot(head);
@@ -257,21 +258,18 @@ __global__ __launch_bounds__(kHeadsBlock) void k_chain_heads(const unsigned char
 // One wave per segment, taken off the list in strides of the grid: segments sit side by side in the sorted order wherever the system is
 // dense (30 000 of them in the core of the collapsing 1 M-body model), and a wave per 32 sorted places that replays the ones starting
 // there one after the other leaves those stretches to a few waves.
-__global__ __launch_bounds__(64) void k_chain(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
-                                              const float4* __restrict__ sb, const unsigned char* __restrict__ link, const int n,
-                                              const unsigned* __restrict__ box, unsigned long long* __restrict__ out_keys,
-                                              unsigned* __restrict__ out_idx, float4* __restrict__ out_sb, int* __restrict__ counters,
-                                              const int* __restrict__ head_list, const int* __restrict__ head_count, int* __restrict__ tally)
+// the replay of the segment that starts at sorted body p0 (the whole wave; lane = threadIdx.x)
+__device__ __forceinline__ void chain_segment(const int p0, const int lane, const unsigned long long* __restrict__ keys,
+                                              const unsigned* __restrict__ idx, const float4* __restrict__ sb,
+                                              const unsigned char* __restrict__ link, const int n, const unsigned* __restrict__ box,
+                                              unsigned long long* __restrict__ out_keys, unsigned* __restrict__ out_idx,
+                                              float4* __restrict__ out_sb, int& merged_total, int& approx_total)
 {
-    const int lane = threadIdx.x;
-    const int count = *head_count;
-    int merged_total = 0, approx_total = 0;
-    for (int h = blockIdx.x; h < count; h += (int)gridDim.x) {
-        const int p0 = head_list[h];
+    {
         // the segment: lanes 0 .. t - 1 <-> sorted bodies p0 .. p0 + t - 1
         const unsigned long long lw = __ballot(lane >= 1 && chain_linked(link, p0 + lane, n)) | 1ull;
         const int t = ~lw == 0ull ? 64 : __builtin_ctzll(~lw);               // (<= 60 by the cut rule)
-        if (__ballot(lane >= 1 && lane < t && (link[p0 + lane] & 2)) == 0ull) continue;   // nobody within EPS of anybody: as copied
+        if (__ballot(lane >= 1 && lane < t && (link[p0 + lane] & 2)) == 0ull) return;   // nobody within EPS of anybody: as copied
         const bool member = lane < t;
         const int p = member ? p0 + lane : p0;
         const unsigned long long key = keys[p];
@@ -410,12 +408,52 @@ __global__ __launch_bounds__(64) void k_chain(const unsigned long long* __restri
         approx_total += __popcll(__ballot(member && collides));
         if (member) { out_keys[p0 + rank] = out_key; out_idx[p0 + rank] = my_idx; out_sb[p0 + rank] = rec; }
     }
-    // the tallies: over kTallySlots words each, summed into counters[6] / [7] by k_scan_write's last workgroup -- as one atomic per wave on
-    // ONE word they were this kernel: 37 us for 2 600 of them at a million bodies (6 700 replay steps in all), 100 us for 8 000
+}
+
+// the tallies: over kTallySlots words each, summed into counters[6] / [7] by k_scan_write's last workgroup -- as one atomic per wave on
+// ONE word they were k_chain: 37 us for 2 600 of them at a million bodies (6 700 replay steps in all), 100 us for 8 000
+__device__ __forceinline__ void chain_tally(int* __restrict__ tally, const int lane, const int merged_total, const int approx_total)
+{
     if (lane == 0) {
         if (merged_total) atomicAdd(&tally[(blockIdx.x % kTallySlots) * kTallyStride + 1], merged_total);
         if (approx_total) atomicAdd(&tally[(blockIdx.x % kTallySlots) * kTallyStride], approx_total);
     }
+}
+
+__global__ __launch_bounds__(64) void k_chain(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
+                                              const float4* __restrict__ sb, const unsigned char* __restrict__ link, const int n,
+                                              const unsigned* __restrict__ box, unsigned long long* __restrict__ out_keys,
+                                              unsigned* __restrict__ out_idx, float4* __restrict__ out_sb,
+                                              const int* __restrict__ head_list, const int* __restrict__ head_count, int* __restrict__ tally)
+{
+    const int lane = threadIdx.x;
+    const int count = *head_count;
+    int merged_total = 0, approx_total = 0;
+    for (int h = blockIdx.x; h < count; h += (int)gridDim.x)
+        chain_segment(head_list[h], lane, keys, idx, sb, link, n, box, out_keys, out_idx, out_sb, merged_total, approx_total);
+    chain_tally(tally, lane, merged_total, approx_total);
+}
+
+// Small systems (the two-launch front's, up to kSmallFrontMax bodies): no list -- a wave finds the segments that start in its 64 sorted
+// places itself and replays them one after the other; one launch less on a step that is ten launches of 4-25 us (the reference's own
+// scene: 10 000 bodies, 0.10 ms).
+__global__ __launch_bounds__(64) void k_chain_small(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
+                                                    const float4* __restrict__ sb, const unsigned char* __restrict__ link, const int n,
+                                                    const unsigned* __restrict__ box, unsigned long long* __restrict__ out_keys,
+                                                    unsigned* __restrict__ out_idx, float4* __restrict__ out_sb, int* __restrict__ tally)
+{
+    const int lane = threadIdx.x;
+    const int first = blockIdx.x * 64;
+    const unsigned long long la = __ballot(chain_linked(link, first + lane, n));      // bit l: boundary first + l
+    const unsigned long long lb = chain_linked(link, first + 64, n) ? 1ull << 63 : 0ull;
+    unsigned long long heads = ~la & ((la >> 1) | lb);                                  // bodies that start a segment
+    int merged_total = 0, approx_total = 0;
+    while (heads) {
+        const int p0 = first + __builtin_ctzll(heads);
+        heads &= heads - 1;
+        chain_segment(p0, lane, keys, idx, sb, link, n, box, out_keys, out_idx, out_sb, merged_total, approx_total);
+    }
+    chain_tally(tally, lane, merged_total, approx_total);
 }
 
 __device__ __forceinline__ ScanItem scan_item(const float4* __restrict__ sb, const unsigned long long* __restrict__ keys,
@@ -826,12 +864,17 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
         // chains of close bodies replayed in arrival order (3b): links from the sorted bodies (this kernel also gathers them into
         // sorted order), then one wave per 32 sorted places regroups what the reference merges
         hipLaunchKernelGGL(k_chain_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link, k.counters + 1, sb_ready ? 1 : 0,
-                           k.keys0, k.idx0, k.sb2);
-        int* const head_list = reinterpret_cast<int*>(k.big);          // (k_fold_big's queue: the other class's)
-        hipLaunchKernelGGL(k_chain_heads, dim3((unsigned)((n + kHeadsBlock - 1) / kHeadsBlock)), dim3(kHeadsBlock), 0, stream, k.link, n, head_list, k.counters + 4, k.ghosts);
-        const int waves = n / 128 < 64 ? 64 : (n / 128 > 16384 ? 16384 : n / 128);
-        hipLaunchKernelGGL(k_chain, dim3((unsigned)waves), dim3(64), 0, stream, k.keys1, k.idx1, k.sb, k.link, n, k.box, k.keys0, k.idx0, k.sb2,
-                           k.counters, head_list, k.counters + 4, k.ghosts);
+                           k.keys0, k.idx0, k.sb2, k.ghosts);
+        if (n <= kSmallFrontMax) {
+            hipLaunchKernelGGL(k_chain_small, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, k.keys1, k.idx1, k.sb, k.link, n, k.box, k.keys0,
+                               k.idx0, k.sb2, k.ghosts);
+        } else {
+            int* const head_list = reinterpret_cast<int*>(k.big);          // (k_fold_big's queue: the other class's)
+            hipLaunchKernelGGL(k_chain_heads, dim3((unsigned)((n + kHeadsBlock - 1) / kHeadsBlock)), dim3(kHeadsBlock), 0, stream, k.link, n, head_list, k.counters + 4);
+            const int waves = n / 128 < 64 ? 64 : (n / 128 > 16384 ? 16384 : n / 128);
+            hipLaunchKernelGGL(k_chain, dim3((unsigned)waves), dim3(64), 0, stream, k.keys1, k.idx1, k.sb, k.link, n, k.box, k.keys0, k.idx0, k.sb2,
+                               head_list, k.counters + 4, k.ghosts);
+        }
         tally = k.ghosts;
         mi = k.idx0; ms = k.sb2;
     }

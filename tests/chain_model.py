@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
 """CPU model of the exact-sum device build's chain replay (bh_build.hip section 3b: k_chain_links / k_chain_heads / k_chain), the way the
 rule was found and its parameters fixed in round 6 -- numpy for the keys and the links, plain Python for the replay of a segment -- and
-compared with the ORACLE's tree (diagnostic tool: the oracle is the checker here, as in tools/bh_device_tree_probe.py):
-    python tools/bh_chain_model.py [seed]          20 000 bodies + 600 chains of 2-6 bodies within EPS, random arrival order
-    from bh_chain_model import compare; compare(particles, W=1 << 30, K=3, LINK=np.float32(2e-4))
+compared with the ORACLE's tree (test infrastructure like tests/f32_exact.py: tests/test_chain_model.py holds the rule to the oracle on
+every CPU run; pytest does not collect this file):
+    python tests/chain_model.py [seed]          20 000 bodies + 600 chains of 2-6 bodies within EPS, random arrival order
+    from chain_model import compare; compare(particles, W=1 << 30, K=3, LINK=np.float32(2e-4))
 `compare` returns how many leaves / nodes the model's tree and the oracle's differ by, and the segment statistics.  Parameters: K = how many
 sorted places ahead a body links boundaries, LINK = the link distance (2 EPS shipped), CUTW / MCUT = where chains longer than CUTW + 2 MCUT are
 cut (32 / 14 shipped), LOOSECUT = also cut chains longer than this at boundaries no pair within EPS spans (0 = off: shipped).
 Results that fixed them: docs/rounds/r06.md section 2."""
-import sys, numpy as np
-sys.path.insert(0, "/root/repo")
-from oracle import binding as ob
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import binding as ob  # noqa: E402
 f32 = np.float32
 EPS = f32(1e-4)
 LEVELS = 31

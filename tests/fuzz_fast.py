@@ -13,7 +13,9 @@ request since round 6): whenever that build is kept its forces must equal the ho
 DEVICE build must have served the evaluation (bit for bit the exact-sum engine's forces), not the host; and four Barnes-Hut steps enqueued back to
 back (the two-slot pipeline without a host wait) must leave the state of four waited-for steps, bit for bit.
 Late round 3: 40 % of the cases get 5 / 50 / 300 clusters of 2 .. 6 bodies around EPS wide in shuffled arrival order (the device
-build replays whole clusters: k_blobs)."""
+build replays whole clusters: k_blobs).  Round 6: those systems are served by the exact-sum device build too (chains replayed in
+arrival order, bh_build.hip 3b) and judged against the oracle's fp64 arbiter on the reference's tree: the device tree's forces must be
+as close to it as the host (= reference) tree's own (see the comment at the check)."""
 import os
 import sys
 import time
@@ -109,20 +111,42 @@ def main():
                 if not np.isfinite(dx_).all():
                     why.append("device tree not finite")
                 elif clumps:
-                    # Systems with injected clusters.  Rounds 3-5 (pairs-only merge): the 99th percentile instead of the 99.9th, and up to
-                    # 8 * max(16, n/2000) bodies beyond the max-error bound -- the bodies left unmerged and their blob-mates, which feel
-                    # O(1) different forces.  Round 6 (chains replayed in arrival order, bh_build.hip 3b): NOBODY beyond the max-error
-                    # bound -- except at the 3e3 scale, where neighbouring floats are 2.4e-4 apart, more than EPS: a cluster is then a
+                    # Systems with injected clusters (up to half the bodies sit in one).  Rounds 3-5 (pairs-only merge) sent most of them
+                    # to the host build and held the rest to the host tree's forces: p99 <= 4e-4, up to 8 * max(16, n/2000) bodies
+                    # beyond the max-error bound.  Round 6 replays the chains on the device (bh_build.hip 3b), so the device tree serves
+                    # them -- same nodes, same leaves (tests/test_gpu_bh_chains.py, tests/test_chain_model.py) -- and what is left to
+                    # compare are the INTERIOR records: exact sums here, the reference's f32 running fold there.  A cluster's near field
+                    # is 1e4 times the far field, and at theta = 0.85 the last bits of a centre flip the opening decision of the tiny
+                    # nodes around a blob for percents of the bodies: measured on the cases a 12 000-case campaign flagged, the host
+                    # tree's forces are 8e-4 .. 3.5e-3 (p99), up to 1.1e-2 (max) off the fp64 arbiter on the SAME tree
+                    # (orc_bh_forces_exact), the device tree's 2e-4 .. 1.8e-3, up to 4.3e-3.  So the arbiter is the yardstick: at the
+                    # 99th and 99.9th percentile and at the maximum the device tree must be within the bounds every other system is held
+                    # to (2e-4 / 4e-4; 5e-3 / 1e-2) OR as close to the arbiter as the reference's own tree is (25 % + the walk's fp32
+                    # rounding of slack).  At the 3e3 scale neighbouring floats are 2.4e-4 apart, more than EPS: a cluster is then a
                     # handful of bodies on one or two positions whose folded centre drifts by an ulp and makes the reference split bodies
-                    # of ONE position (nbody.rs:315-317), which no order of keys can express (counted in NBX_STAT_BH_CHAIN_APPROX, the
-                    # old allowance stays).  The percentile stays the 99th: a cluster's near field is 1e4 times the far field, and the
-                    # exact-sum class's interior records differ from the reference's folds in the last bits.
-                    allowed = min(8 * max(16, n // 2000), max(8, n // 20)) if scale >= 1e3 else 0
-                    far = err > (1e-2 if theta > 0.8 else 5e-3)
-                    beyond = int(far.sum())
-                    if np.percentile(err[~far], 99.0) > 4e-4 or beyond > allowed:   # (the percentile over everybody else: of 270 bodies 1 % is 3)
-                        why.append("device tree (clustered, exact sums) p99 %.2e, %d bodies beyond the max-error bound (%d allowed)"
-                                   % (np.percentile(err, 99.0), beyond, allowed))
+                    # of ONE position (nbody.rs:315-317), which no order of keys can express (NBX_STAT_BH_CHAIN_APPROX counts them):
+                    # there the old allowance of bodies beyond the max-error bound stays.
+                    from oracle import binding as ob
+
+                    rc_a, ax_, ay_ = ob.bh_forces_exact(ob.particles(x, y, vx, vy, m), theta, nthreads=os.cpu_count() or 8)
+                    if rc_a != 0:
+                        why.append("oracle arbiter rc %d" % rc_a)
+                    else:
+                        e_dev = np.maximum(np.abs(dx_ - ax_), np.abs(dy_ - ay_)) / bsc
+                        e_ref = np.maximum(np.abs(bfx - ax_), np.abs(bfy - ay_)) / bsc
+                        top = 1e-2 if theta > 0.8 else 5e-3
+                        allowed = min(8 * max(16, n // 2000), max(8, n // 20)) if scale >= 1e3 else 0
+                        far = e_dev > np.maximum(top, 1.25 * e_ref.max() + 2e-5)
+                        if int(far.sum()) > allowed:
+                            why.append("device tree (clustered, exact sums): %d bodies beyond the max-error bound (%d allowed), max %.2e (host tree vs arbiter %.2e)"
+                                       % (int(far.sum()), allowed, e_dev.max(), e_ref.max()))
+                        else:
+                            bulk = 4e-4 if n > 100000 else 2e-4
+                            for q, bound in ((99.0, bulk), (99.9, bulk if n >= 2000 else top)):
+                                if np.percentile(e_dev[~far], q) > max(bound, 1.25 * np.percentile(e_ref, q) + 2e-5):
+                                    why.append("device tree (clustered, exact sums) further from the fp64 arbiter than the host tree at p%g: %.2e vs %.2e"
+                                               % (q, np.percentile(e_dev[~far], q), np.percentile(e_ref, q)))
+                                    break
                 elif np.percentile(err, 99.9) > (4e-4 if n > 100000 else 2e-4) or err.max() > (1e-2 if theta > 0.8 else 5e-3):
                     why.append("device tree p99.9 %.2e max %.2e" % (np.percentile(err, 99.9), err.max()))
                 from rust_exp_amd.engine import NBX_OPT_BH_ASYNC, NBX_STAT_BH_LAST_TREE

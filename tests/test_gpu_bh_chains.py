@@ -185,7 +185,7 @@ def test_two_million_bodies_the_device_tree_is_the_host_tree(rx, ob, steps, stra
     """The benchmark's 2-D Plummer model at twice config #4's size, as generated and a few steps into its collapse (from ~1.5 M
     bodies on rounds 2-5 handed steps of this run to the host build): node set, skip pointers, sizes and every leaf record of the
     exact-sum device tree equal the host tree's.  22 steps in -- the densest moment: 40 000 blobs, 230 000 bodies in chains -- all but
-    a few dozen of 2 050 000 leaves (tools/bh_chain_model.py counted 65 on the oracle's run of the same model)."""
+    a few dozen of 2 050 000 leaves (tests/chain_model.py counted 65 on the oracle's run of the same model)."""
     from rust_exp_amd.engine import NBX_STAT_BH_CHAIN_MERGED, NBX_STAT_BH_FALLBACKS
 
     st = rx.plummer_sphere(2097152, dim=2)
