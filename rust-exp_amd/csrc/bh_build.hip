@@ -434,19 +434,20 @@ __global__ __launch_bounds__(64) void k_chain(const unsigned long long* __restri
     chain_tally(tally, lane, merged_total, approx_total);
 }
 
-// Small systems (the two-launch front's, up to kSmallFrontMax bodies): no list -- a wave finds the segments that start in its 64 sorted
+// Small systems (the two-launch front's, up to kSmallFrontMax bodies): no list -- a wave finds the segments that start in its 16 sorted
 // places itself and replays them one after the other; one launch less on a step that is ten launches of 4-25 us (the reference's own
 // scene: 10 000 bodies, 0.10 ms).
+constexpr int kSmallBlock = 16;   // sorted places per wave of k_chain_small (64: the 10 000-body disc's core left 157 waves 0.17 ms per step, from 0.14)
 __global__ __launch_bounds__(64) void k_chain_small(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ idx,
                                                     const float4* __restrict__ sb, const unsigned char* __restrict__ link, const int n,
                                                     const unsigned* __restrict__ box, unsigned long long* __restrict__ out_keys,
                                                     unsigned* __restrict__ out_idx, float4* __restrict__ out_sb, int* __restrict__ tally)
 {
     const int lane = threadIdx.x;
-    const int first = blockIdx.x * 64;
-    const unsigned long long la = __ballot(chain_linked(link, first + lane, n));      // bit l: boundary first + l
-    const unsigned long long lb = chain_linked(link, first + 64, n) ? 1ull << 63 : 0ull;
-    unsigned long long heads = ~la & ((la >> 1) | lb);                                  // bodies that start a segment
+    const int first = blockIdx.x * kSmallBlock;
+    // bit l: boundary first + l (lanes 0 .. kSmallBlock); a body starts a segment when its own boundary is not linked and the next one is
+    const unsigned long long la = __ballot(lane <= kSmallBlock && chain_linked(link, first + lane, n));
+    unsigned long long heads = ~la & (la >> 1) & ((1ull << kSmallBlock) - 1ull);
     int merged_total = 0, approx_total = 0;
     while (heads) {
         const int p0 = first + __builtin_ctzll(heads);
@@ -866,12 +867,14 @@ hipError_t device_tree_build_begin(const float4* posm, int n, void* workspace, s
         hipLaunchKernelGGL(k_chain_links, dim3(nb), dim3(kTile), 0, stream, posm, k.sb, k.keys1, k.idx1, n, k.link, k.counters + 1, sb_ready ? 1 : 0,
                            k.keys0, k.idx0, k.sb2, k.ghosts);
         if (n <= kSmallFrontMax) {
-            hipLaunchKernelGGL(k_chain_small, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, k.keys1, k.idx1, k.sb, k.link, n, k.box, k.keys0,
+            hipLaunchKernelGGL(k_chain_small, dim3((unsigned)((n + kSmallBlock - 1) / kSmallBlock)), dim3(64), 0, stream, k.keys1, k.idx1, k.sb, k.link, n, k.box, k.keys0,
                                k.idx0, k.sb2, k.ghosts);
         } else {
             int* const head_list = reinterpret_cast<int*>(k.big);          // (k_fold_big's queue: the other class's)
             hipLaunchKernelGGL(k_chain_heads, dim3((unsigned)((n + kHeadsBlock - 1) / kHeadsBlock)), dim3(kHeadsBlock), 0, stream, k.link, n, head_list, k.counters + 4);
-            const int waves = n / 128 < 64 ? 64 : (n / 128 > 16384 ? 16384 : n / 128);
+            // (a wave per 16 bodies, at most 16 384: a wave without a segment reads the count and leaves -- with a wave per 128 bodies the 5 000
+            //  segments of nb_random_disk(65536)'s core had 512 waves to share: k_chain 80 us of a 0.26 ms step)
+            const int waves = n / 16 < 256 ? 256 : (n / 16 > 16384 ? 16384 : n / 16);
             hipLaunchKernelGGL(k_chain, dim3((unsigned)waves), dim3(64), 0, stream, k.keys1, k.idx1, k.sb, k.link, n, k.box, k.keys0, k.idx0, k.sb2,
                                head_list, k.counters + 4, k.ghosts);
         }
