@@ -92,7 +92,17 @@ def main():
             elif max(np.abs(fx - sx).max(), np.abs(fy - sy).max()) > (2.0 if clumps else 1.0) * 5e-5 * sc * max(1.0, np.sqrt(n) / 64):
                 # summation-order class, grows with sqrt(N); wide mass ranges sit near it, and injected clusters (pair terms up to
                 # 1e4 times the far field, cancelling) past it: seed 70692 reached 1.07 x the plain bound
-                why.append("brute tol %.2e" % (max(np.abs(fx - sx).max(), np.abs(fy - sy).max()) / sc))
+                # Past the bound (1 of 12 000 cases in round 6: seed 411270, 70 000 bodies at the 3e3 scale, one common mass of 0.37 with 30
+                # exceptions up to 918): which of the two is off?  The bit-exact kernel's ascending f32 sum is the reference's arithmetic,
+                # not the truth; the oracle's float64 sum arbitrates, as in tests/test_gpu_randomized.py -- the fast kernel must be as close
+                # to it as the reference's own arithmetic is (x 2, or the fp32 rounding of a single sum).
+                from oracle import binding as ob
+
+                tx, ty = ob.brute_forces_f64(ob.particles(x, y, vx, vy, m))
+                e_fast = max(np.abs(fx - tx).max(), np.abs(fy - ty).max()) / sc
+                e_strict = max(np.abs(sx - tx).max(), np.abs(sy - ty).max()) / sc
+                if e_fast > max(2.0 * e_strict, 2e-6):
+                    why.append("brute tol %.2e (vs float64: fast %.2e, bit-exact %.2e)" % (max(np.abs(fx - sx).max(), np.abs(fy - sy).max()) / sc, e_fast, e_strict))
             try:
                 bsx, bsy, _ = fs.forces(theta)
                 tree_ok = True
