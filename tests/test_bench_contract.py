@@ -104,6 +104,11 @@ def test_companions_block_is_flat_scalars_and_survives_a_failed_child():
                                      "c5_fp16_sources_524288": {"config": "x", "argv": "y", "error": "rc 1: boom", "wall_s": 0.1}})
     assert flat["c2_value"] == 5.4e12 and flat["c2_frac"] == 0.6 and flat["c4_build_ms"] == 0.36 and flat["c5_error"] == "rc 1: boom"
     assert all(v is None or isinstance(v, (int, float, str)) for v in flat.values())
+    # round 6: config #4's model at twice its size rides along as c6_* -- the same summary as c4's, with the steps handed to the host build
+    assert argv["c6_barnes_hut_2097152"][:6] == ["--workload", "bh", "--bodies", "2097152", "--theta", "0.5"]
+    c6 = bench.companion_summary("c6_barnes_hut_2097152", dict(bh_line, bh_fallbacks=0))
+    f6 = bench.flatten_companions({"c6_barnes_hut_2097152": dict(c6, config="x", argv="y", wall_s=9.0)})
+    assert f6["c6_fallbacks"] == 0 and f6["c6_build_ms"] == 0.36 and f6["c6_err_p999"] == 1.1e-5 and f6["c6_ms_per_step"] == 0.79
     json.dumps(flat)
     # round 6: the reference's one published number rides on the line as c0_* -- ms per nb_step_barnes_hut call of
     # its default scene, the oracle's 1-thread median beside it (BASELINE.md section 3 row CB), the error against the oracle's traversal
